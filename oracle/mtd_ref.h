@@ -1,0 +1,119 @@
+/* oracle/mtd_ref.h — CPU restatement of the reference's metadynamics hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under oracle/ is part of the product: only tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library, and only as
+ * the checker / reported CPU baseline.  The product path (metadynamics-plugin_amd/) never links
+ * or calls it and fails loudly when its HIP library is missing.
+ *
+ * PARITY PINNING.  The reference (jglaser/metadynamics-plugin) ships no golden vectors, no
+ * asserts and no unit tests (test/test_2d.py, test/test_mesh.py are eyeball scripts that need a
+ * full HOOMD-blue v2 install, which is absent here).  Only IndexGrid.cc and the header-only
+ * spherical_harmonics.hpp compile standalone; they are built from the sources where they lie
+ * into oracle/_ref/ (see oracle/Makefile, oracle/ref_shim.cc) and pin ref_index_* and ref_sph_*
+ * below.  Every other function in this file is a statement-by-statement restatement of the cited
+ * .cc lines, pinned only by analytic known-answer tests (tests/test_oracle_*.py):
+ *     ==> lamellar, bias grid, WTE, mesh: "parity unpinned" (no reference-run vectors exist).
+ *
+ * All arithmetic is double precision ("Scalar" = double, HOOMD's default build) and serial,
+ * exactly like the reference CPU path (which has no threading, only MPI ranks).
+ * Citations are file:line relative to /root/reference/metadynamics/.
+ */
+#ifndef MTD_REF_H
+#define MTD_REF_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* HOOMD BoxDim restated: lattice vectors
+ * a1=(Lx,0,0), a2=(xy*Ly,Ly,0), a3=(xz*Lz,yz*Lz,Lz); lo = lower corner. */
+typedef struct ref_box
+    {
+    double L[3];
+    double lo[3];
+    double xy, xz, yz;
+    } ref_box;
+
+/* ---------------- IndexGrid (IndexGrid.cc:20-58) ---------------- */
+unsigned int ref_index_get(unsigned int dim, const unsigned int *lengths, const unsigned int *coords);
+void ref_index_coords(unsigned int dim, const unsigned int *lengths, unsigned int idx, unsigned int *coords);
+
+/* ---------------- Lamellar (LamellarOrderParameter.cc) ---------------- */
+/* postype: double[4*N] = (x,y,z,type as double holding the integer type id).
+ * lattice: int[3*n_wave].  mode: double[ntypes].  modes_out: double[2*n_wave] = (Re,Im). */
+void ref_lamellar_fourier_modes(unsigned int n_wave, const int *lattice, unsigned int N,
+                                const double *postype, const double *mode, const ref_box *global_box,
+                                double *modes_out);                         /* .cc:143-179 */
+double ref_lamellar_cv(unsigned int n_wave, const double *modes, unsigned int N_global); /* .cc:58-68 */
+void ref_lamellar_forces(unsigned int n_wave, const int *lattice, unsigned int N,
+                         const double *postype, const double *mode, const ref_box *global_box,
+                         unsigned int N_global, double bias, double *force_out /*4*N*/); /* .cc:77-140 */
+
+/* ---------------- Bias-grid engine (IntegratorMetaDynamics.cc) ---------------- */
+enum { REF_MODE_STANDARD = 0, REF_MODE_WELL_TEMPERED = 1 };
+
+typedef struct ref_metad ref_metad;
+
+ref_metad *ref_metad_create(unsigned int n_cv, const double *sigma, const double *cv_min,
+                            const double *cv_max, const unsigned int *num_points,
+                            double W, double T_shift, double T, unsigned int stride,
+                            int mode, int add_bias);                        /* ctor :23-72, prepRun :121-217, setupGrid :590-661 */
+void ref_metad_destroy(ref_metad *m);
+unsigned int ref_metad_num_elements(const ref_metad *m);
+void ref_metad_set_stride(ref_metad *m, unsigned int stride);
+void ref_metad_set_add_bias(ref_metad *m, int add_bias);
+void ref_metad_set_mode(ref_metad *m, int mode);
+void ref_metad_set_sigma_inv(ref_metad *m, const double *sigma_inv /*n_cv^2*/);
+void ref_metad_reset_histogram(ref_metad *m);                               /* :1195-1203 */
+
+/* updateBiasPotential (:314-588), grid branch.  bias_out[n_cv] = dV/ds_i. */
+void ref_metad_update_bias(ref_metad *m, unsigned int timestep, const double *current_val, double *bias_out);
+
+/* the same, split at the multiple-walker all-reduce (:393-409): phase A = histogram, sigma grid,
+ * scal, updateGrid (fills the four delta arrays); phase B = reweight + accumulate + evaluate. */
+int  ref_metad_update_phase_a(ref_metad *m, unsigned int timestep, const double *current_val);
+void ref_metad_update_phase_b(ref_metad *m, int deposited, const double *current_val, double *bias_out);
+
+double ref_metad_interpolate(ref_metad *m, const double *val, int reweight);  /* :663-736 */
+double ref_metad_derivative(ref_metad *m, unsigned int cv, const double *val);/* :738-776 */
+double ref_metad_sigma_determinant(const ref_metad *m);                       /* :1296-1313 */
+double ref_metad_curr_bias(const ref_metad *m);      /* log quantity "bias"   (:448) */
+double ref_metad_curr_weight(const ref_metad *m);    /* log quantity "weight" (:451) */
+unsigned int ref_metad_num_gaussians(const ref_metad *m);
+unsigned int ref_metad_num_oob_warnings(const ref_metad *m);
+
+/* raw array access for comparisons: which = 0 grid, 1 grid_delta, 2 reweighted, 3 weight,
+ * 4 sigma_grid, 5 sigma_grid_delta (double*); 6 hist, 7 hist_delta, 8 hist_gauss, 9 hist_gauss_delta (unsigned*) */
+void *ref_metad_array(ref_metad *m, int which);
+
+/* writeGrid (:831-926) / readGrid (:928-1000).  names: n_cv C strings.  Returns 0 on success. */
+int ref_metad_write_grid(ref_metad *m, const char *filename, unsigned int timestep, const char *const *names);
+int ref_metad_read_grid(ref_metad *m, const char *filename);
+
+/* standalone pieces, for unit comparisons */
+void ref_update_grid(unsigned int dim, const unsigned int *lengths, const double *cv_min, const double *cv_max,
+                     const double *sigma_inv, const double *current_val, double scal, double W,
+                     double *grid_delta);                                     /* updateGrid :1002-1047 */
+
+/* ---------------- Umbrella (CollectiveVariable.cc:22-106) ---------------- */
+enum { REF_NO_UMBRELLA = 0, REF_LINEAR, REF_HARMONIC, REF_WALL, REF_GAUSSIAN };
+double ref_umbrella_bias(int umbrella, double val, double bias_in, double cv0, double kappa,
+                         double width_flat, double scale);                   /* :22-60 */
+double ref_umbrella_energy(int umbrella, double val, double cv0, double kappa,
+                           double width_flat, double scale);                 /* :68-106 */
+
+/* ---------------- Box CVs needed by test_2d.py (AspectRatio.cc:24-57, Density.cc:20-27) -------- */
+double ref_aspect_ratio(const ref_box *box, unsigned int dir1, unsigned int dir2);
+double ref_density(const ref_box *box, unsigned int N_group);
+
+/* ---------------- WellTemperedEnsemble (WellTemperedEnsemble.cc:30-68, 135-188) ---------------- */
+double ref_wte_potential_energy(unsigned int N, const double *net_force /*4N*/, double external_energy);
+void ref_wte_scale(unsigned int N, double *net_force /*4N*/, double *net_torque /*4N*/,
+                   double *net_virial /*6*pitch*/, unsigned int pitch, double *external_virial /*6*/, double bias);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
