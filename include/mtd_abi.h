@@ -1,0 +1,227 @@
+/* include/mtd_abi.h — C ABI of libmtd_hip.so: the MI355X (gfx950) metadynamics hot path.
+ *
+ * This is the drop-in boundary.  Every entry point is `extern "C"`, takes plain pointers, sizes
+ * and PODs (no torch / pybind / HOOMD types), enqueues work on an explicit HIP stream and returns
+ * an int status (0 = success, >0 = hipError_t, <0 = MTD_ERR_*).  No entry point synchronises the
+ * device unless its comment says so.  The host classes in metadynamics-plugin_amd/host (the mirror
+ * of the reference's CollectiveVariable / IntegratorMetaDynamics C++ classes) and the test / bench
+ * harness (ctypes) call nothing else.
+ *
+ * Each block cites the reference interface it replaces (file:line under
+ * /root/reference/metadynamics/).  The reference's kernel drivers are C++ free functions taking
+ * HOOMD PODs (BoxDim, Index2D, GPUPartition) and raw device pointers borrowed from ArrayHandle;
+ * here BoxDim becomes `mtd_box`, the default stream becomes an explicit `mtd_stream_t`, and the
+ * tiny per-CV configuration arrays (Miller indices, per-type mode coefficients, grid geometry) are
+ * passed as HOST pointers and travel in the kernel-argument segment instead of device arrays.
+ *
+ * Particle arrays keep HOOMD's layout: postype = Scalar4 (x, y, z, type bit-cast into w),
+ * force = Scalar4 (fx, fy, fz, energy), with Scalar selected per call by `dtype`
+ * (MTD_F32: w holds the int32 type bit pattern; MTD_F64: the LOW 32 bits of w hold it, HOOMD's
+ * __scalar_as_int convention).  All reductions and the whole bias grid are double precision.
+ */
+#ifndef MTD_ABI_H
+#define MTD_ABI_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MTD_ABI_VERSION 1
+
+typedef void *mtd_stream_t; /* hipStream_t */
+
+enum mtd_dtype { MTD_F32 = 0, MTD_F64 = 1 };
+
+enum mtd_status
+    {
+    MTD_SUCCESS = 0,
+    MTD_ERR_INVALID_ARGUMENT = -1, /* the reference throws std::runtime_error for these */
+    MTD_ERR_UNSUPPORTED = -2,
+    MTD_ERR_NO_DEVICE = -3
+    };
+
+/* HOOMD BoxDim as a POD (reference: hoomd/BoxDim.h, passed by const-ref to every driver) */
+typedef struct mtd_box
+    {
+    double L[3];
+    double lo[3];
+    double xy, xz, yz;
+    unsigned char periodic[3];
+    unsigned char _pad[5];
+    } mtd_box;
+
+int mtd_abi_version(void);
+const char *mtd_status_string(int status);
+/* number of visible HIP devices, or a negative mtd_status */
+int mtd_device_count(void);
+
+/* ================================================================================================
+ * Lamellar order parameter
+ * replaces LamellarOrderParameterGPU.cuh:21-54 (gpu_calculate_fourier_modes, gpu_compute_sq_forces)
+ * ============================================================================================== */
+
+#define MTD_MAX_CV 8     /* lamellar CVs fused into one pass over the particles */
+#define MTD_MAX_MODES 64 /* total Fourier modes over the fused CVs */
+#define MTD_MAX_TYPES 16
+
+/* n_cv lamellar CVs evaluated in ONE pass over the positions (the reference launches one
+ * kernel grid per CV and re-reads every position n_wave times, LamellarOrderParameterGPU.cu:130). */
+typedef struct mtd_lamellar_set
+    {
+    unsigned int n_cv;
+    unsigned int n_types;
+    unsigned int n_modes;                       /* total, CV-major: modes of CV c are [first[c], first[c+1]) */
+    unsigned int first[MTD_MAX_CV + 1];
+    int hkl[MTD_MAX_MODES][3];                  /* Miller indices (cv.py:251-256, std_vector_int3) */
+    double coeff[MTD_MAX_CV][MTD_MAX_TYPES];    /* per-type mode coefficients (cv.py:242-249) */
+    } mtd_lamellar_set;
+
+/* workspace (device doubles) needed for n_particles: block partial sums */
+size_t mtd_lamellar_scratch_doubles(unsigned int n_particles);
+
+/* gpu_calculate_fourier_modes (LamellarOrderParameterGPU.cuh:21-29, .cu:104-147), one CV:
+ * d_fourier_modes[2*n_wave] = sum_j a(type_j) (cos, sin)(q_k . r_j), k < n_wave, as doubles.
+ * lattice_vectors / mode are HOST arrays (int[3*n_wave], double[n_types]). */
+int mtd_calculate_fourier_modes(unsigned int n_wave, const int *lattice_vectors, unsigned int n_particles,
+                                const void *d_postype, int dtype, const double *mode, unsigned int n_types,
+                                double *d_fourier_modes, double *d_scratch, const mtd_box *global_box,
+                                mtd_stream_t stream);
+
+/* Fused hot path (no reference counterpart; replaces computeCV's kernel + D2H + host sum,
+ * LamellarOrderParameterGPU.cc:34-96): for every CV c of the set,
+ *   d_partials[b * n_cv + c] = sum over the particles of block b of a_c(type_j) sum_k cos(q_k . r_j)
+ * for b < *n_partials.  The CV value is s_c = (1/N_global) sum_b d_partials[b*n_cv + c]; that last
+ * tiny sum is done by the consumer (mtd_metad_set_cv_source) or by mtd_reduce_partials. */
+int mtd_lamellar_cv_partials(const mtd_lamellar_set *set, unsigned int n_particles, const void *d_postype,
+                             int dtype, const mtd_box *global_box, double *d_partials,
+                             unsigned int *n_partials, mtd_stream_t stream);
+
+/* out[c] = shift + scale * sum_{b<n_partials} d_partials[b*stride + c], c < count (one tiny block,
+ * fixed summation order => bitwise reproducible) */
+int mtd_reduce_partials(const double *d_partials, unsigned int n_partials, unsigned int stride,
+                        unsigned int count, double scale, double shift, double *d_out, mtd_stream_t stream);
+
+/* gpu_compute_sq_forces (LamellarOrderParameterGPU.cuh:43-54, .cu:198-236), one CV, bias as a host
+ * scalar exactly like the reference: F_j = bias * (2/n_global) a(type_j) sum_k q_k sin(q_k . r_j), w = 0 */
+int mtd_compute_sq_forces(unsigned int n_particles, const void *d_postype, void *d_force, int dtype,
+                          unsigned int n_wave, const int *lattice_vectors, const double *mode,
+                          unsigned int n_types, unsigned int n_global, double bias,
+                          const mtd_box *global_box, mtd_stream_t stream);
+
+/* Fused hot path: forces of all CVs of the set in one pass; the bias factors dV/ds_c are read from
+ * DEVICE memory (d_bias[c], written by mtd_metad_update_bias) so no host round trip separates the
+ * CV reduction from the force pass.  d_force[c] (host array of n_cv device pointers) receives CV c's
+ * Scalar4 force array (the reference's per-CV ForceCompute::m_force). */
+int mtd_lamellar_forces(const mtd_lamellar_set *set, unsigned int n_particles, const void *d_postype,
+                        void *const *d_force, int dtype, unsigned int n_global, const double *d_bias,
+                        const mtd_box *global_box, mtd_stream_t stream);
+
+/* 0: accurate trig (ocml sinpi/cospi, default); 1: hardware v_sin_f32 / v_cos_f32 on the phase in turns */
+int mtd_lamellar_set_fast_trig(int enable);
+
+/* ================================================================================================
+ * Bias grid ("IntegratorMetaDynamics" grid engine), device resident
+ * replaces IntegratorMetaDynamics.cuh:1-11 (gpu_update_grid) and moves the host passes of
+ * IntegratorMetaDynamics.cc:314-588, 663-776, 1053-1155 onto the device
+ * ============================================================================================== */
+
+#define MTD_METAD_MAX_CV 6
+
+enum mtd_metad_mode { MTD_MODE_STANDARD = 0, MTD_MODE_WELL_TEMPERED = 1 };
+
+/* gpu_update_grid (IntegratorMetaDynamics.cuh:1-11, .cu:67-93):
+ * d_grid_delta[g] += W * scal * exp(-1/2 sum_ij d_i d_j sigma_inv_ij^2) over all num_elements cells,
+ * d = node coordinate - *d_current_val.  lengths/cv_min/cv_max/sigma_inv are HOST arrays,
+ * d_current_val and d_grid_delta are device doubles. */
+int mtd_update_grid(unsigned int num_elements, const unsigned int *lengths, unsigned int dim,
+                    const double *d_current_val, double *d_grid_delta, const double *cv_min,
+                    const double *cv_max, const double *sigma_inv, double scal, double W,
+                    mtd_stream_t stream);
+
+typedef struct mtd_metad mtd_metad; /* opaque; owns the ten grid arrays (IntegratorMetaDynamics.h:276-330) */
+
+/* constructor + registerCollectiveVariable + setGrid(true) + prepRun/setupGrid
+ * (IntegratorMetaDynamics.cc:23-72, .h:117-134, .cc:778-815, 121-200, 590-661).
+ * Returns MTD_ERR_INVALID_ARGUMENT where the reference throws (cv_min >= cv_max, num_points < 2). */
+int mtd_metad_create(mtd_metad **out, unsigned int n_cv, const double *sigma, const double *cv_min,
+                     const double *cv_max, const unsigned int *num_points, double W, double T_shift,
+                     double T, unsigned int stride, int mode, int add_bias);
+int mtd_metad_destroy(mtd_metad *m);
+
+int mtd_metad_set_stride(mtd_metad *m, unsigned int stride);   /* setStride  .h:205 */
+int mtd_metad_set_add_hills(mtd_metad *m, int add_bias);       /* setAddHills .h:237 */
+int mtd_metad_set_mode(mtd_metad *m, int mode);                /* setMode    .h:197 */
+int mtd_metad_set_sigma_inv(mtd_metad *m, const double *sigma_inv /* n_cv^2, host */);
+int mtd_metad_reset_histogram(mtd_metad *m, mtd_stream_t stream); /* resetHistogram .cc:1195-1203 */
+
+/* Where the engine takes CV c's current value from (replaces the host
+ * `Scalar val = cv->getCurrentValue(timestep)` of .cc:323-327):
+ *   s_c = shift + scale * sum_{b<n_partials} d_partials[b*stride + offset]
+ * d_partials stays owned by the caller and must stay valid; n_partials may be 1 (a plain value). */
+int mtd_metad_set_cv_source(mtd_metad *m, unsigned int cv, const double *d_partials, unsigned int n_partials,
+                            unsigned int stride, unsigned int offset, double scale, double shift);
+
+/* CV c's value is a host scalar (box-shape CVs such as AspectRatio / Density): it travels in the
+ * kernel arguments of the next update.  This is also the default source (value 0). */
+int mtd_metad_set_cv_value(mtd_metad *m, unsigned int cv, double value);
+
+/* device double[n_cv]: dV/ds_c after the most recent mtd_metad_update_bias — what the reference
+ * hands to CollectiveVariable::setBiasFactor (.cc:578-584).  Force kernels read it in place. */
+const double *mtd_metad_bias_device(const mtd_metad *m);
+/* device double[n_cv]: the CV values the engine used in the most recent update */
+const double *mtd_metad_cv_device(const mtd_metad *m);
+
+/* updateBiasPotential (.cc:314-588), grid branch, entirely on the device and asynchronous:
+ * histogram; on deposit steps (add_bias && timestep % stride == 0) sigma grid, well-tempered scale,
+ * Gaussian deposit, reweighted estimator, accumulate + clear; then dV/ds_c (finite difference of
+ * the multilinear interpolant), V(s) and the reweighting factor w(s). */
+int mtd_metad_update_bias(mtd_metad *m, unsigned int timestep, mtd_stream_t stream);
+
+/* The same split at the multiple-walker exchange (.cc:393-409): phase A fills the four delta arrays
+ * (packed contiguously, see mtd_metad_delta_buffers) and returns *deposited; the caller all-reduces
+ * them over the walkers (RCCL); phase B reweights, accumulates and evaluates. */
+int mtd_metad_update_phase_a(mtd_metad *m, unsigned int timestep, int *deposited, mtd_stream_t stream);
+int mtd_metad_update_phase_b(mtd_metad *m, int deposited, mtd_stream_t stream);
+/* d_real: {grid_delta[G], sigma_grid_delta[G]} doubles; d_count: {hist_delta[G], hist_gauss_delta[G]} uint32 */
+int mtd_metad_delta_buffers(mtd_metad *m, double **d_real, unsigned int **d_count, unsigned int *num_elements);
+
+/* Host-visible state (SYNCHRONISES the stream): what getCurrentValue / the log quantities
+ * "bias", "weight" (.h:161-189) report.  Any output pointer may be NULL. */
+int mtd_metad_get_state(mtd_metad *m, double *cv, double *bias, double *bias_potential, double *weight,
+                        unsigned int *num_gaussians, unsigned int *num_out_of_bounds, mtd_stream_t stream);
+double mtd_metad_sigma_determinant(const mtd_metad *m); /* sigmaDeterminant .cc:1296-1313 */
+unsigned int mtd_metad_num_elements(const mtd_metad *m);
+
+/* raw grid arrays for writeGrid / readGrid (.cc:831-1000); SYNCHRONISE.  which: 0 grid, 1 grid_delta,
+ * 2 reweighted, 3 weight, 4 sigma_grid, 5 sigma_grid_delta (double[G]); 6 hist, 7 hist_delta,
+ * 8 hist_gauss, 9 hist_gauss_delta (uint32[G]) */
+int mtd_metad_get_array(mtd_metad *m, int which, void *host_out, mtd_stream_t stream);
+int mtd_metad_set_array(mtd_metad *m, int which, const void *host_in, mtd_stream_t stream);
+int mtd_metad_set_num_gaussians(mtd_metad *m, unsigned int n, mtd_stream_t stream);
+void *mtd_metad_device_array(mtd_metad *m, int which);
+
+/* ================================================================================================
+ * WellTemperedEnsemble (potential energy as CV)
+ * replaces WellTemperedEnsemble.cuh:3-19 (gpu_scale_netforce, gpu_reduce_potential_energy)
+ * ============================================================================================== */
+
+size_t mtd_wte_scratch_doubles(unsigned int n_particles);
+
+/* gpu_reduce_potential_energy (.cu:195-243): block partial sums of net_force.w.
+ * PE = external_energy + sum_b d_partials[b]; consume with mtd_metad_set_cv_source / mtd_reduce_partials */
+int mtd_wte_energy_partials(unsigned int n_particles, const void *d_net_force, int dtype,
+                            double *d_partials, unsigned int *n_partials, mtd_stream_t stream);
+
+/* gpu_scale_netforce (.cu:53-89): net_force.xyz, net_torque.xyz and the six net_virial rows are
+ * multiplied by (1 + bias); bias = *d_bias when d_bias != NULL (device resident), else bias_host.
+ * scale_torque_w != 0 also scales net_torque.w like the reference CPU path (WellTemperedEnsemble.cc:169). */
+int mtd_wte_scale_netforce(unsigned int n_particles, void *d_net_force, void *d_net_torque,
+                           void *d_net_virial, unsigned int virial_pitch, int dtype, const double *d_bias,
+                           double bias_host, int scale_torque_w, mtd_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MTD_ABI_H */

@@ -1,0 +1,192 @@
+"""ctypes binding of libmtd_hip.so (include/mtd_abi.h) — the C-ABI drop-in boundary.
+
+The library is the product: if it is missing or does not load this module raises, it never falls
+back to a CPU path.  Device buffers are passed as raw addresses (``tensor.data_ptr()``).
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+PKG_ROOT = os.path.dirname(_HERE)
+REPO_ROOT = os.path.dirname(PKG_ROOT)
+LIB_PATH = os.path.join(PKG_ROOT, "lib", "libmtd_hip.so")
+HEADER_PATH = os.path.join(REPO_ROOT, "include", "mtd_abi.h")
+
+MTD_MAX_CV = 8
+MTD_MAX_MODES = 64
+MTD_MAX_TYPES = 16
+MTD_METAD_MAX_CV = 6
+MTD_F32, MTD_F64 = 0, 1
+MODE_STANDARD, MODE_WELL_TEMPERED = 0, 1
+
+ARRAY_NAMES = ["grid", "grid_delta", "reweighted", "weight", "sigma_grid", "sigma_grid_delta",
+               "hist", "hist_delta", "hist_gauss", "hist_gauss_delta"]
+
+
+class MtdError(RuntimeError):
+    pass
+
+
+class Box(C.Structure):
+    _fields_ = [("L", C.c_double * 3), ("lo", C.c_double * 3),
+                ("xy", C.c_double), ("xz", C.c_double), ("yz", C.c_double),
+                ("periodic", C.c_ubyte * 3), ("_pad", C.c_ubyte * 5)]
+
+    @classmethod
+    def make(cls, L, lo=None, xy=0.0, xz=0.0, yz=0.0):
+        if isinstance(L, (int, float)):
+            L = [float(L)] * 3
+        L = [float(x) for x in L]
+        if lo is None:
+            lo = [-0.5 * x for x in L]
+        b = cls()
+        b.L[:] = L
+        b.lo[:] = [float(x) for x in lo]
+        b.xy, b.xz, b.yz = float(xy), float(xz), float(yz)
+        b.periodic[:] = [1, 1, 1]
+        return b
+
+
+class LamellarSet(C.Structure):
+    _fields_ = [("n_cv", C.c_uint), ("n_types", C.c_uint), ("n_modes", C.c_uint),
+                ("first", C.c_uint * (MTD_MAX_CV + 1)),
+                ("hkl", (C.c_int * 3) * MTD_MAX_MODES),
+                ("coeff", (C.c_double * MTD_MAX_TYPES) * MTD_MAX_CV)]
+
+    @classmethod
+    def make(cls, cvs):
+        """cvs: list of (lattice_vectors [(h,k,l)...], mode coefficients per type [a_0, a_1, ...])."""
+        s = cls()
+        if not 1 <= len(cvs) <= MTD_MAX_CV:
+            raise MtdError("between 1 and %d lamellar CVs can be fused" % MTD_MAX_CV)
+        n_types = len(cvs[0][1])
+        k = 0
+        s.first[0] = 0
+        for c, (lattice, mode) in enumerate(cvs):
+            if len(mode) != n_types:
+                raise MtdError("cv.lamellar: Number of mode parameters has to equal the number of particle types!")
+            if len(lattice) == 0:
+                raise MtdError("cv.lamellar: List of supplied latice vectors is empty.")
+            for hkl in lattice:
+                if len(hkl) != 3:
+                    raise MtdError("cv.lamellar: List of input lattice vectors not a list of triples.")
+                if k >= MTD_MAX_MODES:
+                    raise MtdError("too many Fourier modes (max %d)" % MTD_MAX_MODES)
+                s.hkl[k][:] = [int(x) for x in hkl]
+                k += 1
+            s.first[c + 1] = k
+            for t, a in enumerate(mode):
+                s.coeff[c][t] = float(a)
+        s.n_cv, s.n_types, s.n_modes = len(cvs), n_types, k
+        return s
+
+
+_vp = C.c_void_p
+_dp = C.POINTER(C.c_double)
+_up = C.POINTER(C.c_uint)
+_ip = C.POINTER(C.c_int)
+
+_SIGNATURES = {
+    "mtd_abi_version": (C.c_int, []),
+    "mtd_status_string": (C.c_char_p, [C.c_int]),
+    "mtd_device_count": (C.c_int, []),
+    "mtd_lamellar_scratch_doubles": (C.c_size_t, [C.c_uint]),
+    "mtd_calculate_fourier_modes": (C.c_int, [C.c_uint, _ip, C.c_uint, _vp, C.c_int, _dp, C.c_uint, _vp, _vp,
+                                               C.POINTER(Box), _vp]),
+    "mtd_lamellar_cv_partials": (C.c_int, [C.POINTER(LamellarSet), C.c_uint, _vp, C.c_int, C.POINTER(Box), _vp,
+                                            _up, _vp]),
+    "mtd_reduce_partials": (C.c_int, [_vp, C.c_uint, C.c_uint, C.c_uint, C.c_double, C.c_double, _vp, _vp]),
+    "mtd_compute_sq_forces": (C.c_int, [C.c_uint, _vp, _vp, C.c_int, C.c_uint, _ip, _dp, C.c_uint, C.c_uint,
+                                         C.c_double, C.POINTER(Box), _vp]),
+    "mtd_lamellar_forces": (C.c_int, [C.POINTER(LamellarSet), C.c_uint, _vp, C.POINTER(_vp), C.c_int, C.c_uint,
+                                       _vp, C.POINTER(Box), _vp]),
+    "mtd_lamellar_set_fast_trig": (C.c_int, [C.c_int]),
+    "mtd_update_grid": (C.c_int, [C.c_uint, _up, C.c_uint, _vp, _vp, _dp, _dp, _dp, C.c_double, C.c_double, _vp]),
+    "mtd_metad_create": (C.c_int, [C.POINTER(_vp), C.c_uint, _dp, _dp, _dp, _up, C.c_double, C.c_double,
+                                    C.c_double, C.c_uint, C.c_int, C.c_int]),
+    "mtd_metad_destroy": (C.c_int, [_vp]),
+    "mtd_metad_set_stride": (C.c_int, [_vp, C.c_uint]),
+    "mtd_metad_set_add_hills": (C.c_int, [_vp, C.c_int]),
+    "mtd_metad_set_mode": (C.c_int, [_vp, C.c_int]),
+    "mtd_metad_set_sigma_inv": (C.c_int, [_vp, _dp]),
+    "mtd_metad_reset_histogram": (C.c_int, [_vp, _vp]),
+    "mtd_metad_set_cv_source": (C.c_int, [_vp, C.c_uint, _vp, C.c_uint, C.c_uint, C.c_uint, C.c_double, C.c_double]),
+    "mtd_metad_set_cv_value": (C.c_int, [_vp, C.c_uint, C.c_double]),
+    "mtd_metad_bias_device": (_vp, [_vp]),
+    "mtd_metad_cv_device": (_vp, [_vp]),
+    "mtd_metad_update_bias": (C.c_int, [_vp, C.c_uint, _vp]),
+    "mtd_metad_update_phase_a": (C.c_int, [_vp, C.c_uint, _ip, _vp]),
+    "mtd_metad_update_phase_b": (C.c_int, [_vp, C.c_int, _vp]),
+    "mtd_metad_delta_buffers": (C.c_int, [_vp, C.POINTER(_vp), C.POINTER(_vp), _up]),
+    "mtd_metad_get_state": (C.c_int, [_vp, _dp, _dp, _dp, _dp, _up, _up, _vp]),
+    "mtd_metad_sigma_determinant": (C.c_double, [_vp]),
+    "mtd_metad_num_elements": (C.c_uint, [_vp]),
+    "mtd_metad_get_array": (C.c_int, [_vp, C.c_int, _vp, _vp]),
+    "mtd_metad_set_array": (C.c_int, [_vp, C.c_int, _vp, _vp]),
+    "mtd_metad_set_num_gaussians": (C.c_int, [_vp, C.c_uint, _vp]),
+    "mtd_metad_device_array": (_vp, [_vp, C.c_int]),
+    "mtd_wte_scratch_doubles": (C.c_size_t, [C.c_uint]),
+    "mtd_wte_energy_partials": (C.c_int, [C.c_uint, _vp, C.c_int, _vp, _up, _vp]),
+    "mtd_wte_scale_netforce": (C.c_int, [C.c_uint, _vp, _vp, _vp, C.c_uint, C.c_int, _vp, C.c_double, C.c_int, _vp]),
+}
+
+_lib = None
+
+
+def load():
+    """Load libmtd_hip.so; raises MtdError when the HIP library has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise MtdError("libmtd_hip.so not found at %s — build it with __graft_entry__.build() "
+                           "(make -C metadynamics-plugin_amd/csrc); there is no CPU fallback." % LIB_PATH)
+        # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64.so (SONAME
+        # libamdhip64.so.7).  Importing torch FIRST makes the dynamic linker satisfy this library's
+        # DT_NEEDED with that already-loaded copy, so torch tensors, streams and RCCL buffers and
+        # our kernels share one runtime; loaded the other way round two runtimes would coexist.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGNATURES.items():
+            if not hasattr(lib, name):
+                continue  # optional blocks are bound by their own modules
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def bind(name, restype, argtypes):
+    """Bind an additional entry point (used by the mesh / steinhardt modules)."""
+    fn = getattr(load(), name)
+    fn.restype = restype
+    fn.argtypes = argtypes
+    return fn
+
+
+def check(rc):
+    if rc != 0:
+        msg = load().mtd_status_string(int(rc))
+        raise MtdError("libmtd_hip: %s (status %d)" % (msg.decode() if msg else "?", rc))
+
+
+def declared_symbols():
+    """Every function name include/mtd_abi.h declares (for the export test)."""
+    import re
+    text = open(HEADER_PATH).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(mtd_[a-z0-9_]+)\s*\(", text)))
+
+
+def ptr(t):
+    """Device (or host) address of a torch tensor / numpy array / int / None."""
+    if t is None:
+        return None
+    if isinstance(t, int):
+        return t
+    if hasattr(t, "data_ptr"):
+        return t.data_ptr()
+    return t.ctypes.data

@@ -1,0 +1,47 @@
+"""pytest configuration: `gpu` marker, import paths, shared fixtures.
+
+Import-path policy: the product package lives in metadynamics-plugin_amd/ (imported as
+`metadynamics`), the CPU oracle in oracle/ (imported as `mtd_ref`, tests only).
+"""
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (os.path.join(ROOT, "metadynamics-plugin_amd"), os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests"), ROOT):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def pytest_collection_modifyitems(config, items):
+    # GPU tests must never silently pass on a box without a GPU: skip them loudly instead.
+    try:
+        import torch
+        has_gpu = torch.cuda.is_available()
+    except Exception:
+        has_gpu = False
+    if has_gpu:
+        return
+    skip = pytest.mark.skip(reason="no GPU visible (gpu-marked tests run on the MI355X box)")
+    for item in items:
+        if "gpu" in item.keywords:
+            item.add_marker(skip)
+
+
+@pytest.fixture(scope="session")
+def abi():
+    from metadynamics import _abi
+    _abi.load()
+    return _abi
+
+
+@pytest.fixture(scope="session")
+def ref():
+    import mtd_ref
+    mtd_ref.lib()
+    return mtd_ref

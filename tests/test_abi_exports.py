@@ -1,0 +1,58 @@
+"""CPU: the C-ABI library loads and exports every symbol include/mtd_abi.h declares; argument
+validation that needs no GPU.  No compute calls here (no GPU in the build container)."""
+import ctypes as C
+
+import pytest
+
+import util
+
+
+def test_header_symbols_exported(abi):
+    lib = abi.load()
+    declared = abi.declared_symbols()
+    assert len(declared) >= 35
+    missing = [s for s in declared if not hasattr(lib, s)]
+    assert not missing, "libmtd_hip.so does not export %s" % missing
+
+
+def test_abi_version_and_status_strings(abi):
+    lib = abi.load()
+    assert lib.mtd_abi_version() == 1
+    assert lib.mtd_status_string(0) == b"success"
+    assert lib.mtd_status_string(-1) == b"invalid argument"
+    with pytest.raises(abi.MtdError):
+        abi.check(-2)
+
+
+def test_struct_layouts_match_header(abi):
+    """ctypes mirrors of the PODs must have the C layout (sizes computed from the header's field list)"""
+    assert C.sizeof(abi.Box) == 9 * 8 + 8
+    assert C.sizeof(abi.LamellarSet) == 4 * 3 + 4 * 9 + 12 * 64 + 8 * 8 * 16
+    s = abi.LamellarSet.make([(util.CV1_VECTORS, [1.0, -1.0]), (util.CV2_VECTORS, [1.0, -1.0])])
+    assert (s.n_cv, s.n_types, s.n_modes) == (2, 2, 16)
+    assert list(s.first[:3]) == [0, 8, 16]
+    assert list(s.hkl[8]) == [1, 1, 1]
+
+
+def test_python_side_validation(abi):
+    with pytest.raises(abi.MtdError):
+        abi.LamellarSet.make([([], [1.0])])                      # empty lattice-vector list (cv.py:232-234)
+    with pytest.raises(abi.MtdError):
+        abi.LamellarSet.make([([(0, 0, 1)], [1.0]), ([(0, 0, 1)], [1.0, 2.0])])
+    with pytest.raises(abi.MtdError):
+        abi.LamellarSet.make([([(0, 1)], [1.0])])                # not a triple (cv.py:252-254)
+
+
+def test_argument_validation_without_gpu(abi):
+    """entry points reject bad arguments before touching the device"""
+    lib = abi.load()
+    box = abi.Box.make(10.0)
+    n = C.c_uint()
+    assert lib.mtd_lamellar_cv_partials(None, 0, None, 0, C.byref(box), None, C.byref(n), None) == -1
+    assert lib.mtd_metad_update_bias(None, 0, None) == -1
+    h = C.c_void_p()
+    bad = lib.mtd_metad_create(C.byref(h), 1, util.dbl_array([0.1]), util.dbl_array([1.0]), util.dbl_array([0.0]),
+                               util.uint_array([10]), 1.0, 1.0, 1.0, 1, 0, 1)
+    assert bad == -1                                              # cv_min >= cv_max (IntegratorMetaDynamics.cc:800-805)
+    assert lib.mtd_metad_create(C.byref(h), 7, util.dbl_array([0.1] * 7), util.dbl_array([0.0] * 7),
+                                util.dbl_array([1.0] * 7), util.uint_array([2] * 7), 1.0, 1.0, 1.0, 1, 0, 1) == -2

@@ -1,0 +1,69 @@
+"""Shared test helpers: seeded particle snapshots and tensor packing."""
+import ctypes as C
+
+import numpy as np
+
+# lattice vectors of the headline config
+CV1_VECTORS = [(0, 0, 3), (0, 3, 0), (3, 0, 0), (0, 0, 6), (0, 6, 0), (6, 0, 0), (3, 3, 0), (0, 3, 3)]
+CV2_VECTORS = [(1, 1, 1), (1, -1, 1), (1, 1, -1), (-1, 1, 1), (2, 2, 2), (2, -2, 2), (2, 2, -2), (-2, 2, 2)]
+MODE_AB = [1.0, -1.0]
+
+
+def snapshot_config0b():
+    """N=4096: 16^3 simple-cubic lattice + U(-0.1,0.1) noise, lamellae of period 4a along z."""
+    rng = np.random.default_rng(2024)
+    n = 16
+    ix, iy, iz = np.meshgrid(np.arange(n), np.arange(n), np.arange(n), indexing="ij")
+    pos = np.stack([ix, iy, iz], axis=-1).reshape(-1, 3).astype(np.float64) + 0.5 - n / 2
+    pos += rng.uniform(-0.1, 0.1, size=pos.shape)
+    types = (iz.reshape(-1) % 4 >= 2).astype(np.int32)  # A (0) if iz mod 4 < 2 else B (1)
+    return pos, types, float(n)
+
+
+def snapshot_random(N, L, seed=12345, modulated=False, dtype=np.float32):
+    """config 2 style: uniform random positions, types = index parity; optional lamellar modulation
+    z <- z + 1.5 sign(a) sin(2 pi 3 z / L) so that |s_1| = O(0.1)."""
+    rng = np.random.default_rng(seed)
+    pos = rng.random((N, 3)) * L - L / 2
+    types = (np.arange(N) % 2).astype(np.int32)
+    if modulated:
+        a = np.where(types == 0, 1.0, -1.0)
+        pos[:, 2] = pos[:, 2] + 1.5 * a * np.sin(2 * np.pi * 3 * pos[:, 2] / L)
+    pos = pos.astype(dtype)  # the snapshot IS the rounded array; the oracle sees the same values
+    return pos, types
+
+
+def pack_postype(pos, types, dtype):
+    """HOOMD Scalar4 postype as a numpy array: float32 (N,4) with the int32 type bit-cast into w,
+    or float64 (N,4) with the type in the LOW 32 bits of w."""
+    N = pos.shape[0]
+    if dtype == np.float32:
+        out = np.empty((N, 4), dtype=np.float32)
+        out[:, :3] = pos
+        out[:, 3] = np.asarray(types, dtype=np.int32).view(np.float32)
+    else:
+        out = np.empty((N, 4), dtype=np.float64)
+        out[:, :3] = pos
+        w = np.zeros(N, dtype=np.int64)
+        w[:] = np.asarray(types, dtype=np.int64) & 0xFFFFFFFF
+        out[:, 3] = w.view(np.float64)
+    return out
+
+
+def oracle_postype(pos, types):
+    out = np.empty((pos.shape[0], 4), dtype=np.float64)
+    out[:, :3] = pos.astype(np.float64)
+    out[:, 3] = types
+    return out
+
+
+def flat_lattice(vectors):
+    return (C.c_int * (3 * len(vectors)))(*[int(x) for v in vectors for x in v])
+
+
+def dbl_array(values):
+    return (C.c_double * len(values))(*[float(v) for v in values])
+
+
+def uint_array(values):
+    return (C.c_uint * len(values))(*[int(v) for v in values])
