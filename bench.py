@@ -47,6 +47,8 @@ def parse():
     ap.add_argument("--stride", type=int, default=1, help="hill deposition stride (headline: 1)")
     ap.add_argument("--particles", type=int, default=N_PER_GPU, help="particles per GPU")
     ap.add_argument("--fast-trig", type=int, default=int(os.environ.get("MTD_FAST_TRIG", "1")))
+    ap.add_argument("--path", choices=["fused", "generic"], default="fused",
+                    help="fused: two launches per step (headline); generic: separate C-ABI calls per stage")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=4)
     return ap.parse_args()
@@ -55,9 +57,10 @@ def parse():
 class Engine:
     """The hot path through the C-ABI, device resident."""
 
-    def __init__(self, n_local, n_global, rank, seed, stride, fast_trig, dist=None):
+    def __init__(self, n_local, n_global, rank, seed, stride, fast_trig, dist=None, path="fused"):
         self.lib = lib = _abi.load()
         self.dist = dist
+        self.fused = path == "fused"
         self.N, self.N_global = n_local, n_global
         L = BOX_L * (n_global / N_PER_GPU) ** (1.0 / 3.0)  # constant density (config 4: L = 200 at 8e6)
         pos, types = util.snapshot_random(n_global, L, seed=seed, dtype=np.float32) if dist is None else \
@@ -88,30 +91,46 @@ class Engine:
         sl = slice(rank * n_local, (rank + 1) * n_local)
         return pos[sl].copy(), types[sl].copy()
 
+    def _register_sources(self):
+        lib = self.lib
+        for c in range(2):
+            if self.dist is None:
+                _abi.check(lib.mtd_metad_set_cv_source(self.h, c, self.scratch.data_ptr(), self.n_part.value, 2, c,
+                                                       1.0 / self.N_global, 0.0))
+            else:
+                _abi.check(lib.mtd_metad_set_cv_source(self.h, c, self.cv_sum.data_ptr(), 1, 2, c,
+                                                       1.0 / self.N_global, 0.0))
+
     def step(self):
         lib, lset, box = self.lib, self.lset, self.box
-        _abi.check(lib.mtd_lamellar_cv_partials(C.byref(lset), self.N, self.d_pos.data_ptr(), _abi.MTD_F32,
-                                                C.byref(box), self.scratch.data_ptr(), C.byref(self.n_part), None))
-        if self.dist is None:
-            if self.t == 0:
-                for c in range(2):
-                    _abi.check(lib.mtd_metad_set_cv_source(self.h, c, self.scratch.data_ptr(), self.n_part.value, 2, c,
-                                                           1.0 / self.N_global, 0.0))
+        # launch A: per-CV partial sums over the particles (+ the deferred grid pass of the previous deposit)
+        if self.fused:
+            _abi.check(lib.mtd_fused_cv_pass(self.h, C.byref(lset), self.N, self.d_pos.data_ptr(), _abi.MTD_F32,
+                                             C.byref(box), self.scratch.data_ptr(), C.byref(self.n_part), None))
         else:
+            _abi.check(lib.mtd_lamellar_cv_partials(C.byref(lset), self.N, self.d_pos.data_ptr(), _abi.MTD_F32,
+                                                    C.byref(box), self.scratch.data_ptr(), C.byref(self.n_part), None))
+        if self.dist is not None:
             # local partial sums -> 2 doubles -> RCCL all-reduce -> the grid engine reads the reduced sums
             _abi.check(lib.mtd_reduce_partials(self.scratch.data_ptr(), self.n_part.value, 2, 2, 1.0, 0.0,
                                                self.cv_sum.data_ptr(), None))
             self.dist.all_reduce(self.cv_sum)
-            if self.t == 0:
-                for c in range(2):
-                    _abi.check(lib.mtd_metad_set_cv_source(self.h, c, self.cv_sum.data_ptr(), 1, 2, c,
-                                                           1.0 / self.N_global, 0.0))
-        _abi.check(lib.mtd_metad_update_bias(self.h, self.t, None))
+        if self.t == 0:
+            self._register_sources()
         if self.ev is not None:
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            a.record()
-        _abi.check(lib.mtd_lamellar_forces(C.byref(lset), self.N, self.d_pos.data_ptr(), self.fptr, _abi.MTD_F32,
-                                           self.N_global, self.d_bias, C.byref(box), None))
+        # launch B: bias-grid update + bias forces
+        if self.fused:
+            if self.ev is not None:
+                a.record()
+            _abi.check(lib.mtd_fused_force_pass(self.h, C.byref(lset), self.N, self.d_pos.data_ptr(), self.fptr,
+                                                _abi.MTD_F32, self.N_global, C.byref(box), self.t, None))
+        else:
+            _abi.check(lib.mtd_metad_update_bias(self.h, self.t, None))
+            if self.ev is not None:
+                a.record()
+            _abi.check(lib.mtd_lamellar_forces(C.byref(lset), self.N, self.d_pos.data_ptr(), self.fptr, _abi.MTD_F32,
+                                               self.N_global, self.d_bias, C.byref(box), None))
         if self.ev is not None:
             b.record()
             self.ev.append((a, b))
@@ -163,7 +182,7 @@ def main():
     n_local = args.particles
     n_global = n_local * world
     eng = Engine(n_local, n_global, rank, seed=12345 if world == 1 else 12346, stride=args.stride,
-                 fast_trig=args.fast_trig, dist=dist)
+                 fast_trig=args.fast_trig, dist=dist, path=args.path)
 
     for _ in range(args.warmup):
         eng.step()
@@ -199,7 +218,12 @@ def main():
     if rank == 0:
         steps_per_s = args.steps / elapsed
         value = steps_per_s * n_global * 2
-        force_bytes = n_local * (16 + 2 * 16)  # read Scalar4 positions, write one Scalar4 force per CV
+        # dominant kernel's algorithmic bytes per launch: read Scalar4 positions + write one Scalar4
+        # force per CV (48 B/particle); the fused kernel also carries the first grid pass of the deposit
+        # (per cell: 8 B dV written, 8+8 B reweighted r/w, 4 B hist_delta read)
+        force_bytes = n_local * (16 + 2 * 16)
+        if args.path == "fused" and args.stride == 1:
+            force_bytes += 256 * 256 * 28
         achieved = force_bytes / (force_us_mean * 1e-6) / 1e9
         out = {
             "metric": "particle_cv_evals_per_s",
@@ -218,8 +242,8 @@ def main():
             "config": {"workload": "1xMI355X: 10^6 particles, 2 lamellar CVs (8 Fourier modes each), 256^2 bias grid, well-tempered"
                        if world == 1 else "%dxMI355X: %d particles sharded, 2 lamellar CVs, RCCL all-reduce of CV sums, replicated 256^2 grid" % (world, n_global),
                        "particles_per_gpu": n_local, "n_cv": 2, "modes_per_cv": 8, "grid": "256x256",
-                       "stride": args.stride, "fast_trig": int(args.fast_trig)},
-            "roofline": {"bound": "hbm", "kernel": "k_lamellar_forces", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                       "stride": args.stride, "fast_trig": int(args.fast_trig), "path": args.path},
+            "roofline": {"bound": "hbm", "kernel": "k_fused_force" if args.path == "fused" else "k_lamellar_forces", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "algorithmic_bytes_per_launch": force_bytes, "avg_launch_us": force_us_mean,
                          "median_launch_us": force_us},

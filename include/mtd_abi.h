@@ -203,6 +203,29 @@ int mtd_metad_set_num_gaussians(mtd_metad *m, unsigned int n, mtd_stream_t strea
 void *mtd_metad_device_array(mtd_metad *m, int which);
 
 /* ================================================================================================
+ * Fused bias step for lamellar CVs — the headline path (no reference counterpart: it replaces the
+ * whole of IntegratorMetaDynamics::updateBiasPotential + the CVs' computeCV / computeBiasForces,
+ * IntegratorMetaDynamics.cc:314-588, LamellarOrderParameterGPU.cc:34-132, by TWO launches)
+ * ============================================================================================== */
+
+/* Launch A: per-CV partial sums over the particles (as mtd_lamellar_cv_partials) and, in the same
+ * launch, the deferred second reweighting pass + accumulate of the previous deposit if one is pending.
+ * Between the two passes the caller registers the sums as CV sources (mtd_metad_set_cv_source, once)
+ * or, multi-GPU, reduces them (mtd_reduce_partials), all-reduces over RCCL and registers the result. */
+int mtd_fused_cv_pass(mtd_metad *m, const mtd_lamellar_set *set, unsigned int n_particles, const void *d_postype,
+                      int dtype, const mtd_box *global_box, double *d_partials, unsigned int *n_partials,
+                      mtd_stream_t stream);
+
+/* Launch B: updateBiasPotential(timestep) for the CV values defined by the registered sources
+ * (histogram; on deposit steps sigma grid, well-tempered scale, Gaussian increment, first reweighting
+ * pass; dV/ds_c, V(s)) and, in the same launch, the bias forces of every CV of the set
+ * (CV c of the set must be CV c of the grid).  The second reweighting pass + accumulate stay pending
+ * until the next mtd_fused_cv_pass or any call that reads the grid (get_state / get_array flush it). */
+int mtd_fused_force_pass(mtd_metad *m, const mtd_lamellar_set *set, unsigned int n_particles, const void *d_postype,
+                         void *const *d_force, int dtype, unsigned int n_global, const mtd_box *global_box,
+                         unsigned int timestep, mtd_stream_t stream);
+
+/* ================================================================================================
  * WellTemperedEnsemble (potential energy as CV)
  * replaces WellTemperedEnsemble.cuh:3-19 (gpu_scale_netforce, gpu_reduce_potential_energy)
  * ============================================================================================== */

@@ -1,0 +1,454 @@
+// fused.hip — the whole metadynamics bias step for lamellar CVs in TWO launches (headline path).
+//
+// Reference step being replaced (IntegratorMetaDynamics.cc:219-312, 314-588 with LamellarOrderParameterGPU):
+//   CV kernel x n_wave x n_cv + final reduce + D2H + host sum  ->  host grid passes (+H2D/D2H of the
+//   grid arrays around gpu_update_grid)  ->  host bias scalar  ->  force kernel per CV.
+//
+// On MI355X a tiny dependent kernel costs 4-7 us of pure latency (measured: profiles/), more than
+// streaming the whole 16 MB position array.  So the step is cut only where a true grid-wide
+// dependency sits, and everything small is recomputed redundantly per block instead of being
+// handed between blocks (no atomics, no in-launch flags, every cross-block hand-off is a kernel
+// boundary):
+//
+//   launch A  k_fused_cv     [apply blocks]  second reweighting pass + accumulate of the PREVIOUS deposit
+//                            [CV blocks]     per-CV partial sums over the particles (one pass, all CVs)
+//   (multi-GPU: reduce + RCCL all-reduce of n_cv doubles here)
+//   launch B  k_fused_force  every block: CV values from the partial sums, V_old(s), well-tempered
+//                                         scale, post-deposit node values in closed form on the
+//                                         finite-difference stencil -> dV/ds_c           (redundant)
+//                            [grid blocks]   Gaussian increment per cell, histogram / sigma-grid bin,
+//                                            R += hist_delta, block sums of R*dV and R   (first pass)
+//                            [force blocks]  forces of every CV for every particle (one pass)
+//
+// The second reweighting pass needs <dV> = sum(R dV)/sum(R) over the whole grid, i.e. a grid-wide
+// dependency on the first pass: it is deferred into the next launch A (or mtd_metad_get_state /
+// get_array, which flush it), so the grid arrays are "one apply behind" between B and the next A.
+// Forces never wait for it: dV/ds_c only needs grid_old + dV on <= (2 n_cv + 1) 2^n_cv cells.
+#include "lamellar_host.hpp"
+#include "metad_host.hpp"
+
+#include <cstdlib>
+
+// Diagnostic build only (-DMTD_STAMPS, tools/stamps.sh): s_memrealtime (100 MHz) stamps of one grid block and
+// one particle block per kernel, written to a buffer of their own; the product build has no stamps.
+#ifdef MTD_STAMPS
+__device__ unsigned long long g_stamps[64];
+#define MTD_STAMP(slot, cond)                                                   \
+    do                                                                          \
+        {                                                                       \
+        if (cond) g_stamps[slot] = wall_clock64();                              \
+        } while (0)
+extern "C" int mtd_debug_read_stamps(unsigned long long *host)
+    {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 64);
+    }
+#else
+#define MTD_STAMP(slot, cond) do { } while (0)
+#endif
+
+namespace
+{
+
+using namespace mtd;
+
+constexpr int FCV_THREADS = 512;
+constexpr int FCV_UNROLL = 4;
+constexpr int FF_THREADS = 256;
+constexpr int FF_UNROLL = 2;
+
+template<typename S4, int NCV, bool FAST>
+__global__ __launch_bounds__(FCV_THREADS) void k_fused_cv(const LamKArgs a, const S4 *__restrict__ postype, const unsigned int N,
+                                                          double *__restrict__ partials, const MetadCfg c,
+                                                          const unsigned int n_apply_blocks)
+    {
+    __shared__ float s_coeff[MTD_MAX_CV * MTD_MAX_TYPES];
+    __shared__ double s_wave[(FCV_THREADS / MTD_WAVE) * NCV];
+    __shared__ double s_red[16];
+    __shared__ ModeTables s_mt;
+
+    MTD_STAMP(0, blockIdx.x == 0 && threadIdx.x == 0);
+    MTD_STAMP(3, blockIdx.x == n_apply_blocks && threadIdx.x == 0);
+    if (blockIdx.x < n_apply_blocks)
+        {
+        const unsigned int b0 = blockIdx.x * FCV_THREADS;
+        apply_cells(c, b0, min(c.len, b0 + FCV_THREADS), blockIdx.x == 0, s_red);
+        MTD_STAMP(1, blockIdx.x == 0 && threadIdx.x == 0);
+        return;
+        }
+    const unsigned int block_id = blockIdx.x - n_apply_blocks;
+    const unsigned int n_blocks = gridDim.x - n_apply_blocks;
+
+    load_coeff(a, s_coeff);
+    load_modes(a, s_mt, false);
+    __syncthreads();
+    MTD_STAMP(4, block_id == 0 && threadIdx.x == 0);
+    float acc[NCV];
+#pragma unroll
+    for (int i = 0; i < NCV; ++i) acc[i] = 0.0f;
+    lam_cv_accumulate<S4, NCV, FAST, FCV_UNROLL>(a, postype, N, block_id * FCV_THREADS + threadIdx.x, n_blocks * FCV_THREADS,
+                                                 s_coeff, s_mt, acc);
+    MTD_STAMP(5, block_id == 0 && threadIdx.x == 0);
+    lam_cv_block_reduce<NCV>(acc, s_wave, partials, block_id);
+    MTD_STAMP(6, block_id == 0 && threadIdx.x == 0);
+    }
+
+// Fast form (n_cv <= 3): wave 0 of every block runs the scalar chain with shuffles only while waves 1-3
+// already stream their particles and form the unscaled forces; one __syncthreads joins them.
+constexpr int FF_STREAM_WAVES = FF_THREADS / MTD_WAVE - 1;
+constexpr int FF_STREAM_THREADS = FF_STREAM_WAVES * MTD_WAVE;
+constexpr int FF_U = 4;        // particles per register group
+// register groups per streaming thread: 2 (= 8 particles, every block of a 10^6-particle launch resident at
+// once) where that fits 128 VGPRs without spilling (fp32 particle data, <= 2 CVs), else 1
+template<typename S4, int NCV> struct ff_groups { static constexpr int value = 1; };
+template<> struct ff_groups<float4, 1> { static constexpr int value = 2; };
+template<> struct ff_groups<float4, 2> { static constexpr int value = 2; };
+
+template<typename S4, int NCV, bool FAST, int GROUPS>
+__global__ __launch_bounds__(FF_THREADS, 4) void k_fused_force(const LamKArgs a, const S4 *__restrict__ postype, const ForcePtrs out,
+                                                            const unsigned int N, const double two_over_n, const MetadCfg c,
+                                                            const int deposit, const unsigned int n_grid_blocks)
+    {
+    __shared__ ChainResult s_chain;
+    __shared__ float s_wcoef[MTD_MAX_CV * MTD_MAX_TYPES];
+    __shared__ double s_red[16];
+    __shared__ ModeTables s_mt;
+
+    const int wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    const bool grid_block = blockIdx.x < n_grid_blocks;
+    const unsigned int block_id = blockIdx.x - n_grid_blocks;
+    const unsigned int n_blocks = gridDim.x - n_grid_blocks;
+    const unsigned int stride = n_blocks * FF_STREAM_THREADS;
+    const unsigned int first = block_id * FF_STREAM_THREADS + (wave - 1) * MTD_WAVE + lane;
+    const unsigned int first1 = first + FF_U * stride;
+
+    ForceRegs<NCV, FF_U> R, R1;
+    MTD_STAMP(16, blockIdx.x == 0 && threadIdx.x == 0);
+    MTD_STAMP(24, blockIdx.x == n_grid_blocks && threadIdx.x == 0);
+    if (!grid_block)
+        {
+        load_modes(a, s_mt, true);
+        __syncthreads();
+        }
+    MTD_STAMP(25, blockIdx.x == n_grid_blocks && threadIdx.x == 0);
+    if (wave == 0)
+        {
+        const ChainResult r = chain_wave(c, deposit != 0, true);
+        MTD_STAMP(17, blockIdx.x == 0 && threadIdx.x == 0);
+        MTD_STAMP(26, blockIdx.x == n_grid_blocks && threadIdx.x == 0);
+        if (lane == 0)
+            {
+            s_chain.cv[0] = r.cv[0]; s_chain.cv[1] = r.cv[1]; s_chain.cv[2] = r.cv[2];
+            s_chain.bias[0] = r.bias[0]; s_chain.bias[1] = r.bias[1]; s_chain.bias[2] = r.bias[2];
+            s_chain.scal = r.scal; s_chain.V = r.V; s_chain.w = r.w;
+            s_chain.bin = r.bin; s_chain.on_grid = r.on_grid; s_chain.oob = r.oob;
+            }
+        if (!grid_block)
+            for (unsigned int i = lane; i < NCV * MTD_MAX_TYPES; i += MTD_WAVE)
+                {
+                const unsigned int cv = i / MTD_MAX_TYPES;
+                const double b = cv == 0 ? r.bias[0] : (cv == 1 ? r.bias[1] : r.bias[2]);
+                s_wcoef[i] = (cv < a.n_cv) ? (float)((double)a.coeff[cv][i % MTD_MAX_TYPES] * b * two_over_n) : 0.0f;
+                }
+        }
+    else if (!grid_block)
+        {
+        lam_force_unscaled<S4, NCV, FAST, FF_U>(a, postype, N, first, stride, s_mt, R);
+        if (GROUPS > 1) lam_force_unscaled<S4, NCV, FAST, FF_U>(a, postype, N, first1, stride, s_mt, R1);
+        MTD_STAMP(27, blockIdx.x == n_grid_blocks && threadIdx.x == 64);
+        }
+    __syncthreads();
+    MTD_STAMP(18, blockIdx.x == 0 && threadIdx.x == 0);
+    MTD_STAMP(28, blockIdx.x == n_grid_blocks && threadIdx.x == 64);
+
+    if (grid_block)
+        {
+        // ---- first grid pass of a deposit step: updateGrid (:1002-1047), updateHistogram (:1092-1119),
+        //      updateSigmaGrid (:1122-1155), first loop of updateReweightedEstimator (:1070-1075)
+        const unsigned int g = blockIdx.x * FF_THREADS + threadIdx.x;
+        double s1 = 0.0, s2 = 0.0;
+        if (g < c.len)
+            {
+            const double dV = (c.W * s_chain.scal) * exp(-gauss_exponent3(c, g, s_chain.cv[0], s_chain.cv[1], s_chain.cv[2]));
+            c.grid_delta[g] = dV;
+            unsigned int hd = c.hist_delta[g];
+            if (s_chain.on_grid && g == s_chain.bin)
+                {
+                hd += 1;
+                c.hist_delta[g] = hd;
+                c.sigma_grid_delta[g] += c.det_sigma;
+                c.hist_gauss_delta[g] += 1;
+                }
+            const double Rw = c.rew[g] + (double)hd;
+            c.rew[g] = Rw;
+            s1 = Rw * dV;
+            s2 = Rw;
+            }
+        MTD_STAMP(19, blockIdx.x == 0 && threadIdx.x == 0);
+        s1 = wave_sum(s1);
+        s2 = wave_sum(s2);
+        if (lane == 0)
+            {
+            s_red[2 * wave] = s1;
+            s_red[2 * wave + 1] = s2;
+            }
+        __syncthreads();
+        if (threadIdx.x == 0)
+            {
+            double t1 = 0.0, t2 = 0.0;
+            for (int w = 0; w < FF_THREADS / MTD_WAVE; ++w)
+                {
+                t1 += s_red[2 * w];
+                t2 += s_red[2 * w + 1];
+                }
+            c.gpart[2 * blockIdx.x] = t1;
+            c.gpart[2 * blockIdx.x + 1] = t2;
+            }
+        MTD_STAMP(20, blockIdx.x == 0 && threadIdx.x == 0);
+        }
+    else if (wave != 0)
+        {
+        lam_force_store<S4, NCV, FF_U>(a, out, first, stride, s_wcoef, R);
+        if (GROUPS > 1) lam_force_store<S4, NCV, FF_U>(a, out, first1, stride, s_wcoef, R1);
+        MTD_STAMP(29, blockIdx.x == n_grid_blocks && threadIdx.x == 64);
+        }
+
+    // one block publishes the step's scalars for the host (lazy read-back) and, on non-deposit steps,
+    // owns the histogram increment (:366) and the weight read-out (the weight grid is final then)
+    if (blockIdx.x == 0 && wave == 0)
+        {
+        double w_now = 1.0;
+        if (!deposit) w_now = chain_wave(c, false, false).w;     // w(s) from the (final) weight grid
+        if (lane < (int)c.n_cv)
+            {
+            c.st->cv[lane] = lane == 0 ? s_chain.cv[0] : (lane == 1 ? s_chain.cv[1] : s_chain.cv[2]);
+            c.st->bias[lane] = lane == 0 ? s_chain.bias[0] : (lane == 1 ? s_chain.bias[1] : s_chain.bias[2]);
+            }
+        if (lane == 0)
+            {
+            c.st->V = s_chain.V;
+            c.st->bin = s_chain.bin;
+            c.st->on_grid = (unsigned int)s_chain.on_grid;
+            if (deposit)
+                c.st->scal = s_chain.scal;
+            else
+                {
+                c.st->w = w_now;
+                if (s_chain.on_grid) c.hist_delta[s_chain.bin] += 1;
+                }
+            if (s_chain.oob) c.st->n_oob += (deposit && c.mode == MTD_MODE_WELL_TEMPERED) ? 2 : 1;
+            }
+        }
+    }
+
+// General form (any n_cv the grid engine supports): block-cooperative prologue, then the force pass.
+template<typename S4, bool FAST>
+__global__ __launch_bounds__(FF_THREADS) void k_fused_force_general(const LamKArgs a, const S4 *__restrict__ postype, const ForcePtrs out,
+                                                            const unsigned int N, const double two_over_n, const MetadCfg c,
+                                                            const int deposit, const unsigned int n_grid_blocks)
+    {
+    __shared__ EvalShared sh;
+    __shared__ float s_wcoef[MTD_MAX_CV * MTD_MAX_TYPES];
+    __shared__ double s_red[16];
+    __shared__ ModeTables s_mt;
+
+    load_modes(a, s_mt, true);
+    reduce_cv_sources(c, sh.cv, s_red);             // replaces getCurrentValue's D2H + host sum (.cc:323-327)
+    __syncthreads();
+    evaluate_bias(c, sh, deposit != 0, true);
+
+    if (blockIdx.x < n_grid_blocks)
+        {
+        // ---- first grid pass of a deposit step: updateGrid (:1002-1047), updateHistogram (:1092-1119),
+        //      updateSigmaGrid (:1122-1155), first loop of updateReweightedEstimator (:1070-1075)
+        const unsigned int g = blockIdx.x * FF_THREADS + threadIdx.x;
+        double s1 = 0.0, s2 = 0.0;
+        if (g < c.len)
+            {
+            const double dV = (c.W * sh.scal) * exp(-gauss_exponent(c, g, sh.cv));
+            c.grid_delta[g] = dV;
+            unsigned int hd = c.hist_delta[g];
+            if (sh.on_grid && g == sh.bin)
+                {
+                hd += 1;
+                c.hist_delta[g] = hd;
+                c.sigma_grid_delta[g] += c.det_sigma;
+                c.hist_gauss_delta[g] += 1;
+                }
+            const double R = c.rew[g] + (double)hd;
+            c.rew[g] = R;
+            s1 = R * dV;
+            s2 = R;
+            }
+        s1 = block_sum(s1, s_red);
+        s2 = block_sum(s2, s_red);
+        if (threadIdx.x == 0)
+            {
+            c.gpart[2 * blockIdx.x] = s1;
+            c.gpart[2 * blockIdx.x + 1] = s2;
+            }
+        }
+
+    // one block publishes the step's scalars for the host (lazy read-back) and, on non-deposit steps,
+    // owns the histogram increment (:366)
+    if (blockIdx.x == 0)
+        {
+        if (threadIdx.x < c.n_cv)
+            {
+            c.st->cv[threadIdx.x] = sh.cv[threadIdx.x];
+            c.st->bias[threadIdx.x] = sh.bias[threadIdx.x];
+            }
+        if (threadIdx.x == 0)
+            {
+            c.st->V = sh.res[0];
+            c.st->bin = sh.bin;
+            c.st->on_grid = (unsigned int)sh.on_grid;
+            if (deposit)
+                c.st->scal = sh.scal;
+            else
+                {
+                c.st->w = sh.res[1];
+                if (sh.on_grid) c.hist_delta[sh.bin] += 1;
+                }
+            if (sh.oob[0]) c.st->n_oob += (deposit && c.mode == MTD_MODE_WELL_TEMPERED) ? 2 : 1;
+            }
+        }
+    if (blockIdx.x < n_grid_blocks) return;
+
+    // ---- force blocks
+    const unsigned int block_id = blockIdx.x - n_grid_blocks;
+    const unsigned int n_blocks = gridDim.x - n_grid_blocks;
+    for (unsigned int i = threadIdx.x; i < MTD_MAX_CV * MTD_MAX_TYPES; i += blockDim.x)
+        {
+        const unsigned int cv = i / MTD_MAX_TYPES;
+        const double b = cv < a.n_cv ? sh.bias[cv] : 0.0;
+        s_wcoef[i] = (float)((double)a.coeff[cv][i % MTD_MAX_TYPES] * b * two_over_n);
+        }
+    __syncthreads();
+    lam_force_pass<S4, FAST, FF_UNROLL>(a, postype, out, N, block_id * FF_THREADS + threadIdx.x, n_blocks * FF_THREADS, s_wcoef, s_mt);
+    }
+
+template<typename S4, bool FAST>
+int launch_fused_cv(const LamKArgs &k, unsigned int N, const void *d_postype, double *d_partials, unsigned int cv_blocks,
+                    const MetadCfg &cfg, unsigned int n_apply, hipStream_t s)
+    {
+    const S4 *p = (const S4 *)d_postype;
+    const unsigned int grid = cv_blocks + n_apply;
+    switch (k.n_cv)
+        {
+        case 1: k_fused_cv<S4, 1, FAST><<<grid, FCV_THREADS, 0, s>>>(k, p, N, d_partials, cfg, n_apply); break;
+        case 2: k_fused_cv<S4, 2, FAST><<<grid, FCV_THREADS, 0, s>>>(k, p, N, d_partials, cfg, n_apply); break;
+        case 3: k_fused_cv<S4, 3, FAST><<<grid, FCV_THREADS, 0, s>>>(k, p, N, d_partials, cfg, n_apply); break;
+        case 4: k_fused_cv<S4, 4, FAST><<<grid, FCV_THREADS, 0, s>>>(k, p, N, d_partials, cfg, n_apply); break;
+        case 5: k_fused_cv<S4, 5, FAST><<<grid, FCV_THREADS, 0, s>>>(k, p, N, d_partials, cfg, n_apply); break;
+        case 6: k_fused_cv<S4, 6, FAST><<<grid, FCV_THREADS, 0, s>>>(k, p, N, d_partials, cfg, n_apply); break;
+        default: return MTD_ERR_UNSUPPORTED;
+        }
+    MTD_LAUNCH_CHECK();
+    return MTD_SUCCESS;
+    }
+
+} // namespace
+
+extern "C" {
+
+int mtd_fused_cv_pass(mtd_metad *m, const mtd_lamellar_set *set, unsigned int n_particles, const void *d_postype,
+                      int dtype, const mtd_box *global_box, double *d_partials, unsigned int *n_partials,
+                      mtd_stream_t stream)
+    {
+    if (!m) return MTD_ERR_INVALID_ARGUMENT;
+    LamKArgs k;
+    int rc = fill_kargs(k, set, global_box);
+    if (rc) return rc;
+    if (!d_partials || !n_partials || (n_particles && !d_postype)) return MTD_ERR_INVALID_ARGUMENT;
+    if (dtype != MTD_F32 && dtype != MTD_F64) return MTD_ERR_INVALID_ARGUMENT;
+    if (set->n_cv > (unsigned int)MAXCV) return MTD_ERR_UNSUPPORTED;
+    hipStream_t s = (hipStream_t)stream;
+    const unsigned int blocks = lam_cv_blocks(n_particles);
+    *n_partials = blocks;
+    const unsigned int n_apply = m->pending_apply ? (m->cfg.len + FCV_THREADS - 1) / FCV_THREADS : 0;
+    const bool fast = lam_fast_trig() != 0;
+    if (dtype == MTD_F32)
+        rc = fast ? launch_fused_cv<float4, true>(k, n_particles, d_postype, d_partials, blocks, m->cfg, n_apply, s)
+                  : launch_fused_cv<float4, false>(k, n_particles, d_postype, d_partials, blocks, m->cfg, n_apply, s);
+    else
+        rc = fast ? launch_fused_cv<double4, true>(k, n_particles, d_postype, d_partials, blocks, m->cfg, n_apply, s)
+                  : launch_fused_cv<double4, false>(k, n_particles, d_postype, d_partials, blocks, m->cfg, n_apply, s);
+    if (rc) return rc;
+    m->pending_apply = 0;
+    return MTD_SUCCESS;
+    }
+
+int mtd_fused_force_pass(mtd_metad *m, const mtd_lamellar_set *set, unsigned int n_particles, const void *d_postype,
+                         void *const *d_force, int dtype, unsigned int n_global, const mtd_box *global_box,
+                         unsigned int timestep, mtd_stream_t stream)
+    {
+    if (!m) return MTD_ERR_INVALID_ARGUMENT;
+    LamKArgs k;
+    int rc = fill_kargs(k, set, global_box);
+    if (rc) return rc;
+    if (!d_force || n_global == 0 || (n_particles && !d_postype)) return MTD_ERR_INVALID_ARGUMENT;
+    if (dtype != MTD_F32 && dtype != MTD_F64) return MTD_ERR_INVALID_ARGUMENT;
+    if (set->n_cv != m->cfg.n_cv) return MTD_ERR_UNSUPPORTED;   // CV c of the set is CV c of the grid
+    hipStream_t s = (hipStream_t)stream;
+    rc = metad_flush(m, s);                                     // a deposit may only be pending across ONE cv pass
+    if (rc) return rc;
+    ForcePtrs out;
+    for (unsigned int c = 0; c < MTD_MAX_CV; ++c) out.f[c] = nullptr;
+    for (unsigned int c = 0; c < set->n_cv; ++c)
+        {
+        if (!d_force[c] && n_particles) return MTD_ERR_INVALID_ARGUMENT;
+        out.f[c] = d_force[c];
+        }
+    const int dep = (m->add_bias && (timestep % m->stride == 0)) ? 1 : 0;   // .cc:368
+    const unsigned int n_grid = dep ? m->cfg.n_gblocks : 0;
+    const double two_over_n = 2.0 / (double)n_global;
+    const bool fast = lam_fast_trig() != 0;
+    static const bool force_general = std::getenv("MTD_FUSED_GENERAL") != nullptr;
+    if (set->n_cv <= (unsigned int)CHAIN_MAX_CV && !force_general)
+        {
+        const unsigned int groups = (dtype == MTD_F32 && set->n_cv <= 2) ? 2 : 1;
+        unsigned int fblocks = (n_particles + FF_STREAM_THREADS * FF_U * groups - 1) / (FF_STREAM_THREADS * FF_U * groups);
+        if (fblocks == 0 && n_grid == 0) fblocks = 1;               // still one block to publish the scalars
+        const unsigned int grid = n_grid + fblocks;
+#define MTD_LAUNCH_FF(S4, NCV, FASTV) \
+        k_fused_force<S4, NCV, FASTV, ff_groups<S4, NCV>::value><<<grid, FF_THREADS, 0, s>>>(k, (const S4 *)d_postype, out, n_particles, two_over_n, m->cfg, dep, n_grid)
+#define MTD_LAUNCH_FF_NCV(S4, FASTV) \
+        switch (set->n_cv) { case 1: MTD_LAUNCH_FF(S4, 1, FASTV); break; case 2: MTD_LAUNCH_FF(S4, 2, FASTV); break; default: MTD_LAUNCH_FF(S4, 3, FASTV); break; }
+        if (dtype == MTD_F32)
+            {
+            if (fast) { MTD_LAUNCH_FF_NCV(float4, true) } else { MTD_LAUNCH_FF_NCV(float4, false) }
+            }
+        else
+            {
+            if (fast) { MTD_LAUNCH_FF_NCV(double4, true) } else { MTD_LAUNCH_FF_NCV(double4, false) }
+            }
+#undef MTD_LAUNCH_FF_NCV
+#undef MTD_LAUNCH_FF
+        }
+    else
+        {
+        unsigned int fblocks = lam_force_blocks(n_particles);
+        if (n_particles == 0) fblocks = n_grid ? 0 : 1;
+        const unsigned int grid = n_grid + fblocks;
+        if (dtype == MTD_F32)
+            {
+            if (fast)
+                k_fused_force_general<float4, true><<<grid, FF_THREADS, 0, s>>>(k, (const float4 *)d_postype, out, n_particles, two_over_n, m->cfg, dep, n_grid);
+            else
+                k_fused_force_general<float4, false><<<grid, FF_THREADS, 0, s>>>(k, (const float4 *)d_postype, out, n_particles, two_over_n, m->cfg, dep, n_grid);
+            }
+        else
+            {
+            if (fast)
+                k_fused_force_general<double4, true><<<grid, FF_THREADS, 0, s>>>(k, (const double4 *)d_postype, out, n_particles, two_over_n, m->cfg, dep, n_grid);
+            else
+                k_fused_force_general<double4, false><<<grid, FF_THREADS, 0, s>>>(k, (const double4 *)d_postype, out, n_particles, two_over_n, m->cfg, dep, n_grid);
+            }
+        }
+    MTD_LAUNCH_CHECK();
+    m->pending_apply = dep;
+    return MTD_SUCCESS;
+    }
+
+} // extern "C"

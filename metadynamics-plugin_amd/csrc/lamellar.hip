@@ -13,64 +13,25 @@
 // and per-wave sums in fp32 (<= 2^11 terms), everything across waves/blocks in fp64 with a fixed
 // order (bitwise reproducible, no atomics).  Both kernels are pure streams: 16 B/lane coalesced
 // loads, 16 B/lane coalesced stores, no LDS traffic in the inner loop beyond the coefficient lookup.
-#include "mtd_device.hpp"
+#include "lamellar_device.hpp"
 
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+
+#include "lamellar_host.hpp"
 
 namespace
 {
 
 using namespace mtd;
 
-struct LamKArgs
-    {
-    double B[3][3];                           // reciprocal rows without 2*pi
-    unsigned int n_cv, n_modes, n_types, _pad;
-    unsigned int first[MTD_MAX_CV + 1];
-    unsigned int _pad2[3];
-    float h[MTD_MAX_MODES][3];                // Miller indices
-    float q[MTD_MAX_MODES][3];                // Cartesian wave vectors (with 2*pi)
-    float coeff[MTD_MAX_CV][MTD_MAX_TYPES];
-    };
-
-struct ForcePtrs
-    {
-    void *f[MTD_MAX_CV];
-    };
-
 constexpr int CV_THREADS = 512;
 constexpr int CV_UNROLL = 4;
 constexpr int FORCE_THREADS = 256;
-constexpr unsigned int LAM_MAX_BLOCKS = 1024;
+constexpr int FORCE_UNROLL = 2;
 
 int g_fast_trig = 0;
-
-// cos / sin of 2*pi*t.  FAST: hardware v_cos_f32 / v_sin_f32 take the angle in turns (domain
-// [-256, 256]); v_fract first so the full fp32 mantissa is spent on the fractional phase.
-template<bool FAST> __device__ __forceinline__ float cos2pi(float t)
-    {
-    if (FAST)
-        return __builtin_amdgcn_cosf(__builtin_amdgcn_fractf(t));
-    else
-        return cospif(2.0f * t);
-    }
-
-template<bool FAST> __device__ __forceinline__ float sin2pi(float t)
-    {
-    if (FAST)
-        return __builtin_amdgcn_sinf(__builtin_amdgcn_fractf(t));
-    else
-        return sinpif(2.0f * t);
-    }
-
-__device__ __forceinline__ void project(const LamKArgs &a, const Particle &p, float &g0, float &g1, float &g2)
-    {
-    g0 = (float)(a.B[0][0] * p.x + a.B[0][1] * p.y + a.B[0][2] * p.z);
-    g1 = (float)(a.B[1][0] * p.x + a.B[1][1] * p.y + a.B[1][2] * p.z);
-    g2 = (float)(a.B[2][0] * p.x + a.B[2][1] * p.y + a.B[2][2] * p.z);
-    }
 
 // ---------------------------------------------------------------------------------------------
 // Hot path: per-CV sums  partials[b][c] = sum_{j in block b} a_c(type_j) sum_k cos(q_k . r_j)
@@ -80,68 +41,17 @@ __global__ __launch_bounds__(CV_THREADS) void k_lamellar_cv_partials(const LamKA
                                                                      const unsigned int N, double *__restrict__ partials)
     {
     __shared__ float s_coeff[MTD_MAX_CV * MTD_MAX_TYPES];
-    __shared__ double s_wave[CV_THREADS / MTD_WAVE][NCV];
-
-    for (unsigned int i = threadIdx.x; i < MTD_MAX_CV * MTD_MAX_TYPES; i += blockDim.x)
-        s_coeff[i] = a.coeff[i / MTD_MAX_TYPES][i % MTD_MAX_TYPES];
+    __shared__ double s_wave[(CV_THREADS / MTD_WAVE) * NCV];
+    __shared__ ModeTables s_mt;
+    load_coeff(a, s_coeff);
+    load_modes(a, s_mt, false);
     __syncthreads();
-
     float acc[NCV];
 #pragma unroll
     for (int c = 0; c < NCV; ++c) acc[c] = 0.0f;
-
-    const unsigned int stride = gridDim.x * blockDim.x;
-    for (unsigned int base = blockIdx.x * blockDim.x + threadIdx.x; base < N; base += CV_UNROLL * stride)
-        {
-        Particle p[CV_UNROLL];
-        bool ok[CV_UNROLL];
-#pragma unroll
-        for (int u = 0; u < CV_UNROLL; ++u)
-            {
-            const unsigned int i = base + u * stride;
-            ok[u] = i < N;
-            p[u] = scalar4_traits<S4>::load(postype, ok[u] ? i : base);
-            }
-#pragma unroll
-        for (int u = 0; u < CV_UNROLL; ++u)
-            {
-            float g0, g1, g2;
-            project(a, p[u], g0, g1, g2);
-#pragma unroll
-            for (int c = 0; c < NCV; ++c)
-                {
-                if (c < (int)a.n_cv)
-                    {
-                    float sum = 0.0f;
-                    const unsigned int k1 = a.first[c + 1];
-#pragma unroll 4
-                    for (unsigned int k = a.first[c]; k < k1; ++k)
-                        {
-                        const float t = a.h[k][0] * g0 + a.h[k][1] * g1 + a.h[k][2] * g2;
-                        sum += cos2pi<FAST>(t);
-                        }
-                    const float w = ok[u] ? s_coeff[c * MTD_MAX_TYPES + p[u].type] : 0.0f;
-                    acc[c] += w * sum;
-                    }
-                }
-            }
-        }
-
-    const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
-#pragma unroll
-    for (int c = 0; c < NCV; ++c)
-        {
-        const float v = wave_sum(acc[c]);
-        if (lane == 0) s_wave[wave][c] = (double)v;
-        }
-    __syncthreads();
-    if (threadIdx.x < NCV)
-        {
-        double r = 0.0;
-        for (int w = 0; w < CV_THREADS / MTD_WAVE; ++w) r += s_wave[w][threadIdx.x];
-        partials[blockIdx.x * NCV + threadIdx.x] = r;
-        }
+    lam_cv_accumulate<S4, NCV, FAST, CV_UNROLL>(a, postype, N, blockIdx.x * blockDim.x + threadIdx.x,
+                                                gridDim.x * blockDim.x, s_coeff, s_mt, acc);
+    lam_cv_block_reduce<NCV>(acc, s_wave, partials, blockIdx.x);
     }
 
 // ---------------------------------------------------------------------------------------------
@@ -179,7 +89,8 @@ __global__ __launch_bounds__(CV_THREADS) void k_lamellar_mode_partials(const Lam
                 const unsigned int k = k0 + m;
                 if (k < a.n_modes)
                     {
-                    const float t = a.h[k][0] * g0 + a.h[k][1] * g1 + a.h[k][2] * g2;
+                    const float4 h = a.h[k];
+                    const float t = h.x * g0 + h.y * g1 + h.z * g2;
                     re[m] += w * cos2pi<FAST>(t);
                     im[m] += w * sin2pi<FAST>(t);
                     }
@@ -236,77 +147,25 @@ __global__ __launch_bounds__(FORCE_THREADS) void k_lamellar_forces(const LamKArg
                                                                    const double *__restrict__ d_bias, const double bias_host,
                                                                    const double two_over_n)
     {
-    typedef typename scalar4_traits<S4>::scalar scalar;
-    __shared__ float s_coeff[MTD_MAX_CV * MTD_MAX_TYPES];
-
+    __shared__ float s_wcoef[MTD_MAX_CV * MTD_MAX_TYPES];
+    __shared__ ModeTables s_mt;
+    load_modes(a, s_mt, true);
     // fold bias_c * 2 / N_global into the per-type coefficient once per block
     for (unsigned int i = threadIdx.x; i < MTD_MAX_CV * MTD_MAX_TYPES; i += blockDim.x)
         {
         const unsigned int c = i / MTD_MAX_TYPES;
         double b = 0.0;
         if (c < a.n_cv) b = d_bias ? d_bias[c] : bias_host;
-        s_coeff[i] = (float)((double)a.coeff[c][i % MTD_MAX_TYPES] * b * two_over_n);
+        s_wcoef[i] = (float)((double)a.coeff[c][i % MTD_MAX_TYPES] * b * two_over_n);
         }
     __syncthreads();
-
-    const unsigned int stride = gridDim.x * blockDim.x;
-    for (unsigned int i = blockIdx.x * blockDim.x + threadIdx.x; i < N; i += stride)
-        {
-        const Particle p = scalar4_traits<S4>::load(postype, i);
-        float g0, g1, g2;
-        project(a, p, g0, g1, g2);
-        for (unsigned int c = 0; c < a.n_cv; ++c)
-            {
-            float fx = 0.0f, fy = 0.0f, fz = 0.0f;
-            const unsigned int k1 = a.first[c + 1];
-#pragma unroll 4
-            for (unsigned int k = a.first[c]; k < k1; ++k)
-                {
-                const float t = a.h[k][0] * g0 + a.h[k][1] * g1 + a.h[k][2] * g2;
-                const float s = sin2pi<FAST>(t);
-                fx += a.q[k][0] * s;
-                fy += a.q[k][1] * s;
-                fz += a.q[k][2] * s;
-                }
-            const float w = s_coeff[c * MTD_MAX_TYPES + p.type];
-            S4 *f = (S4 *)out.f[c];
-            f[i] = scalar4_traits<S4>::make((scalar)(fx * w), (scalar)(fy * w), (scalar)(fz * w), (scalar)0);
-            }
-        }
+    lam_force_pass<S4, FAST, FORCE_UNROLL>(a, postype, out, N, blockIdx.x * blockDim.x + threadIdx.x,
+                                           gridDim.x * blockDim.x, s_wcoef, s_mt);
     }
 
 // ---------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------
-
-int fill_kargs(LamKArgs &k, const mtd_lamellar_set *set, const mtd_box *box)
-    {
-    if (!set || !box) return MTD_ERR_INVALID_ARGUMENT;
-    if (set->n_cv == 0 || set->n_cv > MTD_MAX_CV || set->n_modes == 0 || set->n_modes > MTD_MAX_MODES
-        || set->n_types == 0 || set->n_types > MTD_MAX_TYPES)
-        return MTD_ERR_INVALID_ARGUMENT;
-    if (set->first[0] != 0 || set->first[set->n_cv] != set->n_modes) return MTD_ERR_INVALID_ARGUMENT;
-    for (unsigned int c = 0; c < set->n_cv; ++c)
-        if (set->first[c + 1] <= set->first[c]) return MTD_ERR_INVALID_ARGUMENT; // cv.py:232-234: empty list is an error
-    if (!(box->L[0] > 0.0) || !(box->L[1] > 0.0) || !(box->L[2] > 0.0)) return MTD_ERR_INVALID_ARGUMENT;
-
-    std::memset(&k, 0, sizeof(k));
-    reciprocal_rows(*box, k.B);
-    k.n_cv = set->n_cv;
-    k.n_modes = set->n_modes;
-    k.n_types = set->n_types;
-    for (unsigned int c = 0; c <= set->n_cv; ++c) k.first[c] = set->first[c];
-    const double two_pi = 2.0 * M_PI;
-    for (unsigned int m = 0; m < set->n_modes; ++m)
-        for (int d = 0; d < 3; ++d)
-            {
-            k.h[m][d] = (float)set->hkl[m][d];
-            k.q[m][d] = (float)(two_pi * (set->hkl[m][0] * k.B[0][d] + set->hkl[m][1] * k.B[1][d] + set->hkl[m][2] * k.B[2][d]));
-            }
-    for (unsigned int c = 0; c < set->n_cv; ++c)
-        for (unsigned int t = 0; t < set->n_types; ++t) k.coeff[c][t] = (float)set->coeff[c][t];
-    return MTD_SUCCESS;
-    }
 
 unsigned int env_uint(const char *name, unsigned int dflt)
     {
@@ -320,9 +179,10 @@ unsigned int cv_blocks(unsigned int N)
     {
     static const unsigned int forced = env_uint("MTD_LAM_CV_BLOCKS", 0);
     if (forced) return forced > LAM_MAX_BLOCKS ? LAM_MAX_BLOCKS : forced;
+    // one 512-thread block per CU at most: few partial sums for the consumer's prologue to reduce
     unsigned int b = (N + CV_THREADS * CV_UNROLL - 1) / (CV_THREADS * CV_UNROLL);
     if (b < 1) b = 1;
-    if (b > LAM_MAX_BLOCKS) b = LAM_MAX_BLOCKS;
+    if (b > 256) b = 256;
     return b;
     }
 
@@ -330,9 +190,9 @@ unsigned int force_blocks(unsigned int N)
     {
     static const unsigned int forced = env_uint("MTD_LAM_FORCE_BLOCKS", 0);
     if (forced) return forced;
-    unsigned int b = (N + FORCE_THREADS - 1) / FORCE_THREADS;
+    unsigned int b = (N + FORCE_THREADS * FORCE_UNROLL * 2 - 1) / (FORCE_THREADS * FORCE_UNROLL * 2);
     if (b < 1) b = 1;
-    if (b > 4096) b = 4096;
+    if (b > 1024) b = 1024;
     return b;
     }
 
@@ -365,6 +225,46 @@ int launch_cv(const LamKArgs &k, unsigned int N, const void *d_postype, double *
     }
 
 } // namespace
+
+namespace mtd
+{
+int fill_kargs(LamKArgs &k, const mtd_lamellar_set *set, const mtd_box *box)
+    {
+    if (!set || !box) return MTD_ERR_INVALID_ARGUMENT;
+    if (set->n_cv == 0 || set->n_cv > MTD_MAX_CV || set->n_modes == 0 || set->n_modes > MTD_MAX_MODES
+        || set->n_types == 0 || set->n_types > MTD_MAX_TYPES)
+        return MTD_ERR_INVALID_ARGUMENT;
+    if (set->first[0] != 0 || set->first[set->n_cv] != set->n_modes) return MTD_ERR_INVALID_ARGUMENT;
+    for (unsigned int c = 0; c < set->n_cv; ++c)
+        if (set->first[c + 1] <= set->first[c]) return MTD_ERR_INVALID_ARGUMENT; // cv.py:232-234: empty list is an error
+    if (!(box->L[0] > 0.0) || !(box->L[1] > 0.0) || !(box->L[2] > 0.0)) return MTD_ERR_INVALID_ARGUMENT;
+
+    std::memset(&k, 0, sizeof(k));
+    reciprocal_rows(*box, k.B);
+    k.n_cv = set->n_cv;
+    k.n_modes = set->n_modes;
+    k.n_types = set->n_types;
+    for (unsigned int c = 0; c <= set->n_cv; ++c) k.first[c] = set->first[c];
+    const double two_pi = 2.0 * M_PI;
+    for (unsigned int m = 0; m < set->n_modes; ++m)
+        for (int d = 0; d < 3; ++d)
+            {
+            const float hv = (float)set->hkl[m][d];
+            const float qv = (float)(two_pi * (set->hkl[m][0] * k.B[0][d] + set->hkl[m][1] * k.B[1][d] + set->hkl[m][2] * k.B[2][d]));
+            if (d == 0) { k.h[m].x = hv; k.q[m].x = qv; }
+            if (d == 1) { k.h[m].y = hv; k.q[m].y = qv; }
+            if (d == 2) { k.h[m].z = hv; k.q[m].z = qv; }
+            }
+    for (unsigned int c = 0; c < set->n_cv; ++c)
+        for (unsigned int t = 0; t < set->n_types; ++t) k.coeff[c][t] = (float)set->coeff[c][t];
+    return MTD_SUCCESS;
+    }
+
+
+unsigned int lam_cv_blocks(unsigned int N) { return cv_blocks(N); }
+unsigned int lam_force_blocks(unsigned int N) { return force_blocks(N); }
+int lam_fast_trig() { return g_fast_trig; }
+} // namespace mtd
 
 extern "C" {
 

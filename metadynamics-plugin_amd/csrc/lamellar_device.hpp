@@ -1,0 +1,307 @@
+// lamellar_device.hpp — device code of the lamellar order parameter, shared by the stand-alone
+// kernels (lamellar.hip) and the fused bias-step kernels (fused.hip).
+//
+// Reference arithmetic: LamellarOrderParameter.cc:143-179 (Fourier modes), :77-140 (forces).
+// Phase in TURNS: t_k = h g1 + k g2 + l g3 with g_i = b_i' . r formed in double (b_i' = reciprocal
+// rows without 2 pi), rounded once to fp32; cos/sin(2 pi t) in fp32.  Loops are mode-outer /
+// particle-inner over U particles held in registers, so each mode's constants are fetched once
+// per U particles (broadcast LDS reads of the staged mode tables) and the trig pipes see U
+// independent chains.
+#pragma once
+
+#include "mtd_device.hpp"
+
+namespace mtd
+{
+
+struct LamKArgs
+    {
+    double B[3][3];                           // reciprocal rows without 2*pi
+    unsigned int n_cv, n_modes, n_types, _pad;
+    unsigned int first[MTD_MAX_CV + 1];
+    unsigned int _pad2[3];
+    float4 h[MTD_MAX_MODES];                  // Miller indices (h, k, l, 0)
+    float4 q[MTD_MAX_MODES];                  // Cartesian wave vectors with 2*pi (qx, qy, qz, 0)
+    float coeff[MTD_MAX_CV][MTD_MAX_TYPES];
+    };
+
+struct ForcePtrs
+    {
+    void *f[MTD_MAX_CV];
+    };
+
+// cos / sin of 2*pi*t.  FAST: hardware v_cos_f32 / v_sin_f32 take the angle in turns (domain
+// [-256, 256]); v_fract first so the full fp32 mantissa is spent on the fractional phase.
+template<bool FAST> __device__ __forceinline__ float cos2pi(float t)
+    {
+    if (FAST)
+        return __builtin_amdgcn_cosf(__builtin_amdgcn_fractf(t));
+    else
+        return cospif(2.0f * t);
+    }
+
+template<bool FAST> __device__ __forceinline__ float sin2pi(float t)
+    {
+    if (FAST)
+        return __builtin_amdgcn_sinf(__builtin_amdgcn_fractf(t));
+    else
+        return sinpif(2.0f * t);
+    }
+
+__device__ __forceinline__ void project(const LamKArgs &a, const Particle &p, float &g0, float &g1, float &g2)
+    {
+    g0 = (float)(a.B[0][0] * p.x + a.B[0][1] * p.y + a.B[0][2] * p.z);
+    g1 = (float)(a.B[1][0] * p.x + a.B[1][1] * p.y + a.B[1][2] * p.z);
+    g2 = (float)(a.B[2][0] * p.x + a.B[2][1] * p.y + a.B[2][2] * p.z);
+    }
+
+// s_coeff[MTD_MAX_CV * MTD_MAX_TYPES] <- per-type mode coefficients (call from all threads, then sync)
+__device__ __forceinline__ void load_coeff(const LamKArgs &a, float *s_coeff)
+    {
+    for (unsigned int i = threadIdx.x; i < MTD_MAX_CV * MTD_MAX_TYPES; i += blockDim.x)
+        s_coeff[i] = a.coeff[i / MTD_MAX_TYPES][i % MTD_MAX_TYPES];
+    }
+
+// Mode tables staged in LDS: the inner loops read them with wave-uniform (broadcast) ds_read_b128,
+// which the compiler can issue several modes ahead; reading them from the kernel-argument segment
+// costs an s_load + s_waitcnt lgkmcnt(0) stall every other mode (seen in the gfx950 ISA).
+struct ModeTables
+    {
+    float4 h[MTD_MAX_MODES];
+    float4 q[MTD_MAX_MODES];
+    };
+
+__device__ __forceinline__ void load_modes(const LamKArgs &a, ModeTables &t, const bool with_q)
+    {
+    for (unsigned int k = threadIdx.x; k < a.n_modes; k += blockDim.x)
+        {
+        t.h[k] = a.h[k];
+        if (with_q) t.q[k] = a.q[k];
+        }
+    }
+
+// acc[c] += sum over this thread's particles of a_c(type_j) sum_k cos(q_k . r_j)
+// thread `tid` of `n_threads` walks particles tid, tid + n_threads, ... in groups of U.
+template<typename S4, int NCV, bool FAST, int U>
+__device__ __forceinline__ void lam_cv_accumulate(const LamKArgs &a, const S4 *__restrict__ postype, const unsigned int N,
+                                                  const unsigned int tid, const unsigned int n_threads,
+                                                  const float *s_coeff, const ModeTables &mt, float (&acc)[NCV])
+    {
+    for (unsigned int base = tid; base < N; base += U * n_threads)
+        {
+        float g0[U], g1[U], g2[U];
+        int type[U];
+        bool ok[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            {
+            const unsigned int i = base + u * n_threads;
+            ok[u] = i < N;
+            const Particle p = scalar4_traits<S4>::load(postype, ok[u] ? i : base);
+            project(a, p, g0[u], g1[u], g2[u]);
+            type[u] = p.type;
+            }
+#pragma unroll
+        for (int c = 0; c < NCV; ++c)
+            {
+            if (c < (int)a.n_cv)
+                {
+                float sum[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) sum[u] = 0.0f;
+                const unsigned int k1 = a.first[c + 1];
+#pragma unroll 4
+                for (unsigned int k = a.first[c]; k < k1; ++k)
+                    {
+                    const float4 h = mt.h[k];
+#pragma unroll
+                    for (int u = 0; u < U; ++u) sum[u] += cos2pi<FAST>(h.x * g0[u] + h.y * g1[u] + h.z * g2[u]);
+                    }
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+                    {
+                    const float w = ok[u] ? s_coeff[c * MTD_MAX_TYPES + type[u]] : 0.0f;
+                    acc[c] += w * sum[u];
+                    }
+                }
+            }
+        }
+    }
+
+// Block-level tail of the CV pass: fp32 wave sums -> fp64 across waves (fixed order) ->
+// partials[block_id * NCV + c].  s_wave: [blockDim/64][NCV] doubles.
+template<int NCV>
+__device__ __forceinline__ void lam_cv_block_reduce(const float (&acc)[NCV], double *s_wave, double *__restrict__ partials,
+                                                    const unsigned int block_id)
+    {
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int n_waves = blockDim.x >> 6;
+#pragma unroll
+    for (int c = 0; c < NCV; ++c)
+        {
+        const float v = wave_sum(acc[c]);
+        if (lane == 0) s_wave[wave * NCV + c] = (double)v;
+        }
+    __syncthreads();
+    if (threadIdx.x < NCV)
+        {
+        double r = 0.0;
+        for (int w = 0; w < n_waves; ++w) r += s_wave[w * NCV + threadIdx.x];
+        partials[block_id * NCV + threadIdx.x] = r;
+        }
+    }
+
+// Force arrays are written once per step and not re-read by this library: non-temporal stores keep
+// 32 MB of dirty lines out of the L2s, whose write-back otherwise lands on the kernel's tail (measured:
+// -1.9 us per step at 10^6 particles, 2 CVs).
+__device__ __forceinline__ void nt_store(const float4 v, float4 *p)
+    {
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    v4f x = { v.x, v.y, v.z, v.w };
+    __builtin_nontemporal_store(x, (v4f *)p);
+    }
+__device__ __forceinline__ void nt_store(const double4 v, double4 *p)
+    {
+    typedef double v2d __attribute__((ext_vector_type(2)));
+    v2d x = { v.x, v.y }, y = { v.z, v.w };
+    __builtin_nontemporal_store(x, (v2d *)p);
+    __builtin_nontemporal_store(y, (v2d *)p + 1);
+    }
+
+// Forces of every fused CV for this thread's particles.  s_wcoef[c*MTD_MAX_TYPES + type] must hold
+// a_c(type) * bias_c * 2 / N_global (LamellarOrderParameter.cc:120-133 folded into one factor).
+template<typename S4, bool FAST, int U>
+__device__ __forceinline__ void lam_force_pass(const LamKArgs &a, const S4 *__restrict__ postype, const ForcePtrs &out,
+                                               const unsigned int N, const unsigned int tid, const unsigned int n_threads,
+                                               const float *s_wcoef, const ModeTables &mt)
+    {
+    typedef typename scalar4_traits<S4>::scalar scalar;
+    for (unsigned int base = tid; base < N; base += U * n_threads)
+        {
+        float g0[U], g1[U], g2[U];
+        int type[U];
+        bool ok[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            {
+            const unsigned int i = base + u * n_threads;
+            ok[u] = i < N;
+            const Particle p = scalar4_traits<S4>::load(postype, ok[u] ? i : base);
+            project(a, p, g0[u], g1[u], g2[u]);
+            type[u] = p.type;
+            }
+        for (unsigned int c = 0; c < a.n_cv; ++c)
+            {
+            float fx[U], fy[U], fz[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) fx[u] = fy[u] = fz[u] = 0.0f;
+            const unsigned int k1 = a.first[c + 1];
+#pragma unroll 4
+            for (unsigned int k = a.first[c]; k < k1; ++k)
+                {
+                const float4 h = mt.h[k];
+                const float4 q = mt.q[k];
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+                    {
+                    const float s = sin2pi<FAST>(h.x * g0[u] + h.y * g1[u] + h.z * g2[u]);
+                    fx[u] += q.x * s;
+                    fy[u] += q.y * s;
+                    fz[u] += q.z * s;
+                    }
+                }
+            S4 *f = (S4 *)out.f[c];
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                {
+                if (ok[u])
+                    {
+                    const float w = s_wcoef[c * MTD_MAX_TYPES + type[u]];
+                    nt_store(scalar4_traits<S4>::make((scalar)(fx[u] * w), (scalar)(fy[u] * w), (scalar)(fz[u] * w), (scalar)0),
+                             &f[base + u * n_threads]);
+                    }
+                }
+            }
+        }
+    }
+
+// ------------------------------------------------------------------------------------------------
+// Split form of the force pass for the fused kernel: the trig sums do not depend on the bias factor,
+// so a thread first forms the UNSCALED forces  a-free sum_k q_k sin(q_k . r_j)  of its U particles in
+// registers (lam_force_unscaled) and scales + stores them once the bias is known (lam_force_store).
+template<int NCV, int U> struct ForceRegs
+    {
+    float f[U][NCV][3];
+    int type[U];
+    bool ok[U];
+    };
+
+template<typename S4, int NCV, bool FAST, int U>
+__device__ __forceinline__ void lam_force_unscaled(const LamKArgs &a, const S4 *__restrict__ postype, const unsigned int N,
+                                                   const unsigned int first, const unsigned int stride, const ModeTables &mt,
+                                                   ForceRegs<NCV, U> &R)
+    {
+    float g0[U], g1[U], g2[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+        {
+        const unsigned int i = first + u * stride;
+        R.ok[u] = i < N;
+        const Particle p = scalar4_traits<S4>::load(postype, R.ok[u] ? i : (N ? N - 1 : 0));
+        project(a, p, g0[u], g1[u], g2[u]);
+        R.type[u] = p.type;
+        }
+#pragma unroll
+    for (int c = 0; c < NCV; ++c)
+        {
+#pragma unroll
+        for (int u = 0; u < U; ++u) R.f[u][c][0] = R.f[u][c][1] = R.f[u][c][2] = 0.0f;
+        if (c < (int)a.n_cv)
+            {
+            const unsigned int k1 = a.first[c + 1];
+#pragma unroll 4
+            for (unsigned int k = a.first[c]; k < k1; ++k)
+                {
+                const float4 h = mt.h[k];
+                const float4 q = mt.q[k];
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+                    {
+                    const float s = sin2pi<FAST>(h.x * g0[u] + h.y * g1[u] + h.z * g2[u]);
+                    R.f[u][c][0] += q.x * s;
+                    R.f[u][c][1] += q.y * s;
+                    R.f[u][c][2] += q.z * s;
+                    }
+                }
+            }
+        }
+    }
+
+template<typename S4, int NCV, int U>
+__device__ __forceinline__ void lam_force_store(const LamKArgs &a, const ForcePtrs &out, const unsigned int first,
+                                                const unsigned int stride, const float *s_wcoef, const ForceRegs<NCV, U> &R)
+    {
+    typedef typename scalar4_traits<S4>::scalar scalar;
+#pragma unroll
+    for (int c = 0; c < NCV; ++c)
+        {
+        if (c < (int)a.n_cv)
+            {
+            S4 *f = (S4 *)out.f[c];
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                {
+                if (R.ok[u])
+                    {
+                    const float w = s_wcoef[c * MTD_MAX_TYPES + R.type[u]];
+                    const S4 v = scalar4_traits<S4>::make((scalar)(R.f[u][c][0] * w), (scalar)(R.f[u][c][1] * w),
+                                                          (scalar)(R.f[u][c][2] * w), (scalar)0);
+                    nt_store(v, &f[first + u * stride]);
+                    }
+                }
+            }
+        }
+    }
+
+} // namespace mtd

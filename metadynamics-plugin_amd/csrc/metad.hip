@@ -15,216 +15,46 @@
 //   k_reweight1 (G/256)   [deposit] Gaussian increment per cell, R += hist_delta, block sums of R*dV, R
 //   k_apply (G/256)       [deposit] <dV>, fac = exp(-(dV-<dV>)/T), R *= fac, w /= fac, grids += deltas
 //   k_evaluate (1 block)  dV/ds_c by finite differences of the multilinear interpolant, V(s), w(s)
-#include "mtd_device.hpp"
+#include "metad_device.hpp"
 
 #include <cmath>
 #include <cstring>
 #include <new>
+
+#include "metad_host.hpp"
 
 namespace
 {
 
 using namespace mtd;
 
-constexpr int MAXCV = MTD_METAD_MAX_CV;
-constexpr int GRID_THREADS = 256;
-constexpr int MAX_POINTS = 2 * MAXCV + 2;
-constexpr int MAX_TERMS = 1 << MAXCV;
-
-struct CvSource
-    {
-    const double *partials;
-    unsigned int n_partials, stride, offset, _pad;
-    double scale, shift;
-    };
-
-struct MetadState
-    {
-    double cv[MAXCV];
-    double bias[MAXCV];
-    double V;        // log quantity "bias"   (IntegratorMetaDynamics.cc:448)
-    double w;        // log quantity "weight" (:451)
-    double scal;     // well-tempered scale of the current deposit (:374-379)
-    double avg_dV;   // <dV> of the last reweighting step (:1077)
-    unsigned int num_gaussians;
-    unsigned int n_oob;
-    unsigned int bin;
-    unsigned int on_grid;
-    };
-
-struct MetadCfg
-    {
-    unsigned int n_cv, len;
-    unsigned int lengths[MAXCV];
-    unsigned int factors[MAXCV];
-    double cv_min[MAXCV], cv_max[MAXCV], delta[MAXCV];
-    double sigma_inv[MAXCV * MAXCV];
-    double W, T_shift, temp, det_sigma;
-    int mode, _pad;
-    double *grid, *grid_delta, *rew, *weight, *sigma_grid, *sigma_grid_delta;
-    unsigned int *hist, *hist_delta, *hist_gauss, *hist_gauss_delta;
-    MetadState *st;
-    double *gpart;
-    unsigned int n_gblocks, _pad2;
-    CvSource src[MAXCV];
-    };
-
-// IndexGrid::getCoordinates (IndexGrid.cc:46-58)
-__device__ __forceinline__ void decode(const MetadCfg &c, unsigned int idx, unsigned int *coords)
-    {
-    unsigned int rest = idx;
-    for (int i = (int)c.n_cv - 1; i >= 0; --i)
-        {
-        coords[i] = rest / c.factors[i];
-        rest -= coords[i] * c.factors[i];
-        }
-    }
-
-// floor-bin shared by updateHistogram (:1092-1119) and updateSigmaGrid (:1122-1155).  The reference
-// converts (s-min)/delta to unsigned: undefined for values <= -1 or >= 2^32, treated as off-grid.
-__device__ bool bin_of(const MetadCfg &c, const double *val, unsigned int &idx)
-    {
-    bool on_grid = true;
-    unsigned int r = 0;
-    for (unsigned int i = 0; i < c.n_cv; ++i)
-        {
-        const double q = (val[i] - c.cv_min[i]) / c.delta[i];
-        if (!(q > -1.0) || !(q < 4294967296.0))
-            {
-            on_grid = false;
-            continue;
-            }
-        const unsigned int coord = (unsigned int)q;
-        if (coord >= c.lengths[i]) on_grid = false;
-        r += coord * c.factors[i];
-        }
-    idx = r;
-    return on_grid;
-    }
-
-// One term of interpolateGrid's multilinear sum (:711-733) for evaluation point val[], corner `bits`.
-// Returns false when the point is out of bounds (:677-683 => whole interpolation is 0).
-__device__ bool interp_term(const MetadCfg &c, const double *val, unsigned int bits, const double *arr, double &term)
-    {
-    double t = 1.0;
-    unsigned int idx = 0;
-    for (unsigned int i = 0; i < c.n_cv; ++i)
-        {
-        const double v = val[i];
-        if (v < c.cv_min[i] || v >= c.cv_max[i]) return false;
-        int lower = (int)((v - c.cv_min[i]) / c.delta[i]);
-        int upper = lower + 1;
-        if (upper >= (int)c.lengths[i])
-            {
-            lower--;
-            upper--;
-            }
-        const double lower_bound = c.cv_min[i] + c.delta[i] * lower;
-        const double upper_bound = c.cv_min[i] + c.delta[i] * upper;
-        const double rel = (v - lower_bound) / (upper_bound - lower_bound);
-        if (bits & (1u << i))
-            {
-            idx += (unsigned int)lower * c.factors[i];
-            t *= (1.0 - rel);
-            }
-        else
-            {
-            idx += (unsigned int)upper * c.factors[i];
-            t *= rel;
-            }
-        }
-    term = t * arr[idx];
-    return true;
-    }
-
-// Evaluate n_points interpolations cooperatively: every (point, corner) pair is one lane's work (one
-// L2 read each, all in flight together); the corner terms are then summed in the reference's order.
-// pts[p][i] evaluation points, which[p] != 0 -> weight grid.  Results in s_res[p]; s_oob[p] flags.
-__device__ void interpolate_points(const MetadCfg &c, const double (*pts)[MAXCV], const int *which, int n_points,
-                                   double (*s_terms)[MAX_TERMS], int *s_oob, double *s_res)
-    {
-    const int n_term = 1 << c.n_cv;
-    for (int p = threadIdx.x; p < n_points; p += blockDim.x) s_oob[p] = 0;
-    __syncthreads();
-    for (int idx = threadIdx.x; idx < n_points * n_term; idx += blockDim.x)
-        {
-        const int p = idx / n_term;
-        const unsigned int bits = idx % n_term;
-        double term = 0.0;
-        const bool ok = interp_term(c, pts[p], bits, which[p] ? c.weight : c.grid, term);
-        s_terms[p][bits] = ok ? term : 0.0;
-        if (!ok && bits == 0) s_oob[p] = 1;
-        }
-    __syncthreads();
-    for (int p = threadIdx.x; p < n_points; p += blockDim.x)
-        {
-        double res = 0.0;
-        for (int b = 0; b < n_term; ++b) res += s_terms[p][b];
-        s_res[p] = res;
-        }
-    __syncthreads();
-    }
-
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(GRID_THREADS) void k_prepare(const MetadCfg c, const int deposit)
     {
-    __shared__ double s_cv[MAXCV];
-    __shared__ double s_pts[1][MAXCV];
-    __shared__ int s_which[1];
-    __shared__ double s_terms[1][MAX_TERMS];
-    __shared__ int s_oob[1];
-    __shared__ double s_res[1];
-
-    const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
-
-    // CV values from their block partial sums (replaces getCurrentValue's D2H + host sum, .cc:323-327)
-    for (unsigned int i = wave; i < c.n_cv; i += GRID_THREADS / MTD_WAVE)
-        {
-        const CvSource s = c.src[i];
-        double v = 0.0;
-        if (s.partials)
-            for (unsigned int b = lane; b < s.n_partials; b += MTD_WAVE) v += s.partials[(size_t)b * s.stride + s.offset];
-        v = wave_sum(v);
-        if (lane == 0)
-            {
-            const double val = s.partials ? s.shift + s.scale * v : s.shift;   // host-provided value
-            s_cv[i] = val;
-            c.st->cv[i] = val;
-            }
-        }
+    __shared__ EvalShared sh;
+    __shared__ double s_tmp[16];
+    reduce_cv_sources(c, sh.cv, s_tmp);     // replaces getCurrentValue's D2H + host sum (.cc:323-327)
     __syncthreads();
-
+    evaluate_bias(c, sh, deposit != 0, false);   // V_old(s) -> well-tempered scale (:374-379); bin
+    if (threadIdx.x < c.n_cv) c.st->cv[threadIdx.x] = sh.cv[threadIdx.x];
     if (threadIdx.x == 0)
         {
-        unsigned int bin = 0;
-        const bool on_grid = bin_of(c, s_cv, bin);
-        c.st->bin = bin;
-        c.st->on_grid = on_grid ? 1u : 0u;
-        if (on_grid)
+        c.st->bin = sh.bin;
+        c.st->on_grid = (unsigned int)sh.on_grid;
+        if (sh.on_grid)
             {
-            c.hist_delta[bin] += 1;                  // updateHistogram, every step (:366)
+            c.hist_delta[sh.bin] += 1;                      // updateHistogram, every step (:366)
             if (deposit)
                 {
-                c.sigma_grid_delta[bin] += c.det_sigma;  // updateSigmaGrid (:371)
-                c.hist_gauss_delta[bin] += 1;
+                c.sigma_grid_delta[sh.bin] += c.det_sigma;  // updateSigmaGrid (:371)
+                c.hist_gauss_delta[sh.bin] += 1;
                 }
             }
-        }
-
-    if (deposit)
-        {
-        double scal = 1.0;
-        if (c.mode == MTD_MODE_WELL_TEMPERED)
+        if (deposit)
             {
-            if (threadIdx.x < c.n_cv) s_pts[0][threadIdx.x] = s_cv[threadIdx.x];
-            if (threadIdx.x == 0) s_which[0] = 0;
-            __syncthreads();
-            interpolate_points(c, s_pts, s_which, 1, s_terms, s_oob, s_res);
-            scal = exp(-s_res[0] / c.T_shift);       // :377-378
-            if (threadIdx.x == 0 && s_oob[0]) c.st->n_oob += 1;
+            c.st->scal = sh.scal;
+            if (c.mode == MTD_MODE_WELL_TEMPERED && sh.oob[0]) c.st->n_oob += 1;
             }
-        if (threadIdx.x == 0) c.st->scal = scal;
         }
     }
 
@@ -234,6 +64,12 @@ template<bool COMPUTE_DELTA, bool REWEIGHT>
 __global__ __launch_bounds__(GRID_THREADS) void k_reweight1(const MetadCfg c)
     {
     __shared__ double s_red[16];
+    __shared__ double s_cv[MAXCV];
+    if (COMPUTE_DELTA)
+        {
+        if (threadIdx.x < c.n_cv) s_cv[threadIdx.x] = c.st->cv[threadIdx.x];
+        __syncthreads();
+        }
     const unsigned int g = blockIdx.x * GRID_THREADS + threadIdx.x;
     double s1 = 0.0, s2 = 0.0;
     if (g < c.len)
@@ -241,22 +77,7 @@ __global__ __launch_bounds__(GRID_THREADS) void k_reweight1(const MetadCfg c)
         double dV;
         if (COMPUTE_DELTA)
             {
-            unsigned int coords[MAXCV];
-            decode(c, g, coords);
-            double d[MAXCV];
-            for (unsigned int i = 0; i < c.n_cv; ++i)
-                {
-                const double val_i = c.cv_min[i] + coords[i] * c.delta[i];
-                d[i] = val_i - c.st->cv[i];
-                }
-            double gauss_exp = 0.0;
-            for (unsigned int i = 0; i < c.n_cv; ++i)
-                for (unsigned int j = 0; j < c.n_cv; ++j)
-                    {
-                    const double sij = c.sigma_inv[i * c.n_cv + j];
-                    gauss_exp += d[i] * d[j] * (1.0 / 2.0) * (sij * sij);   // element-wise square: Q12
-                    }
-            dV = c.W * c.st->scal * exp(-gauss_exp);
+            dV = (c.W * c.st->scal) * exp(-gauss_exponent(c, g, s_cv));
             c.grid_delta[g] = dV;                                            // CPU semantics: overwrite (:1043)
             }
         else
@@ -285,83 +106,24 @@ __global__ __launch_bounds__(GRID_THREADS) void k_reweight1(const MetadCfg c)
 __global__ __launch_bounds__(GRID_THREADS) void k_apply(const MetadCfg c)
     {
     __shared__ double s_red[16];
-    double s1 = 0.0, s2 = 0.0;
-    for (unsigned int b = threadIdx.x; b < c.n_gblocks; b += GRID_THREADS)
-        {
-        s1 += c.gpart[2 * b];
-        s2 += c.gpart[2 * b + 1];
-        }
-    s1 = block_sum(s1, s_red);
-    s2 = block_sum(s2, s_red);
-    const double avg_dV = s1 / s2;                                           // norm == 0 -> NaN like the reference (Q15)
-
-    const unsigned int g = blockIdx.x * GRID_THREADS + threadIdx.x;
-    if (g < c.len)
-        {
-        const double dV = c.grid_delta[g];
-        const double fac = exp(-(dV - avg_dV) / c.temp);                     // T, not deltaT (:1084)
-        c.rew[g] *= fac;
-        c.weight[g] /= fac;
-        c.grid[g] += dV;
-        c.sigma_grid[g] += c.sigma_grid_delta[g];
-        c.hist[g] += c.hist_delta[g];
-        c.hist_gauss[g] += c.hist_gauss_delta[g];
-        c.grid_delta[g] = 0.0;
-        c.sigma_grid_delta[g] = 0.0;
-        c.hist_delta[g] = 0;
-        c.hist_gauss_delta[g] = 0;
-        }
-    if (blockIdx.x == 0 && threadIdx.x == 0)
-        {
-        c.st->avg_dV = avg_dV;
-        c.st->num_gaussians += 1;                                            // :440
-        }
+    const unsigned int b0 = blockIdx.x * GRID_THREADS;
+    apply_cells(c, b0, min(c.len, b0 + GRID_THREADS), blockIdx.x == 0, s_red);
     }
 
 // ---------------------------------------------------------------------------------------------
 // biasPotentialDerivative for every CV (:444-445 -> :738-776), V(s) (:448) and w(s) (:451)
 __global__ __launch_bounds__(GRID_THREADS) void k_evaluate(const MetadCfg c)
     {
-    __shared__ double s_pts[MAX_POINTS][MAXCV];
-    __shared__ int s_which[MAX_POINTS];
-    __shared__ double s_terms[MAX_POINTS][MAX_TERMS];
-    __shared__ int s_oob[MAX_POINTS];
-    __shared__ double s_res[MAX_POINTS];
-
-    const unsigned int n = c.n_cv;
-    const int n_points = 2 + 2 * (int)n;
-    // point 0: s on the bias grid; point 1: s on the weight grid; 2+2i: s - delta_i e_i; 3+2i: s + delta_i e_i
-    for (unsigned int idx = threadIdx.x; idx < (unsigned int)n_points * n; idx += blockDim.x)
-        {
-        const unsigned int p = idx / n, i = idx % n;
-        double v = c.st->cv[i];
-        if (p >= 2 && (p - 2) / 2 == i) v = ((p - 2) & 1) ? v + c.delta[i] : v - c.delta[i];
-        s_pts[p][i] = v;
-        }
-    if (threadIdx.x < (unsigned int)n_points) s_which[threadIdx.x] = (threadIdx.x == 1) ? 1 : 0;
+    __shared__ EvalShared sh;
+    if (threadIdx.x < c.n_cv) sh.cv[threadIdx.x] = c.st->cv[threadIdx.x];
     __syncthreads();
-
-    interpolate_points(c, s_pts, s_which, n_points, s_terms, s_oob, s_res);
-
-    if (threadIdx.x < n)
-        {
-        const unsigned int i = threadIdx.x;
-        const double s = s_pts[0][i];
-        const double delta = c.delta[i];
-        double b;
-        if (s - delta < c.cv_min[i])
-            b = (s_res[3 + 2 * i] - s_res[0]) / delta;                        // forward  (:746-755)
-        else if (s + delta > c.cv_max[i])
-            b = (s_res[0] - s_res[2 + 2 * i]) / delta;                        // backward (:756-764)
-        else
-            b = (s_res[3 + 2 * i] - s_res[2 + 2 * i]) / (2.0 * delta);        // central  (:765-775)
-        c.st->bias[i] = b;
-        }
+    evaluate_bias(c, sh, false, false);
+    if (threadIdx.x < c.n_cv) c.st->bias[threadIdx.x] = sh.bias[threadIdx.x];
     if (threadIdx.x == 0)
         {
-        c.st->V = s_res[0];
-        c.st->w = s_res[1];
-        if (s_oob[0]) c.st->n_oob += 1;
+        c.st->V = sh.res[0];
+        c.st->w = sh.res[1];
+        if (sh.oob[0]) c.st->n_oob += 1;
         }
     }
 
@@ -443,13 +205,19 @@ double host_determinant(const double *m, unsigned int n)
 
 } // namespace
 
-struct mtd_metad
+namespace mtd
+{
+int metad_flush(mtd_metad *m, hipStream_t s)
     {
-    MetadCfg cfg;
-    unsigned int stride;
-    int add_bias;
-    void *slab;
-    };
+    if (m && m->pending_apply)
+        {
+        k_apply<<<m->cfg.n_gblocks, GRID_THREADS, 0, s>>>(m->cfg);
+        MTD_LAUNCH_CHECK();
+        m->pending_apply = 0;
+        }
+    return MTD_SUCCESS;
+    }
+}
 
 extern "C" {
 
@@ -529,6 +297,7 @@ int mtd_metad_create(mtd_metad **out, unsigned int n_cv, const double *sigma, co
     c.n_gblocks = (c.len + GRID_THREADS - 1) / GRID_THREADS;
     m->stride = stride;
     m->add_bias = add_bias ? 1 : 0;
+    m->pending_apply = 0;
 
     const size_t G = c.len;
     const size_t bytes_d = 6 * G * sizeof(double);
@@ -624,6 +393,7 @@ int mtd_metad_set_sigma_inv(mtd_metad *m, const double *sigma_inv)
 int mtd_metad_reset_histogram(mtd_metad *m, mtd_stream_t stream)
     {
     if (!m) return MTD_ERR_INVALID_ARGUMENT;
+    { int frc = mtd::metad_flush(m, (hipStream_t)stream); if (frc) return frc; }
     k_reset_hist<<<(m->cfg.len + 255) / 256, 256, 0, (hipStream_t)stream>>>(m->cfg.hist, m->cfg.hist_delta, m->cfg.len);
     MTD_LAUNCH_CHECK();
     return MTD_SUCCESS;
@@ -661,6 +431,7 @@ double mtd_metad_sigma_determinant(const mtd_metad *m) { return m ? m->cfg.det_s
 int mtd_metad_update_phase_a(mtd_metad *m, unsigned int timestep, int *deposited, mtd_stream_t stream)
     {
     if (!m || !deposited) return MTD_ERR_INVALID_ARGUMENT;
+    { int frc = mtd::metad_flush(m, (hipStream_t)stream); if (frc) return frc; }
     hipStream_t s = (hipStream_t)stream;
     const int dep = (m->add_bias && (timestep % m->stride == 0)) ? 1 : 0;   // .cc:368
     k_prepare<<<1, GRID_THREADS, 0, s>>>(m->cfg, dep);
@@ -693,6 +464,7 @@ int mtd_metad_update_phase_b(mtd_metad *m, int deposited, mtd_stream_t stream)
 int mtd_metad_update_bias(mtd_metad *m, unsigned int timestep, mtd_stream_t stream)
     {
     if (!m) return MTD_ERR_INVALID_ARGUMENT;
+    { int frc = mtd::metad_flush(m, (hipStream_t)stream); if (frc) return frc; }
     hipStream_t s = (hipStream_t)stream;
     const int dep = (m->add_bias && (timestep % m->stride == 0)) ? 1 : 0;
     k_prepare<<<1, GRID_THREADS, 0, s>>>(m->cfg, dep);
@@ -722,6 +494,13 @@ int mtd_metad_get_state(mtd_metad *m, double *cv, double *bias, double *bias_pot
                         unsigned int *num_gaussians, unsigned int *num_out_of_bounds, mtd_stream_t stream)
     {
     if (!m) return MTD_ERR_INVALID_ARGUMENT;
+    if (m->pending_apply)
+        {
+        int frc = mtd::metad_flush(m, (hipStream_t)stream);
+        if (frc) return frc;
+        k_evaluate<<<1, GRID_THREADS, 0, (hipStream_t)stream>>>(m->cfg);   // w(s) of the now-final weight grid
+        MTD_LAUNCH_CHECK();
+        }
     MetadState st;
     MTD_HIP_TRY(hipMemcpyAsync(&st, m->cfg.st, sizeof(st), hipMemcpyDeviceToHost, (hipStream_t)stream));
     MTD_HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
@@ -766,6 +545,7 @@ void *mtd_metad_device_array(mtd_metad *m, int which)
 int mtd_metad_get_array(mtd_metad *m, int which, void *host_out, mtd_stream_t stream)
     {
     if (!m || !host_out) return MTD_ERR_INVALID_ARGUMENT;
+    { int frc = mtd::metad_flush(m, (hipStream_t)stream); if (frc) return frc; }
     size_t e;
     void *p = array_ptr(m, which, &e);
     if (!p) return MTD_ERR_INVALID_ARGUMENT;
@@ -777,6 +557,7 @@ int mtd_metad_get_array(mtd_metad *m, int which, void *host_out, mtd_stream_t st
 int mtd_metad_set_array(mtd_metad *m, int which, const void *host_in, mtd_stream_t stream)
     {
     if (!m || !host_in) return MTD_ERR_INVALID_ARGUMENT;
+    { int frc = mtd::metad_flush(m, (hipStream_t)stream); if (frc) return frc; }
     size_t e;
     void *p = array_ptr(m, which, &e);
     if (!p) return MTD_ERR_INVALID_ARGUMENT;

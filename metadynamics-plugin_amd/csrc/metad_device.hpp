@@ -1,0 +1,574 @@
+// metad_device.hpp — device structures and functions of the bias-grid engine, shared by the generic
+// kernels (metad.hip) and the fused bias-step kernels (fused.hip).
+//
+// Reference arithmetic: IntegratorMetaDynamics.cc:663-736 (interpolateGrid), :738-776
+// (biasPotentialDerivative), :1002-1047 (updateGrid), :1092-1155 (histogram bins), IndexGrid.cc:20-58.
+#pragma once
+
+#include "mtd_device.hpp"
+
+namespace mtd
+{
+
+constexpr int MAXCV = MTD_METAD_MAX_CV;
+constexpr int GRID_THREADS = 256;
+constexpr int MAX_POINTS = 2 * MAXCV + 2;
+constexpr int MAX_TERMS = 1 << MAXCV;
+
+struct CvSource
+    {
+    const double *partials;     // nullptr: the value is `shift` (host-provided)
+    unsigned int n_partials, stride, offset, _pad;
+    double scale, shift;
+    };
+
+struct MetadState
+    {
+    double cv[MAXCV];
+    double bias[MAXCV];
+    double V;        // log quantity "bias"   (IntegratorMetaDynamics.cc:448)
+    double w;        // log quantity "weight" (:451)
+    double scal;     // well-tempered scale of the current deposit (:374-379)
+    double avg_dV;   // <dV> of the last reweighting step (:1077)
+    unsigned int num_gaussians;
+    unsigned int n_oob;
+    unsigned int bin;
+    unsigned int on_grid;
+    };
+
+struct MetadCfg
+    {
+    unsigned int n_cv, len;
+    unsigned int lengths[MAXCV];
+    unsigned int factors[MAXCV];
+    double cv_min[MAXCV], cv_max[MAXCV], delta[MAXCV];
+    double sigma_inv[MAXCV * MAXCV];
+    double W, T_shift, temp, det_sigma;
+    int mode, _pad;
+    double *grid, *grid_delta, *rew, *weight, *sigma_grid, *sigma_grid_delta;
+    unsigned int *hist, *hist_delta, *hist_gauss, *hist_gauss_delta;
+    MetadState *st;
+    double *gpart;
+    unsigned int n_gblocks, _pad2;
+    CvSource src[MAXCV];
+    };
+
+// IndexGrid::getCoordinates (IndexGrid.cc:46-58)
+__device__ __forceinline__ void decode(const MetadCfg &c, unsigned int idx, unsigned int *coords)
+    {
+    unsigned int rest = idx;
+    for (int i = (int)c.n_cv - 1; i >= 0; --i)
+        {
+        coords[i] = rest / c.factors[i];
+        rest -= coords[i] * c.factors[i];
+        }
+    }
+
+// exponent of updateGrid's Gaussian at grid cell `idx` for CV values s[] (:1019-1039):
+// 1/2 sum_ij d_i d_j (sigma_inv_ij)^2 — element-wise square (Q12)
+__device__ __forceinline__ double gauss_exponent(const MetadCfg &c, unsigned int idx, const double *s)
+    {
+    unsigned int coords[MAXCV];
+    decode(c, idx, coords);
+    double d[MAXCV];
+    for (unsigned int i = 0; i < c.n_cv; ++i)
+        {
+        const double val_i = c.cv_min[i] + coords[i] * c.delta[i];
+        d[i] = val_i - s[i];
+        }
+    double gauss_exp = 0.0;
+    for (unsigned int i = 0; i < c.n_cv; ++i)
+        for (unsigned int j = 0; j < c.n_cv; ++j)
+            {
+            const double sij = c.sigma_inv[i * c.n_cv + j];
+            gauss_exp += d[i] * d[j] * (1.0 / 2.0) * (sij * sij);
+            }
+    return gauss_exp;
+    }
+
+// floor-bin shared by updateHistogram (:1092-1119) and updateSigmaGrid (:1122-1155).  The reference
+// converts (s-min)/delta to unsigned: undefined for values <= -1 or >= 2^32, treated as off-grid.
+__device__ __forceinline__ bool bin_of(const MetadCfg &c, const double *val, unsigned int &idx)
+    {
+    bool on_grid = true;
+    unsigned int r = 0;
+    for (unsigned int i = 0; i < c.n_cv; ++i)
+        {
+        const double q = (val[i] - c.cv_min[i]) / c.delta[i];
+        if (!(q > -1.0) || !(q < 4294967296.0))
+            {
+            on_grid = false;
+            continue;
+            }
+        const unsigned int coord = (unsigned int)q;
+        if (coord >= c.lengths[i]) on_grid = false;
+        r += coord * c.factors[i];
+        }
+    idx = r;
+    return on_grid;
+    }
+
+// Corner `bits` of interpolateGrid's multilinear sum (:685-733) for evaluation point val[]: grid cell
+// and weight.  Returns false when the point is out of bounds (:677-683 => the interpolation is 0).
+__device__ __forceinline__ bool interp_corner(const MetadCfg &c, const double *val, unsigned int bits, unsigned int &cell,
+                                              double &weight)
+    {
+    double t = 1.0;
+    unsigned int idx = 0;
+    for (unsigned int i = 0; i < c.n_cv; ++i)
+        {
+        const double v = val[i];
+        if (v < c.cv_min[i] || v >= c.cv_max[i]) return false;
+        int lower = (int)((v - c.cv_min[i]) / c.delta[i]);
+        int upper = lower + 1;
+        if (upper >= (int)c.lengths[i])
+            {
+            lower--;
+            upper--;
+            }
+        const double lower_bound = c.cv_min[i] + c.delta[i] * lower;
+        const double upper_bound = c.cv_min[i] + c.delta[i] * upper;
+        const double rel = (v - lower_bound) / (upper_bound - lower_bound);
+        if (bits & (1u << i))
+            {
+            idx += (unsigned int)lower * c.factors[i];
+            t *= (1.0 - rel);
+            }
+        else
+            {
+            idx += (unsigned int)upper * c.factors[i];
+            t *= rel;
+            }
+        }
+    cell = idx;
+    weight = t;
+    return true;
+    }
+
+// CV values from their sources, cooperatively by the whole block, in a fixed order (bitwise the same in
+// every block).  All loads of a CV are issued before the first add (a serial `v += p[b]` loop costs one
+// memory round trip per iteration).  Result in s_cv[] (shared); s_tmp: >= 16 doubles of shared memory.
+// The caller must __syncthreads() before reading s_cv.
+__device__ __forceinline__ void reduce_cv_sources(const MetadCfg &c, double *s_cv, double *s_tmp)
+    {
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int n_waves = blockDim.x >> 6;
+    for (unsigned int i = 0; i < c.n_cv; ++i)
+        {
+        const CvSource s = c.src[i];
+        double v = 0.0;
+        if (s.partials)
+            {
+            for (unsigned int b0 = threadIdx.x; b0 < s.n_partials; b0 += 4 * blockDim.x)
+                {
+                double x[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    {
+                    const unsigned int b = b0 + j * blockDim.x;
+                    x[j] = b < s.n_partials ? s.partials[(size_t)b * s.stride + s.offset] : 0.0;
+                    }
+                v += (x[0] + x[1]) + (x[2] + x[3]);
+                }
+            }
+        v = wave_sum(v);
+        __syncthreads();
+        if (lane == 0) s_tmp[wave] = v;
+        __syncthreads();
+        if (threadIdx.x == 0)
+            {
+            double r = 0.0;
+            for (int w = 0; w < n_waves; ++w) r += s_tmp[w];
+            s_cv[i] = s.partials ? s.shift + s.scale * r : s.shift;
+            }
+        }
+    }
+
+// Shared-memory workspace of evaluate_bias()
+struct EvalShared
+    {
+    double cv[MAXCV];
+    double pts[MAX_POINTS][MAXCV];
+    double val[MAX_POINTS][MAX_TERMS];   // grid value at the corner cell
+    double wt[MAX_POINTS][MAX_TERMS];    // multilinear weight of the corner
+    unsigned int cell[MAX_POINTS][MAX_TERMS];
+    int oob[MAX_POINTS];
+    double res[MAX_POINTS];
+    double bias[MAXCV];
+    double scal;
+    double V_old;
+    unsigned int bin;
+    int on_grid;
+    };
+
+// The scalar part of updateBiasPotential for CV values sh.cv[], cooperatively by one block:
+//   V_old(s) and the well-tempered scale (:374-379); then dV/ds_c (:444-445 -> :738-776), V(s) (:448)
+//   and w(s) (:451) of the grid AFTER the deposit.  With `closed_form` the deposit has not been applied
+//   to c.grid yet: the post-deposit node values are formed as grid[cell] + W*scal*exp(-gauss(cell))
+//   for the <= (2 n_cv + 1) 2^n_cv cells the finite-difference stencil touches (the values the deferred
+//   apply pass will store, up to FMA-contraction rounding of the same dV expression).
+// Results: sh.scal, sh.bias[], sh.res[0] = V, sh.res[1] = w (w only meaningful when !closed_form).
+__device__ __forceinline__ void evaluate_bias(const MetadCfg &c, EvalShared &sh, const bool deposit, const bool closed_form)
+    {
+    const unsigned int n = c.n_cv;
+    const int n_points = 2 + 2 * (int)n;
+    const int n_term = 1 << n;
+    // point 0: s on the bias grid; point 1: s on the weight grid; 2+2i: s - delta_i e_i; 3+2i: s + delta_i e_i
+    for (unsigned int idx = threadIdx.x; idx < (unsigned int)n_points * n; idx += blockDim.x)
+        {
+        const unsigned int p = idx / n, i = idx % n;
+        double v = sh.cv[i];
+        if (p >= 2 && (p - 2) / 2 == i) v = ((p - 2) & 1) ? v + c.delta[i] : v - c.delta[i];
+        sh.pts[p][i] = v;
+        }
+    for (int p = threadIdx.x; p < n_points; p += blockDim.x) sh.oob[p] = 0;
+    if (threadIdx.x == 0)
+        {
+        unsigned int bin = 0;
+        sh.on_grid = bin_of(c, sh.cv, bin) ? 1 : 0;
+        sh.bin = bin;
+        }
+    __syncthreads();
+    // every (point, corner) pair is one lane's work: one grid read each, all in flight together
+    for (int idx = threadIdx.x; idx < n_points * n_term; idx += blockDim.x)
+        {
+        const int p = idx / n_term;
+        const unsigned int bits = idx % n_term;
+        unsigned int cell = 0;
+        double wt = 0.0;
+        const bool ok = interp_corner(c, sh.pts[p], bits, cell, wt);
+        sh.cell[p][bits] = cell;
+        sh.wt[p][bits] = ok ? wt : 0.0;
+        sh.val[p][bits] = ok ? (p == 1 ? c.weight[cell] : c.grid[cell]) : 0.0;
+        if (!ok && bits == 0) sh.oob[p] = 1;
+        }
+    __syncthreads();
+    if (threadIdx.x == 0)
+        {
+        double V = 0.0;
+        for (int b = 0; b < n_term; ++b) V += sh.wt[0][b] * sh.val[0][b];      // corner order of :711-733
+        sh.V_old = V;
+        double scal = 1.0;
+        if (deposit && c.mode == MTD_MODE_WELL_TEMPERED) scal = exp(-V / c.T_shift);  // :377-378
+        sh.scal = scal;
+        }
+    __syncthreads();
+    if (closed_form && deposit)
+        {
+        const double amp = c.W * sh.scal;
+        for (int idx = threadIdx.x; idx < n_points * n_term; idx += blockDim.x)
+            {
+            const int p = idx / n_term;
+            const unsigned int bits = idx % n_term;
+            if (p != 1 && !sh.oob[p])
+                {
+                const double dV = amp * exp(-gauss_exponent(c, sh.cell[p][bits], sh.cv));
+                sh.val[p][bits] += dV;
+                }
+            }
+        __syncthreads();
+        }
+    for (int p = threadIdx.x; p < n_points; p += blockDim.x)
+        {
+        double res = 0.0;
+        for (int b = 0; b < n_term; ++b) res += sh.wt[p][b] * sh.val[p][b];
+        sh.res[p] = res;
+        }
+    __syncthreads();
+    if (threadIdx.x < n)
+        {
+        const unsigned int i = threadIdx.x;
+        const double s = sh.cv[i];
+        const double delta = c.delta[i];
+        double b;
+        if (s - delta < c.cv_min[i])
+            b = (sh.res[3 + 2 * i] - sh.res[0]) / delta;                        // forward  (:746-755)
+        else if (s + delta > c.cv_max[i])
+            b = (sh.res[0] - sh.res[2 + 2 * i]) / delta;                        // backward (:756-764)
+        else
+            b = (sh.res[3 + 2 * i] - sh.res[2 + 2 * i]) / (2.0 * delta);        // central  (:765-775)
+        sh.bias[i] = b;
+        }
+    __syncthreads();
+    }
+
+// second pass of updateReweightedEstimator (:1077-1087) fused with accumulate + clear (:426-437) for grid
+// cells [cell_begin, cell_end) (one cell per thread); every block re-derives <dV> from the pass-1 block
+// partial sums in the same fixed order, so all blocks use the identical value.  s_red: >= 16 doubles of
+// shared memory.  `first` marks the single block that also advances the engine's counters.
+__device__ __forceinline__ void apply_cells(const MetadCfg &c, const unsigned int cell_begin, const unsigned int cell_end,
+                                            const bool first, double *s_red)
+    {
+    double s1 = 0.0, s2 = 0.0;
+    for (unsigned int b = threadIdx.x; b < c.n_gblocks; b += blockDim.x)
+        {
+        s1 += c.gpart[2 * b];
+        s2 += c.gpart[2 * b + 1];
+        }
+    s1 = block_sum(s1, s_red);
+    s2 = block_sum(s2, s_red);
+    const double avg_dV = s1 / s2;                                           // norm == 0 -> NaN like the reference (Q15)
+
+    const unsigned int g = cell_begin + threadIdx.x;
+    if (g < cell_end)
+        {
+        const double dV = c.grid_delta[g];
+        const double fac = exp(-(dV - avg_dV) / c.temp);                     // T, not deltaT (:1084)
+        c.rew[g] *= fac;
+        c.weight[g] /= fac;
+        c.grid[g] += dV;
+        c.sigma_grid[g] += c.sigma_grid_delta[g];
+        c.hist[g] += c.hist_delta[g];
+        c.hist_gauss[g] += c.hist_gauss_delta[g];
+        c.grid_delta[g] = 0.0;
+        c.sigma_grid_delta[g] = 0.0;
+        c.hist_delta[g] = 0;
+        c.hist_gauss_delta[g] = 0;
+        }
+    if (first && threadIdx.x == 0)
+        {
+        c.st->avg_dV = avg_dV;
+        c.st->num_gaussians += 1;                                            // :440
+        }
+    }
+
+// ------------------------------------------------------------------------------------------------
+// The same scalar chain as reduce_cv_sources + evaluate_bias, executed by ONE wave with shuffles only
+// (no __syncthreads, no LDS), so the other waves of the block can stream particles meanwhile.
+// Valid for n_cv <= 3 (then (2 n_cv + 2) 2^n_cv <= 64 (point, corner) pairs fit one wave).
+// Must be called by a full wave (all 64 lanes).  Results are returned in every lane.
+struct ChainResult
+    {
+    double cv[3];
+    double bias[3];
+    double scal, V, w;
+    unsigned int bin;
+    int on_grid, oob;
+    };
+
+constexpr int CHAIN_MAX_CV = 3;
+
+__device__ __forceinline__ ChainResult chain_wave(const MetadCfg &c, const bool deposit, const bool closed_form)
+    {
+    const int lane = threadIdx.x & 63;
+    const unsigned int n = c.n_cv;
+    const int n_term = 1 << n;
+    ChainResult r;
+
+    // 1. CV values: eight loads in flight per lane, xor-butterfly sum (every lane gets the same bits)
+#pragma unroll
+    for (int i = 0; i < CHAIN_MAX_CV; ++i)
+        {
+        r.cv[i] = 0.0;
+        r.bias[i] = 0.0;
+        if (i < (int)n)
+            {
+            const CvSource src = c.src[i];
+            double v = 0.0;
+            if (src.partials)
+                {
+                for (unsigned int b0 = lane; b0 < src.n_partials; b0 += 8 * MTD_WAVE)
+                    {
+                    double x[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j)
+                        {
+                        const unsigned int b = b0 + j * MTD_WAVE;
+                        x[j] = b < src.n_partials ? src.partials[(size_t)b * src.stride + src.offset] : 0.0;
+                        }
+                    v += ((x[0] + x[1]) + (x[2] + x[3])) + ((x[4] + x[5]) + (x[6] + x[7]));
+                    }
+                }
+            v = wave_sum(v);
+            r.cv[i] = src.partials ? src.shift + src.scale * v : src.shift;
+            }
+        }
+
+    // 2. per-dimension stencil geometry: lane 3 i + v handles CV i at s_i - delta (v=0), s_i (1), s_i + delta (2)
+    //    (interpolateGrid :675-699 for the values biasPotentialDerivative :746-775 passes in)
+    int g_lower = 0, g_ok = 0;
+    double g_rel = 0.0;
+    if (lane < 3 * (int)n)
+        {
+        // per-lane CV index i = lane / 3: select the (scalar, statically indexed) grid geometry instead of
+        // indexing the kernel-argument arrays with a vector index (that becomes a global load)
+        const int i = lane / 3, v = lane % 3;
+        const double si = i == 0 ? r.cv[0] : (i == 1 ? r.cv[1] : r.cv[2]);
+        const double delta = i == 0 ? c.delta[0] : (i == 1 ? c.delta[1] : c.delta[2]);
+        const double cmin = i == 0 ? c.cv_min[0] : (i == 1 ? c.cv_min[1] : c.cv_min[2]);
+        const double cmax = i == 0 ? c.cv_max[0] : (i == 1 ? c.cv_max[1] : c.cv_max[2]);
+        const int len = (int)(i == 0 ? c.lengths[0] : (i == 1 ? c.lengths[1] : c.lengths[2]));
+        double val = si;
+        if (v == 0) val = si - delta;
+        if (v == 2) val = si + delta;
+        g_ok = !(val < cmin || val >= cmax);
+        int lower = (int)((val - cmin) / delta);
+        int upper = lower + 1;
+        if (upper >= len)
+            {
+            lower--;
+            upper--;
+            }
+        const double lower_bound = cmin + delta * lower;
+        const double upper_bound = cmin + delta * upper;
+        g_rel = (val - lower_bound) / (upper_bound - lower_bound);
+        g_lower = lower;
+        }
+
+    // 3. (point, corner) pairs, one per lane.  points: 0 = s on the bias grid, 1+2i = s - delta_i e_i,
+    //    2+2i = s + delta_i e_i, and (only when the weight grid is final) 1+2n = s on the weight grid
+    const int n_pts = closed_form ? 1 + 2 * (int)n : 2 + 2 * (int)n;
+    const int p = lane / n_term;
+    const unsigned int bits = lane % n_term;
+    const bool is_weight = (!closed_form) && p == 1 + 2 * (int)n;
+    bool ok = p < n_pts;
+    double wt = 1.0;
+    unsigned int cell = 0;
+    double d[CHAIN_MAX_CV];
+#pragma unroll
+    for (int i = 0; i < CHAIN_MAX_CV; ++i)
+        {
+        d[i] = 0.0;
+        if (i < (int)n)
+            {
+            int var = 1;
+            if (p == 1 + 2 * i) var = 0;
+            if (p == 2 + 2 * i) var = 2;
+            const int src_lane = 3 * i + var;
+            const int lower = __shfl(g_lower, src_lane, MTD_WAVE);
+            const double rel = __shfl(g_rel, src_lane, MTD_WAVE);
+            const int oki = __shfl(g_ok, src_lane, MTD_WAVE);
+            ok = ok && oki;
+            unsigned int coord;
+            if (bits & (1u << i))
+                {
+                coord = (unsigned int)lower;
+                wt *= (1.0 - rel);
+                }
+            else
+                {
+                coord = (unsigned int)(lower + 1);
+                wt *= rel;
+                }
+            cell += coord * c.factors[i];
+            d[i] = (c.cv_min[i] + coord * c.delta[i]) - r.cv[i];     // updateGrid :1023-1026
+            }
+        }
+    double val = 0.0;
+    if (ok) val = is_weight ? c.weight[cell] : c.grid[cell];
+
+    // 4. V_old(s): corner terms of point 0 summed in the reference's order (:711-733)
+    double term = ok ? wt * val : 0.0;
+    double V_old = 0.0;
+    for (int b = 0; b < n_term; ++b) V_old += __shfl(term, b, MTD_WAVE);
+    r.scal = 1.0;
+    if (deposit && c.mode == MTD_MODE_WELL_TEMPERED) r.scal = exp(-V_old / c.T_shift);   // :377-378
+
+    // 5. post-deposit node values in closed form on the stencil
+    if (closed_form && deposit && ok)
+        {
+        double gauss_exp = 0.0;
+#pragma unroll
+        for (int i = 0; i < CHAIN_MAX_CV; ++i)
+#pragma unroll
+            for (int j = 0; j < CHAIN_MAX_CV; ++j)
+                if (i < (int)n && j < (int)n)
+                    {
+                    const double sij = c.sigma_inv[i * n + j];
+                    gauss_exp += d[i] * d[j] * (1.0 / 2.0) * (sij * sij);
+                    }
+        val += (c.W * r.scal) * exp(-gauss_exp);
+        term = wt * val;
+        }
+
+    // 6. every lane: the interpolated value of its own point, corners in order
+    const int base = (p < n_pts ? p : 0) * n_term;
+    double res = 0.0;
+    for (int b = 0; b < n_term; ++b) res += __shfl(term, base + b, MTD_WAVE);
+
+    // 7. finite differences (:738-776); all lanes execute the shuffles, every lane keeps all n results
+    const double res0 = __shfl(res, 0, MTD_WAVE);
+    r.V = res0;
+    r.w = closed_form ? 1.0 : __shfl(res, (1 + 2 * (int)n) * n_term, MTD_WAVE);
+    r.oob = !__shfl((int)ok, 0, MTD_WAVE);
+#pragma unroll
+    for (int i = 0; i < CHAIN_MAX_CV; ++i)
+        {
+        if (i < (int)n)
+            {
+            const double rm = __shfl(res, (1 + 2 * i) * n_term, MTD_WAVE);
+            const double rp = __shfl(res, (2 + 2 * i) * n_term, MTD_WAVE);
+            const double s = r.cv[i];
+            const double delta = c.delta[i];
+            double b;
+            if (s - delta < c.cv_min[i])
+                b = (rp - res0) / delta;                          // forward  (:746-755)
+            else if (s + delta > c.cv_max[i])
+                b = (res0 - rm) / delta;                          // backward (:756-764)
+            else
+                b = (rp - rm) / (2.0 * delta);                    // central  (:765-775)
+            r.bias[i] = b;
+            }
+        }
+    // histogram bin (updateHistogram :1092-1119), statically unrolled (no private-memory arrays)
+    bool on_grid = true;
+    unsigned int bin = 0;
+#pragma unroll
+    for (int i = 0; i < CHAIN_MAX_CV; ++i)
+        {
+        if (i < (int)n)
+            {
+            const double q = (r.cv[i] - c.cv_min[i]) / c.delta[i];
+            if (!(q > -1.0) || !(q < 4294967296.0))
+                on_grid = false;
+            else
+                {
+                const unsigned int coord = (unsigned int)q;
+                if (coord >= c.lengths[i]) on_grid = false;
+                bin += coord * c.factors[i];
+                }
+            }
+        }
+    r.on_grid = on_grid ? 1 : 0;
+    r.bin = bin;
+    return r;
+    }
+
+// gauss_exponent for n_cv <= 3 without private-memory arrays or integer division loops over a runtime
+// dimension count (same arithmetic, statically unrolled)
+__device__ __forceinline__ double gauss_exponent3(const MetadCfg &c, unsigned int idx, const double s0, const double s1,
+                                                  const double s2)
+    {
+    const unsigned int n = c.n_cv;
+    unsigned int rest = idx;
+    unsigned int c2 = 0, c1 = 0, c0;
+    if (n > 2)
+        {
+        c2 = rest / c.factors[2];
+        rest -= c2 * c.factors[2];
+        }
+    if (n > 1)
+        {
+        c1 = rest / c.factors[1];
+        rest -= c1 * c.factors[1];
+        }
+    c0 = rest;
+    double d[3];
+    d[0] = (c.cv_min[0] + c0 * c.delta[0]) - s0;
+    d[1] = n > 1 ? (c.cv_min[1] + c1 * c.delta[1]) - s1 : 0.0;
+    d[2] = n > 2 ? (c.cv_min[2] + c2 * c.delta[2]) - s2 : 0.0;
+    double gauss_exp = 0.0;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+            if (i < (int)n && j < (int)n)
+                {
+                const double sij = c.sigma_inv[i * n + j];
+                gauss_exp += d[i] * d[j] * (1.0 / 2.0) * (sij * sij);
+                }
+    return gauss_exp;
+    }
+
+} // namespace mtd

@@ -9,7 +9,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 PKG_ROOT = os.path.dirname(_HERE)
 REPO_ROOT = os.path.dirname(PKG_ROOT)
-LIB_PATH = os.path.join(PKG_ROOT, "lib", "libmtd_hip.so")
+LIB_PATH = os.environ.get("MTD_LIB_OVERRIDE") or os.path.join(PKG_ROOT, "lib", "libmtd_hip.so")  # override: diagnostic builds only
 HEADER_PATH = os.path.join(REPO_ROOT, "include", "mtd_abi.h")
 
 MTD_MAX_CV = 8
@@ -125,6 +125,9 @@ _SIGNATURES = {
     "mtd_metad_set_array": (C.c_int, [_vp, C.c_int, _vp, _vp]),
     "mtd_metad_set_num_gaussians": (C.c_int, [_vp, C.c_uint, _vp]),
     "mtd_metad_device_array": (_vp, [_vp, C.c_int]),
+    "mtd_fused_cv_pass": (C.c_int, [_vp, C.POINTER(LamellarSet), C.c_uint, _vp, C.c_int, C.POINTER(Box), _vp, _up, _vp]),
+    "mtd_fused_force_pass": (C.c_int, [_vp, C.POINTER(LamellarSet), C.c_uint, _vp, C.POINTER(_vp), C.c_int, C.c_uint,
+                                        C.POINTER(Box), C.c_uint, _vp]),
     "mtd_wte_scratch_doubles": (C.c_size_t, [C.c_uint]),
     "mtd_wte_energy_partials": (C.c_int, [C.c_uint, _vp, C.c_int, _vp, _up, _vp]),
     "mtd_wte_scale_netforce": (C.c_int, [C.c_uint, _vp, _vp, _vp, C.c_uint, C.c_int, _vp, C.c_double, C.c_int, _vp]),

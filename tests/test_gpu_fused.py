@@ -1,0 +1,144 @@
+"""GPU parity: the fused two-launch bias step (mtd_fused_cv_pass / mtd_fused_force_pass) vs the oracle.
+
+The fused path forms dV/ds_c from closed-form post-deposit node values and defers the second
+reweighting pass into the next launch; after a flush (get_state / get_array) every grid array,
+V(s), w(s), the bias factors and the per-particle forces must match the oracle's
+updateBiasPotential + computeBiasForces sequence.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import util
+from test_gpu_metad import GpuMetad, compare
+
+torch = pytest.importorskip("torch")
+
+pytestmark = pytest.mark.gpu
+
+CVS = [(util.CV1_VECTORS, util.MODE_AB), (util.CV2_VECTORS, util.MODE_AB)]
+
+
+def make_traj(N, L, steps, dtype=np.float32):
+    """a modulated snapshot whose modulation amplitude drifts, so both CVs move from step to step"""
+    rng = np.random.default_rng(42)
+    base = rng.random((N, 3)) * L - L / 2
+    types = (np.arange(N) % 2).astype(np.int32)
+    a = np.where(types == 0, 1.0, -1.0)
+    out = []
+    for t in range(steps):
+        pos = base.copy()
+        pos[:, 2] += (1.0 + 0.15 * t) * a * np.sin(2 * np.pi * 3 * pos[:, 2] / L)
+        pos[:, 0] += (0.4 + 0.1 * t) * a * np.sin(2 * np.pi * (pos[:, 0] + pos[:, 1] + pos[:, 2]) / L)
+        out.append(pos.astype(dtype))
+    return out, types
+
+
+class Fused:
+    def __init__(self, abi, g, N, dtype):
+        self.abi, self.g, self.N = abi, g, N
+        self.lib = abi.load()
+        self.lset = abi.LamellarSet.make(CVS)
+        self.dt = abi.MTD_F32 if dtype == np.float32 else abi.MTD_F64
+        self.tdt = torch.float32 if dtype == np.float32 else torch.float64
+        self.scratch = torch.zeros(self.lib.mtd_lamellar_scratch_doubles(N), dtype=torch.float64, device="cuda")
+        self.forces = [torch.zeros((N, 4), dtype=self.tdt, device="cuda") for _ in CVS]
+        self.fptr = (C.c_void_p * 2)(*[f.data_ptr() for f in self.forces])
+        self.registered = False
+
+    def step(self, t, d_pos, box, n_global=None):
+        lib, abi = self.lib, self.abi
+        n_part = C.c_uint()
+        abi.check(lib.mtd_fused_cv_pass(self.g.h, C.byref(self.lset), self.N, abi.ptr(d_pos), self.dt, C.byref(box),
+                                        abi.ptr(self.scratch), C.byref(n_part), None))
+        if not self.registered:
+            for c in range(2):
+                abi.check(lib.mtd_metad_set_cv_source(self.g.h, c, abi.ptr(self.scratch), n_part.value, 2, c,
+                                                      1.0 / (n_global or self.N), 0.0))
+            self.registered = True
+        abi.check(lib.mtd_fused_force_pass(self.g.h, C.byref(self.lset), self.N, abi.ptr(d_pos), self.fptr, self.dt,
+                                           n_global or self.N, C.byref(box), t, None))
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("stride,add_bias", [(1, True), (3, True), (1, False)])
+def test_fused_sequence(abi, ref, dtype, stride, add_bias):
+    N, L, steps = 30011, 50.0, 7
+    traj, types = make_traj(N, L, steps, dtype)
+    box, rbox = abi.Box.make(L), ref.Box.make(L)
+    kw = dict(sigma=[0.02, 0.01], cv_min=[-0.6, -0.3], cv_max=[0.4, 0.3], num_points=[64, 48], W=1.0, T_shift=7.0,
+              T=1.0, stride=stride, mode="well_tempered", add_bias=add_bias)
+
+    # run 1: flush (get_state) after every step and compare everything step by step
+    g = GpuMetad(abi, **kw)
+    r = ref.Metad(**kw)
+    cv_log = []
+    try:
+        f = Fused(abi, g, N, dtype)
+        for t in range(steps):
+            d_pos = torch.from_numpy(util.pack_postype(traj[t], types, dtype)).cuda()
+            f.step(t, d_pos, box)
+            torch.cuda.synchronize()
+            # the forces were computed from the closed-form bias BEFORE any flush: grab them first
+            F = [x.cpu().numpy().astype(np.float64) for x in f.forces]
+            st = g.state()
+            opt = util.oracle_postype(traj[t], types)
+            s_ref = [ref.lamellar_cv(v, opt, m, rbox) for v, m in CVS]
+            assert abs(st["cv"][0] - s_ref[0]) <= 1e-6 * abs(s_ref[0])
+            assert abs(st["cv"][1] - s_ref[1]) <= max(1e-6 * abs(s_ref[1]), 1e-6 * 8 / np.sqrt(N))
+            cv_log.append(st["cv"].copy())
+            b = r.update_bias(t, st["cv"])          # oracle grid driven with the device's CV values
+            compare(g, r, b, label="fused step %d" % t)
+            for c, (v, m) in enumerate(CVS):
+                F_ref = ref.lamellar_forces(v, opt, m, rbox, b[c])
+                scale = np.abs(F_ref[:, :3]).max()
+                if scale > 0:
+                    assert np.abs(F[c][:, :3] - F_ref[:, :3]).max() <= 1e-5 * scale, (t, c)
+                else:
+                    assert np.all(F[c][:, :3] == 0.0)
+                assert np.all(F[c][:, 3] == 0.0)
+    finally:
+        g.close()
+
+    # run 2: no host read-back between steps — the deferred apply rides in the next CV launch
+    g = GpuMetad(abi, **kw)
+    r = ref.Metad(**kw)
+    try:
+        f = Fused(abi, g, N, dtype)
+        d_traj = [torch.from_numpy(util.pack_postype(p, types, dtype)).cuda() for p in traj]
+        for t in range(steps):
+            f.step(t, d_traj[t], box)
+        for t in range(steps):
+            b = r.update_bias(t, cv_log[t])
+        compare(g, r, b, label="fused deferred")
+        assert np.array_equal(g.state()["cv"], cv_log[-1])   # deterministic: same bits as run 1
+    finally:
+        g.close()
+
+
+def test_fused_sharded_n_global(abi, ref):
+    """a shard of a larger system: N_global != N scales CV and forces (what each rank does multi-GPU)"""
+    N, L = 10007, 30.0
+    traj, types = make_traj(N, L, 1)
+    box, rbox = abi.Box.make(L), ref.Box.make(L)
+    kw = dict(sigma=[0.02, 0.01], cv_min=[-0.6, -0.3], cv_max=[0.4, 0.3], num_points=[32, 32], W=1.0, T_shift=7.0,
+              T=1.0, stride=1, mode="well_tempered")
+    g = GpuMetad(abi, **kw)
+    r = ref.Metad(**kw)
+    try:
+        f = Fused(abi, g, N, np.float32)
+        d_pos = torch.from_numpy(util.pack_postype(traj[0], types, np.float32)).cuda()
+        f.step(0, d_pos, box, n_global=4 * N)
+        torch.cuda.synchronize()
+        F = f.forces[0].cpu().numpy().astype(np.float64)
+        st = g.state()
+        opt = util.oracle_postype(traj[0], types)
+        s_ref = ref.lamellar_cv(util.CV1_VECTORS, opt, util.MODE_AB, rbox, n_global=4 * N)
+        assert abs(st["cv"][0] - s_ref) <= 1e-6 * abs(s_ref)
+        b = r.update_bias(0, st["cv"])
+        compare(g, r, b)
+        F_ref = ref.lamellar_forces(util.CV1_VECTORS, opt, util.MODE_AB, rbox, b[0], n_global=4 * N)
+        assert np.abs(F[:, :3] - F_ref[:, :3]).max() <= 1e-5 * np.abs(F_ref[:, :3]).max()
+    finally:
+        g.close()

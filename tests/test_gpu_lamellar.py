@@ -75,7 +75,7 @@ def test_config0b_cv_and_forces(abi, ref, fast):
     box, rbox = _box(abi, ref, L)
     lat = [(0, 0, 4)]
     s_ref = ref.lamellar_cv(lat, util.oracle_postype(pos, types), util.MODE_AB, rbox)
-    assert abs(s_ref) > 0.5  # strongly ordered by construction
+    assert abs(s_ref) > 0.4  # strongly ordered by construction
     s = gpu_cv(abi, [(lat, util.MODE_AB)], util.pack_postype(pos, types, np.float32), box, fast=fast)
     assert abs(s[0] - s_ref) <= 1e-6 * abs(s_ref)
     F_ref = ref.lamellar_forces(lat, util.oracle_postype(pos, types), util.MODE_AB, rbox, bias=-3.25)

@@ -74,8 +74,8 @@ def compare(g, r, bias_ref, label=""):
     if not np.isnan(bias_ref).any():
         assert np.allclose(st["bias"], bias_ref, rtol=1e-9, atol=1e-9 * max(1.0, np.abs(r.array("grid")).max())), \
             (label, st["bias"], bias_ref)
-        assert st["V"] == pytest.approx(r.curr_bias, rel=1e-11, abs=1e-300), label
-        assert st["w"] == pytest.approx(r.curr_weight, rel=1e-11, abs=1e-300), label
+        assert st["V"] == pytest.approx(r.curr_bias, rel=1e-11, abs=1e-300, nan_ok=True), label
+        assert st["w"] == pytest.approx(r.curr_weight, rel=1e-11, abs=1e-300, nan_ok=True), label
     assert st["num_gaussians"] == r.num_gaussians, label
 
 

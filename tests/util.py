@@ -14,7 +14,7 @@ def snapshot_config0b():
     rng = np.random.default_rng(2024)
     n = 16
     ix, iy, iz = np.meshgrid(np.arange(n), np.arange(n), np.arange(n), indexing="ij")
-    pos = np.stack([ix, iy, iz], axis=-1).reshape(-1, 3).astype(np.float64) + 0.5 - n / 2
+    pos = np.stack([ix, iy, iz], axis=-1).reshape(-1, 3).astype(np.float64) - n / 2  # lattice sites at lo + i*a
     pos += rng.uniform(-0.1, 0.1, size=pos.shape)
     types = (iz.reshape(-1) % 4 >= 2).astype(np.int32)  # A (0) if iz mod 4 < 2 else B (1)
     return pos, types, float(n)
