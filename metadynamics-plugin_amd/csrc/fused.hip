@@ -24,10 +24,7 @@
 // dependency on the first pass: it is deferred into the next launch A (or mtd_metad_get_state /
 // get_array, which flush it), so the grid arrays are "one apply behind" between B and the next A.
 // Forces never wait for it: dV/ds_c only needs grid_old + dV on <= (2 n_cv + 1) 2^n_cv cells.
-#include "lamellar_host.hpp"
-#include "metad_host.hpp"
-
-#include <cstdlib>
+#include <hip/hip_runtime.h>
 
 // Diagnostic build only (-DMTD_STAMPS, tools/stamps.sh): s_memrealtime (100 MHz) stamps of one grid block and
 // one particle block per kernel, written to a buffer of their own; the product build has no stamps.
@@ -45,6 +42,11 @@ extern "C" int mtd_debug_read_stamps(unsigned long long *host)
 #else
 #define MTD_STAMP(slot, cond) do { } while (0)
 #endif
+
+#include "lamellar_host.hpp"
+#include "metad_host.hpp"
+
+#include <cstdlib>
 
 namespace
 {

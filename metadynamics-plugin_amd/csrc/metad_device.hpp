@@ -7,6 +7,10 @@
 
 #include "mtd_device.hpp"
 
+#ifndef MTD_STAMP
+#define MTD_STAMP(slot, cond) do { } while (0)
+#endif
+
 namespace mtd
 {
 
@@ -356,7 +360,29 @@ __device__ __forceinline__ ChainResult chain_wave(const MetadCfg &c, const bool 
     const int n_term = 1 << n;
     ChainResult r;
 
-    // 1. CV values: eight loads in flight per lane, xor-butterfly sum (every lane gets the same bits)
+    // 1. CV values: the loads of ALL CVs are issued before the first add (one memory round trip, not one
+    //    per CV), eight in flight per lane and CV; xor-butterfly sums give every lane the same bits
+    double x[CHAIN_MAX_CV][8];
+    unsigned int n_part_max = 0;
+#pragma unroll
+    for (int i = 0; i < CHAIN_MAX_CV; ++i)
+        if (i < (int)n && c.src[i].partials) n_part_max = max(n_part_max, c.src[i].n_partials);
+    double v[CHAIN_MAX_CV] = { 0.0, 0.0, 0.0 };
+    for (unsigned int b0 = lane; b0 < n_part_max; b0 += 8 * MTD_WAVE)
+        {
+#pragma unroll
+        for (int i = 0; i < CHAIN_MAX_CV; ++i)
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                {
+                const unsigned int b = b0 + j * MTD_WAVE;
+                x[i][j] = (i < (int)n && c.src[i].partials && b < c.src[i].n_partials)
+                              ? c.src[i].partials[(size_t)b * c.src[i].stride + c.src[i].offset] : 0.0;
+                }
+#pragma unroll
+        for (int i = 0; i < CHAIN_MAX_CV; ++i)
+            v[i] += ((x[i][0] + x[i][1]) + (x[i][2] + x[i][3])) + ((x[i][4] + x[i][5]) + (x[i][6] + x[i][7]));
+        }
 #pragma unroll
     for (int i = 0; i < CHAIN_MAX_CV; ++i)
         {
@@ -364,27 +390,12 @@ __device__ __forceinline__ ChainResult chain_wave(const MetadCfg &c, const bool 
         r.bias[i] = 0.0;
         if (i < (int)n)
             {
-            const CvSource src = c.src[i];
-            double v = 0.0;
-            if (src.partials)
-                {
-                for (unsigned int b0 = lane; b0 < src.n_partials; b0 += 8 * MTD_WAVE)
-                    {
-                    double x[8];
-#pragma unroll
-                    for (int j = 0; j < 8; ++j)
-                        {
-                        const unsigned int b = b0 + j * MTD_WAVE;
-                        x[j] = b < src.n_partials ? src.partials[(size_t)b * src.stride + src.offset] : 0.0;
-                        }
-                    v += ((x[0] + x[1]) + (x[2] + x[3])) + ((x[4] + x[5]) + (x[6] + x[7]));
-                    }
-                }
-            v = wave_sum(v);
-            r.cv[i] = src.partials ? src.shift + src.scale * v : src.shift;
+            const double t = wave_sum(v[i]);
+            r.cv[i] = c.src[i].partials ? c.src[i].shift + c.src[i].scale * t : c.src[i].shift;
             }
         }
 
+    MTD_STAMP(40, blockIdx.x == 0 && threadIdx.x == 0 && closed_form);
     // 2. per-dimension stencil geometry: lane 3 i + v handles CV i at s_i - delta (v=0), s_i (1), s_i + delta (2)
     //    (interpolateGrid :675-699 for the values biasPotentialDerivative :746-775 passes in)
     int g_lower = 0, g_ok = 0;
@@ -416,6 +427,7 @@ __device__ __forceinline__ ChainResult chain_wave(const MetadCfg &c, const bool 
         g_lower = lower;
         }
 
+    MTD_STAMP(41, blockIdx.x == 0 && threadIdx.x == 0 && closed_form);
     // 3. (point, corner) pairs, one per lane.  points: 0 = s on the bias grid, 1+2i = s - delta_i e_i,
     //    2+2i = s + delta_i e_i, and (only when the weight grid is final) 1+2n = s on the weight grid
     const int n_pts = closed_form ? 1 + 2 * (int)n : 2 + 2 * (int)n;
@@ -458,6 +470,7 @@ __device__ __forceinline__ ChainResult chain_wave(const MetadCfg &c, const bool 
     double val = 0.0;
     if (ok) val = is_weight ? c.weight[cell] : c.grid[cell];
 
+    MTD_STAMP(42, blockIdx.x == 0 && threadIdx.x == 0 && closed_form);
     // 4. V_old(s): corner terms of point 0 summed in the reference's order (:711-733)
     double term = ok ? wt * val : 0.0;
     double V_old = 0.0;
@@ -465,6 +478,7 @@ __device__ __forceinline__ ChainResult chain_wave(const MetadCfg &c, const bool 
     r.scal = 1.0;
     if (deposit && c.mode == MTD_MODE_WELL_TEMPERED) r.scal = exp(-V_old / c.T_shift);   // :377-378
 
+    MTD_STAMP(43, blockIdx.x == 0 && threadIdx.x == 0 && closed_form);
     // 5. post-deposit node values in closed form on the stencil
     if (closed_form && deposit && ok)
         {
@@ -482,6 +496,7 @@ __device__ __forceinline__ ChainResult chain_wave(const MetadCfg &c, const bool 
         term = wt * val;
         }
 
+    MTD_STAMP(44, blockIdx.x == 0 && threadIdx.x == 0 && closed_form);
     // 6. every lane: the interpolated value of its own point, corners in order
     const int base = (p < n_pts ? p : 0) * n_term;
     double res = 0.0;
@@ -511,6 +526,7 @@ __device__ __forceinline__ ChainResult chain_wave(const MetadCfg &c, const bool 
             r.bias[i] = b;
             }
         }
+    MTD_STAMP(45, blockIdx.x == 0 && threadIdx.x == 0 && closed_form);
     // histogram bin (updateHistogram :1092-1119), statically unrolled (no private-memory arrays)
     bool on_grid = true;
     unsigned int bin = 0;

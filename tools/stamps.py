@@ -24,3 +24,4 @@ print("k_fused_cv   cv block0   : entry->tables %s  ->accumulate %s  ->reduce/st
 print("k_fused_force grid block0 : entry->chain %s  ->sync %s  ->cells %s  ->block sums %s | kernel A start -> B start %s" % (rel(16, 17), rel(17, 18), rel(18, 19), rel(19, 20), rel(0, 16)))
 print("k_fused_force force block : entry->tables %s  wave0 chain %s | wave1: tables->unscaled %s ->sync %s ->stored %s | grid entry -> force entry %s" % (rel(24, 25), rel(25, 26), rel(25, 27), rel(27, 28), rel(28, 29), rel(16, 24)))
 print("A entry -> next... B end(grid blk) %s ; B force store end %s (both from B grid-block entry)" % (rel(16, 20), rel(16, 29)))
+print("chain (grid block0): entry->cv sums %s  ->geometry %s  ->pairs+grid loads %s  ->V_old,scal %s  ->closed form %s  ->res,bias %s  ->bin(end) %s" % (rel(16, 40), rel(40, 41), rel(41, 42), rel(42, 43), rel(43, 44), rel(44, 45), rel(45, 17)))
