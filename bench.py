@@ -55,94 +55,58 @@ def parse():
 
 
 class Engine:
-    """The hot path through the C-ABI, device resident."""
+    """The hot path through the C-ABI, device resident (metadynamics.sharded.HipLamellarBackend)."""
 
     def __init__(self, n_local, n_global, rank, seed, stride, fast_trig, dist=None, path="fused"):
-        self.lib = lib = _abi.load()
+        from metadynamics.sharded import HipLamellarBackend, ShardedBiasStep
         self.dist = dist
-        self.fused = path == "fused"
-        self.N, self.N_global = n_local, n_global
         L = BOX_L * (n_global / N_PER_GPU) ** (1.0 / 3.0)  # constant density (config 4: L = 200 at 8e6)
-        pos, types = util.snapshot_random(n_global, L, seed=seed, dtype=np.float32) if dist is None else \
-            self._shard(n_global, L, seed, rank, n_local)
+        pos, types = util.snapshot_random(n_global, L, seed=seed, dtype=np.float32)
+        if dist is not None:
+            # every rank draws the same global snapshot and keeps its contiguous slice (lamellar CVs need no locality)
+            sl = slice(rank * n_local, (rank + 1) * n_local)
+            pos, types = pos[sl].copy(), types[sl].copy()
         self.pos_np, self.types_np, self.L = pos, types, L
-        self.box = _abi.Box.make(L)
-        self.cvs = [(util.CV1_VECTORS, util.MODE_AB), (util.CV2_VECTORS, util.MODE_AB)]
-        self.lset = _abi.LamellarSet.make(self.cvs)
-        self.d_pos = torch.from_numpy(util.pack_postype(pos, types, np.float32)).cuda()
-        self.scratch = torch.zeros(lib.mtd_lamellar_scratch_doubles(n_local), dtype=torch.float64, device="cuda")
-        self.cv_sum = torch.zeros(2, dtype=torch.float64, device="cuda")
-        self.forces = [torch.zeros((n_local, 4), dtype=torch.float32, device="cuda") for _ in self.cvs]
-        self.fptr = (C.c_void_p * 2)(*[f.data_ptr() for f in self.forces])
-        self.h = C.c_void_p()
-        _abi.check(lib.mtd_metad_create(C.byref(self.h), 2, util.dbl_array(GRID["sigma"]), util.dbl_array(GRID["cv_min"]),
-                                        util.dbl_array(GRID["cv_max"]), util.uint_array(GRID["num_points"]), W, DELTA_T,
-                                        T, stride, _abi.MODE_WELL_TEMPERED, 1))
-        self.d_bias = lib.mtd_metad_bias_device(self.h)
-        self.n_part = C.c_uint()
-        _abi.check(lib.mtd_lamellar_set_fast_trig(int(fast_trig)))
+        cvs = [(util.CV1_VECTORS, util.MODE_AB), (util.CV2_VECTORS, util.MODE_AB)]
+        d_pos = torch.from_numpy(util.pack_postype(pos, types, np.float32)).cuda()
+        self.be = HipLamellarBackend(cvs, d_pos, n_global, L, GRID, W, DELTA_T, T, stride, "well_tempered",
+                                     fast_trig=bool(fast_trig), fused=(path == "fused"))
+        self.sharded = ShardedBiasStep(self.be, dist) if dist is not None else None
         self.t = 0
         self.ev = None
 
-    @staticmethod
-    def _shard(n_global, L, seed, rank, n_local):
-        # every rank draws the same global snapshot and keeps its contiguous slice (lamellar CVs need no locality)
-        pos, types = util.snapshot_random(n_global, L, seed=seed, dtype=np.float32)
-        sl = slice(rank * n_local, (rank + 1) * n_local)
-        return pos[sl].copy(), types[sl].copy()
-
-    def _register_sources(self):
-        lib = self.lib
-        for c in range(2):
-            if self.dist is None:
-                _abi.check(lib.mtd_metad_set_cv_source(self.h, c, self.scratch.data_ptr(), self.n_part.value, 2, c,
-                                                       1.0 / self.N_global, 0.0))
-            else:
-                _abi.check(lib.mtd_metad_set_cv_source(self.h, c, self.cv_sum.data_ptr(), 1, 2, c,
-                                                       1.0 / self.N_global, 0.0))
-
     def step(self):
-        lib, lset, box = self.lib, self.lset, self.box
-        # launch A: per-CV partial sums over the particles (+ the deferred grid pass of the previous deposit)
-        if self.fused:
-            _abi.check(lib.mtd_fused_cv_pass(self.h, C.byref(lset), self.N, self.d_pos.data_ptr(), _abi.MTD_F32,
-                                             C.byref(box), self.scratch.data_ptr(), C.byref(self.n_part), None))
+        be = self.be
+        if self.ev is None:
+            if self.sharded is not None:
+                self.sharded.step(self.t)      # launch A, reduce, RCCL all-reduce of n_cv doubles, launch B
+            else:
+                be.step_single(self.t)         # launch A, launch B
         else:
-            _abi.check(lib.mtd_lamellar_cv_partials(C.byref(lset), self.N, self.d_pos.data_ptr(), _abi.MTD_F32,
-                                                    C.byref(box), self.scratch.data_ptr(), C.byref(self.n_part), None))
-        if self.dist is not None:
-            # local partial sums -> 2 doubles -> RCCL all-reduce -> the grid engine reads the reduced sums
-            _abi.check(lib.mtd_reduce_partials(self.scratch.data_ptr(), self.n_part.value, 2, 2, 1.0, 0.0,
-                                               self.cv_sum.data_ptr(), None))
-            self.dist.all_reduce(self.cv_sum)
-        if self.t == 0:
-            self._register_sources()
-        if self.ev is not None:
+            # same step with the dominant kernel bracketed by events on the launch stream
+            if self.sharded is not None:
+                sums = be.cv_pass()
+                self.dist.all_reduce(sums)
+            else:
+                be.cv_partials()
+                sums = None
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        # launch B: bias-grid update + bias forces
-        if self.fused:
-            if self.ev is not None:
+            if be.fused:
                 a.record()
-            _abi.check(lib.mtd_fused_force_pass(self.h, C.byref(lset), self.N, self.d_pos.data_ptr(), self.fptr,
-                                                _abi.MTD_F32, self.N_global, C.byref(box), self.t, None))
-        else:
-            _abi.check(lib.mtd_metad_update_bias(self.h, self.t, None))
-            if self.ev is not None:
+                be.force_pass(sums, self.t)
+            else:
+                # generic path: the grid kernels run first, the events bracket the force kernel only
+                be._set_sources(be.scratch.data_ptr(), be.n_part.value) if sums is None else be._set_sources(sums.data_ptr(), 1)
+                _abi.check(be.lib.mtd_metad_update_bias(be.h, self.t, None))
                 a.record()
-            _abi.check(lib.mtd_lamellar_forces(C.byref(lset), self.N, self.d_pos.data_ptr(), self.fptr, _abi.MTD_F32,
-                                               self.N_global, self.d_bias, C.byref(box), None))
-        if self.ev is not None:
+                _abi.check(be.lib.mtd_lamellar_forces(C.byref(be.lset), be.N, be.d_pos.data_ptr(), be.fptr, be.dt,
+                                                      be.N_global, be.d_bias, C.byref(be.box), None))
             b.record()
             self.ev.append((a, b))
         self.t += 1
 
     def state(self):
-        cv = (C.c_double * 2)()
-        bias = (C.c_double * 2)()
-        V, w = C.c_double(), C.c_double()
-        ng = C.c_uint()
-        _abi.check(self.lib.mtd_metad_get_state(self.h, cv, bias, C.byref(V), C.byref(w), C.byref(ng), None, None))
-        return dict(cv=list(cv), bias=list(bias), V=V.value, w=w.value, num_gaussians=ng.value)
+        return self.be.state()
 
 
 def cpu_baseline(pos, types, L, steps):
@@ -204,14 +168,25 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
-    # dominant kernel (force pass): per-launch durations from events on the launch stream, same loop
+    # dominant kernel (force pass): per-launch durations from HIP events on the launch stream, over the same
+    # loop.  An event pair costs the command processor two extra barrier packets; that fixed overhead is
+    # calibrated with empty pairs (nothing between the two records) and subtracted, so the figure is
+    # comparable with the kernel-trace duration of the rocprofv3 summary under profiles/.
     eng.ev = []
     n_ev = min(args.steps, 500)
     for _ in range(n_ev):
         eng.step()
+    empty = []
+    for _ in range(200):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        b.record()
+        empty.append((a, b))
     torch.cuda.synchronize()
-    force_us = float(np.median([a.elapsed_time(b) for a, b in eng.ev]) * 1e3)
-    force_us_mean = float(np.mean([a.elapsed_time(b) for a, b in eng.ev]) * 1e3)
+    ev_overhead_us = float(np.median([a.elapsed_time(b) for a, b in empty]) * 1e3)
+    raw = np.array([a.elapsed_time(b) for a, b in eng.ev]) * 1e3
+    force_us = float(np.median(raw) - ev_overhead_us)
+    force_us_mean = float(np.mean(raw) - ev_overhead_us)
     eng.ev = None
     st = eng.state()
 
@@ -246,7 +221,7 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "k_fused_force" if args.path == "fused" else "k_lamellar_forces", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "algorithmic_bytes_per_launch": force_bytes, "avg_launch_us": force_us_mean,
-                         "median_launch_us": force_us},
+                         "median_launch_us": force_us, "event_pair_overhead_us": ev_overhead_us},
             "state": st,
         }
         if not args.no_cpu_baseline:
