@@ -1,0 +1,765 @@
+// metadynamics_host.cc — see metadynamics_host.h.  Reference citations are file:line under
+// /root/reference/metadynamics/.
+#include "metadynamics_host.h"
+
+#include <sys/stat.h>
+
+#include <cstdio>
+#include <iomanip>
+#include <iostream>
+#include <sstream>
+
+namespace mtdhost
+{
+
+// ------------------------------------------------------------------------------------------------
+// CollectiveVariable
+// ------------------------------------------------------------------------------------------------
+
+CollectiveVariable::CollectiveVariable(std::shared_ptr<SystemDefinition> sysdef, const std::string &name)
+    : ForceCompute(sysdef), m_bias(0.0), m_bias_device(nullptr), m_cv_name(name), m_umbrella(no_umbrella), m_cv0(0.0),
+      m_kappa(1.0), m_width_flat(0.0), m_scale(1.0)
+    {
+    }
+
+void CollectiveVariable::enqueueCurrentValue(unsigned int timestep, mtd_metad *engine, unsigned int slot)
+    {
+    mtd_check(mtd_metad_set_cv_value(engine, slot, getCurrentValue(timestep)), "mtd_metad_set_cv_value");
+    }
+
+// CollectiveVariable.cc:22-66
+void CollectiveVariable::computeForces(unsigned int timestep)
+    {
+    if (m_umbrella != no_umbrella)
+        {
+        // the umbrella adds to a HOST bias factor: fetch the device-resident one first (synchronises)
+        if (m_bias_device)
+            {
+            double b = 0.0;
+            hip_check(hipMemcpy(&b, m_bias_device, sizeof(double), hipMemcpyDeviceToHost), "bias read-back");
+            setBiasFactor(b);
+            }
+        double val = getCurrentValue(timestep);
+        if ((val < m_cv0 + m_width_flat / 2.0) && (val > m_cv0 - m_width_flat / 2.0))
+            {
+            // leave bias as it is
+            }
+        else
+            {
+            double delta = 0.0;
+            if (val > m_cv0)
+                delta = val - m_cv0 - m_width_flat / 2.0;
+            else
+                delta = val - m_cv0 + m_width_flat / 2.0;
+
+            if (m_umbrella == linear)
+                setBiasFactor(m_bias + m_scale * 1.0);
+            else if (m_umbrella == harmonic)
+                setBiasFactor(m_bias + m_kappa * delta);
+            else if (m_umbrella == wall)
+                setBiasFactor(m_bias + m_scale * 12.0 * std::pow(delta / m_kappa, 11.0) / m_kappa);
+            else if (m_umbrella == gaussian)
+                setBiasFactor(m_bias - m_scale * (val - m_cv0) * std::exp(-(val - m_cv0) * (val - m_cv0) / m_kappa / m_kappa / 2.0));
+            }
+        }
+
+    computeBiasForces(timestep);
+
+    // reset bias factor
+    setBiasFactor(0.0);
+    }
+
+// CollectiveVariable.cc:68-106
+double CollectiveVariable::getUmbrellaPotential(unsigned int timestep)
+    {
+    if (m_umbrella != no_umbrella)
+        {
+        double val = getCurrentValue(timestep);
+        if ((val < m_cv0 + m_width_flat / 2.0) && (val > m_cv0 - m_width_flat / 2.0)) return 0.0;
+        double delta = 0.0;
+        if (val > m_cv0)
+            delta = val - m_cv0 - m_width_flat / 2.0;
+        else if (val < m_cv0)
+            delta = val - m_cv0 + m_width_flat / 2.0;
+        if (m_umbrella == linear) return m_scale * delta;
+        if (m_umbrella == harmonic) return (1.0 / 2.0) * delta * delta * m_kappa;
+        if (m_umbrella == wall) return m_scale * std::pow(delta / m_kappa, 12.0);
+        if (m_umbrella == gaussian) return m_scale * std::exp(-(val - m_cv0) * (val - m_cv0) / m_kappa / m_kappa / 2.0) - m_scale;
+        }
+    return 0.0;
+    }
+
+// ------------------------------------------------------------------------------------------------
+// LamellarOrderParameterGPU
+// ------------------------------------------------------------------------------------------------
+
+LamellarOrderParameterGPU::LamellarOrderParameterGPU(std::shared_ptr<SystemDefinition> sysdef, const std::vector<double> &mode,
+                                                     const std::vector<int3> &lattice_vectors, const std::string &suffix)
+    : CollectiveVariable(sysdef, "cv_lamellar"), m_mode(mode), m_lattice_vectors(lattice_vectors), m_n_partials(0), m_cv(0.0),
+      m_cv_last_updated(0)
+    {
+    if (mode.size() != m_pdata->getNTypes())                          // LamellarOrderParameter.cc:14-18
+        throw std::runtime_error("cv.lamellar: Number of mode parameters has to equal the number of particle types!");
+    if (lattice_vectors.empty() || lattice_vectors.size() > MTD_MAX_MODES)
+        throw std::runtime_error("cv.lamellar: between 1 and " + std::to_string(MTD_MAX_MODES) + " lattice vectors are supported");
+    if (mode.size() > MTD_MAX_TYPES) throw std::runtime_error("cv.lamellar: too many particle types");
+    m_cv_name += suffix;
+    m_log_name = m_cv_name;
+
+    std::memset(&m_set, 0, sizeof(m_set));
+    m_set.n_cv = 1;
+    m_set.n_types = (unsigned int)mode.size();
+    m_set.n_modes = (unsigned int)lattice_vectors.size();
+    m_set.first[0] = 0;
+    m_set.first[1] = m_set.n_modes;
+    for (unsigned int k = 0; k < m_set.n_modes; ++k)
+        {
+        m_set.hkl[k][0] = lattice_vectors[k].x;
+        m_set.hkl[k][1] = lattice_vectors[k].y;
+        m_set.hkl[k][2] = lattice_vectors[k].z;
+        }
+    for (unsigned int t = 0; t < m_set.n_types; ++t) m_set.coeff[0][t] = mode[t];
+
+    m_partials.resize(sizeof(double) * mtd_lamellar_scratch_doubles(m_pdata->getN()));
+    m_cv_dev.resize(sizeof(double));
+    }
+
+void LamellarOrderParameterGPU::enqueuePartials()
+    {
+    const mtd_box box = m_pdata->getGlobalBox().toMtd();
+    mtd_check(mtd_lamellar_cv_partials(&m_set, m_pdata->getN(), m_pdata->positionsPtr(), m_pdata->getDtype(), &box,
+                                       (double *)m_partials.data(), &m_n_partials, m_exec_conf->getStream()),
+              "mtd_lamellar_cv_partials");
+    }
+
+void LamellarOrderParameterGPU::enqueueCurrentValue(unsigned int timestep, mtd_metad *engine, unsigned int slot)
+    {
+    enqueuePartials();
+    mtd_check(mtd_metad_set_cv_source(engine, slot, (const double *)m_partials.data(), m_n_partials, 1, 0,
+                                      1.0 / (double)m_pdata->getNGlobal(), 0.0),
+              "mtd_metad_set_cv_source");
+    m_cv_last_updated = timestep;
+    }
+
+double LamellarOrderParameterGPU::getCurrentValue(unsigned int timestep)
+    {
+    enqueuePartials();
+    mtd_check(mtd_reduce_partials((const double *)m_partials.data(), m_n_partials, 1, 1, 1.0 / (double)m_pdata->getNGlobal(), 0.0,
+                                  (double *)m_cv_dev.data(), m_exec_conf->getStream()),
+              "mtd_reduce_partials");
+    m_exec_conf->sync();
+    m_cv_dev.download(&m_cv, sizeof(double));
+    m_cv_last_updated = timestep;
+    return m_cv;
+    }
+
+void LamellarOrderParameterGPU::computeBiasForces(unsigned int timestep)
+    {
+    const mtd_box box = m_pdata->getGlobalBox().toMtd();
+    void *f[1] = {m_force.data()};
+    if (m_bias_device)
+        mtd_check(mtd_lamellar_forces(&m_set, m_pdata->getN(), m_pdata->positionsPtr(), f, m_pdata->getDtype(),
+                                      m_pdata->getNGlobal(), m_bias_device, &box, m_exec_conf->getStream()),
+                  "mtd_lamellar_forces");
+    else
+        {
+        std::vector<int> lat(3 * m_lattice_vectors.size());
+        for (size_t k = 0; k < m_lattice_vectors.size(); ++k)
+            {
+            lat[3 * k] = m_lattice_vectors[k].x;
+            lat[3 * k + 1] = m_lattice_vectors[k].y;
+            lat[3 * k + 2] = m_lattice_vectors[k].z;
+            }
+        mtd_check(mtd_compute_sq_forces(m_pdata->getN(), m_pdata->positionsPtr(), m_force.data(), m_pdata->getDtype(),
+                                        (unsigned int)m_lattice_vectors.size(), lat.data(), m_mode.data(),
+                                        (unsigned int)m_mode.size(), m_pdata->getNGlobal(), m_bias, &box, m_exec_conf->getStream()),
+                  "mtd_compute_sq_forces");
+        }
+    }
+
+// ------------------------------------------------------------------------------------------------
+// WellTemperedEnsemble
+// ------------------------------------------------------------------------------------------------
+
+WellTemperedEnsemble::WellTemperedEnsemble(std::shared_ptr<SystemDefinition> sysdef, const std::string &name)
+    : CollectiveVariable(sysdef, name), m_pe(0.0), m_log_name("cv_potential_energy"), m_n_partials(0)
+    {
+    m_partials.resize(sizeof(double) * mtd_wte_scratch_doubles(m_pdata->getN()));
+    m_sum.resize(sizeof(double));
+    }
+
+void WellTemperedEnsemble::enqueuePartials()
+    {
+    mtd_check(mtd_wte_energy_partials(m_pdata->getN(), m_pdata->getNetForce().data(), m_pdata->getDtype(),
+                                      (double *)m_partials.data(), &m_n_partials, m_exec_conf->getStream()),
+              "mtd_wte_energy_partials");
+    }
+
+void WellTemperedEnsemble::enqueueCurrentValue(unsigned int, mtd_metad *engine, unsigned int slot)
+    {
+    enqueuePartials();
+    // PE = sum_j net_force_j.w + external energy (WellTemperedEnsemble.cc:45-56)
+    mtd_check(mtd_metad_set_cv_source(engine, slot, (const double *)m_partials.data(), m_n_partials, 1, 0, 1.0,
+                                      m_pdata->getExternalEnergy()),
+              "mtd_metad_set_cv_source");
+    }
+
+double WellTemperedEnsemble::getCurrentValue(unsigned int)
+    {
+    enqueuePartials();
+    mtd_check(mtd_reduce_partials((const double *)m_partials.data(), m_n_partials, 1, 1, 1.0, m_pdata->getExternalEnergy(),
+                                  (double *)m_sum.data(), m_exec_conf->getStream()),
+              "mtd_reduce_partials");
+    m_exec_conf->sync();
+    m_sum.download(&m_pe, sizeof(double));
+    return m_pe;
+    }
+
+// WellTemperedEnsemble.cc:135-188; the CPU path (the parity target) also scales net_torque.w (Q18)
+void WellTemperedEnsemble::computeBiasForces(unsigned int)
+    {
+    mtd_check(mtd_wte_scale_netforce(m_pdata->getN(), m_pdata->getNetForce().data(), m_pdata->getNetTorqueArray().data(),
+                                     m_pdata->getNetVirial().data(), m_pdata->getNetVirialPitch(), m_pdata->getDtype(),
+                                     m_bias_device, m_bias, 1, m_exec_conf->getStream()),
+              "mtd_wte_scale_netforce");
+    bool any_virial = false;
+    for (unsigned int i = 0; i < 6; ++i) any_virial = any_virial || (m_pdata->getExternalVirial(i) != 0.0);
+    if (any_virial)
+        {
+        double bias = m_bias;
+        if (m_bias_device) hip_check(hipMemcpy(&bias, m_bias_device, sizeof(double), hipMemcpyDeviceToHost), "bias read-back");
+        const double fac = 1.0 + bias;
+        for (unsigned int i = 0; i < 6; ++i) m_pdata->setExternalVirial(i, fac * m_pdata->getExternalVirial(i));   // :180-184
+        }
+    }
+
+// ------------------------------------------------------------------------------------------------
+// AspectRatio, Density
+// ------------------------------------------------------------------------------------------------
+
+AspectRatio::AspectRatio(std::shared_ptr<SystemDefinition> sysdef, unsigned int dir1, unsigned int dir2)
+    : CollectiveVariable(sysdef, "cv_aspect_ratio"), m_dir1(dir1), m_dir2(dir2)
+    {
+    if (dir1 == dir2 || dir1 >= 3 || dir2 >= 3) throw std::runtime_error("Error setting up metadynamics.aspect_ratio");   // AspectRatio.cc:8-12
+    }
+
+// AspectRatio.cc:24-57, including `length1 = L.x` in the dir2 switch (:46)
+double AspectRatio::getCurrentValue(unsigned int)
+    {
+    const auto L = m_pdata->getGlobalBox().getL();
+    double length1 = 0.0, length2 = 0.0;
+    switch (m_dir1)
+        {
+        case 0: length1 = L[0]; break;
+        case 1: length1 = L[1]; break;
+        case 2: length1 = L[2]; break;
+        }
+    switch (m_dir2)
+        {
+        case 0: length1 = L[0]; break;
+        case 1: length2 = L[1]; break;
+        case 2: length2 = L[2]; break;
+        }
+    return length1 / length2;
+    }
+
+static double host_bias(double bias, const double *d_bias)
+    {
+    if (d_bias) hip_check(hipMemcpy(&bias, d_bias, sizeof(double), hipMemcpyDeviceToHost), "bias read-back");
+    return bias;
+    }
+
+// AspectRatio.cc:59-130
+void AspectRatio::computeBiasForces(unsigned int)
+    {
+    const double bias = host_bias(m_bias, m_bias_device);
+    const BoxDim &box = m_pdata->getGlobalBox();
+    const auto L = box.getL();
+    double d_l_x = 0.0, d_l_y = 0.0, d_l_z = 0.0;
+    switch (m_dir1)
+        {
+        case 0:
+            if (m_dir2 == 1) { d_l_x = 1.0 / L[1]; d_l_y = -L[0] / L[1] / L[1]; }
+            if (m_dir2 == 2) { d_l_x = 1.0 / L[2]; d_l_z = -L[0] / L[2] / L[2]; }
+            break;
+        case 1:
+            if (m_dir2 == 0) { d_l_x = -L[1] / L[0] / L[0]; d_l_y = 1.0 / L[0]; }
+            if (m_dir2 == 2) { d_l_y = 1.0 / L[2]; d_l_z = -L[1] / L[2] / L[2]; }
+            break;
+        case 2:
+            if (m_dir2 == 0) { d_l_x = -L[2] / L[0] / L[0]; d_l_z = 1.0 / L[0]; }
+            if (m_dir2 == 1) { d_l_y = -L[2] / L[1] / L[1]; d_l_z = 1.0 / L[1]; }
+            break;
+        }
+    const double xy = box.getTiltFactorXY(), xz = box.getTiltFactorXZ(), yz = box.getTiltFactorYZ();
+    m_external_virial[0] = -bias * d_l_x * L[0];
+    m_external_virial[1] = -bias * d_l_x * (L[1] * xy);
+    m_external_virial[2] = -bias * d_l_x * (L[2] * xz);
+    m_external_virial[3] = -bias * d_l_y * L[1];
+    m_external_virial[4] = -bias * d_l_y * (L[2] * yz);
+    m_external_virial[5] = -bias * d_l_z * L[2];
+    }
+
+Density::Density(std::shared_ptr<SystemDefinition> sysdef, const std::string &suffix)
+    : CollectiveVariable(sysdef, "cv_density" + (suffix != "" ? "_" + suffix : ""))   // Density.cc:8
+    {
+    }
+
+double Density::getCurrentValue(unsigned int)
+    {
+    const double V = m_pdata->getGlobalBox().getVolume();
+    return (double)m_pdata->getNGlobal() / V;                          // Density.cc:22-26
+    }
+
+void Density::computeBiasForces(unsigned int)
+    {
+    const double bias = host_bias(m_bias, m_bias_device);
+    const double V = m_pdata->getGlobalBox().getVolume();
+    const double fac = -(double)m_pdata->getNGlobal() / (V * V);       // Density.cc:44
+    const auto L = m_pdata->getGlobalBox().getL();
+    const double v = -bias * fac * L[0] * L[1] * L[2];
+    m_external_virial = {v, 0.0, 0.0, v, 0.0, v};                      // Density.cc:47-52
+    }
+
+// ------------------------------------------------------------------------------------------------
+// IntegratorMetaDynamics
+// ------------------------------------------------------------------------------------------------
+
+IntegratorMetaDynamics::IntegratorMetaDynamics(std::shared_ptr<SystemDefinition> sysdef, double deltaT, double W, double T_shift,
+                                               double T, unsigned int stride, bool add_bias, const std::string &filename,
+                                               bool overwrite, const Enum mode)
+    : m_sysdef(sysdef), m_pdata(sysdef->getParticleData()), m_exec_conf(sysdef->getExecConf()), m_deltaT(deltaT), m_W(W),
+      m_T_shift(T_shift), m_stride(stride), m_is_initialized(false), m_filename(filename), m_overwrite(overwrite),
+      m_is_appending(false), m_delimiter("\t"), m_use_grid(false), m_add_bias(add_bias), m_grid_period(0), m_cur_file(0),
+      m_sigma_g(1.0), m_adaptive(false), m_temp(T), m_mode(mode), m_multiple_walkers(false), m_engine(nullptr),
+      m_allow_fused(true), m_used_fused(false), m_fused_n_partials(0)
+    {
+    if (!(T_shift > 0.0) || !(W > 0.0)) throw std::runtime_error("IntegratorMetaDynamics: W and deltaT must be positive");   // asserts :58-59
+    if (stride == 0) throw std::runtime_error("IntegratorMetaDynamics: stride must be positive");
+    m_log_names = {"bias", "det_sigma", "weight"};                     // :61-63
+    std::memset(&m_fused_set, 0, sizeof(m_fused_set));
+    }
+
+IntegratorMetaDynamics::~IntegratorMetaDynamics()
+    {
+    if (m_engine) (void)mtd_metad_destroy(m_engine);
+    }
+
+void IntegratorMetaDynamics::registerCollectiveVariable(std::shared_ptr<CollectiveVariable> cv, double sigma, double cv_min,
+                                                        double cv_max, int num_points)
+    {
+    if (!cv) throw std::runtime_error("registerCollectiveVariable: null collective variable");
+    if (!(sigma > 0.0)) throw std::runtime_error("registerCollectiveVariable: sigma must be positive");
+    CollectiveVariableItem item;
+    item.m_cv = cv;
+    item.m_sigma = sigma;
+    item.m_cv_min = cv_min;
+    item.m_cv_max = cv_max;
+    item.m_num_points = (unsigned int)num_points;
+    m_variables.push_back(item);
+    }
+
+// :778-815
+void IntegratorMetaDynamics::setGrid(bool use_grid)
+    {
+    if (m_is_initialized) throw std::runtime_error("Error setting up metadynamics parameters.");   // :785-789
+    m_use_grid = use_grid;
+    if (use_grid)
+        for (const auto &it : m_variables)
+            {
+            if (it.m_cv_min >= it.m_cv_max) throw std::runtime_error("Error creating collective variable.");   // :800-805
+            if (it.m_num_points < 2) throw std::runtime_error("Error creating collective variable.");         // :807-811
+            }
+    }
+
+void IntegratorMetaDynamics::setMode(Enum mode)
+    {
+    m_mode = mode;
+    if (m_engine) mtd_check(mtd_metad_set_mode(m_engine, mode == mode_well_tempered ? MTD_MODE_WELL_TEMPERED : MTD_MODE_STANDARD), "mtd_metad_set_mode");
+    }
+
+void IntegratorMetaDynamics::setStride(unsigned int stride)
+    {
+    if (stride == 0) throw std::runtime_error("integrate.mode_metadynamics: stride must be positive");
+    m_stride = stride;
+    if (m_engine) mtd_check(mtd_metad_set_stride(m_engine, stride), "mtd_metad_set_stride");
+    }
+
+void IntegratorMetaDynamics::setAddHills(bool add_bias)
+    {
+    m_add_bias = add_bias;
+    if (m_engine) mtd_check(mtd_metad_set_add_hills(m_engine, add_bias ? 1 : 0), "mtd_metad_set_add_hills");
+    }
+
+void IntegratorMetaDynamics::setAdaptive(bool adaptive)
+    {
+    // computeSigma (:1205-1294) is SURVEY §8f row N2 ("next"), not built yet: fail loudly rather than ignore
+    if (adaptive) throw std::runtime_error("integrate.mode_metadynamics: adaptive Gaussians are not available in this build");
+    m_adaptive = false;
+    }
+
+void IntegratorMetaDynamics::resetHistogram()
+    {
+    if (m_engine) mtd_check(mtd_metad_reset_histogram(m_engine, m_exec_conf->getStream()), "mtd_metad_reset_histogram");
+    }
+
+// :74-96
+void IntegratorMetaDynamics::openOutputFile()
+    {
+    struct stat buffer;
+    bool file_exists = stat(m_filename.c_str(), &buffer) == 0;
+    if (file_exists && !m_overwrite)
+        {
+        m_file.open(m_filename.c_str(), std::ios_base::in | std::ios_base::out | std::ios_base::ate);
+        m_is_appending = true;
+        }
+    else
+        {
+        m_file.open(m_filename.c_str(), std::ios_base::out);
+        m_is_appending = false;
+        }
+    if (!m_file.good()) throw std::runtime_error("Error initializing IntegratorMetadynamics");
+    }
+
+// :98-119
+void IntegratorMetaDynamics::writeFileHeader()
+    {
+    m_file << "timestep" << m_delimiter << "W" << m_delimiter;
+    for (size_t i = 0; i < m_variables.size(); ++i)
+        {
+        m_file << m_variables[i].m_cv->getName();
+        for (size_t j = 0; j < m_variables.size(); ++j)
+            m_file << m_delimiter << "sigma_" << m_variables[i].m_cv->getName() << "_" << i << "_" << j;
+        m_file << m_delimiter;
+        }
+    m_file << std::endl;
+    }
+
+// :590-661 on the device
+void IntegratorMetaDynamics::setupGrid()
+    {
+    std::vector<double> sigma, lo, hi;
+    std::vector<unsigned int> n;
+    for (const auto &it : m_variables)
+        {
+        sigma.push_back(it.m_sigma);
+        lo.push_back(it.m_cv_min);
+        hi.push_back(it.m_cv_max);
+        n.push_back(it.m_num_points);
+        }
+    if (m_engine)
+        {
+        mtd_check(mtd_metad_destroy(m_engine), "mtd_metad_destroy");
+        m_engine = nullptr;
+        }
+    int rc = mtd_metad_create(&m_engine, (unsigned int)m_variables.size(), sigma.data(), lo.data(), hi.data(), n.data(), m_W,
+                              m_T_shift, m_temp, m_stride, m_mode == mode_well_tempered ? MTD_MODE_WELL_TEMPERED : MTD_MODE_STANDARD,
+                              m_add_bias ? 1 : 0);
+    if (rc == MTD_ERR_INVALID_ARGUMENT) throw std::runtime_error("Error creating collective variable.");
+    mtd_check(rc, "mtd_metad_create");
+    }
+
+// :121-217
+void IntegratorMetaDynamics::prepRun(unsigned int timestep)
+    {
+    if (!m_is_initialized && m_filename != "")
+        {
+        openOutputFile();
+        if (!m_is_appending) writeFileHeader();
+        }
+    if (!m_is_initialized && !m_variables.empty())
+        {
+        if (!m_use_grid)
+            throw std::runtime_error("integrate.mode_metadynamics: only grid mode is available (integrate.py:266-267 always enables it)");
+        setupGrid();
+        if (m_restart_filename != "")
+            {
+            readGrid(m_restart_filename);                              // :189-197
+            m_restart_filename = "";
+            }
+        }
+    m_is_initialized = true;
+
+    // initial update of the potential (:214) — deposits a hill when timestep % stride == 0 (Q17)
+    updateBiasPotential(timestep);
+    // IntegratorTwoStep::prepRun computes the net force at `timestep`
+    computeNetForce(timestep);
+    }
+
+void IntegratorMetaDynamics::computeNetForce(unsigned int timestep)
+    {
+    // HOOMD's Integrator::computeNetForce calls compute(timestep) on every ForceCompute and sums them into the net
+    // force; the summation itself is HOOMD core and not part of the plugin
+    for (auto &f : m_forces) f->compute(timestep);
+    }
+
+// :219-312 (no integration methods in the stand-alone system: integrateStepOne/Two are HOOMD's)
+void IntegratorMetaDynamics::update(unsigned int timestep)
+    {
+    if (!m_is_initialized) throw std::runtime_error("IntegratorMetaDynamics::update called before prepRun");
+    bool net_force_first = (m_variables.size() == 1 && m_variables[0].m_cv->requiresNetForce());   // :259
+    if (!net_force_first)
+        for (const auto &it : m_variables)
+            if (it.m_cv->requiresNetForce())
+                throw std::runtime_error("Only one collective variable requiring the potential energy may be defined.\n");   // :264-270
+
+    if (net_force_first) computeNetForce(timestep + 1);                // :273-282
+    updateBiasPotential(timestep + 1);                                 // :285
+    if (!net_force_first)
+        computeNetForce(timestep + 1);                                 // :287-296
+    else
+        m_variables[0].m_cv->compute(timestep);                        // :300 — bias forces *after* everything else
+    }
+
+bool IntegratorMetaDynamics::fusedLamellarPossible() const
+    {
+    if (!m_allow_fused || m_variables.empty() || m_variables.size() > MTD_METAD_MAX_CV) return false;
+    unsigned int n_modes = 0;
+    for (const auto &it : m_variables)
+        {
+        auto lam = std::dynamic_pointer_cast<LamellarOrderParameterGPU>(it.m_cv);
+        if (!lam || lam->hasUmbrella()) return false;
+        n_modes += (unsigned int)lam->getLatticeVectors().size();
+        }
+    return n_modes <= MTD_MAX_MODES;
+    }
+
+// the two-launch step (fused.hip): launch A = CV partial sums (+ deferred grid pass), launch B = grid update + forces
+void IntegratorMetaDynamics::fusedLamellarStep(unsigned int timestep)
+    {
+    const unsigned int n_cv = (unsigned int)m_variables.size();
+    std::memset(&m_fused_set, 0, sizeof(m_fused_set));
+    m_fused_set.n_cv = n_cv;
+    m_fused_set.n_types = m_pdata->getNTypes();
+    unsigned int k = 0;
+    m_fused_force_ptrs.assign(n_cv, nullptr);
+    for (unsigned int c = 0; c < n_cv; ++c)
+        {
+        auto lam = std::static_pointer_cast<LamellarOrderParameterGPU>(m_variables[c].m_cv);
+        m_fused_set.first[c] = k;
+        for (const auto &v : lam->getLatticeVectors())
+            {
+            m_fused_set.hkl[k][0] = v.x;
+            m_fused_set.hkl[k][1] = v.y;
+            m_fused_set.hkl[k][2] = v.z;
+            ++k;
+            }
+        for (unsigned int t = 0; t < m_fused_set.n_types; ++t) m_fused_set.coeff[c][t] = lam->getMode()[t];
+        m_fused_force_ptrs[c] = lam->getForceArray().data();
+        }
+    m_fused_set.first[n_cv] = k;
+    m_fused_set.n_modes = k;
+    if (m_fused_partials.bytes() == 0) m_fused_partials.resize(sizeof(double) * mtd_lamellar_scratch_doubles(m_pdata->getN()));
+
+    const mtd_box box = m_pdata->getGlobalBox().toMtd();
+    hipStream_t s = m_exec_conf->getStream();
+    unsigned int n_partials = 0;
+    mtd_check(mtd_fused_cv_pass(m_engine, &m_fused_set, m_pdata->getN(), m_pdata->positionsPtr(), m_pdata->getDtype(), &box,
+                                (double *)m_fused_partials.data(), &n_partials, s),
+              "mtd_fused_cv_pass");
+    if (n_partials != m_fused_n_partials || !m_used_fused)
+        {
+        for (unsigned int c = 0; c < n_cv; ++c)
+            mtd_check(mtd_metad_set_cv_source(m_engine, c, (const double *)m_fused_partials.data(), n_partials, n_cv, c,
+                                              1.0 / (double)m_pdata->getNGlobal(), 0.0),
+                      "mtd_metad_set_cv_source");
+        m_fused_n_partials = n_partials;
+        }
+    mtd_check(mtd_fused_force_pass(m_engine, &m_fused_set, m_pdata->getN(), m_pdata->positionsPtr(), m_fused_force_ptrs.data(),
+                                   m_pdata->getDtype(), m_pdata->getNGlobal(), &box, timestep, s),
+              "mtd_fused_force_pass");
+    // launch B wrote every CV's force array for `timestep`: computeNetForce's cv->compute(timestep) is a no-op
+    for (auto &it : m_variables) it.m_cv->markComputed(timestep);
+    m_used_fused = true;
+    }
+
+// :314-588, grid branch
+void IntegratorMetaDynamics::updateBiasPotential(unsigned int timestep)
+    {
+    if (m_variables.empty()) return;                                   // :317-318
+    hipStream_t s = m_exec_conf->getStream();
+
+    if (fusedLamellarPossible())
+        fusedLamellarStep(timestep);
+    else
+        {
+        m_used_fused = false;
+        // collect values of collective variables (:321-327) — they stay on the device
+        for (unsigned int i = 0; i < m_variables.size(); ++i) m_variables[i].m_cv->enqueueCurrentValue(timestep, m_engine, i);
+        mtd_check(mtd_metad_update_bias(m_engine, timestep, s), "mtd_metad_update_bias");
+        // update current bias potential derivative for every collective variable (:578-584)
+        const double *d_bias = mtd_metad_bias_device(m_engine);
+        for (unsigned int i = 0; i < m_variables.size(); ++i) m_variables[i].m_cv->setBiasFactorDevice(d_bias + i);
+        }
+
+    // write hills information (:523-550) — needs host values, only when a hills file was requested
+    if (m_is_initialized && (timestep % m_stride == 0) && m_add_bias && m_file.is_open())
+        {
+        std::vector<double> cv(m_variables.size());
+        double V = 0.0;
+        mtd_check(mtd_metad_get_state(m_engine, cv.data(), nullptr, &V, nullptr, nullptr, nullptr, s), "mtd_metad_get_state");
+        const double W = m_W * std::exp(-V / m_T_shift);               // :528 (written even in standard mode, Q16)
+        m_file << std::setprecision(10) << timestep << m_delimiter;
+        m_file << std::setprecision(10) << W << m_delimiter;
+        for (size_t i = 0; i < cv.size(); ++i)
+            {
+            m_file << std::setprecision(10) << cv[i] << m_delimiter;
+            for (size_t j = 0; j < cv.size(); ++j)
+                m_file << std::setprecision(10) << (i == j ? 1.0 / m_variables[i].m_sigma : 0.0);   // row of sigma_inv, no delimiter (Q16)
+            if (i != cv.size() - 1) m_file << m_delimiter;
+            }
+        m_file << std::endl;
+        }
+
+    // dump grid information if required using alternating scheme (:555-565)
+    if (m_grid_period && (timestep % m_grid_period == 0))
+        {
+        if (m_grid_fname2 != "")
+            {
+            writeGrid(m_cur_file ? m_grid_fname2 : m_grid_fname1, timestep);
+            m_cur_file = m_cur_file ? 0 : 1;
+            }
+        else
+            writeGrid(m_grid_fname1, timestep);
+        }
+    }
+
+double IntegratorMetaDynamics::getLogValue(const std::string &quantity, unsigned int)
+    {
+    if (!m_engine) throw std::runtime_error("Error getting log value");
+    double V = 0.0, w = 1.0;
+    if (quantity == m_log_names[0] || quantity == m_log_names[2])
+        mtd_check(mtd_metad_get_state(m_engine, nullptr, nullptr, &V, &w, nullptr, nullptr, m_exec_conf->getStream()), "mtd_metad_get_state");
+    if (quantity == m_log_names[0]) return V;
+    if (quantity == m_log_names[1]) return mtd_metad_sigma_determinant(m_engine);
+    if (quantity == m_log_names[2]) return w;
+    throw std::runtime_error("Error getting log value");               // .h:184-188
+    }
+
+// :817-829
+void IntegratorMetaDynamics::dumpGrid(const std::string &filename1, const std::string &filename2, unsigned int period)
+    {
+    if (period == 0)
+        {
+        writeGrid(filename1, 0);
+        return;
+        }
+    m_grid_period = period;
+    m_grid_fname1 = filename1;
+    m_grid_fname2 = filename2;
+    }
+
+// :831-926 — the on-disk format users post-process
+void IntegratorMetaDynamics::writeGrid(const std::string &filename, unsigned int timestep)
+    {
+    if (!m_use_grid || !m_engine) throw std::runtime_error("Error dumping grid.");   // :841-845
+    const unsigned int len = mtd_metad_num_elements(m_engine);
+    hipStream_t s = m_exec_conf->getStream();
+    std::vector<double> grid(len), sigma_grid(len), rew(len), weight(len);
+    std::vector<unsigned int> hist(len), hist_gauss(len);
+    mtd_check(mtd_metad_get_array(m_engine, 0, grid.data(), s), "get grid");
+    mtd_check(mtd_metad_get_array(m_engine, 4, sigma_grid.data(), s), "get sigma_grid");
+    mtd_check(mtd_metad_get_array(m_engine, 2, rew.data(), s), "get reweighted");
+    mtd_check(mtd_metad_get_array(m_engine, 3, weight.data(), s), "get weight");
+    mtd_check(mtd_metad_get_array(m_engine, 6, hist.data(), s), "get hist");
+    mtd_check(mtd_metad_get_array(m_engine, 8, hist_gauss.data(), s), "get hist_gauss");
+    unsigned int num_gaussians = 0;
+    mtd_check(mtd_metad_get_state(m_engine, nullptr, nullptr, nullptr, nullptr, &num_gaussians, nullptr, s), "get state");
+
+    std::ofstream file;
+    file.open((filename + "_" + std::to_string(timestep)).c_str(), std::ios_base::out);
+    const size_t dim = m_variables.size();
+    file << "#n_cv: " << dim << std::endl;
+    file << "#dim: ";
+    for (size_t i = 0; i < dim; i++) file << " " << m_variables[i].m_num_points;
+    file << std::endl;
+    file << "#num_gaussians: " << num_gaussians << std::endl;
+    for (size_t i = 0; i < dim; i++) file << m_variables[i].m_cv->getName() << m_delimiter;
+    file << "grid_value" << m_delimiter << "det_sigma" << m_delimiter << "num_gaussians" << m_delimiter << "hist" << m_delimiter
+         << "hist_reweight" << m_delimiter << "weight" << std::endl;
+
+    std::vector<unsigned int> coords(dim);
+    for (unsigned int grid_idx = 0; grid_idx < len; grid_idx++)
+        {
+        unsigned int rest = grid_idx;                                  // IndexGrid::getCoordinates, first CV fastest
+        for (size_t i = 0; i < dim; ++i)
+            {
+            coords[i] = rest % m_variables[i].m_num_points;
+            rest /= m_variables[i].m_num_points;
+            }
+        for (size_t i = 0; i < dim; ++i)
+            {
+            double delta = (m_variables[i].m_cv_max - m_variables[i].m_cv_min) / (m_variables[i].m_num_points - 1);
+            double val = m_variables[i].m_cv_min + coords[i] * delta;
+            file << std::setprecision(10) << val << m_delimiter;
+            }
+        file << std::setprecision(10) << grid[grid_idx];
+        double val = hist_gauss[grid_idx] > 0 ? sigma_grid[grid_idx] / (double)hist_gauss[grid_idx] : 0.0;   // :909-914
+        file << m_delimiter << std::setprecision(10) << val;
+        file << m_delimiter << hist_gauss[grid_idx];
+        file << m_delimiter << hist[grid_idx];
+        file << m_delimiter << std::setprecision(10) << rew[grid_idx];
+        file << m_delimiter << std::setprecision(10) << weight[grid_idx];
+        file << std::endl;
+        }
+    file.close();
+    }
+
+// :928-1000
+void IntegratorMetaDynamics::readGrid(const std::string &filename)
+    {
+    if (!m_use_grid || !m_engine) throw std::runtime_error("Error reading grid.");
+    std::ifstream file(filename.c_str());
+    std::string line, tmp;
+    getline(file, line);
+    getline(file, line);
+    getline(file, line);
+    unsigned int num_gaussians = 0;
+        {
+        std::istringstream iss(line);
+        iss >> tmp >> num_gaussians;
+        }
+    getline(file, line);
+    const unsigned int len = mtd_metad_num_elements(m_engine);
+    std::vector<double> grid(len), sigma_grid(len), rew(len), weight(len);
+    std::vector<unsigned int> hist(len), hist_gauss(len);
+    for (unsigned int grid_idx = 0; grid_idx < len; grid_idx++)
+        {
+        if (!file.good()) throw std::runtime_error("Error reading grid.");   // premature end (:973-977)
+        getline(file, line);
+        std::istringstream iss(line);
+        for (size_t i = 0; i < m_variables.size(); i++) iss >> tmp;
+        iss >> grid[grid_idx];
+        iss >> sigma_grid[grid_idx];
+        iss >> hist_gauss[grid_idx];
+        iss >> hist[grid_idx];
+        sigma_grid[grid_idx] *= hist_gauss[grid_idx];                  // :992
+        iss >> rew[grid_idx];
+        iss >> weight[grid_idx];
+        }
+    hipStream_t s = m_exec_conf->getStream();
+    mtd_check(mtd_metad_set_array(m_engine, 0, grid.data(), s), "set grid");
+    mtd_check(mtd_metad_set_array(m_engine, 4, sigma_grid.data(), s), "set sigma_grid");
+    mtd_check(mtd_metad_set_array(m_engine, 2, rew.data(), s), "set reweighted");
+    mtd_check(mtd_metad_set_array(m_engine, 3, weight.data(), s), "set weight");
+    mtd_check(mtd_metad_set_array(m_engine, 6, hist.data(), s), "set hist");
+    mtd_check(mtd_metad_set_array(m_engine, 8, hist_gauss.data(), s), "set hist_gauss");
+    mtd_check(mtd_metad_set_num_gaussians(m_engine, num_gaussians, s), "set num_gaussians");
+    }
+
+// ------------------------------------------------------------------------------------------------
+// System
+// ------------------------------------------------------------------------------------------------
+
+void System::run(unsigned int nsteps)
+    {
+    if (!m_integrator) throw std::runtime_error("System::run: no integrator set");
+    m_integrator->prepRun(m_cur_tstep);      // HOOMD calls prepRun at the start of every run() (Q17)
+    for (unsigned int i = 0; i < nsteps; ++i)
+        {
+        m_integrator->update(m_cur_tstep);
+        m_cur_tstep++;
+        }
+    }
+
+} // namespace mtdhost

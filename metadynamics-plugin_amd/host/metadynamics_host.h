@@ -1,0 +1,299 @@
+// metadynamics_host.h — host-side mirror of the reference plugin's C++ classes for the hot path.
+//
+// Same class names, method names, argument meaning and error behaviour as the reference
+// (CollectiveVariable.h, LamellarOrderParameterGPU.h, WellTemperedEnsemble.h, AspectRatio.h, Density.h,
+// IntegratorMetaDynamics.h); the bodies call libmtd_hip.so through include/mtd_abi.h instead of the
+// CUDA drivers, and the per-step hand-off between CVs and the integrator stays in device memory:
+//
+//   reference                                   here
+//   Scalar getCurrentValue(t) [D2H + host sum]  enqueueCurrentValue(t, engine, slot)  (async, device)
+//                                               getCurrentValue(t) = the same + lazy read-back
+//   setBiasFactor(Scalar)  [host scalar]        setBiasFactorDevice(const double*)    (device pointer)
+//                                               setBiasFactor(Scalar) kept for umbrella / derivatives
+#pragma once
+
+#include <fstream>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "mini_hoomd.h"
+
+namespace mtdhost
+{
+
+class IntegratorMetaDynamics;
+
+//! CollectiveVariable.h:32-196
+class CollectiveVariable : public ForceCompute
+    {
+    public:
+        enum umbrella_Enum
+            {
+            no_umbrella = 0,
+            linear,
+            harmonic,
+            wall,
+            gaussian
+            };
+
+        CollectiveVariable(std::shared_ptr<SystemDefinition> sysdef, const std::string &name);
+        virtual ~CollectiveVariable() {}
+
+        //! CollectiveVariable.h:55 — synchronising read-back of the CV value
+        virtual double getCurrentValue(unsigned int timestep) { return 0.0; }
+
+        //! device-resident form of getCurrentValue: make `engine` take CV `slot` from this variable.
+        //! Default: the host value of getCurrentValue() travels in the next launch's arguments.
+        virtual void enqueueCurrentValue(unsigned int timestep, mtd_metad *engine, unsigned int slot);
+
+        virtual void setBiasFactor(double bias)                        // CollectiveVariable.h:63-66
+            {
+            m_bias = bias;
+            m_bias_device = nullptr;
+            }
+        //! the bias factor stays in device memory (written by the grid engine, read by the force kernels)
+        virtual void setBiasFactorDevice(const double *d_bias) { m_bias_device = d_bias; }
+
+        void setUmbrella(umbrella_Enum umbrella)                       // CollectiveVariable.h:71-76
+            {
+            m_umbrella = umbrella;
+            if (umbrella == no_umbrella) m_bias = 0.0;
+            }
+        void setKappa(double kappa) { m_kappa = kappa; }
+        void setWidthFlat(double width) { m_width_flat = width; }
+        void setScale(double scale) { m_scale = scale; }
+        void setMinimum(double cv0) { m_cv0 = cv0; }
+        std::string getName() { return m_cv_name; }
+
+        void computeDerivatives(unsigned int timestep)                // CollectiveVariable.h:120-125
+            {
+            setBiasFactor(1.0);
+            computeBiasForces(timestep);
+            }
+        virtual bool canComputeDerivatives() { return true; }
+        double getUmbrellaPotential(unsigned int timestep);           // CollectiveVariable.cc:68-106
+        virtual bool requiresNetForce() { return false; }
+        bool hasUmbrella() const { return m_umbrella != no_umbrella; }
+
+        std::vector<std::string> getProvidedLogQuantities() override
+            {
+            return {"umbrella_energy_" + m_cv_name};
+            }
+        double getLogValue(const std::string &quantity, unsigned int timestep) override
+            {
+            if (quantity == "umbrella_energy_" + m_cv_name) return getUmbrellaPotential(timestep);
+            throw std::runtime_error("Error querying log quantity");     // CollectiveVariable.h:168-170
+            }
+
+    protected:
+        void computeForces(unsigned int timestep) override;            // CollectiveVariable.cc:22-66
+        virtual void computeBiasForces(unsigned int timestep) {}
+
+        double m_bias;
+        const double *m_bias_device;
+        std::string m_cv_name;
+
+    private:
+        umbrella_Enum m_umbrella;
+        double m_cv0, m_kappa, m_width_flat, m_scale;
+    };
+
+//! LamellarOrderParameterGPU.h / LamellarOrderParameter.h:30-101
+class LamellarOrderParameterGPU : public CollectiveVariable
+    {
+    public:
+        LamellarOrderParameterGPU(std::shared_ptr<SystemDefinition> sysdef, const std::vector<double> &mode,
+                                  const std::vector<int3> &lattice_vectors, const std::string &suffix = "");
+        void computeBiasForces(unsigned int timestep) override;        // LamellarOrderParameterGPU.cc:99-132
+        double getCurrentValue(unsigned int timestep) override;        // LamellarOrderParameter.h:75-79 (always recomputes, Q4)
+        void enqueueCurrentValue(unsigned int timestep, mtd_metad *engine, unsigned int slot) override;
+        std::vector<std::string> getProvidedLogQuantities() override
+            {
+            auto l = CollectiveVariable::getProvidedLogQuantities();
+            l.push_back(m_log_name);
+            return l;
+            }
+        double getLogValue(const std::string &quantity, unsigned int timestep) override
+            {
+            if (quantity == m_log_name) return getCurrentValue(timestep);
+            return CollectiveVariable::getLogValue(quantity, timestep);
+            }
+        const std::vector<double> &getMode() const { return m_mode; }
+        const std::vector<int3> &getLatticeVectors() const { return m_lattice_vectors; }
+
+    protected:
+        void enqueuePartials();
+        std::string m_log_name;
+        std::vector<double> m_mode;
+        std::vector<int3> m_lattice_vectors;
+        mtd_lamellar_set m_set;
+        DeviceBuffer m_partials, m_cv_dev;
+        unsigned int m_n_partials;
+        double m_cv;
+        unsigned int m_cv_last_updated;
+    };
+
+//! WellTemperedEnsemble.h:20-113
+class WellTemperedEnsemble : public CollectiveVariable
+    {
+    public:
+        WellTemperedEnsemble(std::shared_ptr<SystemDefinition> sysdef, const std::string &name);
+        bool requiresNetForce() override { return true; }
+        double getCurrentValue(unsigned int timestep) override;        // WellTemperedEnsemble.h:50-54
+        void enqueueCurrentValue(unsigned int timestep, mtd_metad *engine, unsigned int slot) override;
+        void computeBiasForces(unsigned int timestep) override;        // WellTemperedEnsemble.cc:135-188
+        std::vector<std::string> getProvidedLogQuantities() override
+            {
+            auto l = CollectiveVariable::getProvidedLogQuantities();
+            l.push_back(m_log_name);
+            return l;
+            }
+        double getLogValue(const std::string &quantity, unsigned int timestep) override
+            {
+            if (quantity == m_log_name) return getCurrentValue(timestep);
+            return CollectiveVariable::getLogValue(quantity, timestep);
+            }
+
+    protected:
+        void enqueuePartials();
+        double m_pe;
+        std::string m_log_name;
+        DeviceBuffer m_partials, m_sum;
+        unsigned int m_n_partials;
+    };
+
+//! AspectRatio.h / AspectRatio.cc:5-130 — box-shape CV, external virial only
+class AspectRatio : public CollectiveVariable
+    {
+    public:
+        AspectRatio(std::shared_ptr<SystemDefinition> sysdef, unsigned int dir1, unsigned int dir2);
+        double getCurrentValue(unsigned int timestep) override;        // AspectRatio.cc:24-57
+        void computeBiasForces(unsigned int timestep) override;        // AspectRatio.cc:59-130
+        bool canComputeDerivatives() override { return false; }
+
+    private:
+        unsigned int m_dir1, m_dir2;
+    };
+
+//! Density.h / Density.cc:5-54 — N/V, external virial only (group = all particles here)
+class Density : public CollectiveVariable
+    {
+    public:
+        Density(std::shared_ptr<SystemDefinition> sysdef, const std::string &suffix);
+        double getCurrentValue(unsigned int timestep) override;        // Density.cc:20-27
+        void computeBiasForces(unsigned int timestep) override;        // Density.cc:29-54
+        bool canComputeDerivatives() override { return false; }
+    };
+
+//! IntegratorMetaDynamics.h:66-383 (grid mode; the non-grid Gaussian resummation is unreachable from the
+//! Python API, integrate.py:266-267 always calls setGrid(True))
+class IntegratorMetaDynamics
+    {
+    public:
+        enum Enum
+            {
+            mode_standard,
+            mode_well_tempered
+            };
+
+        IntegratorMetaDynamics(std::shared_ptr<SystemDefinition> sysdef, double deltaT, double W, double T_shift, double T,
+                               unsigned int stride, bool add_bias = true, const std::string &filename = "",
+                               bool overwrite = false, const Enum mode = mode_standard);
+        virtual ~IntegratorMetaDynamics();
+
+        virtual void update(unsigned int timestep);                   // IntegratorMetaDynamics.cc:219-312
+        virtual void prepRun(unsigned int timestep);                  // :121-217
+
+        void registerCollectiveVariable(std::shared_ptr<CollectiveVariable> cv, double sigma, double cv_min = 0.0,
+                                        double cv_max = 0.0, int num_points = 0);   // .h:117-134
+        void removeAllVariables() { m_variables.clear(); }
+        //! forces HOOMD's System would hand to computeNetForce (every ForceCompute, CVs included)
+        void addForceCompute(std::shared_ptr<ForceCompute> f) { m_forces.push_back(f); }
+        void removeForceComputes() { m_forces.clear(); }
+
+        std::vector<std::string> getProvidedLogQuantities() { return m_log_names; }
+        double getLogValue(const std::string &quantity, unsigned int timestep);     // .h:161-189
+
+        void setGrid(bool use_grid);                                   // :778-815
+        void setMode(Enum mode);
+        void setStride(unsigned int stride);
+        bool isInitialized() { return m_is_initialized; }
+        void dumpGrid(const std::string &filename1, const std::string &filename2, unsigned int period);   // :817-829
+        void restartFromGridFile(const std::string &filename) { m_restart_filename = filename; }
+        void setAddHills(bool add_bias);
+        void setAdaptive(bool adaptive);
+        void setSigmaG(double sigma_g) { m_sigma_g = sigma_g; }
+        void setMultipleWalkers(bool multiple) { m_multiple_walkers = multiple; }
+        void resetHistogram();                                         // :1195-1203
+
+        //! this build's own knobs
+        void setFusedPath(bool enable) { m_allow_fused = enable; }     // default on: two launches per step for lamellar CVs
+        bool usedFusedPath() const { return m_used_fused; }
+        mtd_metad *getEngine() { return m_engine; }
+
+    private:
+        struct CollectiveVariableItem                                  // IntegratorMetaDynamics.h:21-28
+            {
+            std::shared_ptr<CollectiveVariable> m_cv;
+            double m_sigma, m_cv_min, m_cv_max;
+            unsigned int m_num_points;
+            };
+
+        void updateBiasPotential(unsigned int timestep);               // :314-588
+        void computeNetForce(unsigned int timestep);
+        void openOutputFile();                                         // :74-96
+        void writeFileHeader();                                        // :98-119
+        void setupGrid();                                              // :590-661 (device side: mtd_metad_create)
+        void readGrid(const std::string &filename);                    // :928-1000
+        void writeGrid(const std::string &filename, unsigned int timestep);   // :831-926
+        bool fusedLamellarPossible() const;
+        void fusedLamellarStep(unsigned int timestep);
+
+        std::shared_ptr<SystemDefinition> m_sysdef;
+        std::shared_ptr<ParticleData> m_pdata;
+        std::shared_ptr<ExecutionConfiguration> m_exec_conf;
+        double m_deltaT, m_W, m_T_shift;
+        unsigned int m_stride;
+        std::vector<CollectiveVariableItem> m_variables;
+        std::vector<std::shared_ptr<ForceCompute>> m_forces;
+        std::vector<std::string> m_log_names;
+        bool m_is_initialized;
+        std::string m_filename;
+        bool m_overwrite, m_is_appending;
+        std::ofstream m_file;
+        std::string m_delimiter;
+        bool m_use_grid, m_add_bias;
+        std::string m_restart_filename, m_grid_fname1, m_grid_fname2;
+        unsigned int m_grid_period, m_cur_file;
+        double m_sigma_g;
+        bool m_adaptive;
+        double m_temp;
+        Enum m_mode;
+        bool m_multiple_walkers;
+
+        mtd_metad *m_engine;
+        bool m_allow_fused, m_used_fused;
+        mtd_lamellar_set m_fused_set;
+        DeviceBuffer m_fused_partials;
+        unsigned int m_fused_n_partials;
+        std::vector<void *> m_fused_force_ptrs;
+    };
+
+//! the part of HOOMD's System the plugin relies on: the run loop calling Integrator::update once per step
+class System
+    {
+    public:
+        System(std::shared_ptr<SystemDefinition> sysdef, unsigned int initial_tstep) : m_sysdef(sysdef), m_cur_tstep(initial_tstep) {}
+        void setIntegrator(std::shared_ptr<IntegratorMetaDynamics> integrator) { m_integrator = integrator; }
+        std::shared_ptr<IntegratorMetaDynamics> getIntegrator() { return m_integrator; }
+        void run(unsigned int nsteps);
+        unsigned int getCurrentTimeStep() const { return m_cur_tstep; }
+
+    private:
+        std::shared_ptr<SystemDefinition> m_sysdef;
+        std::shared_ptr<IntegratorMetaDynamics> m_integrator;
+        unsigned int m_cur_tstep;
+    };
+
+} // namespace mtdhost

@@ -1,0 +1,235 @@
+// mini_hoomd.h — the few HOOMD-blue v2 core types the plugin's host classes touch, as a stand-alone
+// stand-in (HOOMD-blue is not part of the reference tree nor of this image; SURVEY.md App. B lists the
+// semantics assumed).  In a real HOOMD-ROCm build these come from hoomd/*.h and this header is not used;
+// the classes in metadynamics_host.h only rely on the members declared here.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <array>
+#include <cmath>
+#include <cstring>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "mtd_abi.h"
+
+namespace mtdhost
+{
+
+// int3 / make_int3: HIP's own vector type (hip/hip_runtime.h), the counterpart of the CUDA int3 HOOMD uses
+using ::int3;
+using ::make_int3;
+
+inline void hip_check(hipError_t e, const char *what)
+    {
+    if (e != hipSuccess) throw std::runtime_error(std::string(what) + ": " + hipGetErrorString(e));
+    }
+
+inline void mtd_check(int rc, const char *what)
+    {
+    if (rc != 0) throw std::runtime_error(std::string(what) + ": " + mtd_status_string(rc));
+    }
+
+//! RAII device buffer (the role of HOOMD's GPUArray / GlobalArray for this plugin)
+class DeviceBuffer
+    {
+    public:
+        DeviceBuffer() : m_ptr(nullptr), m_bytes(0) {}
+        explicit DeviceBuffer(size_t bytes) : m_ptr(nullptr), m_bytes(0) { resize(bytes); }
+        ~DeviceBuffer() { if (m_ptr) (void)hipFree(m_ptr); }
+        DeviceBuffer(const DeviceBuffer &) = delete;
+        DeviceBuffer &operator=(const DeviceBuffer &) = delete;
+        void resize(size_t bytes)
+            {
+            if (bytes == m_bytes) return;
+            if (m_ptr) hip_check(hipFree(m_ptr), "hipFree");
+            m_ptr = nullptr;
+            m_bytes = bytes;
+            if (bytes)
+                {
+                hip_check(hipMalloc(&m_ptr, bytes), "hipMalloc");
+                hip_check(hipMemset(m_ptr, 0, bytes), "hipMemset");
+                }
+            }
+        void upload(const void *host, size_t bytes) { hip_check(hipMemcpy(m_ptr, host, bytes, hipMemcpyHostToDevice), "hipMemcpy H2D"); }
+        void download(void *host, size_t bytes) const { hip_check(hipMemcpy(host, m_ptr, bytes, hipMemcpyDeviceToHost), "hipMemcpy D2H"); }
+        void *data() const { return m_ptr; }
+        size_t bytes() const { return m_bytes; }
+
+    private:
+        void *m_ptr;
+        size_t m_bytes;
+    };
+
+//! BoxDim (orthorhombic + triclinic), HOOMD conventions: a1=(Lx,0,0), a2=(xy Ly,Ly,0), a3=(xz Lz,yz Lz,Lz)
+class BoxDim
+    {
+    public:
+        BoxDim(double Lx = 1.0, double Ly = 1.0, double Lz = 1.0, double xy = 0.0, double xz = 0.0, double yz = 0.0)
+            {
+            m_L[0] = Lx; m_L[1] = Ly; m_L[2] = Lz;
+            m_xy = xy; m_xz = xz; m_yz = yz;
+            for (int i = 0; i < 3; ++i) m_lo[i] = -0.5 * m_L[i];
+            }
+        void setLo(double x, double y, double z) { m_lo[0] = x; m_lo[1] = y; m_lo[2] = z; }
+        std::array<double, 3> getL() const { return {m_L[0], m_L[1], m_L[2]}; }
+        std::array<double, 3> getLo() const { return {m_lo[0], m_lo[1], m_lo[2]}; }
+        double getTiltFactorXY() const { return m_xy; }
+        double getTiltFactorXZ() const { return m_xz; }
+        double getTiltFactorYZ() const { return m_yz; }
+        double getVolume() const { return m_L[0] * m_L[1] * m_L[2]; }
+        //! scale all lengths (system.box = system.box.scale(s=...) in test/test_2d.py:32)
+        BoxDim scale(double s) const
+            {
+            BoxDim b(m_L[0] * s, m_L[1] * s, m_L[2] * s, m_xy, m_xz, m_yz);
+            b.setLo(m_lo[0] * s, m_lo[1] * s, m_lo[2] * s);
+            return b;
+            }
+        mtd_box toMtd() const
+            {
+            mtd_box m;
+            std::memset(&m, 0, sizeof(m));
+            for (int i = 0; i < 3; ++i)
+                {
+                m.L[i] = m_L[i];
+                m.lo[i] = m_lo[i];
+                m.periodic[i] = 1;
+                }
+            m.xy = m_xy; m.xz = m_xz; m.yz = m_yz;
+            return m;
+            }
+
+    private:
+        double m_L[3], m_lo[3], m_xy, m_xz, m_yz;
+    };
+
+class ExecutionConfiguration
+    {
+    public:
+        ExecutionConfiguration() : m_stream(nullptr)
+            {
+            int n = mtd_device_count();
+            if (n <= 0) throw std::runtime_error("metadynamics: no HIP device (this build has no CPU path)");
+            }
+        bool isCUDAEnabled() const { return true; }   // name kept from the reference (cv.py:260)
+        hipStream_t getStream() const { return m_stream; }
+        void sync() const { hip_check(hipStreamSynchronize(m_stream), "hipStreamSynchronize"); }
+
+    private:
+        hipStream_t m_stream;
+    };
+
+//! Particle arrays in HOOMD layout; Scalar is chosen per system (dtype), the arrays live in HBM
+class ParticleData
+    {
+    public:
+        ParticleData(unsigned int N, int dtype, const std::vector<std::string> &type_names, const BoxDim &box)
+            : m_N(N), m_N_global(N), m_dtype(dtype), m_type_names(type_names), m_box(box), m_external_energy(0.0), m_virial_pitch(N)
+            {
+            if (dtype != MTD_F32 && dtype != MTD_F64) throw std::runtime_error("ParticleData: dtype must be MTD_F32 or MTD_F64");
+            m_external_virial.fill(0.0);
+            m_postype.resize(scalar4Bytes() * N);
+            m_net_force.resize(scalar4Bytes() * N);
+            m_net_torque.resize(scalar4Bytes() * N);
+            m_net_virial.resize(scalarBytes() * 6 * m_virial_pitch);
+            }
+        unsigned int getN() const { return m_N; }
+        unsigned int getNGlobal() const { return m_N_global; }
+        void setNGlobal(unsigned int n) { m_N_global = n; }   // a shard of a domain-decomposed system
+        unsigned int getNTypes() const { return (unsigned int)m_type_names.size(); }
+        std::string getNameByType(unsigned int t) const { return m_type_names.at(t); }
+        int getDtype() const { return m_dtype; }
+        size_t scalarBytes() const { return m_dtype == MTD_F32 ? 4 : 8; }
+        size_t scalar4Bytes() const { return 4 * scalarBytes(); }
+        const BoxDim &getGlobalBox() const { return m_box; }
+        const BoxDim &getBox() const { return m_box; }
+        void setGlobalBox(const BoxDim &b) { m_box = b; }
+        DeviceBuffer &getPositions() { return m_postype; }
+        DeviceBuffer &getNetForce() { return m_net_force; }
+        DeviceBuffer &getNetTorqueArray() { return m_net_torque; }
+        DeviceBuffer &getNetVirial() { return m_net_virial; }
+        unsigned int getNetVirialPitch() const { return m_virial_pitch; }
+        double getExternalEnergy() const { return m_external_energy; }
+        void setExternalEnergy(double e) { m_external_energy = e; }
+        double getExternalVirial(unsigned int i) const { return m_external_virial.at(i); }
+        void setExternalVirial(unsigned int i, double v) { m_external_virial.at(i) = v; }
+        //! use caller-owned device memory for the positions (e.g. a torch tensor), no copy
+        void borrowPositions(void *d_ptr) { m_borrowed_pos = d_ptr; }
+        void *positionsPtr() { return m_borrowed_pos ? m_borrowed_pos : m_postype.data(); }
+
+    private:
+        unsigned int m_N, m_N_global;
+        int m_dtype;
+        std::vector<std::string> m_type_names;
+        BoxDim m_box;
+        DeviceBuffer m_postype, m_net_force, m_net_torque, m_net_virial;
+        double m_external_energy;
+        std::array<double, 6> m_external_virial;
+        unsigned int m_virial_pitch;
+        void *m_borrowed_pos = nullptr;
+    };
+
+class SystemDefinition
+    {
+    public:
+        SystemDefinition(std::shared_ptr<ParticleData> pdata, std::shared_ptr<ExecutionConfiguration> exec)
+            : m_pdata(pdata), m_exec(exec) {}
+        std::shared_ptr<ParticleData> getParticleData() const { return m_pdata; }
+        std::shared_ptr<ExecutionConfiguration> getExecConf() const { return m_exec; }
+        unsigned int getNDimensions() const { return 3; }
+
+    private:
+        std::shared_ptr<ParticleData> m_pdata;
+        std::shared_ptr<ExecutionConfiguration> m_exec;
+    };
+
+//! ForceCompute: owns force / virial arrays, compute(timestep) runs computeForces at most once per step
+class ForceCompute
+    {
+    public:
+        explicit ForceCompute(std::shared_ptr<SystemDefinition> sysdef)
+            : m_sysdef(sysdef), m_pdata(sysdef->getParticleData()), m_exec_conf(sysdef->getExecConf()), m_last_computed(0),
+              m_first_compute(true)
+            {
+            m_force.resize(m_pdata->scalar4Bytes() * m_pdata->getN());
+            m_external_virial.fill(0.0);
+            }
+        virtual ~ForceCompute() {}
+        void compute(unsigned int timestep)
+            {
+            if (!m_first_compute && m_last_computed == timestep) return;
+            m_first_compute = false;
+            m_last_computed = timestep;
+            computeForces(timestep);
+            }
+        //! mark the forces of `timestep` as already written (the fused step writes them itself)
+        void markComputed(unsigned int timestep)
+            {
+            m_first_compute = false;
+            m_last_computed = timestep;
+            }
+        DeviceBuffer &getForceArray() { return m_force; }
+        unsigned int numParticles() const { return m_pdata->getN(); }
+        int dtype() const { return m_pdata->getDtype(); }
+        double getExternalVirial(unsigned int i) const { return m_external_virial.at(i); }
+        virtual std::vector<std::string> getProvidedLogQuantities() { return {}; }
+        virtual double getLogValue(const std::string &quantity, unsigned int)
+            {
+            throw std::runtime_error("Error querying log quantity " + quantity);
+            }
+
+    protected:
+        virtual void computeForces(unsigned int timestep) = 0;
+        std::shared_ptr<SystemDefinition> m_sysdef;
+        std::shared_ptr<ParticleData> m_pdata;
+        std::shared_ptr<ExecutionConfiguration> m_exec_conf;
+        DeviceBuffer m_force;
+        std::array<double, 6> m_external_virial;
+        unsigned int m_last_computed;
+        bool m_first_compute;
+    };
+
+} // namespace mtdhost

@@ -1,0 +1,226 @@
+// module.cc — pybind11 module `_metadynamics` (mirror of the reference's module.cc:23-41 and the
+// export_* functions: CollectiveVariable.cc:109-130, IntegratorMetaDynamics.cc:1315-1349,
+// LamellarOrderParameterGPU.cc:134-141, WellTemperedEnsemble.cc:190-197, AspectRatio.cc:132-140,
+// Density.cc:56-64), plus the stand-alone SystemDefinition the reference borrows from HOOMD-blue.
+#include <pybind11/numpy.h>
+#include <pybind11/pybind11.h>
+#include <pybind11/stl.h>
+#include <pybind11/stl_bind.h>
+
+#include "metadynamics_host.h"
+
+namespace py = pybind11;
+using namespace mtdhost;
+
+PYBIND11_MAKE_OPAQUE(std::vector<int3>);
+
+namespace
+{
+
+// HOOMD Scalar4 postype from positions + integer types: the type id is bit-cast into w (fp32) or into the
+// low word of w (fp64), as __scalar_as_int reads it
+py::array pack_postype(py::array_t<double, py::array::c_style | py::array::forcecast> pos,
+                       py::array_t<int, py::array::c_style | py::array::forcecast> types, int dtype)
+    {
+    if (pos.ndim() != 2 || pos.shape(1) != 3) throw std::runtime_error("positions must have shape (N, 3)");
+    const ssize_t N = pos.shape(0);
+    if (types.ndim() != 1 || types.shape(0) != N) throw std::runtime_error("types must have shape (N,)");
+    auto p = pos.unchecked<2>();
+    auto t = types.unchecked<1>();
+    if (dtype == MTD_F32)
+        {
+        py::array_t<float> out({N, (ssize_t)4});
+        auto o = out.mutable_unchecked<2>();
+        for (ssize_t i = 0; i < N; ++i)
+            {
+            o(i, 0) = (float)p(i, 0);
+            o(i, 1) = (float)p(i, 1);
+            o(i, 2) = (float)p(i, 2);
+            int ti = t(i);
+            float w;
+            std::memcpy(&w, &ti, 4);
+            o(i, 3) = w;
+            }
+        return out;
+        }
+    py::array_t<double> out({N, (ssize_t)4});
+    auto o = out.mutable_unchecked<2>();
+    for (ssize_t i = 0; i < N; ++i)
+        {
+        o(i, 0) = p(i, 0);
+        o(i, 1) = p(i, 1);
+        o(i, 2) = p(i, 2);
+        long long ti = (unsigned int)t(i);
+        double w;
+        std::memcpy(&w, &ti, 8);
+        o(i, 3) = w;
+        }
+    return out;
+    }
+
+void upload_array(DeviceBuffer &buf, py::array a, size_t expected_bytes, const char *what)
+    {
+    py::buffer_info info = a.request();
+    const size_t bytes = (size_t)info.size * (size_t)info.itemsize;
+    if (bytes != expected_bytes) throw std::runtime_error(std::string(what) + ": array has the wrong size or dtype");
+    if (!(a.flags() & py::array::c_style)) throw std::runtime_error(std::string(what) + ": array must be C-contiguous");
+    buf.upload(info.ptr, bytes);
+    }
+
+py::array download_scalar_array(const DeviceBuffer &buf, int dtype, std::vector<ssize_t> shape)
+    {
+    if (dtype == MTD_F32)
+        {
+        py::array_t<float> out(shape);
+        buf.download(out.mutable_data(), buf.bytes());
+        return out;
+        }
+    py::array_t<double> out(shape);
+    buf.download(out.mutable_data(), buf.bytes());
+    return out;
+    }
+
+} // namespace
+
+PYBIND11_MODULE(_metadynamics, m)
+    {
+    m.doc() = "MI355X-native metadynamics plugin: host classes over libmtd_hip.so";
+    m.attr("MTD_F32") = (int)MTD_F32;
+    m.attr("MTD_F64") = (int)MTD_F64;
+
+    py::class_<int3>(m, "int3")
+        .def(py::init<>())
+        .def_property("x", [](const int3 &v) { return v.x; }, [](int3 &v, int a) { v.x = a; })
+        .def_property("y", [](const int3 &v) { return v.y; }, [](int3 &v, int a) { v.y = a; })
+        .def_property("z", [](const int3 &v) { return v.z; }, [](int3 &v, int a) { v.z = a; });
+    m.def("make_int3", [](int x, int y, int z) { return make_int3(x, y, z); });
+    py::bind_vector<std::vector<int3>>(m, "std_vector_int3");          // module.cc:25
+    m.def("pack_postype", &pack_postype);
+
+    py::class_<BoxDim>(m, "BoxDim")
+        .def(py::init<double, double, double, double, double, double>(), py::arg("Lx") = 1.0, py::arg("Ly") = 1.0, py::arg("Lz") = 1.0,
+             py::arg("xy") = 0.0, py::arg("xz") = 0.0, py::arg("yz") = 0.0)
+        .def("setLo", &BoxDim::setLo)
+        .def("getL", &BoxDim::getL)
+        .def("getLo", &BoxDim::getLo)
+        .def("getVolume", &BoxDim::getVolume)
+        .def("scale", &BoxDim::scale);
+
+    py::class_<ExecutionConfiguration, std::shared_ptr<ExecutionConfiguration>>(m, "ExecutionConfiguration")
+        .def(py::init<>())
+        .def("isCUDAEnabled", &ExecutionConfiguration::isCUDAEnabled)
+        .def("sync", &ExecutionConfiguration::sync);
+
+    py::class_<ParticleData, std::shared_ptr<ParticleData>>(m, "ParticleData")
+        .def(py::init<unsigned int, int, const std::vector<std::string> &, const BoxDim &>())
+        .def("getN", &ParticleData::getN)
+        .def("getNGlobal", &ParticleData::getNGlobal)
+        .def("setNGlobal", &ParticleData::setNGlobal)
+        .def("getNTypes", &ParticleData::getNTypes)
+        .def("getNameByType", &ParticleData::getNameByType)
+        .def("getDtype", &ParticleData::getDtype)
+        .def("getGlobalBox", &ParticleData::getGlobalBox)
+        .def("setGlobalBox", &ParticleData::setGlobalBox)
+        .def("setPositions", [](ParticleData &p, py::array a) { upload_array(p.getPositions(), a, p.scalar4Bytes() * p.getN(), "setPositions"); })
+        .def("getPositions", [](ParticleData &p) { return download_scalar_array(p.getPositions(), p.getDtype(), {(ssize_t)p.getN(), 4}); })
+        .def("borrowPositions", [](ParticleData &p, size_t ptr) { p.borrowPositions((void *)ptr); },
+             "use caller-owned device memory (Scalar4[N], e.g. tensor.data_ptr()) for the positions")
+        .def("setNetForce", [](ParticleData &p, py::array a) { upload_array(p.getNetForce(), a, p.scalar4Bytes() * p.getN(), "setNetForce"); })
+        .def("getNetForce", [](ParticleData &p) { return download_scalar_array(p.getNetForce(), p.getDtype(), {(ssize_t)p.getN(), 4}); })
+        .def("setNetTorque", [](ParticleData &p, py::array a) { upload_array(p.getNetTorqueArray(), a, p.scalar4Bytes() * p.getN(), "setNetTorque"); })
+        .def("getNetTorque", [](ParticleData &p) { return download_scalar_array(p.getNetTorqueArray(), p.getDtype(), {(ssize_t)p.getN(), 4}); })
+        .def("setNetVirial", [](ParticleData &p, py::array a) { upload_array(p.getNetVirial(), a, p.scalarBytes() * 6 * p.getNetVirialPitch(), "setNetVirial"); })
+        .def("getNetVirial", [](ParticleData &p) { return download_scalar_array(p.getNetVirial(), p.getDtype(), {6, (ssize_t)p.getNetVirialPitch()}); })
+        .def("getExternalEnergy", &ParticleData::getExternalEnergy)
+        .def("setExternalEnergy", &ParticleData::setExternalEnergy)
+        .def("getExternalVirial", &ParticleData::getExternalVirial)
+        .def("setExternalVirial", &ParticleData::setExternalVirial);
+
+    py::class_<SystemDefinition, std::shared_ptr<SystemDefinition>>(m, "SystemDefinition")
+        .def(py::init<std::shared_ptr<ParticleData>, std::shared_ptr<ExecutionConfiguration>>())
+        .def("getParticleData", &SystemDefinition::getParticleData)
+        .def("getExecConf", &SystemDefinition::getExecConf);
+
+    py::class_<ForceCompute, std::shared_ptr<ForceCompute>>(m, "ForceCompute")
+        .def("compute", &ForceCompute::compute)
+        .def("getExternalVirial", &ForceCompute::getExternalVirial)
+        .def("getProvidedLogQuantities", &ForceCompute::getProvidedLogQuantities)
+        .def("getLogValue", &ForceCompute::getLogValue);
+
+    // CollectiveVariable.cc:109-130
+    py::class_<CollectiveVariable, ForceCompute, std::shared_ptr<CollectiveVariable>> collective_variable(m, "CollectiveVariable");
+    collective_variable.def("getCurrentValue", &CollectiveVariable::getCurrentValue)
+        .def("setUmbrella", &CollectiveVariable::setUmbrella)
+        .def("setKappa", &CollectiveVariable::setKappa)
+        .def("setWidthFlat", &CollectiveVariable::setWidthFlat)
+        .def("setMinimum", &CollectiveVariable::setMinimum)
+        .def("setScale", &CollectiveVariable::setScale)
+        .def("requiresNetForce", &CollectiveVariable::requiresNetForce)
+        .def("setBiasFactor", &CollectiveVariable::setBiasFactor)
+        .def("getName", &CollectiveVariable::getName)
+        .def("getUmbrellaPotential", &CollectiveVariable::getUmbrellaPotential)
+        .def("getForceArray", [](CollectiveVariable &cv) {
+            return download_scalar_array(cv.getForceArray(), cv.dtype(), {(ssize_t)cv.numParticles(), 4});
+        });
+    py::enum_<CollectiveVariable::umbrella_Enum>(collective_variable, "umbrella")
+        .value("no_umbrella", CollectiveVariable::no_umbrella)
+        .value("linear", CollectiveVariable::linear)
+        .value("harmonic", CollectiveVariable::harmonic)
+        .value("wall", CollectiveVariable::wall)
+        .value("gaussian", CollectiveVariable::gaussian)
+        .export_values();
+
+    // LamellarOrderParameterGPU.cc:134-141 (the reference's CPU class LamellarOrderParameter has no
+    // counterpart here: this build has no CPU path, cv.lamellar always creates the GPU class)
+    py::class_<LamellarOrderParameterGPU, CollectiveVariable, std::shared_ptr<LamellarOrderParameterGPU>>(m, "LamellarOrderParameterGPU")
+        .def(py::init<std::shared_ptr<SystemDefinition>, const std::vector<double> &, const std::vector<int3> &, const std::string &>());
+
+    py::class_<WellTemperedEnsemble, CollectiveVariable, std::shared_ptr<WellTemperedEnsemble>>(m, "WellTemperedEnsemble")
+        .def(py::init<std::shared_ptr<SystemDefinition>, const std::string &>());
+
+    py::class_<AspectRatio, CollectiveVariable, std::shared_ptr<AspectRatio>>(m, "AspectRatio")
+        .def(py::init<std::shared_ptr<SystemDefinition>, unsigned int, unsigned int>());
+
+    py::class_<Density, CollectiveVariable, std::shared_ptr<Density>>(m, "Density")
+        .def(py::init<std::shared_ptr<SystemDefinition>, const std::string &>());
+
+    // IntegratorMetaDynamics.cc:1315-1349
+    py::class_<IntegratorMetaDynamics, std::shared_ptr<IntegratorMetaDynamics>> integrator_metad(m, "IntegratorMetaDynamics");
+    integrator_metad
+        .def(py::init<std::shared_ptr<SystemDefinition>, double, double, double, double, unsigned int, bool, const std::string &, bool,
+                      IntegratorMetaDynamics::Enum>())
+        .def("registerCollectiveVariable", &IntegratorMetaDynamics::registerCollectiveVariable)
+        .def("removeAllVariables", &IntegratorMetaDynamics::removeAllVariables)
+        .def("isInitialized", &IntegratorMetaDynamics::isInitialized)
+        .def("setGrid", &IntegratorMetaDynamics::setGrid)
+        .def("dumpGrid", &IntegratorMetaDynamics::dumpGrid)
+        .def("restartFromGridFile", &IntegratorMetaDynamics::restartFromGridFile)
+        .def("setAddHills", &IntegratorMetaDynamics::setAddHills)
+        .def("setMode", &IntegratorMetaDynamics::setMode)
+        .def("setStride", &IntegratorMetaDynamics::setStride)
+        .def("setAdaptive", &IntegratorMetaDynamics::setAdaptive)
+        .def("setSigmaG", &IntegratorMetaDynamics::setSigmaG)
+        .def("resetHistogram", &IntegratorMetaDynamics::resetHistogram)
+        .def("setMultipleWalkers", &IntegratorMetaDynamics::setMultipleWalkers)
+        // HOOMD Integrator interface used by System / analyze.log
+        .def("prepRun", &IntegratorMetaDynamics::prepRun)
+        .def("update", &IntegratorMetaDynamics::update)
+        .def("addForceCompute", &IntegratorMetaDynamics::addForceCompute)
+        .def("removeForceComputes", &IntegratorMetaDynamics::removeForceComputes)
+        .def("getProvidedLogQuantities", &IntegratorMetaDynamics::getProvidedLogQuantities)
+        .def("getLogValue", &IntegratorMetaDynamics::getLogValue)
+        // this build
+        .def("setFusedPath", &IntegratorMetaDynamics::setFusedPath)
+        .def("usedFusedPath", &IntegratorMetaDynamics::usedFusedPath)
+        .def("getEngineHandle", [](IntegratorMetaDynamics &i) { return (size_t)i.getEngine(); });
+    py::enum_<IntegratorMetaDynamics::Enum>(integrator_metad, "mode")
+        .value("standard", IntegratorMetaDynamics::mode_standard)
+        .value("well_tempered", IntegratorMetaDynamics::mode_well_tempered)
+        .export_values();
+
+    py::class_<System, std::shared_ptr<System>>(m, "System")
+        .def(py::init<std::shared_ptr<SystemDefinition>, unsigned int>())
+        .def("setIntegrator", &System::setIntegrator)
+        .def("run", &System::run, py::call_guard<py::gil_scoped_release>())
+        .def("getCurrentTimeStep", &System::getCurrentTimeStep);
+    }

@@ -1,5 +1,10 @@
-"""MI355X-native metadynamics hot path behind the reference's `hoomd.metadynamics` API.
+"""MI355X-native metadynamics hot path behind the reference's ``hoomd.metadynamics`` API.
 
-Sub-modules mirror the reference package (metadynamics/__init__.py:1-2): `cv`, `integrate`.
-`_abi` is the ctypes view of the C-ABI library (include/mtd_abi.h).
+Sub-modules mirror the reference package (metadynamics/__init__.py:1-2): ``cv``, ``integrate``; ``context`` stands in
+for the slice of HOOMD the API touches; ``_abi`` is the ctypes view of the C-ABI library (include/mtd_abi.h);
+``_metadynamics`` is the pybind11 module of the C++ host classes (imported lazily: it needs libmtd_hip.so).
 """
+try:  # one HIP runtime per process: torch's bundled libamdhip64 must be the first one loaded (see _abi.load)
+    import torch as _torch  # noqa: F401
+except ImportError:  # pragma: no cover
+    pass

@@ -1,0 +1,152 @@
+"""Collective variables — the reference's ``hoomd.metadynamics.cv`` API (metadynamics/cv.py) over the MI355X host classes.
+
+Class names, constructor arguments, ``set_grid`` / ``set_params`` and the error behaviour follow the reference
+(file:line citations refer to /root/reference/metadynamics/cv.py).  There is no CPU class to choose
+(cv.py:260-265 picks LamellarOrderParameter vs ...GPU by ``exec_conf.isCUDAEnabled()``): the GPU class is the only one.
+"""
+from . import _metadynamics
+from . import context
+
+
+class _collective_variable(object):
+    """Base class (cv.py:11-170): a collective variable is a force with grid / umbrella parameters."""
+
+    def __init__(self, sigma, name=None):
+        self.name = name
+        self.force_name = "cv" if name is None else str(name)
+        self.enabled = True
+        self.log = True
+        self.sigma = sigma
+        self.cv_min = 0.0
+        self.cv_max = 0.0
+        self.num_points = 0
+        self.grid_set = False
+        self.ftm_min = 0.0
+        self.ftm_max = 0.0
+        self.ftm_parameters_set = False
+        self.umbrella = False
+        self.reweight = False
+        self.cpp_force = None
+        context.current.forces.append(self)
+
+    def set_grid(self, cv_min, cv_max, num_points):                 # cv.py:70-86
+        self.cv_min = cv_min
+        self.cv_max = cv_max
+        self.num_points = int(num_points)
+        self.grid_set = True
+
+    def enable_histograms(self, ftm_min, ftm_max):                  # cv.py:88-103
+        self.ftm_min = ftm_min
+        self.ftm_max = ftm_max
+        self.ftm_parameters_set = True
+
+    def set_params(self, sigma=None, kappa=None, cv0=None, umbrella=None, width_flat=None, scale=None, reweight=None):
+        """cv.py:105-170"""
+        if sigma is not None:
+            self.sigma = sigma
+        if umbrella is not None:
+            modes = {"no_umbrella": (self.cpp_force.umbrella.no_umbrella, False),
+                     "linear": (self.cpp_force.umbrella.linear, True),
+                     "harmonic": (self.cpp_force.umbrella.harmonic, True),
+                     "wall": (self.cpp_force.umbrella.wall, True),
+                     "gaussian": (self.cpp_force.umbrella.gaussian, True)}
+            if umbrella not in modes:
+                raise RuntimeError("Error setting parameters of collective variable.")   # cv.py:150-152
+            cpp_umbrella, flag = modes[umbrella]
+            self.reweight = flag
+            self.umbrella = flag
+            self.cpp_force.setUmbrella(cpp_umbrella)
+        if kappa is not None:
+            self.cpp_force.setKappa(kappa)
+        if width_flat is not None:
+            self.cpp_force.setWidthFlat(width_flat)
+        if cv0 is not None:
+            self.cpp_force.setMinimum(cv0)
+        if scale is not None:
+            self.cpp_force.setScale(scale)
+        if reweight is not None:
+            self.reweight = reweight
+
+    def update_coeffs(self):
+        pass
+
+
+def _mode_vector(mode, what):
+    if type(mode) != type(dict()):
+        raise RuntimeError("Error creating collective variable.")    # cv.py:236-238
+    pdata = context.current.system_definition.getParticleData()
+    out = []
+    for i in range(pdata.getNTypes()):
+        t = pdata.getNameByType(i)
+        if t not in mode.keys():
+            raise RuntimeError("Error creating collective variable.")   # cv.py:245-247: missing mode amplitude
+        out.append(float(mode[t]))
+    return out
+
+
+class lamellar(_collective_variable):
+    """Lamellar order parameter (cv.py:173-272): s = (1/N) sum_i sum_j a(type_j) cos(q_i . r_j)."""
+
+    def __init__(self, mode, lattice_vectors, name=None, sigma=1.0):
+        if name is not None:
+            name = "_" + name
+            suffix = name
+        else:
+            suffix = ""
+        _collective_variable.__init__(self, sigma, name)
+        if len(lattice_vectors) == 0:
+            raise RuntimeError("Error creating collective variable.")   # cv.py:232-234
+        cpp_mode = _mode_vector(mode, "cv.lamellar")
+        cpp_lattice_vectors = _metadynamics.std_vector_int3()
+        for l in lattice_vectors:
+            if len(l) != 3:
+                raise RuntimeError("Error creating collective variable.")   # cv.py:252-254
+            cpp_lattice_vectors.append(_metadynamics.make_int3(int(l[0]), int(l[1]), int(l[2])))
+        self.cpp_force = _metadynamics.LamellarOrderParameterGPU(context.current.system_definition, cpp_mode,
+                                                                 cpp_lattice_vectors, suffix)
+
+
+class aspect_ratio(_collective_variable):
+    """cv.py:275-305"""
+
+    def __init__(self, dir1, dir2, name="", sigma=1.0):
+        _collective_variable.__init__(self, sigma, name)
+        self.cpp_force = _metadynamics.AspectRatio(context.current.system_definition, int(dir1), int(dir2))
+
+
+class density(_collective_variable):
+    """cv.py:308-338 (group = all particles)"""
+
+    def __init__(self, group=None, sigma=1.0):
+        name = "all" if group is None else str(group)
+        _collective_variable.__init__(self, sigma, name)
+        self.cpp_force = _metadynamics.Density(context.current.system_definition, name)
+
+
+class potential_energy(_collective_variable):
+    """Well-tempered ensemble: the potential energy as collective variable (cv.py:469-497)."""
+
+    def __init__(self, sigma=1.0):
+        name = "cv_potential_energy"
+        _collective_variable.__init__(self, sigma, name)
+        self.enabled = False                                          # cv.py:486-487: not a regular ForceCompute
+        self.cpp_force = _metadynamics.WellTemperedEnsemble(context.current.system_definition, name)
+
+
+def _not_built(what, row):
+    raise NotImplementedError("%s is SURVEY.md §8 row %s and not built yet in this round (see DESIGN.md §7)" % (what, row))
+
+
+class mesh(_collective_variable):
+    def __init__(self, mode, nx, ny=None, nz=None, name=None, sigma=1.0, zero_modes=None):
+        _not_built("cv.mesh", "A13-A17")
+
+
+class steinhardt(_collective_variable):
+    def __init__(self, r_cut, r_on, lmax, Ql_ref, nlist, type, name=None, sigma=1.0):
+        _not_built("cv.steinhardt", "A18-A19")
+
+
+class wrap(_collective_variable):
+    def __init__(self, force, sigma=1.0):
+        _not_built("cv.wrap", "(f) N2")

@@ -1,0 +1,211 @@
+"""GPU: the reference's Python API (metadynamics.cv / metadynamics.integrate) over the C++ host classes,
+checked against the oracle — including the reference's own test/test_2d.py scenario end to end."""
+import os
+
+import numpy as np
+import pytest
+
+import util
+
+torch = pytest.importorskip("torch")
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture()
+def api():
+    from metadynamics import context, cv, integrate
+    yield context, cv, integrate
+    context.current = None
+
+
+def _loadgrid(path):
+    return np.loadtxt(path, skiprows=4)
+
+
+def test_reference_test_2d_scenario(api, ref, tmp_path):
+    """test/test_2d.py: N=1, V=10; density (sigma .25, [0,1]x20) + aspect_ratio (sigma .1, [0,2]x30); well-tempered,
+    stride 1, deltaT=1, W=1; dump every step; run(1); box volume x0.125; run(1); then a fresh context restarted from
+    bias.dat_1.  "bias.restart_0.dat and bias.dat_2 should be identical up to rounding errors" (test_2d.py:1-2)."""
+    context, cv, integrate = api
+    L1 = 10 ** (1.0 / 3.0)
+    s = 0.125 ** (1.0 / 3.0)
+    os.chdir(tmp_path)
+
+    def block(restart):
+        context.initialize(np.zeros((1, 3)), [0], ["A"], L1, dtype=np.float64)
+        meta = integrate.mode_metadynamics(dt=0.005, mode="well_tempered", stride=1, deltaT=1, W=1)
+        density = cv.density(sigma=0.25)
+        density.set_grid(cv_min=0, cv_max=1, num_points=20)
+        aspect = cv.aspect_ratio(sigma=0.1, dir1=0, dir2=1)
+        aspect.set_grid(cv_min=0, cv_max=2, num_points=30)
+        pdata = context.current.system_definition.getParticleData()
+        if not restart:
+            meta.dump_grid("bias.dat", period=1)
+            meta.set_params(multiple_walkers=True)
+            context.run(1)
+            pdata.setGlobalBox(pdata.getGlobalBox().scale(s))
+            context.run(1)
+        else:
+            meta.restart_from_grid("bias.dat_1")
+            meta.dump_grid("bias_restart.dat", period=1)
+            meta.set_params(multiple_walkers=True)
+            pdata.setGlobalBox(pdata.getGlobalBox().scale(s))
+            context.run(1)
+        assert not meta.cpp_integrator.usedFusedPath()     # box CVs go through the generic path
+        return meta
+
+    block(False)
+    block(True)
+
+    # the same call sequence on the oracle
+    kw = dict(sigma=[0.25, 0.1], cv_min=[0.0, 0.0], cv_max=[1.0, 2.0], num_points=[20, 30], W=1.0, T_shift=1.0, T=1.0,
+              stride=1, mode="well_tempered")
+    names = ["cv_density_all", "cv_aspect_ratio"]
+    b1, b2 = ref.Box.make(L1), ref.Box.make(L1 * s)
+    v1 = [ref.density(b1, 1), ref.aspect_ratio(b1, 0, 1)]
+    v2 = [ref.density(b2, 1), ref.aspect_ratio(b2, 0, 1)]
+    odir = tmp_path / "oracle"
+    odir.mkdir()
+    a = ref.Metad(**kw)
+    for t, v in ((0, v1), (1, v1), (1, v2), (2, v2)):    # prepRun(0), update(0); prepRun(1), update(1)  (Q17)
+        a.update_bias(t, v)
+        a.write_grid(str(odir / "bias.dat"), t, names)
+    b = ref.Metad(**kw)
+    b.read_grid(str(odir / "bias.dat_1"))
+    for t in (0, 1):
+        b.update_bias(t, v2)
+        b.write_grid(str(odir / "bias_restart.dat"), t, names)
+
+    for f in ("bias.dat_0", "bias.dat_1", "bias.dat_2", "bias_restart.dat_0", "bias_restart.dat_1"):
+        got, want = _loadgrid(tmp_path / f), _loadgrid(odir / f)
+        assert got.shape == (600, 8)
+        assert np.allclose(got, want, rtol=1e-9, atol=1e-12), f
+        assert open(tmp_path / f).read().splitlines()[:4] == open(odir / f).read().splitlines()[:4], f
+    # the reference's own acceptance criterion
+    assert np.allclose(_loadgrid(tmp_path / "bias_restart.dat_0"), _loadgrid(tmp_path / "bias.dat_2"), rtol=1e-8, atol=1e-12)
+    assert open(tmp_path / "bias.dat_2").read().splitlines()[2] == "#num_gaussians: 4"
+
+
+@pytest.mark.parametrize("fused", [True, False])
+def test_config0b_through_api(api, ref, tmp_path, fused):
+    """BASELINE.json configs[0]: 4096 particles, 1 lamellar CV [(0,0,4)], grid [-1,1]x128, sigma .05, W=1, dT=7, T=1,
+    stride 1, 10 steps — CV, bias, weight and forces vs the oracle; fused and generic paths"""
+    context, cv, integrate = api
+    pos, types, L = util.snapshot_config0b()
+    pos = pos.astype(np.float32)
+    context.initialize(pos, types, ["A", "B"], L, dtype=np.float32)
+    hills = str(tmp_path / "hills.log")
+    meta = integrate.mode_metadynamics(dt=0.005, stride=1, mode="well_tempered", W=1.0, deltaT=7.0, T=1.0, filename=hills)
+    lam = cv.lamellar(sigma=0.05, mode=dict(A=1.0, B=-1.0), lattice_vectors=[(0, 0, 4)])
+    lam.set_grid(cv_min=-1.0, cv_max=1.0, num_points=128)
+    meta.cpp_integrator.setFusedPath(fused)
+    context.run(10)
+    assert meta.cpp_integrator.usedFusedPath() == fused
+
+    rbox = ref.Box.make(L)
+    opt = util.oracle_postype(pos, types)
+    s_ref = ref.lamellar_cv([(0, 0, 4)], opt, util.MODE_AB, rbox)
+    r = ref.Metad([0.05], [-1.0], [1.0], [128], W=1.0, T_shift=7.0, T=1.0, stride=1, mode="well_tempered")
+    for t in range(11):              # prepRun(0) + 10 updates (timesteps 1..10)
+        b = r.update_bias(t, [s_ref])
+    t_now = context.current.system.getCurrentTimeStep()
+    assert t_now == 10
+    # the forces of the last step were written with the last bias factor
+    F = lam.cpp_force.getForceArray().astype(np.float64)
+    F_ref = ref.lamellar_forces([(0, 0, 4)], opt, util.MODE_AB, rbox, b[0])
+    assert np.abs(F[:, :3] - F_ref[:, :3]).max() <= 1e-5 * np.abs(F_ref[:, :3]).max()
+    # log quantities: bias potential and reweighting factor (IntegratorMetaDynamics.h:161-189)
+    assert meta.cpp_integrator.getLogValue("bias", t_now) == pytest.approx(r.curr_bias, rel=2e-6)
+    assert meta.cpp_integrator.getLogValue("weight", t_now) == pytest.approx(r.curr_weight, rel=2e-6)
+    assert meta.cpp_integrator.getLogValue("det_sigma", t_now) == pytest.approx(1 / 0.05)
+    assert lam.cpp_force.getCurrentValue(t_now) == pytest.approx(s_ref, rel=1e-6)
+    assert lam.cpp_force.getLogValue("cv_lamellar", t_now) == pytest.approx(s_ref, rel=1e-6)
+    # hills file: header + one line per deposit (:98-119, :523-550)
+    lines = open(hills).read().splitlines()
+    assert lines[0].split("\t")[:3] == ["timestep", "W", "cv_lamellar"]
+    assert len(lines) == 1 + 11
+    assert int(lines[1].split("\t")[0]) == 0 and int(lines[-1].split("\t")[0]) == 10
+
+
+def test_two_lamellar_cvs_and_umbrella_fallback(api, ref):
+    """two fused lamellar CVs; adding an umbrella to one of them makes the integrator fall back to the generic
+    path (the umbrella needs the host CV value, CollectiveVariable.cc:22-60) with the same grid evolution"""
+    context, cv, integrate = api
+    N, L = 20011, 30.0
+    pos, types = util.snapshot_random(N, L, seed=8, modulated=True, dtype=np.float32)
+    grids = {}
+    for variant in ("fused", "umbrella"):
+        context.initialize(pos, types, ["A", "B"], L, dtype=np.float32)
+        meta = integrate.mode_metadynamics(dt=0.005, stride=2, mode="well_tempered", W=0.5, deltaT=5.0, T=1.0)
+        c1 = cv.lamellar(sigma=0.02, mode=dict(A=1.0, B=-1.0), lattice_vectors=util.CV1_VECTORS, name="one")
+        c1.set_grid(-0.6, 0.4, 40)
+        c2 = cv.lamellar(sigma=0.01, mode=dict(A=1.0, B=-1.0), lattice_vectors=util.CV2_VECTORS, name="two")
+        c2.set_grid(-0.3, 0.3, 30)
+        if variant == "umbrella":
+            c2.set_params(umbrella="harmonic", kappa=0.0, cv0=0.0)   # zero stiffness: no change in the bias factor
+        context.run(5)
+        assert meta.cpp_integrator.usedFusedPath() == (variant == "fused")
+        meta.dump_grid("/tmp/_mtd_api_%s" % variant)
+        grids[variant] = _loadgrid("/tmp/_mtd_api_%s_0" % variant)
+        assert c1.cpp_force.getName() == "cv_lamellar_one"
+    assert np.allclose(grids["fused"], grids["umbrella"], rtol=1e-9, atol=1e-14)
+    assert grids["fused"][:, 2].max() > 0
+
+
+def test_potential_energy_cv(api, ref):
+    """cv.potential_energy (WellTemperedEnsemble): PE = sum net_force.w + external energy; net force, torque and
+    virial scaled by 1 + dV/dE, torque.w too like the CPU path (Q18); net_force_first ordering (.cc:259-301)"""
+    context, cv, integrate = api
+    N = 5003
+    rng = np.random.default_rng(4)
+    pos = rng.random((N, 3)) * 10 - 5
+    context.initialize(pos, np.zeros(N, dtype=int), ["A"], 10.0, dtype=np.float64)
+    pdata = context.current.system_definition.getParticleData()
+    nf = rng.normal(size=(N, 4)); nf[:, 3] = rng.normal(-2.0, 0.5, N)
+    nt = rng.normal(size=(N, 4))
+    nv = rng.normal(size=(6, N))
+    pdata.setNetForce(nf); pdata.setNetTorque(nt); pdata.setNetVirial(nv)
+    pdata.setExternalEnergy(12.5)
+    for i in range(6):
+        pdata.setExternalVirial(i, float(i + 1))
+    pe_ref = ref.wte_potential_energy(nf, 12.5)
+    meta = integrate.mode_metadynamics(dt=0.005, stride=1, mode="well_tempered", W=2.0, deltaT=50.0, T=1.0)
+    pe = cv.potential_energy(sigma=40.0)
+    pe.set_grid(cv_min=pe_ref - 300.0, cv_max=pe_ref + 300.0, num_points=64)
+    assert pe.cpp_force.requiresNetForce()
+    assert pe.cpp_force.getCurrentValue(0) == pytest.approx(pe_ref, rel=1e-13)
+    context.run(1)
+    # oracle: prepRun deposits at t=0 (bias evaluated, forces of the CV computed at t=0 are not applied to the net
+    # force in prepRun: the WTE compute is not in the force list), update(0): updateBias(1) then cv.compute(0) scales.
+    r = ref.Metad([40.0], [pe_ref - 300.0], [pe_ref + 300.0], [64], W=2.0, T_shift=50.0, T=1.0, stride=1, mode="well_tempered")
+    r.update_bias(0, [pe_ref])
+    b = r.update_bias(1, [pe_ref])
+    f2, t2, v2, e2 = ref.wte_scale(nf, nt, nv.reshape(-1), N, [1, 2, 3, 4, 5, 6], b[0])
+    assert np.allclose(pdata.getNetForce(), f2, rtol=1e-12, atol=1e-14)
+    assert np.allclose(pdata.getNetTorque(), t2, rtol=1e-12, atol=1e-14)
+    assert np.allclose(pdata.getNetVirial().reshape(-1), v2, rtol=1e-12, atol=1e-14)
+    assert np.allclose([pdata.getExternalVirial(i) for i in range(6)], e2, rtol=1e-12)
+
+
+def test_api_errors(api):
+    context, cv, integrate = api
+    context.initialize(np.zeros((4, 3)), [0, 1, 0, 1], ["A", "B"], 5.0)
+    with pytest.raises(RuntimeError):
+        cv.lamellar(mode=dict(A=1.0), lattice_vectors=[(0, 0, 1)])            # missing mode amplitude (cv.py:245-247)
+    with pytest.raises(RuntimeError):
+        cv.lamellar(mode=dict(A=1.0, B=-1.0), lattice_vectors=[])             # empty list (cv.py:232-234)
+    with pytest.raises(RuntimeError):
+        cv.lamellar(mode=[1.0, -1.0], lattice_vectors=[(0, 0, 1)])            # not a dict (cv.py:236-238)
+    with pytest.raises(RuntimeError):
+        integrate.mode_metadynamics(dt=0.005, stride=1, mode="flux_tempered")  # integrate.py:214-216
+    context.current.forces.clear()
+    meta = integrate.mode_metadynamics(dt=0.005, stride=1)
+    c = cv.lamellar(mode=dict(A=1.0, B=-1.0), lattice_vectors=[(0, 0, 1)])
+    c.set_grid(cv_min=1.0, cv_max=1.0, num_points=10)
+    with pytest.raises(RuntimeError):
+        context.run(1)                                                         # cv_min >= cv_max (.cc:800-805)
+    with pytest.raises(RuntimeError):
+        c.set_params(umbrella="bogus")
+    with pytest.raises(RuntimeError):
+        meta.set_params(adaptive=True)
