@@ -49,6 +49,9 @@ def parse():
     ap.add_argument("--fast-trig", type=int, default=int(os.environ.get("MTD_FAST_TRIG", "1")))
     ap.add_argument("--path", choices=["fused", "generic"], default="fused",
                     help="fused: two launches per step (headline); generic: separate C-ABI calls per stage")
+    ap.add_argument("--driver", choices=["host", "abi"], default=None,
+                    help="host: metadynamics.integrate API, C++ run loop (default at N=1); abi: C-ABI calls from Python "
+                         "(default for N>1, where torch.distributed carries the all-reduce)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=4)
     return ap.parse_args()
@@ -109,6 +112,37 @@ class Engine:
         return self.be.state()
 
 
+class HostEngine:
+    """The same workload through the reference-shaped API: metadynamics.cv / metadynamics.integrate over the C++
+    host classes; the step loop is System::run in C++ (what HOOMD's run loop does)."""
+
+    def __init__(self, n, seed, stride, fast_trig, path):
+        from metadynamics import context, cv, integrate
+        pos, types = util.snapshot_random(n, BOX_L, seed=seed, dtype=np.float32)
+        self.pos_np, self.types_np, self.L = pos, types, BOX_L
+        self.ctx = context.initialize(pos, types, ["A", "B"], BOX_L, dtype=np.float32)
+        self.meta = integrate.mode_metadynamics(dt=0.005, stride=stride, mode="well_tempered", W=W, deltaT=DELTA_T, T=T)
+        self.cvs = []
+        for i, vecs in enumerate((util.CV1_VECTORS, util.CV2_VECTORS)):
+            c = cv.lamellar(sigma=GRID["sigma"][i], mode=dict(A=1.0, B=-1.0), lattice_vectors=vecs, name="cv%d" % i)
+            c.set_grid(GRID["cv_min"][i], GRID["cv_max"][i], GRID["num_points"][i])
+            self.cvs.append(c)
+        self.meta.cpp_integrator.setFusedPath(path == "fused")
+        _abi.check(_abi.load().mtd_lamellar_set_fast_trig(int(fast_trig)))
+        self.context = context
+        self.meta.update_forces()
+        self.ctx.system.run(0)          # prepRun: allocate the grid, first deposit (Q17)
+
+    def run(self, k):
+        self.ctx.system.run(k)          # note: every run() starts with prepRun (one extra bias update, as in HOOMD)
+
+    def state(self):
+        t = self.ctx.system.getCurrentTimeStep()
+        integ = self.meta.cpp_integrator
+        return dict(cv=[c.cpp_force.getCurrentValue(t) for c in self.cvs], V=integ.getLogValue("bias", t),
+                    w=integ.getLogValue("weight", t), fused=integ.usedFusedPath())
+
+
 def cpu_baseline(pos, types, L, steps):
     """The CPU restatement (oracle, kind "port") of the same step on ONE host core: the reference CPU
     path is serial (MPI ranks only) and cannot be built here (needs HOOMD)."""
@@ -145,11 +179,9 @@ def main():
 
     n_local = args.particles
     n_global = n_local * world
-    eng = Engine(n_local, n_global, rank, seed=12345 if world == 1 else 12346, stride=args.stride,
-                 fast_trig=args.fast_trig, dist=dist, path=args.path)
-
-    for _ in range(args.warmup):
-        eng.step()
+    driver = args.driver or ("host" if world == 1 else "abi")
+    if driver == "host" and world > 1:
+        raise SystemExit("--driver host is single-GPU; N>1 uses the C-ABI backend with torch.distributed")
 
     def barrier():
         torch.cuda.synchronize()
@@ -157,21 +189,39 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        eng.step()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    # the event-bracketed pass over the dominant kernel always goes through the C-ABI backend (same kernels)
+    eng = Engine(n_local, n_global, rank, seed=12345 if world == 1 else 12346, stride=args.stride,
+                 fast_trig=args.fast_trig, dist=dist, path=args.path)
+    if driver == "host":
+        host = HostEngine(n_local, 12345, args.stride, args.fast_trig, args.path)
+        host.run(max(args.warmup - 1, 0))
+        barrier()
+        t0 = time.perf_counter()
+        host.run(args.steps - 1)        # run(k) = prepRun (one bias update) + k updates: exactly args.steps bias steps
+        barrier()
+        elapsed = time.perf_counter() - t0
+        st = host.state()
+    else:
+        for _ in range(args.warmup):
+            eng.step()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            eng.step()
+        barrier()
+        elapsed = time.perf_counter() - t0
+        if dist is not None:
+            tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            elapsed = float(tt.item())
+        st = eng.state()
 
     # dominant kernel (force pass): per-launch durations from HIP events on the launch stream, over the same
     # loop.  An event pair costs the command processor two extra barrier packets; that fixed overhead is
     # calibrated with empty pairs (nothing between the two records) and subtracted, so the figure is
     # comparable with the kernel-trace duration of the rocprofv3 summary under profiles/.
+    for _ in range(20 if driver == "host" else 0):
+        eng.step()
     eng.ev = []
     n_ev = min(args.steps, 500)
     for _ in range(n_ev):
@@ -188,7 +238,6 @@ def main():
     force_us = float(np.median(raw) - ev_overhead_us)
     force_us_mean = float(np.mean(raw) - ev_overhead_us)
     eng.ev = None
-    st = eng.state()
 
     if rank == 0:
         steps_per_s = args.steps / elapsed
@@ -217,7 +266,7 @@ def main():
             "config": {"workload": "1xMI355X: 10^6 particles, 2 lamellar CVs (8 Fourier modes each), 256^2 bias grid, well-tempered"
                        if world == 1 else "%dxMI355X: %d particles sharded, 2 lamellar CVs, RCCL all-reduce of CV sums, replicated 256^2 grid" % (world, n_global),
                        "particles_per_gpu": n_local, "n_cv": 2, "modes_per_cv": 8, "grid": "256x256",
-                       "stride": args.stride, "fast_trig": int(args.fast_trig), "path": args.path},
+                       "stride": args.stride, "fast_trig": int(args.fast_trig), "path": args.path, "driver": driver},
             "roofline": {"bound": "hbm", "kernel": "k_fused_force" if args.path == "fused" else "k_lamellar_forces", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "algorithmic_bytes_per_launch": force_bytes, "avg_launch_us": force_us_mean,
