@@ -249,6 +249,12 @@ def main():
         if args.path == "fused" and args.stride == 1:
             force_bytes += 256 * 256 * 28
         achieved = force_bytes / (force_us_mean * 1e-6) / 1e9
+        # HBM traffic of the dominant kernel from the PMC passes committed under profiles/ (FETCH_SIZE / WRITE_SIZE
+        # in separate rocprofv3 runs, gfx950 x2 correction on FETCH_SIZE); only valid for the default workload
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "r1", "pmc_summary.json")
+        if os.path.exists(pmc) and args.path == "fused" and args.stride == 1 and n_local == N_PER_GPU:
+            traffic = json.load(open(pmc)).get("k_fused_force", {}).get("hbm_bytes_per_launch")
         out = {
             "metric": "particle_cv_evals_per_s",
             "value": value,
@@ -268,7 +274,8 @@ def main():
                        "particles_per_gpu": n_local, "n_cv": 2, "modes_per_cv": 8, "grid": "256x256",
                        "stride": args.stride, "fast_trig": int(args.fast_trig), "path": args.path, "driver": driver},
             "roofline": {"bound": "hbm", "kernel": "k_fused_force" if args.path == "fused" else "k_lamellar_forces", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "traffic_source": "profiles/r1/pmc_summary.json (rocprofv3 --pmc passes of this command)" if traffic else None,
                          "algorithmic_bytes_per_launch": force_bytes, "avg_launch_us": force_us_mean,
                          "median_launch_us": force_us, "event_pair_overhead_us": ev_overhead_us},
             "state": st,
