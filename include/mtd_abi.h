@@ -226,6 +226,39 @@ int mtd_fused_force_pass(mtd_metad *m, const mtd_lamellar_set *set, unsigned int
                          unsigned int timestep, mtd_stream_t stream);
 
 /* ================================================================================================
+ * Particle-mesh order parameter (cv.mesh)
+ * replaces OrderParameterMeshGPU.cuh:9-109 (gpu_bin_particles, gpu_assign_binned_particles_to_mesh,
+ * gpu_update_meshes, gpu_compute_cv, gpu_compute_forces, gpu_compute_mode_sq) and the cuFFT plans of
+ * OrderParameterMeshGPU.cc:57-152; single rank (no ghost cells), double precision meshes
+ * ============================================================================================== */
+
+typedef struct mtd_mesh mtd_mesh; /* opaque; owns the meshes, the cell list and the FFT twiddles */
+
+/* OrderParameterMesh constructor + setupMesh + initializeFFT (OrderParameterMesh.cc:18-122, 191-229, 263-342).
+ * mode: host double[n_types].  Mesh sizes must be powers of two in [4, 1024] (MTD_ERR_UNSUPPORTED otherwise). */
+int mtd_mesh_create(mtd_mesh **out, unsigned int nx, unsigned int ny, unsigned int nz, const double *mode,
+                    unsigned int n_types, unsigned int max_particles);
+int mtd_mesh_destroy(mtd_mesh *m);
+/* 1 (default): interpolation function with the reference's unsigned integer division; 0: as intended */
+int mtd_mesh_set_bug_compat(mtd_mesh *m, int on);
+unsigned int mtd_mesh_num_cells(const mtd_mesh *m);
+
+/* getCurrentValue (OrderParameterMesh.cc:925-968): assignParticles -> FFT -> updateMeshes -> iFFT -> computeCV.
+ * The CV is s = 1/2 * sum_{b < *n_partials} (*d_partials)[b]  (device doubles owned by the mesh): consume with
+ * mtd_metad_set_cv_source(engine, slot, *d_partials, *n_partials, 1, 0, 0.5, 0.0) or mtd_reduce_partials. */
+int mtd_mesh_compute_cv(mtd_mesh *m, unsigned int n_particles, const void *d_postype, int dtype, const mtd_box *box,
+                        unsigned int n_global, const double **d_partials, unsigned int *n_partials, mtd_stream_t stream);
+
+/* interpolateForces (OrderParameterMesh.cc:749-864) from the inverse mesh of the last mtd_mesh_compute_cv;
+ * bias = *d_bias when d_bias != NULL (device resident), else bias_host */
+int mtd_mesh_forces(mtd_mesh *m, unsigned int n_particles, const void *d_postype, void *d_force, int dtype,
+                    const mtd_box *box, unsigned int n_global, const double *d_bias, double bias_host, mtd_stream_t stream);
+
+/* raw arrays for parity tests (SYNCHRONISES): which = 0 real mesh double[M]; 1 fourier_mesh (normalised) complex double[M];
+ * 3 inv_fourier_mesh complex double[M]; 7 sum of mode^2 (one double) */
+int mtd_mesh_get_array(mtd_mesh *m, int which, void *host_out, mtd_stream_t stream);
+
+/* ================================================================================================
  * WellTemperedEnsemble (potential energy as CV)
  * replaces WellTemperedEnsemble.cuh:3-19 (gpu_scale_netforce, gpu_reduce_potential_energy)
  * ============================================================================================== */

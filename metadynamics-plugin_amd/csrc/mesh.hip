@@ -1,0 +1,756 @@
+// mesh.hip — particle-mesh order parameter (OrderParameterMesh) on gfx950.
+//
+// Reference (CPU path results must match): OrderParameterMesh.cc:517-640 (assignParticles, TSC),
+// :642-747 (updateMeshes), :866-923 (computeCV), :749-864 (interpolateForces), :344-453
+// (computeInfluenceFunction incl. the unsigned-division interpolation function, Q6).  CUDA design
+// replaced: OrderParameterMeshGPU.cu — atomicInc binning with overflow re-runs (:90-152), a 27 x M
+// float scratch (226 MB at 128^3) with memset + reduce (:179-364), cuFFT C2C, separate update / CV /
+// final-reduce launches (:510-541, :771-885), texture-bound force gather (:566-754).
+//
+// MI355X design: single rank, no ghost cells (the multi-GPU plan replicates the mesh).
+//   1 k_mesh_count      cell of every particle, per-cell counts, block sums of mode^2
+//   2 scan (3 tiny kernels)  exclusive scan of the counts -> cell starts
+//   3 k_mesh_fill       particle ids into their cell's slots (atomic cursor)
+//   4 k_mesh_sort       per cell: ids sorted ascending (=> bitwise reproducible sums), (shift, mode) packed
+//   5 k_mesh_gather     one thread per mesh cell sums the TSC weights of the particles in its 27 neighbour
+//                       cells: no atomics on the mesh, no scratch, every mesh cell written exactly once
+//   6 k_fft_lines x3    unnormalised DFT, one pass per axis, lines staged in LDS in [pos][line] layout
+//                       (16 adjacent lines per block so strided axes still move 256-B segments)
+//   7 k_mesh_spectral   f = F/N, G = f(|f|^2 - I^2 sum mode^2 / 2N^2), block sums of the CV integrand
+//   8 k_fft_lines x3    inverse
+//   9 k_mesh_forces     per particle: 27 reads of Re(inv) with TSC' x TSC x TSC weights
+// Everything is double precision: the CV is quartic in the Fourier amplitudes, fp32 meshes cannot hold
+// 1e-6 on it.  Mesh sizes must be powers of two (the reference's own multi-rank restriction,
+// OrderParameterMesh.cc:74-79); other sizes return MTD_ERR_UNSUPPORTED.
+#include "mtd_device.hpp"
+
+#include <cmath>
+#include <cstring>
+#include <new>
+#include <vector>
+
+namespace
+{
+
+using namespace mtd;
+
+struct MeshGeom
+    {
+    unsigned int nx, ny, nz, n_cells;
+    double lo[3], L[3], xy, xz, yz;      // box (local == global: single rank)
+    double binv[3][3];                    // reciprocal rows without 2 pi (force pass, :761-769)
+    };
+
+__device__ __forceinline__ double tsc(double x)                       // :457-468
+    {
+    const double xsq = x * x;
+    const double xabs = sqrt(xsq);
+    if (xsq <= 1.0 / 4.0) return 3.0 / 4.0 - xsq;
+    if (xsq <= 9.0 / 4.0) return 1.0 / 2.0 * (3.0 / 2.0 - xabs) * (3.0 / 2.0 - xabs);
+    return 0.0;
+    }
+
+__device__ __forceinline__ double tsc_deriv(double x)                 // :470-483 (copysignf: float |x|, Q9)
+    {
+    const double xsq = x * x;
+    const double xabs = (double)fabsf((float)x);
+    const double fac = 3.0 / 2.0 - xabs;
+    double ret = 0.0;
+    if (xsq <= 1.0 / 4.0)
+        ret = -2.0 * x;
+    else if (xsq <= 9.0 / 4.0)
+        ret = -fac * x / xabs;
+    return ret;
+    }
+
+// BoxDim::makeFraction / makeCoordinates / minImage (HOOMD-blue v2 semantics)
+__device__ __forceinline__ void make_fraction(const MeshGeom &g, double x, double y, double z, double &fx, double &fy, double &fz)
+    {
+    double dx = x - g.lo[0], dy = y - g.lo[1], dz = z - g.lo[2];
+    dx -= (g.xz - g.yz * g.xy) * dz + g.xy * dy;
+    dy -= g.yz * dz;
+    fx = dx / g.L[0];
+    fy = dy / g.L[1];
+    fz = dz / g.L[2];
+    }
+
+// cell (ix,iy,iz) and in-cell shift (mesh units) of a particle — :540-573 == :784-812
+__device__ __forceinline__ void locate(const MeshGeom &g, const Particle &p, int &ix, int &iy, int &iz, double &sx, double &sy,
+                                       double &sz)
+    {
+    double fx, fy, fz;
+    make_fraction(g, p.x, p.y, p.z, fx, fy, fz);
+    ix = (int)(fx * (double)g.nx);
+    iy = (int)(fy * (double)g.ny);
+    iz = (int)(fz * (double)g.nz);
+    if (ix == (int)g.nx) ix = 0;
+    if (iy == (int)g.ny) iy = 0;
+    if (iz == (int)g.nz) iz = 0;
+    // keep out-of-box particles from indexing outside the mesh (the reference asserts, :588-608)
+    ix = min(max(ix, 0), (int)g.nx - 1);
+    iy = min(max(iy, 0), (int)g.ny - 1);
+    iz = min(max(iz, 0), (int)g.nz - 1);
+    const double cfx = ((double)ix + 0.5) / g.nx, cfy = ((double)iy + 0.5) / g.ny, cfz = ((double)iz + 0.5) / g.nz;
+    // makeCoordinates(cell centre)
+    const double cx = g.lo[0] + cfx * g.L[0] + cfy * g.xy * g.L[1] + cfz * g.xz * g.L[2];
+    const double cy = g.lo[1] + cfy * g.L[1] + cfz * g.yz * g.L[2];
+    const double cz = g.lo[2] + cfz * g.L[2];
+    double wx = p.x - cx, wy = p.y - cy, wz = p.z - cz;
+    // minImage
+    double img = rint(wz / g.L[2]);
+    wz -= g.L[2] * img;
+    wy -= g.L[2] * g.yz * img;
+    wx -= g.L[2] * g.xz * img;
+    img = rint(wy / g.L[1]);
+    wy -= g.L[1] * img;
+    wx -= g.L[1] * g.xy * img;
+    wx -= g.L[0] * rint(wx / g.L[0]);
+    double sfx, sfy, sfz;
+    make_fraction(g, wx + g.lo[0], wy + g.lo[1], wz + g.lo[2], sfx, sfy, sfz);
+    sx = sfx * g.nx;
+    sy = sfy * g.ny;
+    sz = sfz * g.nz;
+    }
+
+__device__ __forceinline__ int wrap(int i, int n)
+    {
+    if (i == n) return 0;
+    if (i < 0) return i + n;
+    return i;
+    }
+
+// ---- 1. cell ids, counts, sum of mode^2 ---------------------------------------------------------
+template<typename S4>
+__global__ __launch_bounds__(256) void k_mesh_count(const MeshGeom g, const S4 *__restrict__ postype, const unsigned int N,
+                                                    const double *__restrict__ mode, unsigned int *__restrict__ cell_of,
+                                                    unsigned int *__restrict__ count, double *__restrict__ modesq_partials)
+    {
+    __shared__ double s_red[16];
+    double msq = 0.0;
+    for (unsigned int i = blockIdx.x * blockDim.x + threadIdx.x; i < N; i += gridDim.x * blockDim.x)
+        {
+        const Particle p = scalar4_traits<S4>::load(postype, i);
+        int ix, iy, iz;
+        double sx, sy, sz;
+        locate(g, p, ix, iy, iz, sx, sy, sz);
+        const unsigned int c = ix + g.nx * (iy + g.ny * iz);
+        cell_of[i] = c;
+        atomicAdd(&count[c], 1u);
+        const double a = mode[p.type];
+        msq += a * a;
+        }
+    msq = block_sum(msq, s_red);
+    if (threadIdx.x == 0) modesq_partials[blockIdx.x] = msq;
+    }
+
+// ---- 2. exclusive scan of the counts (three tiny kernels; 1024 cells per block) ------------------
+constexpr unsigned int SCAN_TILE = 1024;
+
+__global__ __launch_bounds__(256) void k_scan_tiles(const unsigned int *__restrict__ in, unsigned int *__restrict__ out,
+                                                    unsigned int *__restrict__ tile_sums, const unsigned int n)
+    {
+    __shared__ unsigned int s_wave[4];
+    const unsigned int base = blockIdx.x * SCAN_TILE + threadIdx.x * 4;
+    unsigned int v[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = base + j < n ? in[base + j] : 0u;
+    const unsigned int t = v[0] + v[1] + v[2] + v[3];
+    // inclusive scan across the wave, then across the 4 waves
+    unsigned int incl = t;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1)
+        {
+        const unsigned int o = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += o;
+        }
+    if (lane == 63) s_wave[wave] = incl;
+    __syncthreads();
+    unsigned int wave_off = 0;
+    for (int w = 0; w < wave; ++w) wave_off += s_wave[w];
+    unsigned int excl = wave_off + incl - t;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        {
+        if (base + j < n) out[base + j] = excl;
+        excl += v[j];
+        }
+    if (threadIdx.x == 255) tile_sums[blockIdx.x] = wave_off + incl;
+    }
+
+__global__ __launch_bounds__(256) void k_scan_sums(unsigned int *__restrict__ tile_sums, const unsigned int n_tiles)
+    {
+    // one block, serial over chunks of 256 tiles (n_tiles <= 2^21 / 1024 * ... small)
+    __shared__ unsigned int s_wave[4];
+    __shared__ unsigned int s_carry;
+    if (threadIdx.x == 0) s_carry = 0;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (unsigned int b0 = 0; b0 < n_tiles; b0 += 256)
+        {
+        const unsigned int i = b0 + threadIdx.x;
+        const unsigned int t = i < n_tiles ? tile_sums[i] : 0u;
+        unsigned int incl = t;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1)
+            {
+            const unsigned int o = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += o;
+            }
+        if (lane == 63) s_wave[wave] = incl;
+        __syncthreads();
+        unsigned int wave_off = s_carry;
+        for (int w = 0; w < wave; ++w) wave_off += s_wave[w];
+        if (i < n_tiles) tile_sums[i] = wave_off + incl - t;
+        __syncthreads();
+        if (threadIdx.x == 255) s_carry = wave_off + incl;
+        __syncthreads();
+        }
+    }
+
+__global__ __launch_bounds__(256) void k_scan_add(unsigned int *__restrict__ out, const unsigned int *__restrict__ tile_sums,
+                                                  const unsigned int n, const unsigned int total)
+    {
+    const unsigned int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] += tile_sums[i / SCAN_TILE];
+    if (i == 0) out[n] = total;
+    }
+
+// ---- 3. fill: particle ids into their cell's slots ------------------------------------------------
+__global__ __launch_bounds__(256) void k_mesh_fill(const unsigned int *__restrict__ cell_of, const unsigned int N,
+                                                   const unsigned int *__restrict__ start, unsigned int *__restrict__ cursor,
+                                                   unsigned int *__restrict__ ids)
+    {
+    for (unsigned int i = blockIdx.x * blockDim.x + threadIdx.x; i < N; i += gridDim.x * blockDim.x)
+        {
+        const unsigned int c = cell_of[i];
+        const unsigned int slot = atomicAdd(&cursor[c], 1u);
+        ids[start[c] + slot] = i;
+        }
+    }
+
+// ---- 4. per cell: sort ids ascending (deterministic order), pack (shift, mode) ----------------------
+template<typename S4>
+__global__ __launch_bounds__(256) void k_mesh_sort(const MeshGeom g, const S4 *__restrict__ postype, const double *__restrict__ mode,
+                                                   const unsigned int *__restrict__ start, unsigned int *__restrict__ ids,
+                                                   double4 *__restrict__ packed)
+    {
+    const unsigned int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= g.n_cells) return;
+    const unsigned int b = start[c], e = start[c + 1];
+    for (unsigned int i = b + 1; i < e; ++i)          // insertion sort: cells hold O(1) particles
+        {
+        const unsigned int key = ids[i];
+        unsigned int j = i;
+        while (j > b && ids[j - 1] > key)
+            {
+            ids[j] = ids[j - 1];
+            --j;
+            }
+        ids[j] = key;
+        }
+    for (unsigned int i = b; i < e; ++i)
+        {
+        const Particle p = scalar4_traits<S4>::load(postype, ids[i]);
+        int ix, iy, iz;
+        double sx, sy, sz;
+        locate(g, p, ix, iy, iz, sx, sy, sz);
+        packed[i] = make_double4(sx, sy, sz, mode[p.type]);
+        }
+    }
+
+// ---- 5. gather: mesh[c] = sum over particles of the 27 neighbour cells -----------------------------
+__global__ __launch_bounds__(256) void k_mesh_gather(const MeshGeom g, const unsigned int *__restrict__ start,
+                                                     const double4 *__restrict__ packed, double *__restrict__ rho)
+    {
+    const unsigned int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= g.n_cells) return;
+    const int cz = c / (g.nx * g.ny);
+    const int cy = (c - cz * g.nx * g.ny) / g.nx;
+    const int cx = c % g.nx;
+    double acc = 0.0;
+    // this cell receives from the particle cell at offset (-i,-j,-k) with dx = shift - (i,j,k); loop the
+    // source cells in a fixed order
+    for (int k = -1; k <= 1; ++k)
+        for (int j = -1; j <= 1; ++j)
+            for (int i = -1; i <= 1; ++i)
+                {
+                const int sxc = wrap(cx - i, (int)g.nx), syc = wrap(cy - j, (int)g.ny), szc = wrap(cz - k, (int)g.nz);
+                // a source cell reaches this cell through offset (i,j,k) only if cell + offset wraps onto it; with
+                // n >= 3 per axis the 27 offsets map to 27 distinct cells (n < 3 handled by the host check)
+                const unsigned int s = sxc + g.nx * (syc + g.ny * szc);
+                const unsigned int b = start[s], e = start[s + 1];
+                for (unsigned int q = b; q < e; ++q)
+                    {
+                    const double4 pk = packed[q];
+                    acc += pk.w * (tsc(pk.x - i) * tsc(pk.y - j) * tsc(pk.z - k));
+                    }
+                }
+    rho[c] = acc;
+    }
+
+// ---- 6/8. DFT of lines staged in LDS ---------------------------------------------------------------
+// A block transforms `tile` lines of length n.  Element p of line t sits at data[base + t*line_stride + p*elem_stride].
+// LDS layout [p][tile] (consecutive lines in consecutive 16-B slots: conflict-free butterflies).
+constexpr int FFT_THREADS = 256;
+
+template<bool REAL_INPUT>
+__global__ __launch_bounds__(FFT_THREADS) void k_fft_lines(const double *__restrict__ real_in, double2 *__restrict__ data,
+                                                           const double2 *__restrict__ twiddle, const unsigned int n,
+                                                           const unsigned int log2n, const unsigned int tile,
+                                                           const unsigned int elem_stride, const unsigned int line_stride,
+                                                           const unsigned int tiles_per_row, const unsigned int row_stride,
+                                                           const int inverse, const int p_fastest)
+    {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double2 *s = (double2 *)smem;
+    // block -> (row, tile within row): base offset of the tile's first line
+    const unsigned int row = blockIdx.x / tiles_per_row;
+    const unsigned int tin = blockIdx.x % tiles_per_row;
+    const size_t base = (size_t)row * row_stride + (size_t)tin * tile * line_stride;
+    const unsigned int total = n * tile;
+
+    // load with bit-reversed position (decimation in time)
+    for (unsigned int idx = threadIdx.x; idx < total; idx += FFT_THREADS)
+        {
+        unsigned int t, p;
+        if (p_fastest)
+            {
+            t = idx / n;
+            p = idx % n;
+            }
+        else
+            {
+            p = idx / tile;
+            t = idx % tile;
+            }
+        const size_t a = base + (size_t)t * line_stride + (size_t)p * elem_stride;
+        double2 v;
+        if (REAL_INPUT)
+            v = make_double2(real_in[a], 0.0);
+        else
+            v = data[a];
+        const unsigned int pr = __brev(p) >> (32 - log2n);
+        s[pr * tile + t] = v;
+        }
+    __syncthreads();
+
+    const unsigned int half_total = (n / 2) * tile;
+    for (unsigned int len = 2, stage = 1; len <= n; len <<= 1, ++stage)
+        {
+        const unsigned int half = len >> 1;
+        const unsigned int tw_step = n / len;
+        for (unsigned int idx = threadIdx.x; idx < half_total; idx += FFT_THREADS)
+            {
+            const unsigned int t = idx % tile;
+            const unsigned int bf = idx / tile;              // butterfly index 0 .. n/2-1
+            const unsigned int grp = bf / half, j = bf % half;
+            const unsigned int i0 = grp * len + j, i1 = i0 + half;
+            double2 w = twiddle[j * tw_step];                // exp(-2 pi i j / len)
+            if (inverse) w.y = -w.y;
+            const double2 u = s[i0 * tile + t], v = s[i1 * tile + t];
+            const double2 tv = make_double2(v.x * w.x - v.y * w.y, v.x * w.y + v.y * w.x);
+            s[i0 * tile + t] = make_double2(u.x + tv.x, u.y + tv.y);
+            s[i1 * tile + t] = make_double2(u.x - tv.x, u.y - tv.y);
+            }
+        __syncthreads();
+        }
+
+    for (unsigned int idx = threadIdx.x; idx < total; idx += FFT_THREADS)
+        {
+        unsigned int t, p;
+        if (p_fastest)
+            {
+            t = idx / n;
+            p = idx % n;
+            }
+        else
+            {
+            p = idx / tile;
+            t = idx % tile;
+            }
+        data[base + (size_t)t * line_stride + (size_t)p * elem_stride] = s[p * tile + t];
+        }
+    }
+
+// ---- 7. spectral step: updateMeshes :697-712 fused with computeCV :896-905 -------------------------
+__device__ __forceinline__ double tsc_fourier(double x)              // :487-511
+    {
+    const double c[6] = {1.0, -1.0 / 6.0, 1.0 / 120.0, -1.0 / 5040.0, 1.0 / 362880.0, -1.0 / 39916800.0};
+    double sinc = 0.0;
+    if (x * x <= 1.0)
+        {
+        double term = 1.0;
+        for (int i = 0; i < 6; ++i)
+            {
+            sinc += c[i] * term;
+            term *= x * x;
+            }
+        }
+    else
+        sinc = sin(x) / x;
+    return sinc * sinc * sinc;
+    }
+
+__global__ __launch_bounds__(256) void k_mesh_spectral(const MeshGeom g, double2 *__restrict__ fmesh, double2 *__restrict__ gmesh,
+                                                       const double *__restrict__ mode_sq, const double n_global,
+                                                       const int bug_compat, double *__restrict__ cv_partials)
+    {
+    __shared__ double s_red[16];
+    const unsigned int k = blockIdx.x * blockDim.x + threadIdx.x;
+    double term = 0.0;
+    if (k < g.n_cells)
+        {
+        const unsigned int wz = k / (g.nx * g.ny);
+        const unsigned int wy = (k - wz * g.nx * g.ny) / g.nx;
+        const unsigned int wx = k % g.nx;
+        int n0 = (int)wx, n1 = (int)wy, n2 = (int)wz;
+        if (n0 >= (int)(g.nx / 2 + g.nx % 2)) n0 -= (int)g.nx;         // Miller indices :417-422
+        if (n1 >= (int)(g.ny / 2 + g.ny % 2)) n1 -= (int)g.ny;
+        if (n2 >= (int)(g.nz / 2 + g.nz % 2)) n2 -= (int)g.nz;
+        double I;
+        if (bug_compat)
+            {
+            // :448 int / unsigned => unsigned division (Q6): the quotient is 0 for n >= 0 and ~2^32/dim otherwise
+            const double kx = (M_PI * 2.0) * (double)((unsigned int)n0 / g.nx);
+            const double ky = (M_PI * 2.0) * (double)((unsigned int)n1 / g.ny);
+            const double kz = (M_PI * 2.0) * (double)((unsigned int)n2 / g.nz);
+            I = tsc_fourier(kx) * tsc_fourier(ky) * tsc_fourier(kz);
+            }
+        else
+            I = tsc_fourier((M_PI * 2.0) * ((double)n0 / g.nx)) * tsc_fourier((M_PI * 2.0) * ((double)n1 / g.ny))
+                * tsc_fourier((M_PI * 2.0) * ((double)n2 / g.nz));
+        double2 f = fmesh[k];
+        f.x /= n_global;
+        f.y /= n_global;
+        const double val = f.x * f.x + f.y * f.y;
+        const double diagonal_term = 0.5 * I * I * (*mode_sq) / n_global / n_global;
+        double2 G = make_double2(f.x * val, f.y * val);
+        G.x -= f.x * diagonal_term;
+        G.y -= f.y * diagonal_term;
+        fmesh[k] = f;
+        gmesh[k] = G;
+        if (k != 0)                                                    // exclude the DC bin (:889-894)
+            term = (G.x * f.x + G.y * f.y) - 0.5 * val * I * I * (*mode_sq) / n_global / n_global;
+        }
+    term = block_sum(term, s_red);
+    if (threadIdx.x == 0) cv_partials[blockIdx.x] = term;
+    }
+
+// ---- 9. forces --------------------------------------------------------------------------------------
+template<typename S4>
+__global__ __launch_bounds__(256) void k_mesh_forces(const MeshGeom g, const S4 *__restrict__ postype, const unsigned int N,
+                                                     const double *__restrict__ mode, const double2 *__restrict__ inv,
+                                                     S4 *__restrict__ force, const double *__restrict__ d_bias,
+                                                     const double bias_host, const double two_over_n)
+    {
+    typedef typename scalar4_traits<S4>::scalar scalar;
+    const double bias = d_bias ? *d_bias : bias_host;
+    for (unsigned int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < N; idx += gridDim.x * blockDim.x)
+        {
+        const Particle p = scalar4_traits<S4>::load(postype, idx);
+        const double a = mode[p.type];
+        int ix, iy, iz;
+        double sx, sy, sz;
+        locate(g, p, ix, iy, iz, sx, sy, sz);
+        double wxv[3], wyv[3], wzv[3], dxv[3], dyv[3], dzv[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+            {
+            wxv[i] = tsc(sx - (i - 1)); dxv[i] = tsc_deriv(sx - (i - 1));
+            wyv[i] = tsc(sy - (i - 1)); dyv[i] = tsc_deriv(sy - (i - 1));
+            wzv[i] = tsc(sz - (i - 1)); dzv[i] = tsc_deriv(sz - (i - 1));
+            }
+        double g1 = 0.0, g2 = 0.0, g3 = 0.0;   // sums multiplying n_x b1, n_y b2, n_z b3
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j)
+                for (int k = 0; k < 3; ++k)
+                    {
+                    const int ni = wrap(ix + i - 1, (int)g.nx), nj = wrap(iy + j - 1, (int)g.ny), nk = wrap(iz + k - 1, (int)g.nz);
+                    const double r = inv[ni + g.nx * (nj + g.ny * nk)].x;
+                    g1 += dxv[i] * wyv[j] * wzv[k] * r;
+                    g2 += wxv[i] * dyv[j] * wzv[k] * r;
+                    g3 += wxv[i] * wyv[j] * dzv[k] * r;
+                    }
+        const double c1 = -(double)g.nx * a * g1, c2 = -(double)g.ny * a * g2, c3 = -(double)g.nz * a * g3;
+        const double s = two_over_n * bias;                            // :861
+        const double fx = (c1 * g.binv[0][0] + c2 * g.binv[1][0] + c3 * g.binv[2][0]) * s;
+        const double fy = (c1 * g.binv[0][1] + c2 * g.binv[1][1] + c3 * g.binv[2][1]) * s;
+        const double fz = (c1 * g.binv[0][2] + c2 * g.binv[1][2] + c3 * g.binv[2][2]) * s;
+        force[idx] = scalar4_traits<S4>::make((scalar)fx, (scalar)fy, (scalar)fz, (scalar)0);
+        }
+    }
+
+__global__ void k_zero_u32(unsigned int *p, unsigned int n)
+    {
+    const unsigned int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = 0;
+    }
+
+__global__ void k_sum_partials(const double *__restrict__ partials, unsigned int n, double *out)
+    {
+    // one wave, fixed order
+    double v = 0.0;
+    for (unsigned int b = threadIdx.x; b < n; b += 64) v += partials[b];
+    v = wave_sum(v);
+    if (threadIdx.x == 0) *out = v;
+    }
+
+bool is_pow2(unsigned int n) { return n && !(n & (n - 1)); }
+unsigned int ilog2(unsigned int n)
+    {
+    unsigned int l = 0;
+    while ((1u << l) < n) ++l;
+    return l;
+    }
+
+} // namespace
+
+struct mtd_mesh
+    {
+    unsigned int nx, ny, nz, M, n_types, max_particles;
+    int bug_compat;
+    void *slab;
+    double *d_mode, *d_rho, *d_modesq_partials, *d_mode_sq, *d_cv_partials;
+    double2 *d_f, *d_g, *d_tw[3];
+    double4 *d_packed;
+    unsigned int *d_cell_of, *d_count, *d_start, *d_ids, *d_tile_sums;
+    unsigned int n_cv_partials, n_count_blocks;
+    };
+
+namespace
+{
+
+int fill_geom(MeshGeom &g, const mtd_mesh *m, const mtd_box *box)
+    {
+    if (!box || !(box->L[0] > 0.0) || !(box->L[1] > 0.0) || !(box->L[2] > 0.0)) return MTD_ERR_INVALID_ARGUMENT;
+    std::memset(&g, 0, sizeof(g));
+    g.nx = m->nx; g.ny = m->ny; g.nz = m->nz; g.n_cells = m->M;
+    for (int i = 0; i < 3; ++i)
+        {
+        g.lo[i] = box->lo[i];
+        g.L[i] = box->L[i];
+        }
+    g.xy = box->xy; g.xz = box->xz; g.yz = box->yz;
+    reciprocal_rows(*box, g.binv);
+    return MTD_SUCCESS;
+    }
+
+int launch_fft3d(const mtd_mesh *m, const double *real_in, double2 *data, int inverse, hipStream_t s)
+    {
+    const unsigned int nx = m->nx, ny = m->ny, nz = m->nz;
+    // x lines: contiguous; tile = as many lines as keep <= 64 KB of LDS, p fastest for coalescing
+    struct Pass { unsigned int n, tile, elem_stride, line_stride, tiles_per_row, row_stride, n_blocks; int p_fastest; const double2 *tw; };
+    auto tile_for = [](unsigned int n, unsigned int lines) {
+        unsigned int t = 16;
+        while (t > 1 && (size_t)n * t * sizeof(double2) > 64 * 1024) t >>= 1;
+        while (t > 1 && lines % t) t >>= 1;
+        return t;
+    };
+    Pass px, py, pz;
+    // X: all ny*nz lines form one "row"; tile adjacent lines
+    px.n = nx; px.tile = tile_for(nx, ny * nz); px.elem_stride = 1; px.line_stride = nx; px.tiles_per_row = (ny * nz) / px.tile;
+    px.row_stride = 0; px.n_blocks = px.tiles_per_row; px.p_fastest = 1; px.tw = m->d_tw[0];
+    // Y: for each z (row), tiles of adjacent x
+    py.n = ny; py.tile = tile_for(ny, nx); py.elem_stride = nx; py.line_stride = 1; py.tiles_per_row = nx / py.tile;
+    py.row_stride = nx * ny; py.n_blocks = py.tiles_per_row * nz; py.p_fastest = 0; py.tw = m->d_tw[1];
+    // Z: for each y (row), tiles of adjacent x
+    pz.n = nz; pz.tile = tile_for(nz, nx); pz.elem_stride = nx * ny; pz.line_stride = 1; pz.tiles_per_row = nx / pz.tile;
+    pz.row_stride = nx; pz.n_blocks = pz.tiles_per_row * ny; pz.p_fastest = 0; pz.tw = m->d_tw[2];
+    const Pass passes[3] = {px, py, pz};
+    for (int a = 0; a < 3; ++a)
+        {
+        const Pass &p = passes[a];
+        const size_t lds = (size_t)p.n * p.tile * sizeof(double2);
+        if (p.n == 1) continue;
+        if (a == 0 && real_in)
+            k_fft_lines<true><<<p.n_blocks, FFT_THREADS, lds, s>>>(real_in, data, p.tw, p.n, ilog2(p.n), p.tile, p.elem_stride,
+                                                                    p.line_stride, p.tiles_per_row, p.row_stride, inverse, p.p_fastest);
+        else
+            k_fft_lines<false><<<p.n_blocks, FFT_THREADS, lds, s>>>(nullptr, data, p.tw, p.n, ilog2(p.n), p.tile, p.elem_stride,
+                                                                     p.line_stride, p.tiles_per_row, p.row_stride, inverse, p.p_fastest);
+        MTD_LAUNCH_CHECK();
+        }
+    return MTD_SUCCESS;
+    }
+
+} // namespace
+
+extern "C" {
+
+int mtd_mesh_create(mtd_mesh **out, unsigned int nx, unsigned int ny, unsigned int nz, const double *mode,
+                    unsigned int n_types, unsigned int max_particles)
+    {
+    if (!out || !mode || n_types == 0) return MTD_ERR_INVALID_ARGUMENT;
+    if (nx == 0 || ny == 0 || nz == 0) return MTD_ERR_INVALID_ARGUMENT;
+    // power-of-two meshes of at least 4 cells per axis (3x3x3 stencils must not alias), <= 1024 per axis
+    if (!is_pow2(nx) || !is_pow2(ny) || !is_pow2(nz) || nx < 4 || ny < 4 || nz < 4 || nx > 1024 || ny > 1024 || nz > 1024)
+        return MTD_ERR_UNSUPPORTED;
+    const unsigned long long M64 = (unsigned long long)nx * ny * nz;
+    if (M64 > (1ull << 30)) return MTD_ERR_UNSUPPORTED;
+    mtd_mesh *m = new (std::nothrow) mtd_mesh();
+    if (!m) return (int)hipErrorOutOfMemory;
+    std::memset(m, 0, sizeof(*m));
+    m->nx = nx; m->ny = ny; m->nz = nz; m->M = (unsigned int)M64;
+    m->n_types = n_types;
+    m->max_particles = max_particles;
+    m->bug_compat = 1;
+    const size_t M = m->M, N = max_particles;
+    m->n_count_blocks = 1024;
+    m->n_cv_partials = (m->M + 255) / 256;
+    const unsigned int n_tiles = (m->M + SCAN_TILE - 1) / SCAN_TILE;
+    auto al = [](size_t b) { return (b + 255) / 256 * 256; };
+    size_t off = 0;
+    auto take = [&](size_t b) { size_t o = off; off += al(b); return o; };
+    const size_t o_mode = take(sizeof(double) * n_types), o_rho = take(sizeof(double) * M), o_msqp = take(sizeof(double) * m->n_count_blocks),
+                 o_msq = take(sizeof(double)), o_cvp = take(sizeof(double) * m->n_cv_partials), o_f = take(sizeof(double2) * M),
+                 o_g = take(sizeof(double2) * M), o_tw0 = take(sizeof(double2) * nx), o_tw1 = take(sizeof(double2) * ny),
+                 o_tw2 = take(sizeof(double2) * nz), o_packed = take(sizeof(double4) * N), o_cell = take(sizeof(unsigned int) * N),
+                 o_count = take(sizeof(unsigned int) * (M + 1)), o_start = take(sizeof(unsigned int) * (M + 1)),
+                 o_ids = take(sizeof(unsigned int) * N), o_tiles = take(sizeof(unsigned int) * n_tiles);
+    hipError_t e = hipMalloc(&m->slab, off);
+    if (e != hipSuccess)
+        {
+        delete m;
+        return (int)e;
+        }
+    char *p = (char *)m->slab;
+    m->d_mode = (double *)(p + o_mode); m->d_rho = (double *)(p + o_rho); m->d_modesq_partials = (double *)(p + o_msqp);
+    m->d_mode_sq = (double *)(p + o_msq); m->d_cv_partials = (double *)(p + o_cvp); m->d_f = (double2 *)(p + o_f);
+    m->d_g = (double2 *)(p + o_g); m->d_tw[0] = (double2 *)(p + o_tw0); m->d_tw[1] = (double2 *)(p + o_tw1);
+    m->d_tw[2] = (double2 *)(p + o_tw2); m->d_packed = (double4 *)(p + o_packed); m->d_cell_of = (unsigned int *)(p + o_cell);
+    m->d_count = (unsigned int *)(p + o_count); m->d_start = (unsigned int *)(p + o_start); m->d_ids = (unsigned int *)(p + o_ids);
+    m->d_tile_sums = (unsigned int *)(p + o_tiles);
+    e = hipMemset(m->slab, 0, off);
+    if (e == hipSuccess) e = hipMemcpy(m->d_mode, mode, sizeof(double) * n_types, hipMemcpyHostToDevice);
+    // twiddles exp(-2 pi i j / n), j < n/2, in double on the host
+    const unsigned int dims[3] = {nx, ny, nz};
+    for (int a = 0; a < 3 && e == hipSuccess; ++a)
+        {
+        std::vector<double> tw(2 * (size_t)dims[a], 0.0);
+        for (unsigned int j = 0; j < dims[a] / 2; ++j)
+            {
+            const double ang = -2.0 * M_PI * (double)j / (double)dims[a];
+            tw[2 * j] = std::cos(ang);
+            tw[2 * j + 1] = std::sin(ang);
+            }
+        e = hipMemcpy(m->d_tw[a], tw.data(), sizeof(double) * tw.size(), hipMemcpyHostToDevice);
+        }
+    if (e != hipSuccess)
+        {
+        (void)hipFree(m->slab);
+        delete m;
+        return (int)e;
+        }
+    *out = m;
+    return MTD_SUCCESS;
+    }
+
+int mtd_mesh_destroy(mtd_mesh *m)
+    {
+    if (!m) return MTD_SUCCESS;
+    hipError_t e = hipFree(m->slab);
+    delete m;
+    return (int)e;
+    }
+
+int mtd_mesh_set_bug_compat(mtd_mesh *m, int on)
+    {
+    if (!m) return MTD_ERR_INVALID_ARGUMENT;
+    m->bug_compat = on ? 1 : 0;
+    return MTD_SUCCESS;
+    }
+
+int mtd_mesh_compute_cv(mtd_mesh *m, unsigned int n_particles, const void *d_postype, int dtype, const mtd_box *box,
+                        unsigned int n_global, const double **d_partials, unsigned int *n_partials, mtd_stream_t stream)
+    {
+    if (!m || !d_partials || !n_partials || n_global == 0 || (n_particles && !d_postype)) return MTD_ERR_INVALID_ARGUMENT;
+    if (dtype != MTD_F32 && dtype != MTD_F64) return MTD_ERR_INVALID_ARGUMENT;
+    if (n_particles > m->max_particles) return MTD_ERR_INVALID_ARGUMENT;
+    MeshGeom g;
+    int rc = fill_geom(g, m, box);
+    if (rc) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    const unsigned int M = m->M, N = n_particles;
+    const unsigned int cell_blocks = (M + 255) / 256;
+    const unsigned int n_tiles = (M + SCAN_TILE - 1) / SCAN_TILE;
+
+    k_zero_u32<<<(M + 1 + 255) / 256, 256, 0, s>>>(m->d_count, M + 1);
+    MTD_LAUNCH_CHECK();
+    if (dtype == MTD_F32)
+        k_mesh_count<float4><<<m->n_count_blocks, 256, 0, s>>>(g, (const float4 *)d_postype, N, m->d_mode, m->d_cell_of, m->d_count, m->d_modesq_partials);
+    else
+        k_mesh_count<double4><<<m->n_count_blocks, 256, 0, s>>>(g, (const double4 *)d_postype, N, m->d_mode, m->d_cell_of, m->d_count, m->d_modesq_partials);
+    MTD_LAUNCH_CHECK();
+    k_sum_partials<<<1, 64, 0, s>>>(m->d_modesq_partials, m->n_count_blocks, m->d_mode_sq);   // m_mode_sq (:622), fixed order
+    MTD_LAUNCH_CHECK();
+    k_scan_tiles<<<n_tiles, 256, 0, s>>>(m->d_count, m->d_start, m->d_tile_sums, M);
+    MTD_LAUNCH_CHECK();
+    k_scan_sums<<<1, 256, 0, s>>>(m->d_tile_sums, n_tiles);
+    MTD_LAUNCH_CHECK();
+    k_scan_add<<<cell_blocks, 256, 0, s>>>(m->d_start, m->d_tile_sums, M, N);
+    MTD_LAUNCH_CHECK();
+    k_zero_u32<<<cell_blocks, 256, 0, s>>>(m->d_count, M);                                      // reused as the fill cursor
+    MTD_LAUNCH_CHECK();
+    k_mesh_fill<<<m->n_count_blocks, 256, 0, s>>>(m->d_cell_of, N, m->d_start, m->d_count, m->d_ids);
+    MTD_LAUNCH_CHECK();
+    if (dtype == MTD_F32)
+        k_mesh_sort<float4><<<cell_blocks, 256, 0, s>>>(g, (const float4 *)d_postype, m->d_mode, m->d_start, m->d_ids, m->d_packed);
+    else
+        k_mesh_sort<double4><<<cell_blocks, 256, 0, s>>>(g, (const double4 *)d_postype, m->d_mode, m->d_start, m->d_ids, m->d_packed);
+    MTD_LAUNCH_CHECK();
+    k_mesh_gather<<<cell_blocks, 256, 0, s>>>(g, m->d_start, m->d_packed, m->d_rho);
+    MTD_LAUNCH_CHECK();
+    rc = launch_fft3d(m, m->d_rho, m->d_f, 0, s);
+    if (rc) return rc;
+    k_mesh_spectral<<<m->n_cv_partials, 256, 0, s>>>(g, m->d_f, m->d_g, m->d_mode_sq, (double)n_global, m->bug_compat, m->d_cv_partials);
+    MTD_LAUNCH_CHECK();
+    rc = launch_fft3d(m, nullptr, m->d_g, 1, s);
+    if (rc) return rc;
+    *d_partials = m->d_cv_partials;
+    *n_partials = m->n_cv_partials;
+    return MTD_SUCCESS;
+    }
+
+int mtd_mesh_forces(mtd_mesh *m, unsigned int n_particles, const void *d_postype, void *d_force, int dtype, const mtd_box *box,
+                    unsigned int n_global, const double *d_bias, double bias_host, mtd_stream_t stream)
+    {
+    if (!m || n_global == 0 || (n_particles && (!d_postype || !d_force))) return MTD_ERR_INVALID_ARGUMENT;
+    if (dtype != MTD_F32 && dtype != MTD_F64) return MTD_ERR_INVALID_ARGUMENT;
+    if (n_particles == 0) return MTD_SUCCESS;
+    MeshGeom g;
+    int rc = fill_geom(g, m, box);
+    if (rc) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    unsigned int blocks = (n_particles + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    const double two_over_n = 2.0 / (double)n_global;
+    if (dtype == MTD_F32)
+        k_mesh_forces<float4><<<blocks, 256, 0, s>>>(g, (const float4 *)d_postype, n_particles, m->d_mode, m->d_g, (float4 *)d_force, d_bias, bias_host, two_over_n);
+    else
+        k_mesh_forces<double4><<<blocks, 256, 0, s>>>(g, (const double4 *)d_postype, n_particles, m->d_mode, m->d_g, (double4 *)d_force, d_bias, bias_host, two_over_n);
+    MTD_LAUNCH_CHECK();
+    return MTD_SUCCESS;
+    }
+
+int mtd_mesh_get_array(mtd_mesh *m, int which, void *host_out, mtd_stream_t stream)
+    {
+    if (!m || !host_out) return MTD_ERR_INVALID_ARGUMENT;
+    const void *src = nullptr;
+    size_t bytes = 0;
+    switch (which)
+        {
+        case 0: src = m->d_rho; bytes = sizeof(double) * m->M; break;            // real mesh (assignParticles)
+        case 1: src = m->d_f; bytes = sizeof(double2) * m->M; break;             // fourier_mesh, normalised
+        case 3: src = m->d_g; bytes = sizeof(double2) * m->M; break;             // inv_fourier_mesh (G transformed in place)
+        case 7: src = m->d_mode_sq; bytes = sizeof(double); break;
+        default: return MTD_ERR_INVALID_ARGUMENT;
+        }
+    MTD_HIP_TRY(hipMemcpyAsync(host_out, src, bytes, hipMemcpyDeviceToHost, (hipStream_t)stream));
+    MTD_HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    return MTD_SUCCESS;
+    }
+
+unsigned int mtd_mesh_num_cells(const mtd_mesh *m) { return m ? m->M : 0; }
+
+} // extern "C"

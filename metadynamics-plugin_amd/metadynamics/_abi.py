@@ -128,6 +128,13 @@ _SIGNATURES = {
     "mtd_fused_cv_pass": (C.c_int, [_vp, C.POINTER(LamellarSet), C.c_uint, _vp, C.c_int, C.POINTER(Box), _vp, _up, _vp]),
     "mtd_fused_force_pass": (C.c_int, [_vp, C.POINTER(LamellarSet), C.c_uint, _vp, C.POINTER(_vp), C.c_int, C.c_uint,
                                         C.POINTER(Box), C.c_uint, _vp]),
+    "mtd_mesh_create": (C.c_int, [C.POINTER(_vp), C.c_uint, C.c_uint, C.c_uint, _dp, C.c_uint, C.c_uint]),
+    "mtd_mesh_destroy": (C.c_int, [_vp]),
+    "mtd_mesh_set_bug_compat": (C.c_int, [_vp, C.c_int]),
+    "mtd_mesh_num_cells": (C.c_uint, [_vp]),
+    "mtd_mesh_compute_cv": (C.c_int, [_vp, C.c_uint, _vp, C.c_int, C.POINTER(Box), C.c_uint, C.POINTER(_vp), _up, _vp]),
+    "mtd_mesh_forces": (C.c_int, [_vp, C.c_uint, _vp, _vp, C.c_int, C.POINTER(Box), C.c_uint, _vp, C.c_double, _vp]),
+    "mtd_mesh_get_array": (C.c_int, [_vp, C.c_int, _vp, _vp]),
     "mtd_wte_scratch_doubles": (C.c_size_t, [C.c_uint]),
     "mtd_wte_energy_partials": (C.c_int, [C.c_uint, _vp, C.c_int, _vp, _up, _vp]),
     "mtd_wte_scale_netforce": (C.c_int, [C.c_uint, _vp, _vp, _vp, C.c_uint, C.c_int, _vp, C.c_double, C.c_int, _vp]),

@@ -113,6 +113,22 @@ double ref_wte_potential_energy(unsigned int N, const double *net_force /*4N*/, 
 void ref_wte_scale(unsigned int N, double *net_force /*4N*/, double *net_torque /*4N*/,
                    double *net_virial /*6*pitch*/, unsigned int pitch, double *external_virial /*6*/, double bias);
 
+/* ---------------------------------------------------------------- OrderParameterMesh (mtd_ref_mesh.c) */
+typedef struct ref_mesh ref_mesh;
+ref_mesh *ref_mesh_create(unsigned int nx, unsigned int ny, unsigned int nz, unsigned int n_types, const double *mode);
+void ref_mesh_destroy(ref_mesh *m);
+/* 1 (default): interpolation function exactly as the reference computes it (unsigned division, Q6); 0: as intended */
+void ref_mesh_set_bug_compat(ref_mesh *m, int on);
+/* getCurrentValue (OrderParameterMesh.cc:925-968): assignParticles -> FFT -> updateMeshes -> iFFT -> computeCV */
+double ref_mesh_cv(ref_mesh *m, unsigned int N, const double *postype, const ref_box *box, unsigned int N_global);
+/* interpolateForces (:749-864); call after ref_mesh_cv on the same snapshot */
+void ref_mesh_forces(ref_mesh *m, unsigned int N, const double *postype, const ref_box *box, unsigned int N_global,
+                     double bias, double *force_out /*4N*/);
+double ref_mesh_mode_sq(const ref_mesh *m);
+/* which: 0 mesh, 1 fourier_mesh (normalised), 2 fourier_mesh_G, 3 inv_fourier_mesh (complex double[M], (re,im));
+ *        4 interpolation_f, 5 inf_f (double[M]); 6 k (double[3M]) */
+void *ref_mesh_array(ref_mesh *m, int which);
+
 #ifdef __cplusplus
 }
 #endif

@@ -382,3 +382,50 @@ def wte_scale(net_force, net_torque, net_virial, pitch, external_virial, bias):
     ev = np.array(external_virial, dtype=np.float64, order="C")
     lib().ref_wte_scale(nf.shape[0], _d(nf), _d(nt), _d(nv), int(pitch), _d(ev), float(bias))
     return nf, nt, nv, ev
+
+
+class Mesh:
+    """OrderParameterMesh.cc, single rank (no ghost cells)."""
+
+    def __init__(self, nx, ny, nz, mode):
+        self.dims = (int(nx), int(ny), int(nz))
+        self.M = self.dims[0] * self.dims[1] * self.dims[2]
+        md = np.ascontiguousarray(mode, dtype=np.float64)
+        self._h = lib().ref_mesh_create(self.dims[0], self.dims[1], self.dims[2], len(md), _d(md))
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().ref_mesh_destroy(self._h)
+            self._h = None
+
+    def set_bug_compat(self, on):
+        lib().ref_mesh_set_bug_compat(self._h, int(bool(on)))
+
+    def cv(self, postype, box, n_global=None):
+        pt = np.ascontiguousarray(postype, dtype=np.float64)
+        return lib().ref_mesh_cv(self._h, pt.shape[0], _d(pt), C.byref(box), pt.shape[0] if n_global is None else int(n_global))
+
+    def forces(self, postype, box, bias, n_global=None):
+        pt = np.ascontiguousarray(postype, dtype=np.float64)
+        out = np.zeros((pt.shape[0], 4), dtype=np.float64)
+        lib().ref_mesh_forces(self._h, pt.shape[0], _d(pt), C.byref(box), pt.shape[0] if n_global is None else int(n_global),
+                              float(bias), _d(out))
+        return out
+
+    @property
+    def mode_sq(self):
+        return lib().ref_mesh_mode_sq(self._h)
+
+    def array(self, name):
+        names = ["mesh", "fourier_mesh", "fourier_mesh_G", "inv_fourier_mesh", "interpolation_f", "inf_f", "k"]
+        which = names.index(name)
+        ptr = lib().ref_mesh_array(self._h, which)
+        nz, ny, nx = self.dims[2], self.dims[1], self.dims[0]
+        if which < 4:
+            buf = (C.c_double * (2 * self.M)).from_address(ptr)
+            a = np.frombuffer(buf, dtype=np.float64).reshape(nz, ny, nx, 2)
+            return a[..., 0] + 1j * a[..., 1]
+        n = self.M * (3 if which == 6 else 1)
+        buf = (C.c_double * n).from_address(ptr)
+        a = np.frombuffer(buf, dtype=np.float64)
+        return a.reshape(nz, ny, nx, 3) if which == 6 else a.reshape(nz, ny, nx)

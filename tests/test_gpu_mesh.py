@@ -1,0 +1,161 @@
+"""GPU parity: particle-mesh order parameter (C-ABI) vs the oracle restatement of OrderParameterMesh.cc.
+Everything is double precision on both sides: meshes agree to 1e-11, the CV to 1e-9 relative (tolerance stated by
+BASELINE.json: 1e-6), forces to 1e-8 of max|F| (stated: 1e-5)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import util
+
+torch = pytest.importorskip("torch")
+
+pytestmark = pytest.mark.gpu
+
+
+class GpuMesh:
+    def __init__(self, abi, dims, mode, max_particles):
+        self.abi, self.lib = abi, abi.load()
+        self.dims = dims
+        self.h = C.c_void_p()
+        abi.check(self.lib.mtd_mesh_create(C.byref(self.h), dims[0], dims[1], dims[2], util.dbl_array(mode), len(mode), max_particles))
+        self.M = self.lib.mtd_mesh_num_cells(self.h)
+
+    def close(self):
+        if self.h:
+            self.abi.check(self.lib.mtd_mesh_destroy(self.h))
+            self.h = None
+
+    def cv(self, d_pos, dt, box, n_global):
+        parts, n = C.c_void_p(), C.c_uint()
+        self.abi.check(self.lib.mtd_mesh_compute_cv(self.h, d_pos.shape[0], self.abi.ptr(d_pos), dt, C.byref(box), n_global,
+                                                    C.byref(parts), C.byref(n), None))
+        out = torch.zeros(1, dtype=torch.float64, device="cuda")
+        self.abi.check(self.lib.mtd_reduce_partials(parts.value, n.value, 1, 1, 0.5, 0.0, self.abi.ptr(out), None))
+        torch.cuda.synchronize()
+        return out.item()
+
+    def forces(self, d_pos, dt, box, n_global, bias, device_bias=True):
+        f = torch.zeros_like(d_pos)
+        d_bias = torch.tensor([bias], dtype=torch.float64, device="cuda")
+        self.abi.check(self.lib.mtd_mesh_forces(self.h, d_pos.shape[0], self.abi.ptr(d_pos), self.abi.ptr(f), dt, C.byref(box),
+                                                n_global, self.abi.ptr(d_bias) if device_bias else None, bias, None))
+        torch.cuda.synchronize()
+        return f.cpu().numpy().astype(np.float64)
+
+    def array(self, which):
+        nz, ny, nx = self.dims[2], self.dims[1], self.dims[0]
+        if which == 0:
+            out = np.zeros(self.M)
+        elif which == 7:
+            out = np.zeros(1)
+        else:
+            out = np.zeros(2 * self.M)
+        self.abi.check(self.lib.mtd_mesh_get_array(self.h, which, out.ctypes.data, None))
+        if which == 0:
+            return out.reshape(nz, ny, nx)
+        if which == 7:
+            return out[0]
+        return (out[0::2] + 1j * out[1::2]).reshape(nz, ny, nx)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("dims,tilt", [((8, 8, 8), {}), ((16, 8, 32), dict(xy=0.2, xz=-0.1, yz=0.15)), ((32, 32, 32), {})])
+def test_mesh_cv_and_forces(abi, ref, dtype, dims, tilt):
+    N = 6007
+    Ls = (9.0, 7.5, 11.0)
+    rng = np.random.default_rng(11)
+    f = rng.random((N, 3))
+    a1 = np.array([Ls[0], 0, 0]); a2 = np.array([tilt.get("xy", 0) * Ls[1], Ls[1], 0])
+    a3 = np.array([tilt.get("xz", 0) * Ls[2], tilt.get("yz", 0) * Ls[2], Ls[2]])
+    pos = (-0.5 * np.array(Ls) + f[:, :1] * a1 + f[:, 1:2] * a2 + f[:, 2:3] * a3).astype(dtype)
+    # a density wave so the CV is not pure noise
+    types = (np.sin(2 * np.pi * 2 * f[:, 2]) > 0).astype(np.int32)
+    mode = [1.0, -0.6]
+    box, rbox = abi.Box.make(Ls, **tilt), ref.Box.make(Ls, **tilt)
+    dt = abi.MTD_F32 if dtype == np.float32 else abi.MTD_F64
+    d_pos = torch.from_numpy(util.pack_postype(pos, types, dtype)).cuda()
+    opt = util.oracle_postype(pos, types)
+    g = GpuMesh(abi, dims, mode, N)
+    r = ref.Mesh(*dims, mode)
+    try:
+        for bug_compat in (True, False):
+            abi.check(g.lib.mtd_mesh_set_bug_compat(g.h, int(bug_compat)))
+            r.set_bug_compat(bug_compat)
+            s = g.cv(d_pos, dt, box, N)
+            s_ref = r.cv(opt, rbox)
+            assert np.allclose(g.array(0), r.array("mesh").real, rtol=1e-12, atol=1e-13)
+            assert g.array(7) == pytest.approx(r.mode_sq, rel=1e-13)
+            scale = np.abs(r.array("fourier_mesh")).max()
+            assert np.abs(g.array(1) - r.array("fourier_mesh")).max() <= 1e-12 * scale
+            scale = np.abs(r.array("inv_fourier_mesh")).max()
+            assert np.abs(g.array(3) - r.array("inv_fourier_mesh")).max() <= 1e-11 * scale
+            assert s == pytest.approx(s_ref, rel=1e-9)
+            for device_bias in (True, False):
+                F = g.forces(d_pos, dt, box, N, -2.5, device_bias)
+                F_ref = r.forces(opt, rbox, -2.5)
+                tol = 1e-8 if dtype == np.float64 else 2e-7    # fp32 force array: one rounding on store
+                assert np.abs(F[:, :3] - F_ref[:, :3]).max() <= tol * np.abs(F_ref[:, :3]).max()
+                assert np.all(F[:, 3] == 0.0)
+    finally:
+        g.close()
+
+
+def test_mesh_edge_cases(abi, ref):
+    """crowded cells (many particles per cell: per-cell sort), particles exactly on the box boundary (ix == nx -> 0,
+    :556-561), N_global != N, empty system"""
+    lib = abi.load()
+    L = 4.0
+    rng = np.random.default_rng(5)
+    pos = np.concatenate([rng.normal(0.3, 0.05, size=(3000, 3)),          # ~all in a handful of cells
+                          np.array([[2.0, -2.0, 2.0], [-2.0, 2.0, 0.0], [1.999999, 0.0, -2.0]])])
+    pos = np.clip(pos, -2.0, 2.0)
+    types = rng.integers(0, 2, len(pos)).astype(np.int32)
+    N = len(pos)
+    box, rbox = abi.Box.make(L), ref.Box.make(L)
+    d_pos = torch.from_numpy(util.pack_postype(pos, types, np.float64)).cuda()
+    g = GpuMesh(abi, (8, 8, 8), [1.0, -1.0], N)
+    r = ref.Mesh(8, 8, 8, [1.0, -1.0])
+    try:
+        s = g.cv(d_pos, abi.MTD_F64, box, 5 * N)
+        s_ref = r.cv(util.oracle_postype(pos, types), rbox, n_global=5 * N)
+        assert np.allclose(g.array(0), r.array("mesh").real, rtol=1e-12, atol=1e-13)
+        assert s == pytest.approx(s_ref, rel=1e-9)
+        F = g.forces(d_pos, abi.MTD_F64, box, 5 * N, 1.0)
+        F_ref = r.forces(util.oracle_postype(pos, types), rbox, 1.0, n_global=5 * N)
+        assert np.abs(F - F_ref).max() <= 1e-8 * np.abs(F_ref).max()
+        # deterministic: a second evaluation gives the same bits
+        s2 = g.cv(d_pos, abi.MTD_F64, box, 5 * N)
+        assert s2 == s
+        empty = torch.zeros((0, 4), dtype=torch.float64, device="cuda")
+        assert g.cv(empty, abi.MTD_F64, box, 10) == 0.0
+    finally:
+        g.close()
+    h = C.c_void_p()
+    assert lib.mtd_mesh_create(C.byref(h), 12, 8, 8, util.dbl_array([1.0]), 1, 10) == -2   # not a power of two
+    assert lib.mtd_mesh_create(C.byref(h), 8, 8, 0, util.dbl_array([1.0]), 1, 10) == -1
+
+
+def test_mesh_config3_size(abi, ref):
+    """BASELINE.json configs[2] size: 10^6 particles on a 128^3 mesh (bug-compatible), checked through properties that
+    do not need the oracle at full size (charge conservation, determinism) plus the oracle on the CV itself"""
+    N, L = 1_000_000, 100.0
+    pos, types = util.snapshot_random(N, L, seed=12345, modulated=True, dtype=np.float32)
+    box, rbox = abi.Box.make(L), ref.Box.make(L)
+    d_pos = torch.from_numpy(util.pack_postype(pos, types, np.float32)).cuda()
+    g = GpuMesh(abi, (128, 128, 128), util.MODE_AB, N)
+    try:
+        s = g.cv(d_pos, abi.MTD_F32, box, N)
+        rho = g.array(0)
+        a = np.where(types == 0, 1.0, -1.0)
+        assert rho.sum() == pytest.approx(a.sum(), abs=1e-6)            # TSC weights sum to one per particle
+        assert g.array(7) == float(N)
+        r = ref.Mesh(128, 128, 128, util.MODE_AB)
+        s_ref = r.cv(util.oracle_postype(pos, types), rbox)
+        assert s == pytest.approx(s_ref, rel=1e-6)
+        F = g.forces(d_pos, abi.MTD_F32, box, N, 1.0)
+        sl = slice(0, 50_000)
+        F_ref = r.forces(util.oracle_postype(pos, types)[sl], rbox, 1.0, n_global=N)
+        assert np.abs(F[sl, :3] - F_ref[:, :3]).max() <= 1e-5 * np.abs(F_ref[:, :3]).max()
+    finally:
+        g.close()
