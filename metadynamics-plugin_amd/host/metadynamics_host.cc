@@ -234,6 +234,86 @@ void WellTemperedEnsemble::computeBiasForces(unsigned int)
     }
 
 // ------------------------------------------------------------------------------------------------
+// OrderParameterMeshGPU
+// ------------------------------------------------------------------------------------------------
+
+OrderParameterMeshGPU::OrderParameterMeshGPU(std::shared_ptr<SystemDefinition> sysdef, unsigned int nx, unsigned int ny,
+                                             unsigned int nz, std::vector<double> mode, std::vector<int3> zero_modes)
+    : CollectiveVariable(sysdef, "mesh"), m_mesh(nullptr), m_mode(mode), m_zero_modes(zero_modes), m_k_min(0.0), m_k_max(0.0),
+      m_delta_k(0.0), m_use_table(false), m_is_first_step(true), m_partials(nullptr), m_n_partials(0), m_cv_last_updated(0),
+      m_cv(0.0)
+    {
+    if (mode.size() != m_pdata->getNTypes()) throw std::runtime_error("Error setting up cv.mesh");   // OrderParameterMesh.cc:44-49
+    int rc = mtd_mesh_create(&m_mesh, nx, ny, nz, mode.data(), (unsigned int)mode.size(), m_pdata->getN());
+    if (rc == MTD_ERR_UNSUPPORTED)
+        throw std::runtime_error("cv.mesh: the number of mesh points along every direction must be a power of two in [4, 1024]");
+    mtd_check(rc, "mtd_mesh_create");
+    m_cv_dev.resize(sizeof(double));
+    }
+
+OrderParameterMeshGPU::~OrderParameterMeshGPU()
+    {
+    if (m_mesh) (void)mtd_mesh_destroy(m_mesh);
+    }
+
+void OrderParameterMeshGPU::setBugCompatible(bool on)
+    {
+    mtd_check(mtd_mesh_set_bug_compat(m_mesh, on ? 1 : 0), "mtd_mesh_set_bug_compat");
+    m_is_first_step = true;
+    }
+
+// OrderParameterMesh.cc:148-189
+void OrderParameterMeshGPU::setTable(const std::vector<double> &K, const std::vector<double> &d_K, double kmin, double kmax)
+    {
+    if (kmin < 0 || kmax < 0 || kmax <= kmin) throw std::runtime_error("Error setting up OrderParameterMesh");
+    if (K.size() != d_K.size()) throw std::runtime_error("Error setting up OrderParameterMesh");
+    m_k_min = kmin;
+    m_k_max = kmax;
+    m_delta_k = (kmax - kmin) / (double)(K.size() - 1);
+    m_table = K;
+    m_table_d = d_K;
+    }
+
+void OrderParameterMeshGPU::enqueueCV(unsigned int timestep)
+    {
+    if (m_cv_last_updated == timestep && !m_is_first_step) return;   // :927-928
+    const mtd_box box = m_pdata->getGlobalBox().toMtd();
+    mtd_check(mtd_mesh_compute_cv(m_mesh, m_pdata->getN(), m_pdata->positionsPtr(), m_pdata->getDtype(), &box,
+                                  m_pdata->getNGlobal(), &m_partials, &m_n_partials, m_exec_conf->getStream()),
+              "mtd_mesh_compute_cv");
+    m_is_first_step = false;
+    m_cv_last_updated = timestep;
+    }
+
+void OrderParameterMeshGPU::enqueueCurrentValue(unsigned int timestep, mtd_metad *engine, unsigned int slot)
+    {
+    enqueueCV(timestep);
+    mtd_check(mtd_metad_set_cv_source(engine, slot, m_partials, m_n_partials, 1, 0, 0.5, 0.0), "mtd_metad_set_cv_source");   // :907
+    }
+
+double OrderParameterMeshGPU::getCurrentValue(unsigned int timestep)
+    {
+    enqueueCV(timestep);
+    mtd_check(mtd_reduce_partials(m_partials, m_n_partials, 1, 1, 0.5, 0.0, (double *)m_cv_dev.data(), m_exec_conf->getStream()),
+              "mtd_reduce_partials");
+    m_exec_conf->sync();
+    m_cv_dev.download(&m_cv, sizeof(double));
+    return m_cv;
+    }
+
+// OrderParameterMesh.cc:1052-1075 (virial: SURVEY §8f row N3, not built: external virial left at zero like the
+// reference without pressure flags, :1069-1072)
+void OrderParameterMeshGPU::computeBiasForces(unsigned int timestep)
+    {
+    if (m_is_first_step || m_cv_last_updated != timestep) enqueueCV(timestep);   // :1055-1056
+    const mtd_box box = m_pdata->getGlobalBox().toMtd();
+    mtd_check(mtd_mesh_forces(m_mesh, m_pdata->getN(), m_pdata->positionsPtr(), m_force.data(), m_pdata->getDtype(), &box,
+                              m_pdata->getNGlobal(), m_bias_device, m_bias, m_exec_conf->getStream()),
+              "mtd_mesh_forces");
+    for (unsigned int i = 0; i < 6; ++i) m_external_virial[i] = 0.0;
+    }
+
+// ------------------------------------------------------------------------------------------------
 // AspectRatio, Density
 // ------------------------------------------------------------------------------------------------
 
@@ -634,6 +714,20 @@ double IntegratorMetaDynamics::getLogValue(const std::string &quantity, unsigned
     if (quantity == m_log_names[1]) return mtd_metad_sigma_determinant(m_engine);
     if (quantity == m_log_names[2]) return w;
     throw std::runtime_error("Error getting log value");               // .h:184-188
+    }
+
+std::vector<double> IntegratorMetaDynamics::getCurrentValues()
+    {
+    std::vector<double> cv(m_variables.size());
+    if (m_engine) mtd_check(mtd_metad_get_state(m_engine, cv.data(), nullptr, nullptr, nullptr, nullptr, nullptr, m_exec_conf->getStream()), "mtd_metad_get_state");
+    return cv;
+    }
+
+std::vector<double> IntegratorMetaDynamics::getBiasFactors()
+    {
+    std::vector<double> b(m_variables.size());
+    if (m_engine) mtd_check(mtd_metad_get_state(m_engine, nullptr, b.data(), nullptr, nullptr, nullptr, nullptr, m_exec_conf->getStream()), "mtd_metad_get_state");
+    return b;
     }
 
 // :817-829

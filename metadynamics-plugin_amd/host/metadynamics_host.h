@@ -163,6 +163,47 @@ class WellTemperedEnsemble : public CollectiveVariable
         unsigned int m_n_partials;
     };
 
+//! OrderParameterMeshGPU.h / OrderParameterMesh.h:20-180 (single rank: no ghost cells, no dfft)
+class OrderParameterMeshGPU : public CollectiveVariable
+    {
+    public:
+        OrderParameterMeshGPU(std::shared_ptr<SystemDefinition> sysdef, unsigned int nx, unsigned int ny, unsigned int nz,
+                              std::vector<double> mode, std::vector<int3> zero_modes);
+        virtual ~OrderParameterMeshGPU();
+        double getCurrentValue(unsigned int timestep) override;        // OrderParameterMesh.cc:925-968 (cached per timestep)
+        void enqueueCurrentValue(unsigned int timestep, mtd_metad *engine, unsigned int slot) override;
+        void computeBiasForces(unsigned int timestep) override;        // OrderParameterMesh.cc:1052-1075
+        //! convolution-kernel table: stored like the reference, which never applies it to the mesh (Q7)
+        void setTable(const std::vector<double> &K, const std::vector<double> &d_K, double kmin, double kmax);   // :148-189
+        void setUseTable(bool use_table) { m_use_table = use_table; }
+        //! this build: false = interpolation function as intended instead of the reference's unsigned division (Q6)
+        void setBugCompatible(bool on);
+        std::vector<std::string> getProvidedLogQuantities() override
+            {
+            auto l = CollectiveVariable::getProvidedLogQuantities();
+            l.push_back("cv_mesh");
+            return l;
+            }
+        double getLogValue(const std::string &quantity, unsigned int timestep) override
+            {
+            if (quantity == "cv_mesh") return getCurrentValue(timestep);
+            return CollectiveVariable::getLogValue(quantity, timestep);
+            }
+
+    private:
+        void enqueueCV(unsigned int timestep);
+        mtd_mesh *m_mesh;
+        std::vector<double> m_mode;
+        std::vector<int3> m_zero_modes;          // stored and never read, like the reference (OrderParameterMesh.cc:59-63)
+        std::vector<double> m_table, m_table_d;
+        double m_k_min, m_k_max, m_delta_k;
+        bool m_use_table, m_is_first_step;
+        const double *m_partials;
+        unsigned int m_n_partials, m_cv_last_updated;
+        double m_cv;
+        DeviceBuffer m_cv_dev;
+    };
+
 //! AspectRatio.h / AspectRatio.cc:5-130 — box-shape CV, external virial only
 class AspectRatio : public CollectiveVariable
     {
@@ -231,6 +272,9 @@ class IntegratorMetaDynamics
         void setFusedPath(bool enable) { m_allow_fused = enable; }     // default on: two launches per step for lamellar CVs
         bool usedFusedPath() const { return m_used_fused; }
         mtd_metad *getEngine() { return m_engine; }
+        //! CV values and dV/ds_c of the most recent bias update (synchronises)
+        std::vector<double> getCurrentValues();
+        std::vector<double> getBiasFactors();
 
     private:
         struct CollectiveVariableItem                                  // IntegratorMetaDynamics.h:21-28

@@ -175,6 +175,13 @@ PYBIND11_MODULE(_metadynamics, m)
     py::class_<LamellarOrderParameterGPU, CollectiveVariable, std::shared_ptr<LamellarOrderParameterGPU>>(m, "LamellarOrderParameterGPU")
         .def(py::init<std::shared_ptr<SystemDefinition>, const std::vector<double> &, const std::vector<int3> &, const std::string &>());
 
+    // OrderParameterMesh.cc:1181-1193 / OrderParameterMeshGPU.cc:571-584
+    py::class_<OrderParameterMeshGPU, CollectiveVariable, std::shared_ptr<OrderParameterMeshGPU>>(m, "OrderParameterMeshGPU")
+        .def(py::init<std::shared_ptr<SystemDefinition>, unsigned int, unsigned int, unsigned int, std::vector<double>, std::vector<int3>>())
+        .def("setTable", &OrderParameterMeshGPU::setTable)
+        .def("setUseTable", &OrderParameterMeshGPU::setUseTable)
+        .def("setBugCompatible", &OrderParameterMeshGPU::setBugCompatible);
+
     py::class_<WellTemperedEnsemble, CollectiveVariable, std::shared_ptr<WellTemperedEnsemble>>(m, "WellTemperedEnsemble")
         .def(py::init<std::shared_ptr<SystemDefinition>, const std::string &>());
 
@@ -212,6 +219,8 @@ PYBIND11_MODULE(_metadynamics, m)
         // this build
         .def("setFusedPath", &IntegratorMetaDynamics::setFusedPath)
         .def("usedFusedPath", &IntegratorMetaDynamics::usedFusedPath)
+        .def("getCurrentValues", &IntegratorMetaDynamics::getCurrentValues)
+        .def("getBiasFactors", &IntegratorMetaDynamics::getBiasFactors)
         .def("getEngineHandle", [](IntegratorMetaDynamics &i) { return (size_t)i.getEngine(); });
     py::enum_<IntegratorMetaDynamics::Enum>(integrator_metad, "mode")
         .value("standard", IntegratorMetaDynamics::mode_standard)

@@ -138,8 +138,40 @@ def _not_built(what, row):
 
 
 class mesh(_collective_variable):
+    """Particle-mesh order parameter (cv.py:350-466)."""
+
     def __init__(self, mode, nx, ny=None, nz=None, name=None, sigma=1.0, zero_modes=None):
-        _not_built("cv.mesh", "A13-A17")
+        if name is not None:
+            name = "_" + name
+        if ny is None:
+            ny = nx
+        if nz is None:
+            nz = nx
+        _collective_variable.__init__(self, sigma, name)
+        cpp_mode = _mode_vector(mode, "cv.mesh")
+        cpp_zero_modes = _metadynamics.std_vector_int3()
+        if zero_modes is not None:
+            for l in zero_modes:
+                if len(l) != 3:
+                    raise RuntimeError("Error creating collective variable.")   # cv.py:403-405
+                cpp_zero_modes.append(_metadynamics.make_int3(int(l[0]), int(l[1]), int(l[2])))
+        self.cpp_force = _metadynamics.OrderParameterMeshGPU(context.current.system_definition, int(nx), int(ny), int(nz),
+                                                             cpp_mode, cpp_zero_modes)
+
+    def set_params(self, use_table=None, **args):                  # cv.py:423-436
+        if use_table is not None:
+            self.cpp_force.setUseTable(use_table)
+        _collective_variable.set_params(self, **args)
+
+    def set_kernel(self, func, kmin, kmax, width, coeff=dict()):   # cv.py:438-466
+        Ktable, dKtable = [], []
+        dk = (kmax - kmin) / float(width - 1)
+        for i in range(0, width):
+            k = kmin + dk * i
+            (K, dK) = func(k, kmin, kmax, **coeff)
+            Ktable.append(K)
+            dKtable.append(dK)
+        self.cpp_force.setTable(Ktable, dKtable, kmin, kmax)
 
 
 class steinhardt(_collective_variable):

@@ -255,8 +255,8 @@ class Metad:
         self.len = lib().ref_metad_num_elements(self._h)
 
     def __del__(self):
-        if getattr(self, "_h", None):
-            lib().ref_metad_destroy(self._h)
+        if getattr(self, "_h", None) and _lib is not None:
+            _lib.ref_metad_destroy(self._h)
             self._h = None
 
     def update_bias(self, timestep, current_val):
@@ -394,8 +394,8 @@ class Mesh:
         self._h = lib().ref_mesh_create(self.dims[0], self.dims[1], self.dims[2], len(md), _d(md))
 
     def __del__(self):
-        if getattr(self, "_h", None):
-            lib().ref_mesh_destroy(self._h)
+        if getattr(self, "_h", None) and _lib is not None:
+            _lib.ref_mesh_destroy(self._h)
             self._h = None
 
     def set_bug_compat(self, on):

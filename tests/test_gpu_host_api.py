@@ -209,3 +209,61 @@ def test_api_errors(api):
         c.set_params(umbrella="bogus")
     with pytest.raises(RuntimeError):
         meta.set_params(adaptive=True)
+
+
+def test_mesh_cv_with_umbrella_through_api(api, ref):
+    """test/test_mesh.py's set-up in miniature: cv.mesh under a harmonic umbrella (no metadynamics grid): the force is
+    -(dU/ds) grad s with dU/ds = kappa (s - cv0) (CollectiveVariable.cc:43-50) and umbrella_energy_mesh = kappa/2 (s-cv0)^2;
+    plus cv.mesh registered with the bias grid next to a lamellar CV (config 3's CV set, generic path)"""
+    context, cv, integrate = api
+    N, L = 8000, 20.0
+    pos, types = util.snapshot_random(N, L, seed=21, modulated=True, dtype=np.float64)
+    rbox = ref.Box.make(L)
+    opt = util.oracle_postype(pos, types)
+    r = ref.Mesh(16, 16, 16, [1.0, -1.0])
+    s_ref = r.cv(opt, rbox)
+
+    context.initialize(pos, types, ["A", "B"], L, dtype=np.float64)
+    meta = integrate.mode_metadynamics(dt=0.005, stride=1, mode="well_tempered", W=1.0, deltaT=7.0, T=1.0)
+    mesh = cv.mesh(nx=16, mode={"A": 1.0, "B": -1.0})
+    cv0 = 0.5 * s_ref
+    kappa = 10.0 / cv0 ** 2
+    mesh.set_params(umbrella="harmonic", cv0=cv0, kappa=kappa)
+    context.run(2)
+    t = context.current.system.getCurrentTimeStep()
+    assert mesh.cpp_force.getCurrentValue(t) == pytest.approx(s_ref, rel=1e-9)
+    assert mesh.cpp_force.getLogValue("cv_mesh", t) == pytest.approx(s_ref, rel=1e-9)
+    dU = ref.umbrella_bias("harmonic", s_ref, 0.0, cv0, kappa, 0.0, 1.0)
+    assert mesh.cpp_force.getLogValue("umbrella_energy_mesh", t) == pytest.approx(ref.umbrella_energy("harmonic", s_ref, cv0, kappa, 0.0, 1.0), rel=1e-8)
+    F = mesh.cpp_force.getForceArray()
+    F_ref = r.forces(opt, rbox, dU)
+    assert np.abs(F[:, :3] - F_ref[:, :3]).max() <= 1e-7 * np.abs(F_ref[:, :3]).max()
+
+    # config 3's CV set: one lamellar CV + the mesh CV on one 2-d grid (generic path, both CVs device resident)
+    context.initialize(pos, types, ["A", "B"], L, dtype=np.float64)
+    meta = integrate.mode_metadynamics(dt=0.005, stride=1, mode="well_tempered", W=1.0, deltaT=7.0, T=1.0)
+    lam = cv.lamellar(sigma=0.02, mode=dict(A=1.0, B=-1.0), lattice_vectors=util.CV1_VECTORS)
+    lam.set_grid(-0.6, 0.4, 32)
+    mesh = cv.mesh(nx=16, mode={"A": 1.0, "B": -1.0}, sigma=0.05 * abs(s_ref))
+    # the CV must not sit symmetrically between two nodes (there dV/ds is pure rounding noise)
+    mesh.set_grid(0.25 * s_ref, 1.6 * s_ref, 40)
+    context.run(3)
+    assert not meta.cpp_integrator.usedFusedPath()
+    s_lam = ref.lamellar_cv(util.CV1_VECTORS, opt, util.MODE_AB, rbox)
+    cv_gpu = meta.cpp_integrator.getCurrentValues()
+    assert cv_gpu[0] == pytest.approx(s_lam, rel=1e-6) and cv_gpu[1] == pytest.approx(s_ref, rel=1e-9)
+    g = ref.Metad([0.02, 0.05 * abs(s_ref)], [-0.6, 0.25 * s_ref], [0.4, 1.6 * s_ref], [32, 40], W=1.0, T_shift=7.0, T=1.0,
+                  stride=1, mode="well_tempered")
+    for tt in range(4):
+        b = g.update_bias(tt, cv_gpu)          # oracle grid driven with the device's CV values
+    t = context.current.system.getCurrentTimeStep()
+    assert meta.cpp_integrator.getLogValue("bias", t) == pytest.approx(g.curr_bias, rel=1e-9)
+    assert np.allclose(meta.cpp_integrator.getBiasFactors(), b, rtol=1e-7)
+    F = mesh.cpp_force.getForceArray()
+    F_ref = r.forces(opt, rbox, b[1])
+    assert np.abs(F[:, :3] - F_ref[:, :3]).max() <= 1e-5 * np.abs(F_ref[:, :3]).max()
+    F = lam.cpp_force.getForceArray()
+    F_ref = ref.lamellar_forces(util.CV1_VECTORS, opt, util.MODE_AB, rbox, b[0])
+    assert np.abs(F[:, :3] - F_ref[:, :3]).max() <= 1e-5 * np.abs(F_ref[:, :3]).max()
+    with pytest.raises(RuntimeError):
+        cv.mesh(nx=12, mode={"A": 1.0, "B": -1.0})            # not a power of two

@@ -1,0 +1,31 @@
+#!/usr/bin/env python3
+"""Developer tool: BASELINE.json configs[2] (10^6 particles, cv.mesh on 128^3 + 1 lamellar CV, 256^2 grid) through the
+reference-shaped API; prints us/step.  Run under rocprofv3 --kernel-trace --stats for the per-kernel table."""
+import os, sys, time
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [os.path.join(root, "metadynamics-plugin_amd"), os.path.join(root, "tests")]
+import numpy as np, torch
+import util
+from metadynamics import context, cv, integrate
+N, L = 1_000_000, 100.0
+steps = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+pos, types = util.snapshot_random(N, L, seed=12345, modulated=True, dtype=np.float32)
+context.initialize(pos, types, ["A", "B"], L, dtype=np.float32)
+meta = integrate.mode_metadynamics(dt=0.005, stride=1, mode="well_tempered", W=1.0, deltaT=7.0, T=1.0)
+lam = cv.lamellar(sigma=0.02, mode=dict(A=1.0, B=-1.0), lattice_vectors=util.CV1_VECTORS)
+lam.set_grid(-1.0, 1.0, 256)
+mesh = cv.mesh(nx=128, mode={"A": 1.0, "B": -1.0})
+s0 = None
+context.run(0) if False else None
+# range for the mesh CV from its own value
+mesh.set_grid(0.0, 1.0, 256)
+context.run(1)
+s0 = mesh.cpp_force.getCurrentValue(context.current.system.getCurrentTimeStep())
+print("mesh cv =", s0, "lamellar cv =", lam.cpp_force.getCurrentValue(1))
+context.run(10)
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+context.current.system.run(steps - 1)
+torch.cuda.synchronize()
+dt = time.perf_counter() - t0
+print("config 3: %.1f us/step  (%.3e particle-CV-evals/s, 2 CVs)" % (1e6 * dt / steps, 2 * N * steps / dt))
