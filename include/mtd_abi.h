@@ -249,13 +249,14 @@ unsigned int mtd_mesh_num_cells(const mtd_mesh *m);
 int mtd_mesh_compute_cv(mtd_mesh *m, unsigned int n_particles, const void *d_postype, int dtype, const mtd_box *box,
                         unsigned int n_global, const double **d_partials, unsigned int *n_partials, mtd_stream_t stream);
 
-/* interpolateForces (OrderParameterMesh.cc:749-864) from the inverse mesh of the last mtd_mesh_compute_cv;
+/* interpolateForces (OrderParameterMesh.cc:749-864) from the inverse mesh AND the cell-sorted particle records of the last
+ * mtd_mesh_compute_cv, i.e. of the same snapshot (the reference recomputes the CV first when needed, :1055-1056);
  * bias = *d_bias when d_bias != NULL (device resident), else bias_host */
 int mtd_mesh_forces(mtd_mesh *m, unsigned int n_particles, const void *d_postype, void *d_force, int dtype,
                     const mtd_box *box, unsigned int n_global, const double *d_bias, double bias_host, mtd_stream_t stream);
 
 /* raw arrays for parity tests (SYNCHRONISES): which = 0 real mesh double[M]; 1 fourier_mesh (normalised) complex double[M];
- * 3 inv_fourier_mesh complex double[M]; 7 sum of mode^2 (one double) */
+ * 3 Re(inv_fourier_mesh) double[M] (the imaginary part is never used, OrderParameterMesh.cc:851-857); 7 sum of mode^2 */
 int mtd_mesh_get_array(mtd_mesh *m, int which, void *host_out, mtd_stream_t stream);
 
 /* ================================================================================================

@@ -233,7 +233,7 @@ __global__ __launch_bounds__(256) void k_mesh_fill(const unsigned int *__restric
 template<typename S4>
 __global__ __launch_bounds__(256) void k_mesh_sort(const MeshGeom g, const S4 *__restrict__ postype, const double *__restrict__ mode,
                                                    const unsigned int *__restrict__ start, unsigned int *__restrict__ ids,
-                                                   double4 *__restrict__ packed)
+                                                   double4 *__restrict__ packed, unsigned int *__restrict__ cell_sorted)
     {
     const unsigned int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= g.n_cells) return;
@@ -256,10 +256,24 @@ __global__ __launch_bounds__(256) void k_mesh_sort(const MeshGeom g, const S4 *_
         double sx, sy, sz;
         locate(g, p, ix, iy, iz, sx, sy, sz);
         packed[i] = make_double4(sx, sy, sz, mode[p.type]);
+        cell_sorted[i] = c;
         }
     }
 
 // ---- 5. gather: mesh[c] = sum over particles of the 27 neighbour cells -----------------------------
+// Cells are x-fastest, so for a fixed (j,k) the three source cells cx-1, cx, cx+1 own ONE contiguous range of the
+// sorted particle list (except across the periodic wrap in x): 9 ranges per cell instead of 27 cell look-ups.
+__device__ __forceinline__ double gather_range(const double4 *__restrict__ packed, unsigned int b, unsigned int e, int i, int j,
+                                               int k, double acc)
+    {
+    for (unsigned int q = b; q < e; ++q)
+        {
+        const double4 pk = packed[q];
+        acc += pk.w * (tsc(pk.x - i) * tsc(pk.y - j) * tsc(pk.z - k));
+        }
+    return acc;
+    }
+
 __global__ __launch_bounds__(256) void k_mesh_gather(const MeshGeom g, const unsigned int *__restrict__ start,
                                                      const double4 *__restrict__ packed, double *__restrict__ rho)
     {
@@ -269,23 +283,18 @@ __global__ __launch_bounds__(256) void k_mesh_gather(const MeshGeom g, const uns
     const int cy = (c - cz * g.nx * g.ny) / g.nx;
     const int cx = c % g.nx;
     double acc = 0.0;
-    // this cell receives from the particle cell at offset (-i,-j,-k) with dx = shift - (i,j,k); loop the
-    // source cells in a fixed order
+    // this cell receives from the particle cell at offset (-i,-j,-k) with dx = shift - (i,j,k); fixed loop order
     for (int k = -1; k <= 1; ++k)
         for (int j = -1; j <= 1; ++j)
-            for (int i = -1; i <= 1; ++i)
-                {
-                const int sxc = wrap(cx - i, (int)g.nx), syc = wrap(cy - j, (int)g.ny), szc = wrap(cz - k, (int)g.nz);
-                // a source cell reaches this cell through offset (i,j,k) only if cell + offset wraps onto it; with
-                // n >= 3 per axis the 27 offsets map to 27 distinct cells (n < 3 handled by the host check)
-                const unsigned int s = sxc + g.nx * (syc + g.ny * szc);
-                const unsigned int b = start[s], e = start[s + 1];
-                for (unsigned int q = b; q < e; ++q)
-                    {
-                    const double4 pk = packed[q];
-                    acc += pk.w * (tsc(pk.x - i) * tsc(pk.y - j) * tsc(pk.z - k));
-                    }
-                }
+            {
+            const int syc = wrap(cy - j, (int)g.ny), szc = wrap(cz - k, (int)g.nz);
+            const unsigned int row = g.nx * (syc + g.ny * szc);
+            // source x cells: cx+1 (i=-1), cx (i=0), cx-1 (i=+1)
+            const unsigned int xm = (unsigned int)wrap(cx - 1, (int)g.nx), x0 = (unsigned int)cx, xp = (unsigned int)wrap(cx + 1, (int)g.nx);
+            acc = gather_range(packed, start[row + xm], start[row + xm + 1], 1, j, k, acc);
+            acc = gather_range(packed, start[row + x0], start[row + x0 + 1], 0, j, k, acc);
+            acc = gather_range(packed, start[row + xp], start[row + xp + 1], -1, j, k, acc);
+            }
     rho[c] = acc;
     }
 
@@ -294,8 +303,9 @@ __global__ __launch_bounds__(256) void k_mesh_gather(const MeshGeom g, const uns
 // LDS layout [p][tile] (consecutive lines in consecutive 16-B slots: conflict-free butterflies).
 constexpr int FFT_THREADS = 256;
 
-template<bool REAL_INPUT>
+template<bool REAL_INPUT, bool REAL_OUTPUT>
 __global__ __launch_bounds__(FFT_THREADS) void k_fft_lines(const double *__restrict__ real_in, double2 *__restrict__ data,
+                                                           double *__restrict__ real_out,
                                                            const double2 *__restrict__ twiddle, const unsigned int n,
                                                            const unsigned int log2n, const unsigned int tile,
                                                            const unsigned int elem_stride, const unsigned int line_stride,
@@ -369,7 +379,11 @@ __global__ __launch_bounds__(FFT_THREADS) void k_fft_lines(const double *__restr
             p = idx / tile;
             t = idx % tile;
             }
-        data[base + (size_t)t * line_stride + (size_t)p * elem_stride] = s[p * tile + t];
+        const size_t a = base + (size_t)t * line_stride + (size_t)p * elem_stride;
+        if (REAL_OUTPUT)
+            real_out[a] = s[p * tile + t].x;     // interpolateForces only reads Re(inv) (:851-857)
+        else
+            data[a] = s[p * tile + t];
         }
     }
 
@@ -438,21 +452,25 @@ __global__ __launch_bounds__(256) void k_mesh_spectral(const MeshGeom g, double2
     }
 
 // ---- 9. forces --------------------------------------------------------------------------------------
+// One thread per SORTED slot: neighbouring threads read neighbouring stencils of Re(inv) (L1/L2 hits instead of
+// 27 uncoalesced gathers), shift and mode come from the packed records (no second locate()), the force is written to
+// the particle's original index.
 template<typename S4>
-__global__ __launch_bounds__(256) void k_mesh_forces(const MeshGeom g, const S4 *__restrict__ postype, const unsigned int N,
-                                                     const double *__restrict__ mode, const double2 *__restrict__ inv,
-                                                     S4 *__restrict__ force, const double *__restrict__ d_bias,
-                                                     const double bias_host, const double two_over_n)
+__global__ __launch_bounds__(256) void k_mesh_forces(const MeshGeom g, const unsigned int N, const unsigned int *__restrict__ ids,
+                                                     const unsigned int *__restrict__ cell_sorted, const double4 *__restrict__ packed,
+                                                     const double *__restrict__ inv, S4 *__restrict__ force,
+                                                     const double *__restrict__ d_bias, const double bias_host, const double two_over_n)
     {
     typedef typename scalar4_traits<S4>::scalar scalar;
     const double bias = d_bias ? *d_bias : bias_host;
-    for (unsigned int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < N; idx += gridDim.x * blockDim.x)
+    for (unsigned int q = blockIdx.x * blockDim.x + threadIdx.x; q < N; q += gridDim.x * blockDim.x)
         {
-        const Particle p = scalar4_traits<S4>::load(postype, idx);
-        const double a = mode[p.type];
-        int ix, iy, iz;
-        double sx, sy, sz;
-        locate(g, p, ix, iy, iz, sx, sy, sz);
+        const double4 pk = packed[q];
+        const unsigned int c = cell_sorted[q];
+        const int iz = c / (g.nx * g.ny);
+        const int iy = (c - iz * g.nx * g.ny) / g.nx;
+        const int ix = c % g.nx;
+        const double a = pk.w, sx = pk.x, sy = pk.y, sz = pk.z;
         double wxv[3], wyv[3], wzv[3], dxv[3], dyv[3], dzv[3];
 #pragma unroll
         for (int i = 0; i < 3; ++i)
@@ -461,23 +479,29 @@ __global__ __launch_bounds__(256) void k_mesh_forces(const MeshGeom g, const S4 
             wyv[i] = tsc(sy - (i - 1)); dyv[i] = tsc_deriv(sy - (i - 1));
             wzv[i] = tsc(sz - (i - 1)); dzv[i] = tsc_deriv(sz - (i - 1));
             }
+        const unsigned int xs[3] = {(unsigned int)wrap(ix - 1, (int)g.nx), (unsigned int)ix, (unsigned int)wrap(ix + 1, (int)g.nx)};
         double g1 = 0.0, g2 = 0.0, g3 = 0.0;   // sums multiplying n_x b1, n_y b2, n_z b3
-        for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+#pragma unroll
             for (int j = 0; j < 3; ++j)
-                for (int k = 0; k < 3; ++k)
+                {
+                const unsigned int row = g.nx * (wrap(iy + j - 1, (int)g.ny) + g.ny * wrap(iz + k - 1, (int)g.nz));
+#pragma unroll
+                for (int i = 0; i < 3; ++i)
                     {
-                    const int ni = wrap(ix + i - 1, (int)g.nx), nj = wrap(iy + j - 1, (int)g.ny), nk = wrap(iz + k - 1, (int)g.nz);
-                    const double r = inv[ni + g.nx * (nj + g.ny * nk)].x;
+                    const double r = inv[row + xs[i]];
                     g1 += dxv[i] * wyv[j] * wzv[k] * r;
                     g2 += wxv[i] * dyv[j] * wzv[k] * r;
                     g3 += wxv[i] * wyv[j] * dzv[k] * r;
                     }
+                }
         const double c1 = -(double)g.nx * a * g1, c2 = -(double)g.ny * a * g2, c3 = -(double)g.nz * a * g3;
         const double s = two_over_n * bias;                            // :861
         const double fx = (c1 * g.binv[0][0] + c2 * g.binv[1][0] + c3 * g.binv[2][0]) * s;
         const double fy = (c1 * g.binv[0][1] + c2 * g.binv[1][1] + c3 * g.binv[2][1]) * s;
         const double fz = (c1 * g.binv[0][2] + c2 * g.binv[1][2] + c3 * g.binv[2][2]) * s;
-        force[idx] = scalar4_traits<S4>::make((scalar)fx, (scalar)fy, (scalar)fz, (scalar)0);
+        force[ids[q]] = scalar4_traits<S4>::make((scalar)fx, (scalar)fy, (scalar)fz, (scalar)0);
         }
     }
 
@@ -511,10 +535,11 @@ struct mtd_mesh
     unsigned int nx, ny, nz, M, n_types, max_particles;
     int bug_compat;
     void *slab;
-    double *d_mode, *d_rho, *d_modesq_partials, *d_mode_sq, *d_cv_partials;
+    double *d_mode, *d_rho, *d_inv, *d_modesq_partials, *d_mode_sq, *d_cv_partials;
     double2 *d_f, *d_g, *d_tw[3];
     double4 *d_packed;
-    unsigned int *d_cell_of, *d_count, *d_start, *d_ids, *d_tile_sums;
+    unsigned int *d_cell_of, *d_count, *d_start, *d_ids, *d_tile_sums, *d_cell_sorted;
+    unsigned int n_last;   // particle count of the last compute_cv (the sorted list the force pass walks)
     unsigned int n_cv_partials, n_count_blocks;
     };
 
@@ -536,7 +561,7 @@ int fill_geom(MeshGeom &g, const mtd_mesh *m, const mtd_box *box)
     return MTD_SUCCESS;
     }
 
-int launch_fft3d(const mtd_mesh *m, const double *real_in, double2 *data, int inverse, hipStream_t s)
+int launch_fft3d(const mtd_mesh *m, const double *real_in, double2 *data, double *real_out, int inverse, hipStream_t s)
     {
     const unsigned int nx = m->nx, ny = m->ny, nz = m->nz;
     // x lines: contiguous; tile = as many lines as keep <= 64 KB of LDS, p fastest for coalescing
@@ -564,11 +589,14 @@ int launch_fft3d(const mtd_mesh *m, const double *real_in, double2 *data, int in
         const size_t lds = (size_t)p.n * p.tile * sizeof(double2);
         if (p.n == 1) continue;
         if (a == 0 && real_in)
-            k_fft_lines<true><<<p.n_blocks, FFT_THREADS, lds, s>>>(real_in, data, p.tw, p.n, ilog2(p.n), p.tile, p.elem_stride,
-                                                                    p.line_stride, p.tiles_per_row, p.row_stride, inverse, p.p_fastest);
+            k_fft_lines<true, false><<<p.n_blocks, FFT_THREADS, lds, s>>>(real_in, data, nullptr, p.tw, p.n, ilog2(p.n), p.tile, p.elem_stride,
+                                                                           p.line_stride, p.tiles_per_row, p.row_stride, inverse, p.p_fastest);
+        else if (a == 2 && real_out)
+            k_fft_lines<false, true><<<p.n_blocks, FFT_THREADS, lds, s>>>(nullptr, data, real_out, p.tw, p.n, ilog2(p.n), p.tile, p.elem_stride,
+                                                                           p.line_stride, p.tiles_per_row, p.row_stride, inverse, p.p_fastest);
         else
-            k_fft_lines<false><<<p.n_blocks, FFT_THREADS, lds, s>>>(nullptr, data, p.tw, p.n, ilog2(p.n), p.tile, p.elem_stride,
-                                                                     p.line_stride, p.tiles_per_row, p.row_stride, inverse, p.p_fastest);
+            k_fft_lines<false, false><<<p.n_blocks, FFT_THREADS, lds, s>>>(nullptr, data, nullptr, p.tw, p.n, ilog2(p.n), p.tile, p.elem_stride,
+                                                                            p.line_stride, p.tiles_per_row, p.row_stride, inverse, p.p_fastest);
         MTD_LAUNCH_CHECK();
         }
     return MTD_SUCCESS;
@@ -607,7 +635,8 @@ int mtd_mesh_create(mtd_mesh **out, unsigned int nx, unsigned int ny, unsigned i
                  o_g = take(sizeof(double2) * M), o_tw0 = take(sizeof(double2) * nx), o_tw1 = take(sizeof(double2) * ny),
                  o_tw2 = take(sizeof(double2) * nz), o_packed = take(sizeof(double4) * N), o_cell = take(sizeof(unsigned int) * N),
                  o_count = take(sizeof(unsigned int) * (M + 1)), o_start = take(sizeof(unsigned int) * (M + 1)),
-                 o_ids = take(sizeof(unsigned int) * N), o_tiles = take(sizeof(unsigned int) * n_tiles);
+                 o_ids = take(sizeof(unsigned int) * N), o_tiles = take(sizeof(unsigned int) * n_tiles),
+                 o_inv = take(sizeof(double) * M), o_csort = take(sizeof(unsigned int) * N);
     hipError_t e = hipMalloc(&m->slab, off);
     if (e != hipSuccess)
         {
@@ -621,6 +650,8 @@ int mtd_mesh_create(mtd_mesh **out, unsigned int nx, unsigned int ny, unsigned i
     m->d_tw[2] = (double2 *)(p + o_tw2); m->d_packed = (double4 *)(p + o_packed); m->d_cell_of = (unsigned int *)(p + o_cell);
     m->d_count = (unsigned int *)(p + o_count); m->d_start = (unsigned int *)(p + o_start); m->d_ids = (unsigned int *)(p + o_ids);
     m->d_tile_sums = (unsigned int *)(p + o_tiles);
+    m->d_inv = (double *)(p + o_inv);
+    m->d_cell_sorted = (unsigned int *)(p + o_csort);
     e = hipMemset(m->slab, 0, off);
     if (e == hipSuccess) e = hipMemcpy(m->d_mode, mode, sizeof(double) * n_types, hipMemcpyHostToDevice);
     // twiddles exp(-2 pi i j / n), j < n/2, in double on the host
@@ -695,18 +726,19 @@ int mtd_mesh_compute_cv(mtd_mesh *m, unsigned int n_particles, const void *d_pos
     k_mesh_fill<<<m->n_count_blocks, 256, 0, s>>>(m->d_cell_of, N, m->d_start, m->d_count, m->d_ids);
     MTD_LAUNCH_CHECK();
     if (dtype == MTD_F32)
-        k_mesh_sort<float4><<<cell_blocks, 256, 0, s>>>(g, (const float4 *)d_postype, m->d_mode, m->d_start, m->d_ids, m->d_packed);
+        k_mesh_sort<float4><<<cell_blocks, 256, 0, s>>>(g, (const float4 *)d_postype, m->d_mode, m->d_start, m->d_ids, m->d_packed, m->d_cell_sorted);
     else
-        k_mesh_sort<double4><<<cell_blocks, 256, 0, s>>>(g, (const double4 *)d_postype, m->d_mode, m->d_start, m->d_ids, m->d_packed);
+        k_mesh_sort<double4><<<cell_blocks, 256, 0, s>>>(g, (const double4 *)d_postype, m->d_mode, m->d_start, m->d_ids, m->d_packed, m->d_cell_sorted);
     MTD_LAUNCH_CHECK();
     k_mesh_gather<<<cell_blocks, 256, 0, s>>>(g, m->d_start, m->d_packed, m->d_rho);
     MTD_LAUNCH_CHECK();
-    rc = launch_fft3d(m, m->d_rho, m->d_f, 0, s);
+    rc = launch_fft3d(m, m->d_rho, m->d_f, nullptr, 0, s);
     if (rc) return rc;
     k_mesh_spectral<<<m->n_cv_partials, 256, 0, s>>>(g, m->d_f, m->d_g, m->d_mode_sq, (double)n_global, m->bug_compat, m->d_cv_partials);
     MTD_LAUNCH_CHECK();
-    rc = launch_fft3d(m, nullptr, m->d_g, 1, s);
+    rc = launch_fft3d(m, nullptr, m->d_g, m->d_inv, 1, s);   // Re(inv) lands in its own array
     if (rc) return rc;
+    m->n_last = N;
     *d_partials = m->d_cv_partials;
     *n_partials = m->n_cv_partials;
     return MTD_SUCCESS;
@@ -725,10 +757,13 @@ int mtd_mesh_forces(mtd_mesh *m, unsigned int n_particles, const void *d_postype
     unsigned int blocks = (n_particles + 255) / 256;
     if (blocks > 4096) blocks = 4096;
     const double two_over_n = 2.0 / (double)n_global;
+    // the force pass walks the cell-sorted list built by the last mtd_mesh_compute_cv of the same snapshot
+    if (n_particles != m->n_last) return MTD_ERR_INVALID_ARGUMENT;
+    (void)d_postype;
     if (dtype == MTD_F32)
-        k_mesh_forces<float4><<<blocks, 256, 0, s>>>(g, (const float4 *)d_postype, n_particles, m->d_mode, m->d_g, (float4 *)d_force, d_bias, bias_host, two_over_n);
+        k_mesh_forces<float4><<<blocks, 256, 0, s>>>(g, n_particles, m->d_ids, m->d_cell_sorted, m->d_packed, m->d_inv, (float4 *)d_force, d_bias, bias_host, two_over_n);
     else
-        k_mesh_forces<double4><<<blocks, 256, 0, s>>>(g, (const double4 *)d_postype, n_particles, m->d_mode, m->d_g, (double4 *)d_force, d_bias, bias_host, two_over_n);
+        k_mesh_forces<double4><<<blocks, 256, 0, s>>>(g, n_particles, m->d_ids, m->d_cell_sorted, m->d_packed, m->d_inv, (double4 *)d_force, d_bias, bias_host, two_over_n);
     MTD_LAUNCH_CHECK();
     return MTD_SUCCESS;
     }
@@ -742,7 +777,7 @@ int mtd_mesh_get_array(mtd_mesh *m, int which, void *host_out, mtd_stream_t stre
         {
         case 0: src = m->d_rho; bytes = sizeof(double) * m->M; break;            // real mesh (assignParticles)
         case 1: src = m->d_f; bytes = sizeof(double2) * m->M; break;             // fourier_mesh, normalised
-        case 3: src = m->d_g; bytes = sizeof(double2) * m->M; break;             // inv_fourier_mesh (G transformed in place)
+        case 3: src = m->d_inv; bytes = sizeof(double) * m->M; break;            // Re(inv_fourier_mesh), real double[M]
         case 7: src = m->d_mode_sq; bytes = sizeof(double); break;
         default: return MTD_ERR_INVALID_ARGUMENT;
         }

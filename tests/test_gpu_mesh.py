@@ -45,14 +45,14 @@ class GpuMesh:
 
     def array(self, which):
         nz, ny, nx = self.dims[2], self.dims[1], self.dims[0]
-        if which == 0:
+        if which in (0, 3):
             out = np.zeros(self.M)
         elif which == 7:
             out = np.zeros(1)
         else:
             out = np.zeros(2 * self.M)
         self.abi.check(self.lib.mtd_mesh_get_array(self.h, which, out.ctypes.data, None))
-        if which == 0:
+        if which in (0, 3):
             return out.reshape(nz, ny, nx)
         if which == 7:
             return out[0]
@@ -89,7 +89,7 @@ def test_mesh_cv_and_forces(abi, ref, dtype, dims, tilt):
             scale = np.abs(r.array("fourier_mesh")).max()
             assert np.abs(g.array(1) - r.array("fourier_mesh")).max() <= 1e-12 * scale
             scale = np.abs(r.array("inv_fourier_mesh")).max()
-            assert np.abs(g.array(3) - r.array("inv_fourier_mesh")).max() <= 1e-11 * scale
+            assert np.abs(g.array(3) - r.array("inv_fourier_mesh").real).max() <= 1e-11 * scale
             assert s == pytest.approx(s_ref, rel=1e-9)
             for device_bias in (True, False):
                 F = g.forces(d_pos, dt, box, N, -2.5, device_bias)
