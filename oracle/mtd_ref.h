@@ -129,6 +129,21 @@ double ref_mesh_mode_sq(const ref_mesh *m);
  *        4 interpolation_f, 5 inf_f (double[M]); 6 k (double[3M]) */
 void *ref_mesh_array(ref_mesh *m, int which);
 
+/* ---------------------------------------------------------------- Steinhardt Q_l (mtd_ref_steinhardt.c) */
+/* fsph::evaluate_SPH (spherical_harmonics.hpp:229-246), argument order of the header: (phi = polar, theta = azimuth).
+ * out: (re,im) pairs, per point (lmax+1)^2 values (full_m) or (lmax+1)(lmax+2)/2; per l: m = 0..l then -1..-l. */
+void ref_sph_evaluate(double *out, unsigned int lmax, const double *phi, const double *theta, unsigned int N, int full_m);
+/* SteinhardtQl::computeCV (SteinhardtQl.cc:62-201): neighbour list in HOOMD layout (head_list[N], n_neigh[N], nlist[]). */
+double ref_ql_compute_cv(unsigned int N, const double *postype, const ref_box *box, const unsigned int *head_list,
+                         const unsigned int *n_neigh, const unsigned int *nlist, int half_nlist, double rcut, double ron,
+                         unsigned int lmax, unsigned int type, const double *Ql_ref, unsigned int N_global,
+                         double *Qlm_out /*2 (lmax+1)^2*/, double *Ql_out /*lmax+1*/);
+/* SteinhardtQl::computeBiasForces (:203-339) with the Q_lm computeCV left behind (Q20) */
+void ref_ql_compute_forces(unsigned int N, const double *postype, const ref_box *box, const unsigned int *head_list,
+                           const unsigned int *n_neigh, const unsigned int *nlist, int half_nlist, double rcut, double ron,
+                           unsigned int lmax, unsigned int type, const double *Ql_ref, unsigned int N_global,
+                           const double *Qlm_in, double bias, double *force_out /*4N*/);
+
 #ifdef __cplusplus
 }
 #endif

@@ -429,3 +429,45 @@ class Mesh:
         buf = (C.c_double * n).from_address(ptr)
         a = np.frombuffer(buf, dtype=np.float64)
         return a.reshape(nz, ny, nx, 3) if which == 6 else a.reshape(nz, ny, nx)
+
+
+def sph_evaluate(lmax, polar, azimuth, full_m=True):
+    """fsph::evaluate_SPH: complex array (N, per)"""
+    ph = np.ascontiguousarray(polar, dtype=np.float64)
+    th = np.ascontiguousarray(azimuth, dtype=np.float64)
+    per = (lmax + 1) ** 2 if full_m else (lmax + 1) * (lmax + 2) // 2
+    out = np.zeros(2 * per * len(ph))
+    lib().ref_sph_evaluate(_d(out), int(lmax), _d(ph), _d(th), len(ph), int(full_m))
+    out = out.reshape(len(ph), per, 2)
+    return out[..., 0] + 1j * out[..., 1]
+
+
+def ql_compute_cv(postype, box, head_list, n_neigh, nlist, rcut, ron, lmax, type_id, Ql_ref, half=False, n_global=None):
+    """returns (value, Qlm complex[(lmax+1)^2], Ql[lmax+1])"""
+    pt = np.ascontiguousarray(postype, dtype=np.float64)
+    hl = np.ascontiguousarray(head_list, dtype=np.uint32)
+    nn = np.ascontiguousarray(n_neigh, dtype=np.uint32)
+    nl = np.ascontiguousarray(nlist, dtype=np.uint32)
+    qr = np.ascontiguousarray(Ql_ref, dtype=np.float64)
+    cnt = (lmax + 1) ** 2
+    qlm = np.zeros(2 * cnt)
+    ql = np.zeros(lmax + 1)
+    v = lib().ref_ql_compute_cv(pt.shape[0], _d(pt), C.byref(box), _u(hl), _u(nn), _u(nl), int(half), float(rcut), float(ron),
+                                int(lmax), int(type_id), _d(qr), pt.shape[0] if n_global is None else int(n_global), _d(qlm), _d(ql))
+    return v, qlm[0::2] + 1j * qlm[1::2], ql
+
+
+def ql_compute_forces(postype, box, head_list, n_neigh, nlist, rcut, ron, lmax, type_id, Ql_ref, Qlm, bias, half=False,
+                      n_global=None):
+    pt = np.ascontiguousarray(postype, dtype=np.float64)
+    hl = np.ascontiguousarray(head_list, dtype=np.uint32)
+    nn = np.ascontiguousarray(n_neigh, dtype=np.uint32)
+    nl = np.ascontiguousarray(nlist, dtype=np.uint32)
+    qr = np.ascontiguousarray(Ql_ref, dtype=np.float64)
+    q = np.zeros(2 * len(Qlm))
+    q[0::2], q[1::2] = np.real(Qlm), np.imag(Qlm)
+    out = np.zeros((pt.shape[0], 4))
+    lib().ref_ql_compute_forces(pt.shape[0], _d(pt), C.byref(box), _u(hl), _u(nn), _u(nl), int(half), float(rcut), float(ron),
+                                int(lmax), int(type_id), _d(qr), pt.shape[0] if n_global is None else int(n_global), _d(q),
+                                float(bias), _d(out))
+    return out

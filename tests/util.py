@@ -67,3 +67,35 @@ def dbl_array(values):
 
 def uint_array(values):
     return (C.c_uint * len(values))(*[int(v) for v in values])
+
+
+def build_nlist(pos, L, r_cut, half=False):
+    """HOOMD-layout neighbour list (head_list, n_neigh, nlist) of a cubic periodic box with scipy's periodic KD-tree:
+    the stand-in for hoomd.md.nlist in tests (HOOMD's NeighborList is not part of the plugin)."""
+    from scipy.spatial import cKDTree
+    p = np.mod(np.asarray(pos, dtype=np.float64) + L / 2, L)
+    p[p >= L] -= L
+    tree = cKDTree(p, boxsize=L)
+    pairs = tree.query_pairs(r_cut, output_type="ndarray")
+    N = len(p)
+    if half:
+        i, j = pairs[:, 0], pairs[:, 1]
+    else:
+        i = np.concatenate([pairs[:, 0], pairs[:, 1]])
+        j = np.concatenate([pairs[:, 1], pairs[:, 0]])
+    order = np.lexsort((j, i))
+    i, j = i[order], j[order]
+    n_neigh = np.bincount(i, minlength=N).astype(np.uint32)
+    head = np.zeros(N, dtype=np.uint32)
+    head[1:] = np.cumsum(n_neigh)[:-1]
+    return head, n_neigh, j.astype(np.uint32)
+
+
+def fcc_lattice(n, nn_dist=1.0):
+    """n^3 fcc cells x 4 particles, nearest-neighbour distance nn_dist; returns positions centred on 0 and box length"""
+    a = nn_dist * np.sqrt(2.0)
+    basis = np.array([[0, 0, 0], [0.5, 0.5, 0], [0.5, 0, 0.5], [0, 0.5, 0.5]])
+    cells = np.stack(np.meshgrid(np.arange(n), np.arange(n), np.arange(n), indexing="ij"), -1).reshape(-1, 3)
+    pos = (cells[:, None, :] + basis[None, :, :]).reshape(-1, 3) * a
+    L = n * a
+    return pos - L / 2 + 0.25 * a, L
