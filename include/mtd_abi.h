@@ -260,6 +260,30 @@ int mtd_mesh_forces(mtd_mesh *m, unsigned int n_particles, const void *d_postype
 int mtd_mesh_get_array(mtd_mesh *m, int which, void *host_out, mtd_stream_t stream);
 
 /* ================================================================================================
+ * Steinhardt Q_l (cv.steinhardt) — the reference has only a host implementation (SteinhardtQl.cc); these entry points
+ * are what a GPU class of it would call.  Neighbour list in HOOMD's layout (NeighborList::getHeadList / getNNeighArray /
+ * getNListArray, device uint32 arrays); half_nlist = storage mode half (third-law path, SteinhardtQl.cc:80, 173-179, 328-333)
+ * ============================================================================================== */
+
+/* device doubles the two calls share (block partial sums, Q_lm tables, Q_l, CV value) */
+size_t mtd_ql_scratch_doubles(unsigned int lmax);
+
+/* SteinhardtQl::computeCV (SteinhardtQl.cc:62-201).  Ql_ref: host double[lmax+1].  On return *d_value points at the CV value,
+ * *d_Ql at Q_l[lmax+1], *d_Qlm at the complex Q_lm[(lmax+1)^2] table in the reference's order (all inside d_scratch);
+ * consume the value with mtd_metad_set_cv_source(engine, slot, *d_value, 1, 1, 0, 1.0, 0.0).  lmax <= 12. */
+int mtd_ql_accumulate(unsigned int n_particles, const void *d_postype, int dtype, const mtd_box *box, const unsigned int *d_head_list,
+                      const unsigned int *d_n_neigh, const unsigned int *d_nlist, int half_nlist, double rcut, double ron,
+                      unsigned int lmax, unsigned int type, const double *Ql_ref, unsigned int n_global, double *d_scratch,
+                      const double **d_value, const double **d_Ql, const double **d_Qlm, mtd_stream_t stream);
+
+/* SteinhardtQl::computeBiasForces (:203-339) with the Q_lm the last mtd_ql_accumulate left in d_scratch (Q20);
+ * bias = *d_bias when d_bias != NULL, else bias_host */
+int mtd_ql_forces(unsigned int n_particles, const void *d_postype, void *d_force, int dtype, const mtd_box *box,
+                  const unsigned int *d_head_list, const unsigned int *d_n_neigh, const unsigned int *d_nlist, int half_nlist,
+                  double rcut, double ron, unsigned int lmax, unsigned int type, const double *Ql_ref, unsigned int n_global,
+                  const double *d_scratch, const double *d_bias, double bias_host, mtd_stream_t stream);
+
+/* ================================================================================================
  * WellTemperedEnsemble (potential energy as CV)
  * replaces WellTemperedEnsemble.cuh:3-19 (gpu_scale_netforce, gpu_reduce_potential_energy)
  * ============================================================================================== */
