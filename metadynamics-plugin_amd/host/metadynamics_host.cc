@@ -314,6 +314,87 @@ void OrderParameterMeshGPU::computeBiasForces(unsigned int timestep)
     }
 
 // ------------------------------------------------------------------------------------------------
+// SteinhardtQl
+// ------------------------------------------------------------------------------------------------
+
+SteinhardtQl::SteinhardtQl(std::shared_ptr<SystemDefinition> sysdef, double rcut, double ron, unsigned int lmax,
+                           std::shared_ptr<NeighborList> nlist, unsigned int type, const std::vector<double> &Ql_ref,
+                           const std::string &log_suffix)
+    : CollectiveVariable(sysdef, "steinhardt" + log_suffix), m_rcut(rcut), m_ron(ron), m_lmax(lmax), m_nlist(nlist), m_type(type),
+      m_Ql_ref(Ql_ref), m_Ql(lmax + 1, 0.0), m_cv_last_updated(0), m_have_computed(false), m_value(0.0), m_d_value(nullptr),
+      m_d_Ql(nullptr), m_d_Qlm(nullptr)
+    {
+    if (Ql_ref.size() != lmax + 1) throw std::runtime_error("Error setting up Steinhardt CV");   // SteinhardtQl.cc:25-29
+    if (lmax > 12) throw std::runtime_error("cv.steinhardt: lmax <= 12 in this build");
+    if (!nlist) throw std::runtime_error("cv.steinhardt: a neighbour list is required");
+    m_scratch.resize(sizeof(double) * mtd_ql_scratch_doubles(lmax));
+    }
+
+void SteinhardtQl::computeCV(unsigned int timestep)
+    {
+    if (m_cv_last_updated == timestep && m_have_computed) return;    // :64-65
+    m_nlist->compute(timestep);                                      // :68
+    const mtd_box box = m_pdata->getBox().toMtd();
+    mtd_check(mtd_ql_accumulate(m_pdata->getN(), m_pdata->positionsPtr(), m_pdata->getDtype(), &box,
+                                (const unsigned int *)m_nlist->getHeadList().data(), (const unsigned int *)m_nlist->getNNeighArray().data(),
+                                (const unsigned int *)m_nlist->getNListArray().data(), m_nlist->getStorageMode() == NeighborList::half,
+                                m_rcut, m_ron, m_lmax, m_type, m_Ql_ref.data(), m_pdata->getNGlobal(), (double *)m_scratch.data(),
+                                &m_d_value, &m_d_Ql, &m_d_Qlm, m_exec_conf->getStream()),
+              "mtd_ql_accumulate");
+    m_have_computed = true;
+    m_cv_last_updated = timestep;
+    }
+
+void SteinhardtQl::enqueueCurrentValue(unsigned int timestep, mtd_metad *engine, unsigned int slot)
+    {
+    computeCV(timestep);
+    mtd_check(mtd_metad_set_cv_source(engine, slot, m_d_value, 1, 1, 0, 1.0, 0.0), "mtd_metad_set_cv_source");
+    }
+
+double SteinhardtQl::getCurrentValue(unsigned int timestep)
+    {
+    computeCV(timestep);
+    m_exec_conf->sync();
+    hip_check(hipMemcpy(&m_value, m_d_value, sizeof(double), hipMemcpyDeviceToHost), "cv read-back");
+    hip_check(hipMemcpy(m_Ql.data(), m_d_Ql, sizeof(double) * (m_lmax + 1), hipMemcpyDeviceToHost), "Ql read-back");
+    return m_value;
+    }
+
+void SteinhardtQl::computeBiasForces(unsigned int timestep)
+    {
+    m_nlist->compute(timestep);                                      // :206
+    // the reference relies on the Q_lm of the computeCV the integrator triggered earlier in the step (Q20); make sure one exists
+    if (!m_have_computed) computeCV(timestep);
+    const mtd_box box = m_pdata->getBox().toMtd();
+    mtd_check(mtd_ql_forces(m_pdata->getN(), m_pdata->positionsPtr(), m_force.data(), m_pdata->getDtype(), &box,
+                            (const unsigned int *)m_nlist->getHeadList().data(), (const unsigned int *)m_nlist->getNNeighArray().data(),
+                            (const unsigned int *)m_nlist->getNListArray().data(), m_nlist->getStorageMode() == NeighborList::half,
+                            m_rcut, m_ron, m_lmax, m_type, m_Ql_ref.data(), m_pdata->getNGlobal(), (const double *)m_scratch.data(),
+                            m_bias_device, m_bias, m_exec_conf->getStream()),
+              "mtd_ql_forces");
+    }
+
+std::vector<std::string> SteinhardtQl::getProvidedLogQuantities()
+    {
+    auto list = CollectiveVariable::getProvidedLogQuantities();
+    for (unsigned int l = 1; l <= m_lmax; l++) list.push_back("steinhardt_Q" + std::to_string(l));   // SteinhardtQl.h:38-40
+    list.push_back("cv_" + m_cv_name);
+    return list;
+    }
+
+double SteinhardtQl::getLogValue(const std::string &quantity, unsigned int timestep)
+    {
+    if (quantity == "cv_" + m_cv_name) return getCurrentValue(timestep);
+    for (unsigned int l = 1; l <= m_lmax; ++l)
+        if (quantity == "steinhardt_Q" + std::to_string(l))
+            {
+            getCurrentValue(timestep);
+            return m_Ql[l - 1];                                      // off by one like the reference (SteinhardtQl.h:61, Q19)
+            }
+    return CollectiveVariable::getLogValue(quantity, timestep);
+    }
+
+// ------------------------------------------------------------------------------------------------
 // AspectRatio, Density
 // ------------------------------------------------------------------------------------------------
 

@@ -204,6 +204,33 @@ class OrderParameterMeshGPU : public CollectiveVariable
         DeviceBuffer m_cv_dev;
     };
 
+//! SteinhardtQl.h:15-98 (the reference class is host-only; this one runs the same arithmetic on the device)
+class SteinhardtQl : public CollectiveVariable
+    {
+    public:
+        SteinhardtQl(std::shared_ptr<SystemDefinition> sysdef, double rcut, double ron, unsigned int lmax,
+                     std::shared_ptr<NeighborList> nlist, unsigned int type, const std::vector<double> &Ql_ref,
+                     const std::string &log_suffix = "");
+        double getCurrentValue(unsigned int timestep) override;        // SteinhardtQl.h:44-48
+        void enqueueCurrentValue(unsigned int timestep, mtd_metad *engine, unsigned int slot) override;
+        void computeBiasForces(unsigned int timestep) override;        // SteinhardtQl.cc:203-339
+        std::vector<std::string> getProvidedLogQuantities() override;  // SteinhardtQl.h:34-42
+        double getLogValue(const std::string &quantity, unsigned int timestep) override;   // :49-67
+
+    private:
+        void computeCV(unsigned int timestep);                         // SteinhardtQl.cc:62-201
+        double m_rcut, m_ron;
+        unsigned int m_lmax;
+        std::shared_ptr<NeighborList> m_nlist;
+        unsigned int m_type;
+        std::vector<double> m_Ql_ref, m_Ql;
+        unsigned int m_cv_last_updated;
+        bool m_have_computed;
+        double m_value;
+        DeviceBuffer m_scratch;
+        const double *m_d_value, *m_d_Ql, *m_d_Qlm;
+    };
+
 //! AspectRatio.h / AspectRatio.cc:5-130 — box-shape CV, external virial only
 class AspectRatio : public CollectiveVariable
     {

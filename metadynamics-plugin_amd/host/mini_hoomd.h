@@ -232,4 +232,46 @@ class ForceCompute
         bool m_first_compute;
     };
 
+//! The part of HOOMD's md::NeighborList the plugin reads (SteinhardtQl.cc:80-85): head list, neighbour counts, flat list.
+//! Building the list is HOOMD core; in the stand-alone system the arrays are supplied from outside (setLists).
+class NeighborList
+    {
+    public:
+        enum storageMode
+            {
+            half,
+            full
+            };
+        explicit NeighborList(std::shared_ptr<SystemDefinition> sysdef) : m_N(sysdef->getParticleData()->getN()), m_mode(full), m_last(0), m_has(false) {}
+        void setStorageMode(storageMode m) { m_mode = m; }
+        storageMode getStorageMode() const { return m_mode; }
+        void setLists(const unsigned int *head, const unsigned int *n_neigh, size_t n, const unsigned int *nlist, size_t n_list)
+            {
+            if (n != m_N) throw std::runtime_error("NeighborList::setLists: head_list / n_neigh must have N entries");
+            m_head.resize(sizeof(unsigned int) * n);
+            m_nneigh.resize(sizeof(unsigned int) * n);
+            m_nlist.resize(sizeof(unsigned int) * (n_list ? n_list : 1));
+            if (n) m_head.upload(head, sizeof(unsigned int) * n);
+            if (n) m_nneigh.upload(n_neigh, sizeof(unsigned int) * n);
+            if (n_list) m_nlist.upload(nlist, sizeof(unsigned int) * n_list);
+            m_has = true;
+            }
+        //! HOOMD rebuilds the list here when particles moved too far; the stand-in only checks that one was supplied
+        void compute(unsigned int timestep)
+            {
+            if (!m_has) throw std::runtime_error("NeighborList: no neighbour list supplied (nlist.set_lists)");
+            m_last = timestep;
+            }
+        DeviceBuffer &getHeadList() { return m_head; }
+        DeviceBuffer &getNNeighArray() { return m_nneigh; }
+        DeviceBuffer &getNListArray() { return m_nlist; }
+
+    private:
+        unsigned int m_N;
+        storageMode m_mode;
+        unsigned int m_last;
+        bool m_has;
+        DeviceBuffer m_head, m_nneigh, m_nlist;
+    };
+
 } // namespace mtdhost

@@ -182,6 +182,24 @@ PYBIND11_MODULE(_metadynamics, m)
         .def("setUseTable", &OrderParameterMeshGPU::setUseTable)
         .def("setBugCompatible", &OrderParameterMeshGPU::setBugCompatible);
 
+    py::class_<NeighborList, std::shared_ptr<NeighborList>> nlist(m, "NeighborList");
+    nlist.def(py::init<std::shared_ptr<SystemDefinition>>())
+        .def("setStorageMode", &NeighborList::setStorageMode)
+        .def("getStorageMode", &NeighborList::getStorageMode)
+        .def("compute", &NeighborList::compute)
+        .def("setLists", [](NeighborList &n, py::array_t<unsigned int, py::array::c_style | py::array::forcecast> head,
+                            py::array_t<unsigned int, py::array::c_style | py::array::forcecast> nneigh,
+                            py::array_t<unsigned int, py::array::c_style | py::array::forcecast> list) {
+            if (head.size() != nneigh.size()) throw std::runtime_error("setLists: head_list and n_neigh differ in length");
+            n.setLists(head.data(), nneigh.data(), (size_t)head.size(), list.data(), (size_t)list.size());
+        });
+    py::enum_<NeighborList::storageMode>(nlist, "storageMode").value("half", NeighborList::half).value("full", NeighborList::full).export_values();
+
+    // SteinhardtQl.cc:341-347
+    py::class_<SteinhardtQl, CollectiveVariable, std::shared_ptr<SteinhardtQl>>(m, "SteinhardtQl")
+        .def(py::init<std::shared_ptr<SystemDefinition>, double, double, unsigned int, std::shared_ptr<NeighborList>, unsigned int,
+                      const std::vector<double> &, const std::string &>());
+
     py::class_<WellTemperedEnsemble, CollectiveVariable, std::shared_ptr<WellTemperedEnsemble>>(m, "WellTemperedEnsemble")
         .def(py::init<std::shared_ptr<SystemDefinition>, const std::string &>());
 

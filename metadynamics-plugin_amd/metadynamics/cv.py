@@ -175,8 +175,56 @@ class mesh(_collective_variable):
 
 
 class steinhardt(_collective_variable):
+    """Steinhardt Ql (cv.py:540-617): CV = sum_l Ql_ref[l] * Q_l over particles of one type within r_cut."""
+
     def __init__(self, r_cut, r_on, lmax, Ql_ref, nlist, type, name=None, sigma=1.0):
-        _not_built("cv.steinhardt", "A18-A19")
+        suffix = ""
+        if name is not None:
+            suffix = "_" + name
+        _collective_variable.__init__(self, sigma, name)
+        self.type = type
+        self.nlist = nlist
+        self.r_cut = r_cut
+        # cv.py:584-585: the reference forces full storage when HOOMD runs on the GPU — this build always does
+        self.nlist.cpp_nlist.setStorageMode(_metadynamics.NeighborList.storageMode.full)
+        type_list = context.current.type_names
+        if type not in type_list:
+            raise RuntimeError("Error creating collective variable.")     # cv.py:591-593
+        self.cpp_force = _metadynamics.SteinhardtQl(context.current.system_definition, float(r_cut), float(r_on), int(lmax),
+                                                    nlist.cpp_nlist, type_list.index(type), [float(q) for q in Ql_ref], suffix)
+
+
+class nlist_cell(object):
+    """Stand-in for ``hoomd.md.nlist.cell``: HOOMD's NeighborList is not part of the plugin.  The list is built on the host
+    with a periodic KD-tree (cubic boxes) whenever ``update`` is called and handed to the device in HOOMD's layout."""
+
+    def __init__(self, r_cut):
+        self.r_cut = float(r_cut)
+        self.cpp_nlist = _metadynamics.NeighborList(context.current.system_definition)
+
+    def set_lists(self, head_list, n_neigh, nlist):
+        """hand over a list in HOOMD's layout: neighbours of i are nlist[head_list[i] : head_list[i] + n_neigh[i]]"""
+        self.cpp_nlist.setLists(head_list, n_neigh, nlist)
+
+    def update(self):
+        """rebuild from the current positions (cubic boxes; host-side periodic KD-tree)"""
+        import numpy as np
+        from scipy.spatial import cKDTree
+        pdata = context.current.system_definition.getParticleData()
+        L = np.asarray(pdata.getGlobalBox().getL())
+        p = np.mod(np.asarray(pdata.getPositions()[:, :3], dtype=np.float64) + L / 2, L)
+        p[p >= L] = 0.0
+        pairs = cKDTree(p, boxsize=L).query_pairs(self.r_cut, output_type="ndarray")
+        i = np.concatenate([pairs[:, 0], pairs[:, 1]])
+        j = np.concatenate([pairs[:, 1], pairs[:, 0]])
+        order = np.lexsort((j, i))
+        i, j = i[order], j[order]
+        n_neigh = np.bincount(i, minlength=len(p)).astype(np.uint32)
+        head = np.zeros(len(p), dtype=np.uint32)
+        head[1:] = np.cumsum(n_neigh)[:-1]
+        lists = (head, n_neigh, j.astype(np.uint32))
+        self.set_lists(*lists)
+        return lists
 
 
 class wrap(_collective_variable):

@@ -267,3 +267,44 @@ def test_mesh_cv_with_umbrella_through_api(api, ref):
     assert np.abs(F[:, :3] - F_ref[:, :3]).max() <= 1e-5 * np.abs(F_ref[:, :3]).max()
     with pytest.raises(RuntimeError):
         cv.mesh(nx=12, mode={"A": 1.0, "B": -1.0})            # not a power of two
+
+
+def test_steinhardt_through_api(api, ref):
+    """cv.steinhardt on a noisy fcc crystal registered with the bias grid: CV, log quantities (incl. the reference's
+    off-by-one steinhardt_Q{l} = Ql[l-1], Q19), bias and forces vs the oracle"""
+    context, cv, integrate = api
+    pos, L = util.fcc_lattice(5)
+    rng = np.random.default_rng(12)
+    pos = pos + rng.normal(0, 0.05, pos.shape)
+    N = len(pos)
+    types = np.zeros(N, dtype=np.int32)
+    context.initialize(pos, types, ["A"], L, dtype=np.float64)
+    meta = integrate.mode_metadynamics(dt=0.005, stride=1, mode="well_tempered", W=1.0, deltaT=7.0, T=1.0)
+    nl = cv.nlist_cell(r_cut=1.5)
+    lists = nl.update()
+    ref_lists = util.build_nlist(pos, L, 1.5)
+    assert all(np.array_equal(a, b) for a, b in zip(lists, ref_lists))
+    Ql_ref = [0, 0, 0, 0, 1, 0, 1]
+    rbox = ref.Box.make(L)
+    pt = util.oracle_postype(pos, types)
+    val, Qlm, Ql = ref.ql_compute_cv(pt, rbox, *lists, 1.4, 1.2, 6, 0, Ql_ref)
+    st = cv.steinhardt(r_cut=1.4, r_on=1.2, lmax=6, Ql_ref=Ql_ref, nlist=nl, type="A", sigma=0.02 * val)
+    st.set_grid(0.55 * val, 1.3 * val, 64)
+    context.run(2)
+    t = context.current.system.getCurrentTimeStep()
+    assert st.cpp_force.getCurrentValue(t) == pytest.approx(val, rel=1e-10)
+    assert st.cpp_force.getLogValue("cv_steinhardt", t) == pytest.approx(val, rel=1e-10)
+    assert st.cpp_force.getLogValue("steinhardt_Q6", t) == pytest.approx(Ql[5], abs=1e-12)     # off by one (Q19)
+    assert st.cpp_force.getLogValue("steinhardt_Q5", t) == pytest.approx(Ql[4], rel=1e-10)
+    g = ref.Metad([0.02 * val], [0.55 * val], [1.3 * val], [64], W=1.0, T_shift=7.0, T=1.0, stride=1, mode="well_tempered")
+    cvg = meta.cpp_integrator.getCurrentValues()
+    for tt in range(3):
+        b = g.update_bias(tt, cvg)
+    assert np.allclose(meta.cpp_integrator.getBiasFactors(), b, rtol=1e-7)
+    F = st.cpp_force.getForceArray()
+    F_ref = ref.ql_compute_forces(pt, rbox, *lists, 1.4, 1.2, 6, 0, Ql_ref, Qlm, b[0])
+    assert np.abs(F[:, :3] - F_ref[:, :3]).max() <= 1e-7 * np.abs(F_ref[:, :3]).max()
+    with pytest.raises(RuntimeError):
+        cv.steinhardt(r_cut=1.4, r_on=1.2, lmax=6, Ql_ref=[1, 2, 3], nlist=nl, type="A")      # SteinhardtQl.cc:25-29
+    with pytest.raises(RuntimeError):
+        cv.steinhardt(r_cut=1.4, r_on=1.2, lmax=6, Ql_ref=Ql_ref, nlist=nl, type="Z")         # cv.py:591-593
