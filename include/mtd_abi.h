@@ -302,6 +302,35 @@ int mtd_wte_scale_netforce(unsigned int n_particles, void *d_net_force, void *d_
                            void *d_net_virial, unsigned int virial_pitch, int dtype, const double *d_bias,
                            double bias_host, int scale_torque_w, mtd_stream_t stream);
 
+/* ================================================================================================
+ * CollectiveWrapper (energy of an arbitrary ForceCompute as CV)
+ * replaces CollectiveWrapper.cc:74-134 (computeCVGPU / computeBiasForcesGPU, which reuse the WTE drivers)
+ * ============================================================================================== */
+
+/* energy = external_energy + sum_j force_j.w: use mtd_wte_energy_partials on the wrapped force array.
+ * computeBiasForces (:125, :153): force.xyz, torque.xyz(w) and the six virial rows of the WRAPPED compute are
+ * multiplied by the bias factor itself (not 1 + bias as in the WTE) */
+int mtd_wrapper_scale_forces(unsigned int n_particles, void *d_force, void *d_torque, void *d_virial,
+                             unsigned int virial_pitch, int dtype, const double *d_bias, double bias_host,
+                             int scale_torque_w, mtd_stream_t stream);
+
+/* ================================================================================================
+ * Adaptive Gaussians
+ * replaces IntegratorMetaDynamics::computeSigma (IntegratorMetaDynamics.cc:1205-1294)
+ * ============================================================================================== */
+
+size_t mtd_sigma_scratch_doubles(void);
+
+/* sigmasq[i*n_cv+j] = sigma_g^2 * sum_n f_i(n).f_j(n) over this rank's particles (:1241-1246), for the CVs whose
+ * d_force[c] != NULL (those that can compute derivatives); all other entries come back 0 and are the caller's
+ * (:1249: diagonal sigma^2 on the root rank).  Synchronous: sigmasq is a HOST array of n_cv^2 doubles; in a
+ * domain-decomposed run it is all-reduced before mtd_sigma_inverse (:1259-1268). */
+int mtd_sigma_products(unsigned int n_cv, const void *const *d_force, unsigned int n_particles, int dtype, double sigma_g,
+                       double *d_scratch, double *sigmasq, mtd_stream_t stream);
+
+/* sigma_inv = inverse(element-wise sqrt(sigmasq)) (:1273-1286), host arrays of n_cv^2 doubles */
+int mtd_sigma_inverse(unsigned int n_cv, const double *sigmasq, double *sigma_inv);
+
 #ifdef __cplusplus
 }
 #endif

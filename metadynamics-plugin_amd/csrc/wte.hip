@@ -32,9 +32,11 @@ template<typename S4, typename S>
 __global__ __launch_bounds__(WTE_THREADS) void k_wte_scale(S4 *__restrict__ net_force, S4 *__restrict__ net_torque,
                                                            S *__restrict__ net_virial, const unsigned int pitch,
                                                            const unsigned int N, const double *__restrict__ d_bias,
-                                                           const double bias_host, const int scale_torque_w)
+                                                           const double bias_host, const int scale_torque_w,
+                                                           const double offset)
     {
-    const S fac = (S)(1.0 + (d_bias ? *d_bias : bias_host));               // WellTemperedEnsemble.cc:140
+    // offset 1: WellTemperedEnsemble.cc:140 (fac = 1 + bias); offset 0: CollectiveWrapper.cc:125, :153 (fac = bias)
+    const S fac = (S)(offset + (d_bias ? *d_bias : bias_host));
     const unsigned int stride = gridDim.x * blockDim.x;
     for (unsigned int i = blockIdx.x * blockDim.x + threadIdx.x; i < N; i += stride)
         {
@@ -90,9 +92,9 @@ int mtd_wte_energy_partials(unsigned int n_particles, const void *d_net_force, i
     return MTD_SUCCESS;
     }
 
-int mtd_wte_scale_netforce(unsigned int n_particles, void *d_net_force, void *d_net_torque,
-                           void *d_net_virial, unsigned int virial_pitch, int dtype, const double *d_bias,
-                           double bias_host, int scale_torque_w, mtd_stream_t stream)
+static int scale_arrays(unsigned int n_particles, void *d_net_force, void *d_net_torque, void *d_net_virial,
+                        unsigned int virial_pitch, int dtype, const double *d_bias, double bias_host, int scale_torque_w,
+                        double offset, mtd_stream_t stream)
     {
     if (n_particles && !d_net_force) return MTD_ERR_INVALID_ARGUMENT;
     if (dtype != MTD_F32 && dtype != MTD_F64) return MTD_ERR_INVALID_ARGUMENT;
@@ -104,13 +106,29 @@ int mtd_wte_scale_netforce(unsigned int n_particles, void *d_net_force, void *d_
     if (dtype == MTD_F32)
         k_wte_scale<float4, float><<<blocks, WTE_THREADS, 0, s>>>((float4 *)d_net_force, (float4 *)d_net_torque,
                                                                   (float *)d_net_virial, virial_pitch, n_particles,
-                                                                  d_bias, bias_host, scale_torque_w);
+                                                                  d_bias, bias_host, scale_torque_w, offset);
     else
         k_wte_scale<double4, double><<<blocks, WTE_THREADS, 0, s>>>((double4 *)d_net_force, (double4 *)d_net_torque,
                                                                     (double *)d_net_virial, virial_pitch, n_particles,
-                                                                    d_bias, bias_host, scale_torque_w);
+                                                                    d_bias, bias_host, scale_torque_w, offset);
     MTD_LAUNCH_CHECK();
     return MTD_SUCCESS;
+    }
+
+int mtd_wte_scale_netforce(unsigned int n_particles, void *d_net_force, void *d_net_torque,
+                           void *d_net_virial, unsigned int virial_pitch, int dtype, const double *d_bias,
+                           double bias_host, int scale_torque_w, mtd_stream_t stream)
+    {
+    return scale_arrays(n_particles, d_net_force, d_net_torque, d_net_virial, virial_pitch, dtype, d_bias, bias_host,
+                        scale_torque_w, 1.0, stream);
+    }
+
+int mtd_wrapper_scale_forces(unsigned int n_particles, void *d_force, void *d_torque, void *d_virial,
+                             unsigned int virial_pitch, int dtype, const double *d_bias, double bias_host,
+                             int scale_torque_w, mtd_stream_t stream)
+    {
+    return scale_arrays(n_particles, d_force, d_torque, d_virial, virial_pitch, dtype, d_bias, bias_host, scale_torque_w,
+                        0.0, stream);
     }
 
 } // extern "C"

@@ -314,6 +314,58 @@ void OrderParameterMeshGPU::computeBiasForces(unsigned int timestep)
     }
 
 // ------------------------------------------------------------------------------------------------
+// CollectiveWrapper
+// ------------------------------------------------------------------------------------------------
+
+CollectiveWrapper::CollectiveWrapper(std::shared_ptr<SystemDefinition> sysdef, std::shared_ptr<ForceCompute> fc,
+                                     const std::string &name)
+    : CollectiveVariable(sysdef, name), m_fc(fc), m_energy(0.0), m_n_partials(0)
+    {
+    if (!fc) throw std::runtime_error("cv.wrap: a force is required");
+    m_partials.resize(sizeof(double) * mtd_wte_scratch_doubles(m_pdata->getN()));
+    m_sum.resize(sizeof(double));
+    }
+
+void CollectiveWrapper::enqueuePartials(unsigned int timestep)
+    {
+    m_fc->compute(timestep);                                           // CollectiveWrapper.cc:35 (once per time step)
+    mtd_check(mtd_wte_energy_partials(m_pdata->getN(), m_fc->getForceArray().data(), m_pdata->getDtype(),
+                                      (double *)m_partials.data(), &m_n_partials, m_exec_conf->getStream()),
+              "mtd_wte_energy_partials");
+    }
+
+void CollectiveWrapper::enqueueCurrentValue(unsigned int timestep, mtd_metad *engine, unsigned int slot)
+    {
+    enqueuePartials(timestep);
+    // energy = sum_j force_j.w + external energy of the wrapped compute (:50-61)
+    mtd_check(mtd_metad_set_cv_source(engine, slot, (const double *)m_partials.data(), m_n_partials, 1, 0, 1.0,
+                                      m_fc->getExternalEnergy()),
+              "mtd_metad_set_cv_source");
+    }
+
+double CollectiveWrapper::getCurrentValue(unsigned int timestep)
+    {
+    enqueuePartials(timestep);
+    mtd_check(mtd_reduce_partials((const double *)m_partials.data(), m_n_partials, 1, 1, 1.0, m_fc->getExternalEnergy(),
+                                  (double *)m_sum.data(), m_exec_conf->getStream()),
+              "mtd_reduce_partials");
+    m_exec_conf->sync();
+    m_sum.download(&m_energy, sizeof(double));
+    return m_energy;
+    }
+
+// CollectiveWrapper.cc:136-179 — the wrapped compute's own arrays are scaled by the bias factor; the CPU path (the parity
+// target) also scales torque.w
+void CollectiveWrapper::computeBiasForces(unsigned int timestep)
+    {
+    m_fc->compute(timestep);                                           // :139
+    mtd_check(mtd_wrapper_scale_forces(m_pdata->getN(), m_fc->getForceArray().data(), m_fc->getTorqueArray().data(),
+                                       m_fc->getVirialArray().data(), m_fc->getVirialPitch(), m_pdata->getDtype(), m_bias_device,
+                                       m_bias, 1, m_exec_conf->getStream()),
+              "mtd_wrapper_scale_forces");
+    }
+
+// ------------------------------------------------------------------------------------------------
 // SteinhardtQl
 // ------------------------------------------------------------------------------------------------
 
@@ -552,11 +604,23 @@ void IntegratorMetaDynamics::setAddHills(bool add_bias)
     if (m_engine) mtd_check(mtd_metad_set_add_hills(m_engine, add_bias ? 1 : 0), "mtd_metad_set_add_hills");
     }
 
-void IntegratorMetaDynamics::setAdaptive(bool adaptive)
+// :1205-1294 — derivative products reduced on the device, n_cv x n_cv sqrt / inverse on the host
+void IntegratorMetaDynamics::computeSigma()
     {
-    // computeSigma (:1205-1294) is SURVEY §8f row N2 ("next"), not built yet: fail loudly rather than ignore
-    if (adaptive) throw std::runtime_error("integrate.mode_metadynamics: adaptive Gaussians are not available in this build");
-    m_adaptive = false;
+    const unsigned int ncv = (unsigned int)m_variables.size();
+    if (m_sigma_scratch.bytes() == 0) m_sigma_scratch.resize(sizeof(double) * mtd_sigma_scratch_doubles());
+    std::vector<const void *> force(ncv, nullptr);
+    for (unsigned int i = 0; i < ncv; ++i)
+        if (m_variables[i].m_cv->canComputeDerivatives()) force[i] = m_variables[i].m_cv->getForceArray().data();
+    std::vector<double> sigmasq(ncv * ncv, 0.0);
+    mtd_check(mtd_sigma_products(ncv, force.data(), m_pdata->getN(), m_pdata->getDtype(), m_sigma_g,
+                                 (double *)m_sigma_scratch.data(), sigmasq.data(), m_exec_conf->getStream()),
+              "mtd_sigma_products");
+    for (unsigned int i = 0; i < ncv; ++i)
+        if (!force[i]) sigmasq[i * ncv + i] = m_variables[i].m_sigma * m_variables[i].m_sigma;   // :1249
+    m_sigma_inv.assign(ncv * ncv, 0.0);
+    mtd_check(mtd_sigma_inverse(ncv, sigmasq.data(), m_sigma_inv.data()), "mtd_sigma_inverse");
+    mtd_check(mtd_metad_set_sigma_inv(m_engine, m_sigma_inv.data()), "mtd_metad_set_sigma_inv");
     }
 
 void IntegratorMetaDynamics::resetHistogram()
@@ -674,6 +738,7 @@ void IntegratorMetaDynamics::update(unsigned int timestep)
 
 bool IntegratorMetaDynamics::fusedLamellarPossible() const
     {
+    if (m_adaptive) return false;                                      // the deposit width changes between the two launches
     if (!m_allow_fused || m_variables.empty() || m_variables.size() > MTD_METAD_MAX_CV) return false;
     unsigned int n_modes = 0;
     for (const auto &it : m_variables)
@@ -739,6 +804,13 @@ void IntegratorMetaDynamics::updateBiasPotential(unsigned int timestep)
     {
     if (m_variables.empty()) return;                                   // :317-318
     hipStream_t s = m_exec_conf->getStream();
+
+    if (m_adaptive && (timestep % m_stride == 0))                      // :333-341
+        {
+        // compute derivatives of collective variables, then the instantaneous estimate of the standard deviation matrix
+        for (auto &it : m_variables) it.m_cv->computeDerivatives(timestep);
+        computeSigma();
+        }
 
     if (fusedLamellarPossible())
         fusedLamellarStep(timestep);

@@ -204,6 +204,34 @@ class OrderParameterMeshGPU : public CollectiveVariable
         DeviceBuffer m_cv_dev;
     };
 
+//! CollectiveWrapper.h / CollectiveWrapper.cc:13-188: the energy of any ForceCompute as collective variable
+class CollectiveWrapper : public CollectiveVariable
+    {
+    public:
+        CollectiveWrapper(std::shared_ptr<SystemDefinition> sysdef, std::shared_ptr<ForceCompute> fc, const std::string &name);
+        double getCurrentValue(unsigned int timestep) override;        // CollectiveWrapper.h: computeCV then m_energy
+        void enqueueCurrentValue(unsigned int timestep, mtd_metad *engine, unsigned int slot) override;
+        void computeBiasForces(unsigned int timestep) override;        // CollectiveWrapper.cc:136-179
+        std::vector<std::string> getProvidedLogQuantities() override
+            {
+            auto l = CollectiveVariable::getProvidedLogQuantities();
+            l.push_back(m_cv_name);
+            return l;
+            }
+        double getLogValue(const std::string &quantity, unsigned int timestep) override
+            {
+            if (quantity == m_cv_name) return getCurrentValue(timestep);
+            return CollectiveVariable::getLogValue(quantity, timestep);
+            }
+
+    private:
+        void enqueuePartials(unsigned int timestep);
+        std::shared_ptr<ForceCompute> m_fc;
+        double m_energy;
+        DeviceBuffer m_partials, m_sum;
+        unsigned int m_n_partials;
+    };
+
 //! SteinhardtQl.h:15-98 (the reference class is host-only; this one runs the same arithmetic on the device)
 class SteinhardtQl : public CollectiveVariable
     {
@@ -290,7 +318,9 @@ class IntegratorMetaDynamics
         void dumpGrid(const std::string &filename1, const std::string &filename2, unsigned int period);   // :817-829
         void restartFromGridFile(const std::string &filename) { m_restart_filename = filename; }
         void setAddHills(bool add_bias);
-        void setAdaptive(bool adaptive);
+        void setAdaptive(bool adaptive) { m_adaptive = adaptive; }   // IntegratorMetaDynamics.h:248-251
+        //! the inverse width matrix of the last deposit (row major n_cv x n_cv)
+        std::vector<double> getSigmaInv() const { return m_sigma_inv; }
         void setSigmaG(double sigma_g) { m_sigma_g = sigma_g; }
         void setMultipleWalkers(bool multiple) { m_multiple_walkers = multiple; }
         void resetHistogram();                                         // :1195-1203
@@ -339,6 +369,9 @@ class IntegratorMetaDynamics
         unsigned int m_grid_period, m_cur_file;
         double m_sigma_g;
         bool m_adaptive;
+        void computeSigma();                                           // :1205-1294
+        std::vector<double> m_sigma_inv;
+        DeviceBuffer m_sigma_scratch;
         double m_temp;
         Enum m_mode;
         bool m_multiple_walkers;

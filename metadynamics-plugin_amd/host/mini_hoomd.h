@@ -192,7 +192,7 @@ class ForceCompute
     public:
         explicit ForceCompute(std::shared_ptr<SystemDefinition> sysdef)
             : m_sysdef(sysdef), m_pdata(sysdef->getParticleData()), m_exec_conf(sysdef->getExecConf()), m_last_computed(0),
-              m_first_compute(true)
+              m_first_compute(true), m_external_energy(0.0)
             {
             m_force.resize(m_pdata->scalar4Bytes() * m_pdata->getN());
             m_external_virial.fill(0.0);
@@ -212,6 +212,19 @@ class ForceCompute
             m_last_computed = timestep;
             }
         DeviceBuffer &getForceArray() { return m_force; }
+        //! torque Scalar4[N] and virial Scalar[6][pitch] of this compute; allocated (zeroed) on first use
+        DeviceBuffer &getTorqueArray()
+            {
+            if (m_torque.bytes() == 0) m_torque.resize(m_pdata->scalar4Bytes() * m_pdata->getN());
+            return m_torque;
+            }
+        DeviceBuffer &getVirialArray()
+            {
+            if (m_virial.bytes() == 0) m_virial.resize(m_pdata->scalarBytes() * 6 * getVirialPitch());
+            return m_virial;
+            }
+        unsigned int getVirialPitch() const { return m_pdata->getN(); }
+        double getExternalEnergy() const { return m_external_energy; }
         unsigned int numParticles() const { return m_pdata->getN(); }
         int dtype() const { return m_pdata->getDtype(); }
         double getExternalVirial(unsigned int i) const { return m_external_virial.at(i); }
@@ -230,6 +243,38 @@ class ForceCompute
         std::array<double, 6> m_external_virial;
         unsigned int m_last_computed;
         bool m_first_compute;
+        DeviceBuffer m_torque, m_virial;
+        double m_external_energy;
+    };
+
+//! Stand-in for "any other HOOMD ForceCompute" (pair, bond, external ...): force (xyz + energy w), torque and virial
+//! are prescribed from outside and restored on every compute(), as a real compute rewrites its arrays each step.
+class PrescribedForceCompute : public ForceCompute
+    {
+    public:
+        explicit PrescribedForceCompute(std::shared_ptr<SystemDefinition> sysdef) : ForceCompute(sysdef) {}
+        void setArrays(const void *force, const void *torque, const void *virial)
+            {
+            const size_t b4 = m_pdata->scalar4Bytes() * m_pdata->getN(), bv = m_pdata->scalarBytes() * 6 * getVirialPitch();
+            m_src_force.resize(b4);
+            m_src_torque.resize(b4);
+            m_src_virial.resize(bv);
+            if (b4) m_src_force.upload(force, b4);
+            if (b4) m_src_torque.upload(torque, b4);
+            if (bv) m_src_virial.upload(virial, bv);
+            }
+        void setExternalEnergy(double e) { m_external_energy = e; }
+
+    protected:
+        void computeForces(unsigned int) override
+            {
+            if (m_src_force.bytes() == 0) throw std::runtime_error("PrescribedForceCompute: no arrays set");
+            hipStream_t s = m_exec_conf->getStream();
+            hip_check(hipMemcpyAsync(m_force.data(), m_src_force.data(), m_src_force.bytes(), hipMemcpyDeviceToDevice, s), "force copy");
+            hip_check(hipMemcpyAsync(getTorqueArray().data(), m_src_torque.data(), m_src_torque.bytes(), hipMemcpyDeviceToDevice, s), "torque copy");
+            hip_check(hipMemcpyAsync(getVirialArray().data(), m_src_virial.data(), m_src_virial.bytes(), hipMemcpyDeviceToDevice, s), "virial copy");
+            }
+        DeviceBuffer m_src_force, m_src_torque, m_src_virial;
     };
 
 //! The part of HOOMD's md::NeighborList the plugin reads (SteinhardtQl.cc:80-85): head list, neighbour counts, flat list.

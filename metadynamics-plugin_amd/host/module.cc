@@ -144,6 +144,11 @@ PYBIND11_MODULE(_metadynamics, m)
     py::class_<ForceCompute, std::shared_ptr<ForceCompute>>(m, "ForceCompute")
         .def("compute", &ForceCompute::compute)
         .def("getExternalVirial", &ForceCompute::getExternalVirial)
+        .def("getExternalEnergy", &ForceCompute::getExternalEnergy)
+        .def("getVirialPitch", &ForceCompute::getVirialPitch)
+        .def("getForces", [](ForceCompute &f) { return download_scalar_array(f.getForceArray(), f.dtype(), {(ssize_t)f.numParticles(), 4}); })
+        .def("getTorques", [](ForceCompute &f) { return download_scalar_array(f.getTorqueArray(), f.dtype(), {(ssize_t)f.numParticles(), 4}); })
+        .def("getVirial", [](ForceCompute &f) { return download_scalar_array(f.getVirialArray(), f.dtype(), {6, (ssize_t)f.getVirialPitch()}); })
         .def("getProvidedLogQuantities", &ForceCompute::getProvidedLogQuantities)
         .def("getLogValue", &ForceCompute::getLogValue);
 
@@ -195,6 +200,24 @@ PYBIND11_MODULE(_metadynamics, m)
         });
     py::enum_<NeighborList::storageMode>(nlist, "storageMode").value("half", NeighborList::half).value("full", NeighborList::full).export_values();
 
+    py::class_<PrescribedForceCompute, ForceCompute, std::shared_ptr<PrescribedForceCompute>>(m, "PrescribedForceCompute")
+        .def(py::init<std::shared_ptr<SystemDefinition>>())
+        .def("setExternalEnergy", &PrescribedForceCompute::setExternalEnergy)
+        .def("setArrays", [](PrescribedForceCompute &f, py::array force, py::array torque, py::array virial) {
+            auto chk = [](py::array a, size_t bytes, const char *what) {
+                py::buffer_info info = a.request();
+                if ((size_t)info.size * (size_t)info.itemsize != bytes || !(a.flags() & py::array::c_style))
+                    throw std::runtime_error(std::string(what) + ": array has the wrong size, dtype or layout");
+                return info.ptr;
+            };
+            const size_t sb = f.dtype() == MTD_F32 ? 4 : 8, N = f.numParticles();
+            f.setArrays(chk(force, 4 * sb * N, "force"), chk(torque, 4 * sb * N, "torque"), chk(virial, 6 * sb * f.getVirialPitch(), "virial"));
+        });
+
+    // CollectiveWrapper.cc:182-187
+    py::class_<CollectiveWrapper, CollectiveVariable, std::shared_ptr<CollectiveWrapper>>(m, "CollectiveWrapper")
+        .def(py::init<std::shared_ptr<SystemDefinition>, std::shared_ptr<ForceCompute>, const std::string &>());
+
     // SteinhardtQl.cc:341-347
     py::class_<SteinhardtQl, CollectiveVariable, std::shared_ptr<SteinhardtQl>>(m, "SteinhardtQl")
         .def(py::init<std::shared_ptr<SystemDefinition>, double, double, unsigned int, std::shared_ptr<NeighborList>, unsigned int,
@@ -225,6 +248,7 @@ PYBIND11_MODULE(_metadynamics, m)
         .def("setStride", &IntegratorMetaDynamics::setStride)
         .def("setAdaptive", &IntegratorMetaDynamics::setAdaptive)
         .def("setSigmaG", &IntegratorMetaDynamics::setSigmaG)
+        .def("getSigmaInv", &IntegratorMetaDynamics::getSigmaInv)
         .def("resetHistogram", &IntegratorMetaDynamics::resetHistogram)
         .def("setMultipleWalkers", &IntegratorMetaDynamics::setMultipleWalkers)
         // HOOMD Integrator interface used by System / analyze.log

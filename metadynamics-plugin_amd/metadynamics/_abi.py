@@ -143,6 +143,10 @@ _SIGNATURES = {
     "mtd_wte_scratch_doubles": (C.c_size_t, [C.c_uint]),
     "mtd_wte_energy_partials": (C.c_int, [C.c_uint, _vp, C.c_int, _vp, _up, _vp]),
     "mtd_wte_scale_netforce": (C.c_int, [C.c_uint, _vp, _vp, _vp, C.c_uint, C.c_int, _vp, C.c_double, C.c_int, _vp]),
+    "mtd_wrapper_scale_forces": (C.c_int, [C.c_uint, _vp, _vp, _vp, C.c_uint, C.c_int, _vp, C.c_double, C.c_int, _vp]),
+    "mtd_sigma_scratch_doubles": (C.c_size_t, []),
+    "mtd_sigma_products": (C.c_int, [C.c_uint, C.POINTER(C.c_void_p), C.c_uint, C.c_int, C.c_double, _vp, _dp, _vp]),
+    "mtd_sigma_inverse": (C.c_int, [C.c_uint, _dp, _dp]),
 }
 
 _lib = None

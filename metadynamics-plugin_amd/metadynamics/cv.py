@@ -133,10 +133,6 @@ class potential_energy(_collective_variable):
         self.cpp_force = _metadynamics.WellTemperedEnsemble(context.current.system_definition, name)
 
 
-def _not_built(what, row):
-    raise NotImplementedError("%s is SURVEY.md §8 row %s and not built yet in this round (see DESIGN.md §7)" % (what, row))
-
-
 class mesh(_collective_variable):
     """Particle-mesh order parameter (cv.py:350-466)."""
 
@@ -228,5 +224,14 @@ class nlist_cell(object):
 
 
 class wrap(_collective_variable):
+    """Force wrapper (cv.py:500-537): the energy of an arbitrary force as collective variable."""
+
     def __init__(self, force, sigma=1.0):
-        _not_built("cv.wrap", "(f) N2")
+        from . import force as _force_module
+        if not isinstance(force, _force_module._force):
+            raise RuntimeError("cv.wrap needs a md._force instance as argument.")          # cv.py:518-519
+        name = "cv_" + force.name
+        _collective_variable.__init__(self, sigma, name)
+        self.force = force
+        self.cpp_force = _metadynamics.CollectiveWrapper(context.current.system_definition, force.cpp_force, name)
+        self.log = force.log

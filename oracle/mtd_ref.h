@@ -113,6 +113,18 @@ double ref_wte_potential_energy(unsigned int N, const double *net_force /*4N*/, 
 void ref_wte_scale(unsigned int N, double *net_force /*4N*/, double *net_torque /*4N*/,
                    double *net_virial /*6*pitch*/, unsigned int pitch, double *external_virial /*6*/, double bias);
 
+/* ---------------- CollectiveWrapper (CollectiveWrapper.cc:31-72, 136-179, CPU path) ------------------------ */
+double ref_wrapper_energy(unsigned int N, const double *force /*4N*/, double external_energy);
+/* force.xyz, torque.xyzw and the six virial rows of the wrapped compute *= bias (:153-171) */
+void ref_wrapper_scale(unsigned int N, double *force /*4N*/, double *torque /*4N*/, double *virial /*6*pitch*/,
+                       unsigned int pitch, double bias);
+
+/* ---------------- adaptive Gaussians (IntegratorMetaDynamics.cc:1205-1294, single rank) --------------------- */
+/* forces: n_cv arrays of 4N doubles (the derivative arrays after computeDerivatives); can_derive[c] != 0 when CV c
+ * provides derivatives; sigma[c] the registered widths.  Writes sigmasq (n_cv^2) and sigma_inv (n_cv^2). */
+void ref_compute_sigma(unsigned int n_cv, unsigned int N, const double *const *forces, const int *can_derive,
+                       const double *sigma, double sigma_g, double *sigmasq, double *sigma_inv);
+
 /* ---------------------------------------------------------------- OrderParameterMesh (mtd_ref_mesh.c) */
 typedef struct ref_mesh ref_mesh;
 ref_mesh *ref_mesh_create(unsigned int nx, unsigned int ny, unsigned int nz, unsigned int n_types, const double *mode);

@@ -122,6 +122,12 @@ def lib():
         L.ref_wte_potential_energy.argtypes = [C.c_uint, _dp, C.c_double]
         L.ref_wte_scale.restype = None
         L.ref_wte_scale.argtypes = [C.c_uint, _dp, _dp, _dp, C.c_uint, _dp, C.c_double]
+        L.ref_wrapper_energy.restype = C.c_double
+        L.ref_wrapper_energy.argtypes = [C.c_uint, _dp, C.c_double]
+        L.ref_wrapper_scale.restype = None
+        L.ref_wrapper_scale.argtypes = [C.c_uint, _dp, _dp, _dp, C.c_uint, C.c_double]
+        L.ref_compute_sigma.restype = None
+        L.ref_compute_sigma.argtypes = [C.c_uint, C.c_uint, C.POINTER(_dp), C.POINTER(C.c_int), _dp, C.c_double, _dp, _dp]
         _bind_optional(L)
         _lib = L
     return _lib
@@ -382,6 +388,33 @@ def wte_scale(net_force, net_torque, net_virial, pitch, external_virial, bias):
     ev = np.array(external_virial, dtype=np.float64, order="C")
     lib().ref_wte_scale(nf.shape[0], _d(nf), _d(nt), _d(nv), int(pitch), _d(ev), float(bias))
     return nf, nt, nv, ev
+
+
+def wrapper_energy(force, external_energy=0.0):
+    f = np.ascontiguousarray(force, dtype=np.float64)
+    return lib().ref_wrapper_energy(f.shape[0], _d(f), float(external_energy))
+
+
+def wrapper_scale(force, torque, virial, pitch, bias):
+    """In-place on copies; returns (force, torque, virial)."""
+    f = np.array(force, dtype=np.float64, order="C")
+    t = np.array(torque, dtype=np.float64, order="C")
+    v = np.array(virial, dtype=np.float64, order="C")
+    lib().ref_wrapper_scale(f.shape[0], _d(f), _d(t), _d(v), int(pitch), float(bias))
+    return f, t, v
+
+
+def compute_sigma(forces, can_derive, sigma, sigma_g):
+    """IntegratorMetaDynamics::computeSigma; forces = list of (N,4) arrays; returns (sigmasq, sigma_inv) n_cv x n_cv"""
+    n_cv = len(forces)
+    arrs = [np.ascontiguousarray(f, dtype=np.float64) for f in forces]
+    ptrs = (_dp * n_cv)(*[_d(a) for a in arrs])
+    cd = (C.c_int * n_cv)(*[int(bool(c)) for c in can_derive])
+    sg = np.ascontiguousarray(sigma, dtype=np.float64)
+    sq = np.zeros(n_cv * n_cv)
+    inv = np.zeros(n_cv * n_cv)
+    lib().ref_compute_sigma(n_cv, arrs[0].shape[0], ptrs, cd, _d(sg), float(sigma_g), _d(sq), _d(inv))
+    return sq.reshape(n_cv, n_cv), inv.reshape(n_cv, n_cv)
 
 
 class Mesh:

@@ -599,3 +599,89 @@ void ref_wte_scale(unsigned int N, double *net_force, double *net_torque, double
         }
     for (unsigned int i = 0; i < 6; ++i) external_virial[i] = fac * external_virial[i];
     }
+
+/* ------------------------------------------------------------------------------------------------
+ * CollectiveWrapper (CollectiveWrapper.cc), CPU path
+ * ---------------------------------------------------------------------------------------------- */
+
+/* CollectiveWrapper.cc:31-72: energy = sum_j force_j.w + getExternalEnergy() of the wrapped compute */
+double ref_wrapper_energy(unsigned int N, const double *force, double external_energy)
+    {
+    double e = 0.0;
+    for (unsigned int i = 0; i < N; ++i) e += force[4 * i + 3];
+    return e + external_energy;
+    }
+
+/* CollectiveWrapper.cc:136-179: fac = m_bias */
+void ref_wrapper_scale(unsigned int N, double *force, double *torque, double *virial, unsigned int pitch, double bias)
+    {
+    double fac = bias;
+    for (unsigned int i = 0; i < N; ++i)
+        {
+        force[4 * i + 0] *= fac;
+        force[4 * i + 1] *= fac;
+        force[4 * i + 2] *= fac;
+        torque[4 * i + 0] *= fac;
+        torque[4 * i + 1] *= fac;
+        torque[4 * i + 2] *= fac;
+        torque[4 * i + 3] *= fac;
+        for (unsigned int r = 0; r < 6; r++) virial[i + r * pitch] *= fac;
+        }
+    }
+
+/* ------------------------------------------------------------------------------------------------
+ * Adaptive Gaussians: IntegratorMetaDynamics::computeSigma (IntegratorMetaDynamics.cc:1205-1294)
+ * The reference inverts with Eigen (absent here); any exact dense inverse agrees to rounding -> Gauss-Jordan with
+ * partial pivoting.  Parity at that boundary is unpinned (no reference test exercises adaptive Gaussians).
+ * ---------------------------------------------------------------------------------------------- */
+void ref_compute_sigma(unsigned int n_cv, unsigned int N, const double *const *forces, const int *can_derive,
+                       const double *sigma, double sigma_g, double *sigmasq, double *sigma_inv)
+    {
+    for (unsigned int i = 0; i < n_cv; ++i)
+        for (unsigned int j = 0; j < n_cv; ++j)
+            {
+            sigmasq[i * n_cv + j] = 0.0;                                               /* :1233 */
+            if (can_derive[i] && can_derive[j])                                        /* :1234 */
+                {
+                for (unsigned int n = 0; n < N; ++n)                                   /* :1239-1247 */
+                    {
+                    const double *fi = forces[i] + 4 * n, *fj = forces[j] + 4 * n;
+                    sigmasq[i * n_cv + j] += sigma_g * sigma_g * (fi[0] * fj[0] + fi[1] * fj[1] + fi[2] * fj[2]);
+                    }
+                }
+            else if (i == j)
+                sigmasq[i * n_cv + j] = sigma[i] * sigma[i];                           /* :1249 */
+            }
+
+    /* m(i,j) = sqrt(sigmasq) element-wise (:1277-1279), inverse (:1281) */
+    double a[REF_MAX_CV][2 * REF_MAX_CV];
+    for (unsigned int i = 0; i < n_cv; ++i)
+        for (unsigned int j = 0; j < n_cv; ++j)
+            {
+            a[i][j] = sqrt(sigmasq[i * n_cv + j]);
+            a[i][n_cv + j] = (i == j) ? 1.0 : 0.0;
+            }
+    for (unsigned int k = 0; k < n_cv; ++k)
+        {
+        unsigned int piv = k;
+        for (unsigned int r = k + 1; r < n_cv; ++r)
+            if (fabs(a[r][k]) > fabs(a[piv][k])) piv = r;
+        if (piv != k)
+            for (unsigned int j = 0; j < 2 * n_cv; ++j)
+                {
+                double t = a[k][j];
+                a[k][j] = a[piv][j];
+                a[piv][j] = t;
+                }
+        double d = a[k][k];
+        for (unsigned int j = 0; j < 2 * n_cv; ++j) a[k][j] /= d;
+        for (unsigned int r = 0; r < n_cv; ++r)
+            if (r != k)
+                {
+                double f = a[r][k];
+                for (unsigned int j = 0; j < 2 * n_cv; ++j) a[r][j] -= f * a[k][j];
+                }
+        }
+    for (unsigned int i = 0; i < n_cv; ++i)
+        for (unsigned int j = 0; j < n_cv; ++j) sigma_inv[i * n_cv + j] = a[i][n_cv + j];
+    }

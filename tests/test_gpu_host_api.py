@@ -207,8 +207,6 @@ def test_api_errors(api):
         context.run(1)                                                         # cv_min >= cv_max (.cc:800-805)
     with pytest.raises(RuntimeError):
         c.set_params(umbrella="bogus")
-    with pytest.raises(RuntimeError):
-        meta.set_params(adaptive=True)
 
 
 def test_mesh_cv_with_umbrella_through_api(api, ref):
@@ -308,3 +306,81 @@ def test_steinhardt_through_api(api, ref):
         cv.steinhardt(r_cut=1.4, r_on=1.2, lmax=6, Ql_ref=[1, 2, 3], nlist=nl, type="A")      # SteinhardtQl.cc:25-29
     with pytest.raises(RuntimeError):
         cv.steinhardt(r_cut=1.4, r_on=1.2, lmax=6, Ql_ref=Ql_ref, nlist=nl, type="Z")         # cv.py:591-593
+
+
+def test_wrap_through_api(api, ref):
+    """cv.wrap around a prescribed force: energy CV incl. the external energy, grid evolution, and the wrapped
+    compute's own arrays scaled by the bias factor (CollectiveWrapper.cc:136-179)"""
+    context, cv, integrate = api
+    from metadynamics import force
+    N, L = 5000, 20.0
+    rng = np.random.default_rng(3)
+    pos = rng.random((N, 3)) * L - L / 2
+    context.initialize(pos, np.zeros(N, dtype=np.int32), ["A"], L, dtype=np.float64)
+    f = rng.normal(size=(N, 4))
+    f[:, 3] = rng.normal(-0.5, 0.1, N)
+    tq = rng.normal(size=(N, 4))
+    vir = rng.normal(size=(6, N))
+    meta = integrate.mode_metadynamics(dt=0.005, stride=1, mode="well_tempered", W=2.0, deltaT=50.0, T=1.0)
+    frc = force.prescribed(f, tq, vir, external_energy=12.5, name="lj")
+    e_ref = ref.wrapper_energy(f, 12.5)
+    w = cv.wrap(frc, sigma=40.0)
+    assert w.name == "cv_lj"
+    w.set_grid(e_ref - 250.0, e_ref + 330.0, 64)                       # CV off the node mid-point: dV/ds != 0
+    context.run(3)
+    t = context.current.system.getCurrentTimeStep()
+    assert w.cpp_force.getCurrentValue(t) == pytest.approx(e_ref, rel=1e-12)
+    assert w.cpp_force.getLogValue("cv_lj", t) == pytest.approx(e_ref, rel=1e-12)
+    g = ref.Metad([40.0], [e_ref - 250.0], [e_ref + 330.0], [64], W=2.0, T_shift=50.0, T=1.0, stride=1, mode="well_tempered")
+    for tt in range(4):
+        b = g.update_bias(tt, [e_ref])
+    assert abs(b[0]) > 1e-5
+    assert np.allclose(meta.cpp_integrator.getBiasFactors(), b, rtol=1e-8)
+    f2, t2, v2 = ref.wrapper_scale(f, tq, vir.reshape(-1), N, b[0])
+    assert np.allclose(frc.cpp_force.getForces(), f2, rtol=1e-8, atol=0)
+    assert np.allclose(frc.cpp_force.getTorques(), t2, rtol=1e-8, atol=0)
+    assert np.allclose(frc.cpp_force.getVirial().reshape(-1), v2, rtol=1e-8, atol=0)
+    with pytest.raises(RuntimeError):
+        cv.wrap("not a force")
+
+
+def test_adaptive_gaussians_through_api(api, ref):
+    """set_params(adaptive=True, sigma_g): every deposit step the derivative arrays (bias factor 1) give the width
+    matrix (IntegratorMetaDynamics.cc:333-341, 1205-1294); a box CV keeps its registered sigma on the diagonal"""
+    context, cv, integrate = api
+    pos, types, L = util.snapshot_config0b()
+    context.initialize(pos, types, ["A", "B"], L, dtype=np.float64)
+    meta = integrate.mode_metadynamics(dt=0.005, stride=2, mode="well_tempered", W=1.0, deltaT=7.0, T=1.0)
+    lv1, lv2 = [(0, 0, 4)], [(0, 0, 4), (0, 4, 0)]
+    lam1 = cv.lamellar(sigma=0.05, mode=dict(A=1.0, B=-1.0), lattice_vectors=lv1, name="a")
+    lam2 = cv.lamellar(sigma=0.05, mode=dict(A=1.0, B=-1.0), lattice_vectors=lv2, name="b")
+    dens = cv.density(sigma=0.01)
+    lam1.set_grid(-1.0, 1.0, 48)
+    lam2.set_grid(-1.0, 1.0, 40)
+    dens.set_grid(0.5, 1.5, 16)
+    meta.set_params(adaptive=True, sigma_g=0.02)
+    context.run(5)
+    assert not meta.cpp_integrator.usedFusedPath()
+
+    rbox = ref.Box.make(L)
+    pt = util.oracle_postype(pos, types)
+    d1 = ref.lamellar_forces(lv1, pt, util.MODE_AB, rbox, 1.0)
+    d2 = ref.lamellar_forces(lv2, pt, util.MODE_AB, rbox, 1.0)
+    sq, inv = ref.compute_sigma([d1, d2, np.zeros_like(d1)], [1, 1, 0], [0.05, 0.05, 0.01], 0.02)
+    assert np.isfinite(inv).all()
+    got = np.array(meta.cpp_integrator.getSigmaInv()).reshape(3, 3)
+    # the derivative arrays come from the lamellar force kernel (1e-5 force tolerance, fp32 trig): widths agree to ~1e-7
+    assert np.allclose(got, inv, rtol=1e-6, atol=1e-6 * np.abs(inv).max())
+    assert got[2, 2] == pytest.approx(100.0) and got[0, 2] == 0
+
+    s = [ref.lamellar_cv(lv1, pt, util.MODE_AB, rbox), ref.lamellar_cv(lv2, pt, util.MODE_AB, rbox), len(pos) / L ** 3]
+    g = ref.Metad([0.05, 0.05, 0.01], [-1.0, -1.0, 0.5], [1.0, 1.0, 1.5], [48, 40, 16], W=1.0, T_shift=7.0, T=1.0, stride=2,
+                  mode="well_tempered")
+    for tt in range(6):
+        if tt % 2 == 0:
+            g.set_sigma_inv(inv)
+        b = g.update_bias(tt, s)
+    assert np.allclose(meta.cpp_integrator.getCurrentValues(), s, rtol=1e-9)
+    assert np.allclose(meta.cpp_integrator.getBiasFactors(), b, rtol=1e-6, atol=1e-9 * np.abs(b).max())
+    t_now = context.current.system.getCurrentTimeStep()
+    assert meta.cpp_integrator.getLogValue("det_sigma", t_now) == pytest.approx(g.sigma_determinant, rel=1e-6)

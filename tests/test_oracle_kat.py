@@ -216,3 +216,41 @@ def test_wte(ref):
     assert np.allclose(t2, 1.3 * nt)  # CPU path scales torque.w too (Q18)
     assert np.allclose(v2.reshape(6, pitch)[:, :N], 1.3 * nv[:, :N]) and np.array_equal(v2.reshape(6, pitch)[:, N:], nv[:, N:])
     assert np.allclose(e2, 1.3 * ev)
+
+
+def test_compute_sigma_kat(ref):
+    """computeSigma (IntegratorMetaDynamics.cc:1205-1294): closed forms — orthogonal derivative fields give a diagonal
+    sigma = sigma_g*|grad s|, sigma_inv its reciprocal; a CV without derivatives keeps its registered sigma; the
+    matrix inverse agrees with numpy"""
+    rng = np.random.default_rng(5)
+    N = 1000
+    f1 = np.zeros((N, 4)); f1[:, 0] = rng.normal(size=N)
+    f2 = np.zeros((N, 4)); f2[:, 1] = rng.normal(size=N)
+    sq, inv = ref.compute_sigma([f1, f2], [1, 1], [0.1, 0.2], 0.5)
+    assert sq[0, 1] == 0 and sq[1, 0] == 0
+    assert sq[0, 0] == pytest.approx(0.25 * (f1[:, 0] ** 2).sum(), rel=1e-12)
+    assert inv[0, 0] == pytest.approx(1 / np.sqrt(sq[0, 0]), rel=1e-12) and inv[0, 1] == 0
+    # correlated fields with positive products + one CV that cannot compute derivatives
+    g1 = np.abs(rng.normal(size=(N, 4)))
+    g2 = np.abs(rng.normal(size=(N, 4)))
+    g3 = rng.normal(size=(N, 4))
+    sq, inv = ref.compute_sigma([g1, g2, g3], [1, 1, 0], [0.1, 0.2, 0.3], 0.7)
+    assert sq[2, 2] == pytest.approx(0.09) and sq[0, 2] == 0 and sq[2, 1] == 0
+    assert sq[0, 1] == pytest.approx(0.49 * (g1[:, :3] * g2[:, :3]).sum(), rel=1e-12)
+    assert np.allclose(inv, np.linalg.inv(np.sqrt(sq)), rtol=1e-10)
+    # a negative off-diagonal product makes the element-wise sqrt NaN, like the reference
+    sq, inv = ref.compute_sigma([f1, -f1 + f2], [1, 1], [0.1, 0.2], 1.0)
+    assert sq[0, 1] < 0 and np.isnan(inv).all()
+
+
+def test_wrapper_kat(ref):
+    """CollectiveWrapper.cc: energy = sum force.w + external; scaling by the bias itself incl. torque.w"""
+    rng = np.random.default_rng(6)
+    N, pitch = 17, 20
+    f, t, v = rng.normal(size=(N, 4)), rng.normal(size=(N, 4)), rng.normal(size=6 * pitch)
+    assert ref.wrapper_energy(f, 1.5) == pytest.approx(f[:, 3].sum() + 1.5, rel=1e-14)
+    f2, t2, v2 = ref.wrapper_scale(f, t, v, pitch, -0.3)
+    assert np.allclose(f2[:, :3], -0.3 * f[:, :3]) and np.array_equal(f2[:, 3], f[:, 3])
+    assert np.allclose(t2, -0.3 * t)
+    vv = v.reshape(6, pitch)
+    assert np.allclose(v2.reshape(6, pitch)[:, :N], -0.3 * vv[:, :N]) and np.array_equal(v2.reshape(6, pitch)[:, N:], vv[:, N:])
