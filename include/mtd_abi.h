@@ -249,6 +249,15 @@ unsigned int mtd_mesh_num_cells(const mtd_mesh *m);
 int mtd_mesh_compute_cv(mtd_mesh *m, unsigned int n_particles, const void *d_postype, int dtype, const mtd_box *box,
                         unsigned int n_global, const double **d_partials, unsigned int *n_partials, mtd_stream_t stream);
 
+/* The two halves of mtd_mesh_compute_cv for a particle-sharded system with a replicated mesh (replaces the
+ * ghost-cell exchange + distributed FFT of OrderParameterMesh.cc:263-316, 659-746 and the mode_sq all-reduce of :630):
+ * _assign spreads this rank's particles, the ranks all-reduce (sum) the *count doubles at *d_buffer — the real mesh
+ * followed by the sum of mode^2 — and _spectral runs FFT -> updateMeshes -> iFFT -> computeCV on the reduced mesh. */
+int mtd_mesh_assign(mtd_mesh *m, unsigned int n_particles, const void *d_postype, int dtype, const mtd_box *box, mtd_stream_t stream);
+int mtd_mesh_exchange_buffer(mtd_mesh *m, double **d_buffer, size_t *count);
+int mtd_mesh_spectral(mtd_mesh *m, const mtd_box *box, unsigned int n_global, const double **d_partials, unsigned int *n_partials,
+                      mtd_stream_t stream);
+
 /* interpolateForces (OrderParameterMesh.cc:749-864) from the inverse mesh AND the cell-sorted particle records of the last
  * mtd_mesh_compute_cv, i.e. of the same snapshot (the reference recomputes the CV first when needed, :1055-1056);
  * bias = *d_bias when d_bias != NULL (device resident), else bias_host */
@@ -276,8 +285,20 @@ int mtd_ql_accumulate(unsigned int n_particles, const void *d_postype, int dtype
                       unsigned int lmax, unsigned int type, const double *Ql_ref, unsigned int n_global, double *d_scratch,
                       const double **d_value, const double **d_Ql, const double **d_Qlm, mtd_stream_t stream);
 
+/* The two halves of mtd_ql_accumulate for a particle-sharded system (the reference class has no MPI path):
+ * _local leaves this rank's sums Q'_lm (m >= 0, (lmax+1)(lmax+2) doubles) at *d_sums inside d_scratch — the ranks
+ * all-reduce exactly that buffer — and _finalize turns the reduced sums into Q_lm, Q_l and the CV value.
+ * Neighbour indices >= n_particles address ghost particles stored behind the local ones in d_postype. */
+int mtd_ql_accumulate_local(unsigned int n_particles, const void *d_postype, int dtype, const mtd_box *box,
+                            const unsigned int *d_head_list, const unsigned int *d_n_neigh, const unsigned int *d_nlist, int half_nlist,
+                            double rcut, double ron, unsigned int lmax, unsigned int type, unsigned int n_global, double *d_scratch,
+                            double **d_sums, unsigned int *n_sums, mtd_stream_t stream);
+int mtd_ql_finalize(int half_nlist, unsigned int lmax, const double *Ql_ref, unsigned int n_global, double *d_scratch,
+                    const double **d_value, const double **d_Ql, const double **d_Qlm, mtd_stream_t stream);
+
 /* SteinhardtQl::computeBiasForces (:203-339) with the Q_lm the last mtd_ql_accumulate left in d_scratch (Q20);
- * bias = *d_bias when d_bias != NULL, else bias_host */
+ * bias = *d_bias when d_bias != NULL, else bias_host.  Writes d_force[0..n_particles); with half lists the reaction force goes
+ * to LOCAL partners only (j < n_particles, SteinhardtQl.cc:328), so particle-sharded runs use full lists. */
 int mtd_ql_forces(unsigned int n_particles, const void *d_postype, void *d_force, int dtype, const mtd_box *box,
                   const unsigned int *d_head_list, const unsigned int *d_n_neigh, const unsigned int *d_nlist, int half_nlist,
                   double rcut, double ron, unsigned int lmax, unsigned int type, const double *Ql_ref, unsigned int n_global,

@@ -630,8 +630,7 @@ int mtd_mesh_create(mtd_mesh **out, unsigned int nx, unsigned int ny, unsigned i
     auto al = [](size_t b) { return (b + 255) / 256 * 256; };
     size_t off = 0;
     auto take = [&](size_t b) { size_t o = off; off += al(b); return o; };
-    const size_t o_mode = take(sizeof(double) * n_types), o_rho = take(sizeof(double) * M), o_msqp = take(sizeof(double) * m->n_count_blocks),
-                 o_msq = take(sizeof(double)), o_cvp = take(sizeof(double) * m->n_cv_partials), o_f = take(sizeof(double2) * M),
+    const size_t o_mode = take(sizeof(double) * n_types), o_rho = take(sizeof(double) * (M + 1)), o_msqp = take(sizeof(double) * m->n_count_blocks), o_cvp = take(sizeof(double) * m->n_cv_partials), o_f = take(sizeof(double2) * M),
                  o_g = take(sizeof(double2) * M), o_tw0 = take(sizeof(double2) * nx), o_tw1 = take(sizeof(double2) * ny),
                  o_tw2 = take(sizeof(double2) * nz), o_packed = take(sizeof(double4) * N), o_cell = take(sizeof(unsigned int) * N),
                  o_count = take(sizeof(unsigned int) * (M + 1)), o_start = take(sizeof(unsigned int) * (M + 1)),
@@ -645,7 +644,8 @@ int mtd_mesh_create(mtd_mesh **out, unsigned int nx, unsigned int ny, unsigned i
         }
     char *p = (char *)m->slab;
     m->d_mode = (double *)(p + o_mode); m->d_rho = (double *)(p + o_rho); m->d_modesq_partials = (double *)(p + o_msqp);
-    m->d_mode_sq = (double *)(p + o_msq); m->d_cv_partials = (double *)(p + o_cvp); m->d_f = (double2 *)(p + o_f);
+    m->d_mode_sq = m->d_rho + M;   // directly behind the real mesh: one exchange buffer of M + 1 doubles
+    m->d_cv_partials = (double *)(p + o_cvp); m->d_f = (double2 *)(p + o_f);
     m->d_g = (double2 *)(p + o_g); m->d_tw[0] = (double2 *)(p + o_tw0); m->d_tw[1] = (double2 *)(p + o_tw1);
     m->d_tw[2] = (double2 *)(p + o_tw2); m->d_packed = (double4 *)(p + o_packed); m->d_cell_of = (unsigned int *)(p + o_cell);
     m->d_count = (unsigned int *)(p + o_count); m->d_start = (unsigned int *)(p + o_start); m->d_ids = (unsigned int *)(p + o_ids);
@@ -692,10 +692,9 @@ int mtd_mesh_set_bug_compat(mtd_mesh *m, int on)
     return MTD_SUCCESS;
     }
 
-int mtd_mesh_compute_cv(mtd_mesh *m, unsigned int n_particles, const void *d_postype, int dtype, const mtd_box *box,
-                        unsigned int n_global, const double **d_partials, unsigned int *n_partials, mtd_stream_t stream)
+int mtd_mesh_assign(mtd_mesh *m, unsigned int n_particles, const void *d_postype, int dtype, const mtd_box *box, mtd_stream_t stream)
     {
-    if (!m || !d_partials || !n_partials || n_global == 0 || (n_particles && !d_postype)) return MTD_ERR_INVALID_ARGUMENT;
+    if (!m || (n_particles && !d_postype)) return MTD_ERR_INVALID_ARGUMENT;
     if (dtype != MTD_F32 && dtype != MTD_F64) return MTD_ERR_INVALID_ARGUMENT;
     if (n_particles > m->max_particles) return MTD_ERR_INVALID_ARGUMENT;
     MeshGeom g;
@@ -732,16 +731,44 @@ int mtd_mesh_compute_cv(mtd_mesh *m, unsigned int n_particles, const void *d_pos
     MTD_LAUNCH_CHECK();
     k_mesh_gather<<<cell_blocks, 256, 0, s>>>(g, m->d_start, m->d_packed, m->d_rho);
     MTD_LAUNCH_CHECK();
+    m->n_last = N;
+    return MTD_SUCCESS;
+    }
+
+int mtd_mesh_exchange_buffer(mtd_mesh *m, double **d_buffer, size_t *count)
+    {
+    if (!m || !d_buffer || !count) return MTD_ERR_INVALID_ARGUMENT;
+    *d_buffer = m->d_rho;
+    *count = (size_t)m->M + 1;
+    return MTD_SUCCESS;
+    }
+
+int mtd_mesh_spectral(mtd_mesh *m, const mtd_box *box, unsigned int n_global, const double **d_partials, unsigned int *n_partials,
+                      mtd_stream_t stream)
+    {
+    if (!m || !d_partials || !n_partials || n_global == 0) return MTD_ERR_INVALID_ARGUMENT;
+    MeshGeom g;
+    int rc = fill_geom(g, m, box);
+    if (rc) return rc;
+    hipStream_t s = (hipStream_t)stream;
     rc = launch_fft3d(m, m->d_rho, m->d_f, nullptr, 0, s);
     if (rc) return rc;
     k_mesh_spectral<<<m->n_cv_partials, 256, 0, s>>>(g, m->d_f, m->d_g, m->d_mode_sq, (double)n_global, m->bug_compat, m->d_cv_partials);
     MTD_LAUNCH_CHECK();
     rc = launch_fft3d(m, nullptr, m->d_g, m->d_inv, 1, s);   // Re(inv) lands in its own array
     if (rc) return rc;
-    m->n_last = N;
     *d_partials = m->d_cv_partials;
     *n_partials = m->n_cv_partials;
     return MTD_SUCCESS;
+    }
+
+int mtd_mesh_compute_cv(mtd_mesh *m, unsigned int n_particles, const void *d_postype, int dtype, const mtd_box *box,
+                        unsigned int n_global, const double **d_partials, unsigned int *n_partials, mtd_stream_t stream)
+    {
+    if (!m || !d_partials || !n_partials || n_global == 0) return MTD_ERR_INVALID_ARGUMENT;
+    int rc = mtd_mesh_assign(m, n_particles, d_postype, dtype, box, stream);
+    if (rc) return rc;
+    return mtd_mesh_spectral(m, box, n_global, d_partials, n_partials, stream);
     }
 
 int mtd_mesh_forces(mtd_mesh *m, unsigned int n_particles, const void *d_postype, void *d_force, int dtype, const mtd_box *box,

@@ -390,11 +390,17 @@ template<int LMAX>
 int accumulate_impl(unsigned int N, const void *d_postype, int dtype, const mtd_box *box, const unsigned int *d_head,
                     const unsigned int *d_nneigh, const unsigned int *d_nlist, int half, double rcut, double ron, unsigned int lmax,
                     unsigned int type, const double *ql_ref, unsigned int n_global, double *d_partials, unsigned int *n_partials,
-                    double *d_qprime, double *d_qlm, double *d_ql, double *d_value, hipStream_t s)
+                    double *d_qprime, double *d_qlm, double *d_ql, double *d_value, bool accumulate, bool finalize, hipStream_t s)
     {
     QlArgs<LMAX> a;
     int rc = fill_args<LMAX>(a, N, box, rcut, ron, lmax, type, ql_ref, n_global, half);
     if (rc) return rc;
+    if (!accumulate)
+        {
+        k_ql_finalize<LMAX><<<1, 64, 0, s>>>(a, d_qprime, d_qlm, d_ql, d_value);
+        MTD_LAUNCH_CHECK();
+        return MTD_SUCCESS;
+        }
     const unsigned int blocks = ql_blocks(N);
     const unsigned int n_out = (lmax + 1) * (lmax + 2);
     if (dtype == MTD_F32)
@@ -405,6 +411,7 @@ int accumulate_impl(unsigned int N, const void *d_postype, int dtype, const mtd_
     *n_partials = blocks;
     rc = mtd_reduce_partials(d_partials, blocks, n_out, n_out, 1.0, 0.0, d_qprime, (mtd_stream_t)s);
     if (rc) return rc;
+    if (!finalize) return MTD_SUCCESS;
     k_ql_finalize<LMAX><<<1, 64, 0, s>>>(a, d_qprime, d_qlm, d_ql, d_value);
     MTD_LAUNCH_CHECK();
     return MTD_SUCCESS;
@@ -462,12 +469,14 @@ static void ql_layout(double *scratch, unsigned int lmax, double **partials, dou
     *value = *ql + (lmax + 1);
     }
 
-int mtd_ql_accumulate(unsigned int n_particles, const void *d_postype, int dtype, const mtd_box *box, const unsigned int *d_head_list,
-                      const unsigned int *d_n_neigh, const unsigned int *d_nlist, int half_nlist, double rcut, double ron,
-                      unsigned int lmax, unsigned int type, const double *Ql_ref, unsigned int n_global, double *d_scratch,
-                      const double **d_value, const double **d_Ql, const double **d_Qlm, mtd_stream_t stream)
+static int ql_dispatch(unsigned int n_particles, const void *d_postype, int dtype, const mtd_box *box, const unsigned int *d_head_list,
+                       const unsigned int *d_n_neigh, const unsigned int *d_nlist, int half_nlist, double rcut, double ron,
+                       unsigned int lmax, unsigned int type, const double *Ql_ref, unsigned int n_global, double *d_scratch,
+                       const double **d_value, const double **d_Ql, const double **d_Qlm, bool accumulate, bool finalize,
+                       mtd_stream_t stream)
     {
-    if (!d_scratch || (n_particles && (!d_postype || !d_head_list || !d_n_neigh || !d_nlist))) return MTD_ERR_INVALID_ARGUMENT;
+    if (!d_scratch) return MTD_ERR_INVALID_ARGUMENT;
+    if (accumulate && n_particles && (!d_postype || !d_head_list || !d_n_neigh || !d_nlist)) return MTD_ERR_INVALID_ARGUMENT;
     if (dtype != MTD_F32 && dtype != MTD_F64) return MTD_ERR_INVALID_ARGUMENT;
     if (lmax > 12) return MTD_ERR_UNSUPPORTED;
     double *partials, *qprime, *qlm, *ql, *value;
@@ -476,7 +485,7 @@ int mtd_ql_accumulate(unsigned int n_particles, const void *d_postype, int dtype
     hipStream_t s = (hipStream_t)stream;
     int rc;
 #define MTD_QL_ACC(LM) accumulate_impl<LM>(n_particles, d_postype, dtype, box, d_head_list, d_n_neigh, d_nlist, half_nlist, rcut, ron, lmax, \
-                                           type, Ql_ref, n_global, partials, &n_partials, qprime, qlm, ql, value, s)
+                                           type, Ql_ref, n_global, partials, &n_partials, qprime, qlm, ql, value, accumulate, finalize, s)
     if (lmax <= 4)
         rc = MTD_QL_ACC(4);
     else if (lmax <= 6)
@@ -491,6 +500,44 @@ int mtd_ql_accumulate(unsigned int n_particles, const void *d_postype, int dtype
     if (d_Ql) *d_Ql = ql;
     if (d_Qlm) *d_Qlm = qlm;
     return MTD_SUCCESS;
+    }
+
+int mtd_ql_accumulate(unsigned int n_particles, const void *d_postype, int dtype, const mtd_box *box, const unsigned int *d_head_list,
+                      const unsigned int *d_n_neigh, const unsigned int *d_nlist, int half_nlist, double rcut, double ron,
+                      unsigned int lmax, unsigned int type, const double *Ql_ref, unsigned int n_global, double *d_scratch,
+                      const double **d_value, const double **d_Ql, const double **d_Qlm, mtd_stream_t stream)
+    {
+    return ql_dispatch(n_particles, d_postype, dtype, box, d_head_list, d_n_neigh, d_nlist, half_nlist, rcut, ron, lmax, type, Ql_ref,
+                       n_global, d_scratch, d_value, d_Ql, d_Qlm, true, true, stream);
+    }
+
+int mtd_ql_accumulate_local(unsigned int n_particles, const void *d_postype, int dtype, const mtd_box *box,
+                            const unsigned int *d_head_list, const unsigned int *d_n_neigh, const unsigned int *d_nlist, int half_nlist,
+                            double rcut, double ron, unsigned int lmax, unsigned int type, unsigned int n_global, double *d_scratch,
+                            double **d_sums, unsigned int *n_sums, mtd_stream_t stream)
+    {
+    if (!d_sums || !n_sums) return MTD_ERR_INVALID_ARGUMENT;
+    double zeros[13] = {0};
+    int rc = ql_dispatch(n_particles, d_postype, dtype, box, d_head_list, d_n_neigh, d_nlist, half_nlist, rcut, ron, lmax, type, zeros,
+                         n_global, d_scratch, nullptr, nullptr, nullptr, true, false, stream);
+    if (rc) return rc;
+    double *partials, *qprime, *qlm, *ql, *value;
+    ql_layout(d_scratch, lmax, &partials, &qprime, &qlm, &ql, &value);
+    *d_sums = qprime;
+    *n_sums = (lmax + 1) * (lmax + 2);
+    return MTD_SUCCESS;
+    }
+
+int mtd_ql_finalize(int half_nlist, unsigned int lmax, const double *Ql_ref, unsigned int n_global, double *d_scratch,
+                    const double **d_value, const double **d_Ql, const double **d_Qlm, mtd_stream_t stream)
+    {
+    if (!Ql_ref) return MTD_ERR_INVALID_ARGUMENT;
+    // geometry is not used by the finalize step: any valid box / cut-offs satisfy the argument checks
+    mtd_box box;
+    std::memset(&box, 0, sizeof(box));
+    box.L[0] = box.L[1] = box.L[2] = 1.0;
+    return ql_dispatch(0, nullptr, MTD_F64, &box, nullptr, nullptr, nullptr, half_nlist, 1.0, 0.5, lmax, 0, Ql_ref, n_global, d_scratch,
+                       d_value, d_Ql, d_Qlm, false, true, stream);
     }
 
 int mtd_ql_forces(unsigned int n_particles, const void *d_postype, void *d_force, int dtype, const mtd_box *box,

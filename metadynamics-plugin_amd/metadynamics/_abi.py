@@ -132,10 +132,16 @@ _SIGNATURES = {
     "mtd_mesh_destroy": (C.c_int, [_vp]),
     "mtd_mesh_set_bug_compat": (C.c_int, [_vp, C.c_int]),
     "mtd_mesh_num_cells": (C.c_uint, [_vp]),
+    "mtd_mesh_assign": (C.c_int, [_vp, C.c_uint, _vp, C.c_int, C.POINTER(Box), _vp]),
+    "mtd_mesh_exchange_buffer": (C.c_int, [_vp, C.POINTER(_vp), C.POINTER(C.c_size_t)]),
+    "mtd_mesh_spectral": (C.c_int, [_vp, C.POINTER(Box), C.c_uint, C.POINTER(_vp), _up, _vp]),
     "mtd_mesh_compute_cv": (C.c_int, [_vp, C.c_uint, _vp, C.c_int, C.POINTER(Box), C.c_uint, C.POINTER(_vp), _up, _vp]),
     "mtd_mesh_forces": (C.c_int, [_vp, C.c_uint, _vp, _vp, C.c_int, C.POINTER(Box), C.c_uint, _vp, C.c_double, _vp]),
     "mtd_mesh_get_array": (C.c_int, [_vp, C.c_int, _vp, _vp]),
     "mtd_ql_scratch_doubles": (C.c_size_t, [C.c_uint]),
+    "mtd_ql_accumulate_local": (C.c_int, [C.c_uint, _vp, C.c_int, C.POINTER(Box), _vp, _vp, _vp, C.c_int, C.c_double, C.c_double,
+                                           C.c_uint, C.c_uint, C.c_uint, _vp, C.POINTER(_vp), _up, _vp]),
+    "mtd_ql_finalize": (C.c_int, [C.c_int, C.c_uint, _dp, C.c_uint, _vp, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp), _vp]),
     "mtd_ql_accumulate": (C.c_int, [C.c_uint, _vp, C.c_int, C.POINTER(Box), _vp, _vp, _vp, C.c_int, C.c_double, C.c_double, C.c_uint,
                                      C.c_uint, _dp, C.c_uint, _vp, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp), _vp]),
     "mtd_ql_forces": (C.c_int, [C.c_uint, _vp, _vp, C.c_int, C.POINTER(Box), _vp, _vp, _vp, C.c_int, C.c_double, C.c_double, C.c_uint,

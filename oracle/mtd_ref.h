@@ -133,6 +133,10 @@ void ref_mesh_destroy(ref_mesh *m);
 void ref_mesh_set_bug_compat(ref_mesh *m, int on);
 /* getCurrentValue (OrderParameterMesh.cc:925-968): assignParticles -> FFT -> updateMeshes -> iFFT -> computeCV */
 double ref_mesh_cv(ref_mesh *m, unsigned int N, const double *postype, const ref_box *box, unsigned int N_global);
+/* halves of ref_mesh_cv for particle-sharded checks: spread one shard; (sum mesh + mode_sq over shards); spectral part */
+void ref_mesh_assign(ref_mesh *m, unsigned int N, const double *postype, const ref_box *box);
+void ref_mesh_set_mode_sq(ref_mesh *m, double mode_sq);
+double ref_mesh_spectral(ref_mesh *m, unsigned int N_global);
 /* interpolateForces (:749-864); call after ref_mesh_cv on the same snapshot */
 void ref_mesh_forces(ref_mesh *m, unsigned int N, const double *postype, const ref_box *box, unsigned int N_global,
                      double bias, double *force_out /*4N*/);
@@ -150,6 +154,8 @@ double ref_ql_compute_cv(unsigned int N, const double *postype, const ref_box *b
                          const unsigned int *n_neigh, const unsigned int *nlist, int half_nlist, double rcut, double ron,
                          unsigned int lmax, unsigned int type, const double *Ql_ref, unsigned int N_global,
                          double *Qlm_out /*2 (lmax+1)^2*/, double *Ql_out /*lmax+1*/);
+/* tail of computeCV (:181-194) from a summed Q_lm table (particle-sharded checks) */
+double ref_ql_from_qlm(unsigned int lmax, const double *Qlm_in, const double *Ql_ref, unsigned int N_global, double *Ql_out);
 /* SteinhardtQl::computeBiasForces (:203-339) with the Q_lm computeCV left behind (Q20) */
 void ref_ql_compute_forces(unsigned int N, const double *postype, const ref_box *box, const unsigned int *head_list,
                            const unsigned int *n_neigh, const unsigned int *nlist, int half_nlist, double rcut, double ron,

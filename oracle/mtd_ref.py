@@ -147,6 +147,12 @@ def _bind_optional(L):
         L.ref_mesh_array.argtypes = [C.c_void_p, C.c_int]
         L.ref_mesh_mode_sq.restype = C.c_double
         L.ref_mesh_mode_sq.argtypes = [C.c_void_p]
+        L.ref_mesh_assign.restype = None
+        L.ref_mesh_assign.argtypes = [C.c_void_p, C.c_uint, _dp, C.POINTER(Box)]
+        L.ref_mesh_set_mode_sq.restype = None
+        L.ref_mesh_set_mode_sq.argtypes = [C.c_void_p, C.c_double]
+        L.ref_mesh_spectral.restype = C.c_double
+        L.ref_mesh_spectral.argtypes = [C.c_void_p, C.c_uint]
         L.ref_mesh_set_bug_compat.restype = None
         L.ref_mesh_set_bug_compat.argtypes = [C.c_void_p, C.c_int]
     if hasattr(L, "ref_sph_evaluate"):
@@ -157,6 +163,8 @@ def _bind_optional(L):
         L.ref_ql_compute_cv.argtypes = [C.c_uint, _dp, C.POINTER(Box), _up, _up, _up, C.c_int,
                                         C.c_double, C.c_double, C.c_uint, C.c_uint, _dp, C.c_uint,
                                         _dp, _dp]
+        L.ref_ql_from_qlm.restype = C.c_double
+        L.ref_ql_from_qlm.argtypes = [C.c_uint, _dp, _dp, C.c_uint, _dp]
         L.ref_ql_compute_forces.restype = None
         L.ref_ql_compute_forces.argtypes = [C.c_uint, _dp, C.POINTER(Box), _up, _up, _up, C.c_int,
                                             C.c_double, C.c_double, C.c_uint, C.c_uint, _dp, C.c_uint,
@@ -445,6 +453,23 @@ class Mesh:
                               float(bias), _d(out))
         return out
 
+    def assign(self, postype, box):
+        """spread one shard: fills array("mesh") and mode_sq (sharded checks sum both over the shards)"""
+        pt = np.ascontiguousarray(postype, dtype=np.float64)
+        lib().ref_mesh_assign(self._h, pt.shape[0], _d(pt), C.byref(box))
+
+    def raw_mesh(self):
+        """writable (M, 2) view of the real-space mesh (re, im)"""
+        ptr = lib().ref_mesh_array(self._h, 0)
+        buf = (C.c_double * (2 * self.M)).from_address(ptr)
+        return np.frombuffer(buf, dtype=np.float64).reshape(self.M, 2)
+
+    def set_mode_sq(self, v):
+        lib().ref_mesh_set_mode_sq(self._h, float(v))
+
+    def spectral(self, n_global):
+        return lib().ref_mesh_spectral(self._h, int(n_global))
+
     @property
     def mode_sq(self):
         return lib().ref_mesh_mode_sq(self._h)
@@ -485,9 +510,20 @@ def ql_compute_cv(postype, box, head_list, n_neigh, nlist, rcut, ron, lmax, type
     cnt = (lmax + 1) ** 2
     qlm = np.zeros(2 * cnt)
     ql = np.zeros(lmax + 1)
-    v = lib().ref_ql_compute_cv(pt.shape[0], _d(pt), C.byref(box), _u(hl), _u(nn), _u(nl), int(half), float(rcut), float(ron),
+    # central particles = entries of head_list; postype may hold ghost particles behind them (sharded checks)
+    v = lib().ref_ql_compute_cv(hl.shape[0], _d(pt), C.byref(box), _u(hl), _u(nn), _u(nl), int(half), float(rcut), float(ron),
                                 int(lmax), int(type_id), _d(qr), pt.shape[0] if n_global is None else int(n_global), _d(qlm), _d(ql))
     return v, qlm[0::2] + 1j * qlm[1::2], ql
+
+
+def ql_from_qlm(lmax, Qlm, Ql_ref, n_global):
+    """tail of computeCV from a summed Q_lm table: returns (value, Ql)"""
+    q = np.zeros(2 * len(Qlm))
+    q[0::2], q[1::2] = np.real(Qlm), np.imag(Qlm)
+    qr = np.ascontiguousarray(Ql_ref, dtype=np.float64)
+    ql = np.zeros(lmax + 1)
+    v = lib().ref_ql_from_qlm(int(lmax), _d(q), _d(qr), int(n_global), _d(ql))
+    return v, ql
 
 
 def ql_compute_forces(postype, box, head_list, n_neigh, nlist, rcut, ron, lmax, type_id, Ql_ref, Qlm, bias, half=False,
@@ -499,8 +535,8 @@ def ql_compute_forces(postype, box, head_list, n_neigh, nlist, rcut, ron, lmax, 
     qr = np.ascontiguousarray(Ql_ref, dtype=np.float64)
     q = np.zeros(2 * len(Qlm))
     q[0::2], q[1::2] = np.real(Qlm), np.imag(Qlm)
-    out = np.zeros((pt.shape[0], 4))
-    lib().ref_ql_compute_forces(pt.shape[0], _d(pt), C.byref(box), _u(hl), _u(nn), _u(nl), int(half), float(rcut), float(ron),
+    out = np.zeros((pt.shape[0], 4))             # half lists also write reaction forces on neighbours (ghosts included)
+    lib().ref_ql_compute_forces(hl.shape[0], _d(pt), C.byref(box), _u(hl), _u(nn), _u(nl), int(half), float(rcut), float(ron),
                                 int(lmax), int(type_id), _d(qr), pt.shape[0] if n_global is None else int(n_global), _d(q),
                                 float(bias), _d(out))
     return out

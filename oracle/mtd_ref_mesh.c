@@ -369,6 +369,27 @@ double ref_mesh_cv(ref_mesh *m, unsigned int N, const double *postype, const ref
     return m->cv;
     }
 
+/* the two halves of getCurrentValue for particle-sharded checks: spread this shard (mesh + mode_sq), [sum over shards],
+ * then FFT / updateMeshes / computeCV on the summed mesh (the reference sums mode_sq over ranks too, :626-636) */
+void ref_mesh_assign(ref_mesh *m, unsigned int N, const double *postype, const ref_box *box)
+    {
+    if (!m->initialized)
+        {
+        compute_influence_function(m, box);
+        m->initialized = 1;
+        }
+    assign_particles(m, N, postype, box);
+    }
+
+void ref_mesh_set_mode_sq(ref_mesh *m, double mode_sq) { m->mode_sq = mode_sq; }
+
+double ref_mesh_spectral(ref_mesh *m, unsigned int N_global)
+    {
+    update_meshes(m, N_global);
+    m->cv = compute_cv(m, N_global);
+    return m->cv;
+    }
+
 /* interpolateForces, :749-864 (after getCurrentValue of the same snapshot) */
 void ref_mesh_forces(ref_mesh *m, unsigned int N, const double *postype, const ref_box *box, unsigned int N_global,
                      double bias, double *force_out)

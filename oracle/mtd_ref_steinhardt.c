@@ -237,6 +237,26 @@ double ref_ql_compute_cv(unsigned int N, const double *postype, const ref_box *b
     return value;
     }
 
+/* Q_l and the CV value from a (summed) Q_lm table — the tail of computeCV (:181-194) on its own, for particle-sharded checks:
+ * Q_lm is linear in the pair sum, so the table of the whole system is the sum of the shards' tables. */
+double ref_ql_from_qlm(unsigned int lmax, const double *Qlm_in, const double *Ql_ref, unsigned int N_global, double *Ql_out)
+    {
+    unsigned int n = 0;
+    double value = 0.0;
+    for (int l = 0; l <= (int)lmax; ++l)
+        {
+        Ql_out[l] = 0.0;
+        for (int p = 0; p < 2 * l + 1; ++p, ++n)
+            {
+            double sq = Qlm_in[2 * n] * Qlm_in[2 * n] + Qlm_in[2 * n + 1] * Qlm_in[2 * n + 1];
+            sq *= (4.0 * M_PI / (2 * l + 1)) / ((double)N_global * (double)N_global);
+            Ql_out[l] += sq;
+            }
+        value += Ql_ref[l] * Ql_out[l];
+        }
+    return value;
+    }
+
 /* computeBiasForces, :203-339; Qlm_in as left by computeCV (Q20) */
 void ref_ql_compute_forces(unsigned int N, const double *postype, const ref_box *box, const unsigned int *head_list,
                            const unsigned int *n_neigh, const unsigned int *nlist, int half_nlist, double rcut, double ron,

@@ -174,6 +174,110 @@ def _worker_walkers(rank, world, port, out):
         dist.destroy_process_group()
 
 
+class OracleCvSetBackend:
+    """checker backend for a mixed CV set (lamellar + mesh + Steinhardt + wrapped energy): one exchange buffer per CV,
+    exactly the buffers metadynamics.sharded.HipCvSetBackend hands to the all-reduce"""
+
+    LV, MODE = [(0, 0, 3), (0, 3, 0)], [1.0, -1.0]
+    QL = dict(rcut=1.4, ron=1.2, lmax=6, Ql_ref=[0, 0, 0, 0, 1, 0, 1])
+
+    def __init__(self, pos, types, L, ids, energy, ext, grid):
+        import mtd_ref
+        import util
+        self.ref = mtd_ref
+        self.N = len(pos)
+        self.ids = ids
+        self.box = mtd_ref.Box.make(L)
+        self.opt = mtd_ref.as_postype(pos[ids], types[ids])
+        self.mesh = mtd_ref.Mesh(8, 8, 8, self.MODE)
+        # Steinhardt shard: own particles first, every other particle as ghost; neighbour list re-indexed
+        head, nn, nl = util.build_nlist(pos, L, 1.5)
+        other = np.setdiff1d(np.arange(self.N), ids)
+        perm = np.concatenate([ids, other])
+        inv = np.empty(self.N, dtype=np.int64)
+        inv[perm] = np.arange(self.N)
+        h2, n2, l2 = [], [], []
+        for i in ids:
+            h2.append(len(l2))
+            n2.append(nn[i])
+            l2.extend(inv[nl[head[i]:head[i] + nn[i]]])
+        self.nlist = (np.asarray(h2, dtype=np.uint32), np.asarray(n2, dtype=np.uint32), np.asarray(l2, dtype=np.uint32))
+        self.opt_ql = mtd_ref.as_postype(pos[perm], np.zeros(self.N, dtype=np.int32))
+        self.energy, self.ext = energy[ids], ext
+        self.metad = mtd_ref.Metad(**grid, **dict(KW, stride=1))
+
+    def cv_pass(self):
+        r = self.ref
+        lam = torch.tensor([r.lamellar_fourier_modes(self.LV, self.opt, self.MODE, self.box)[:, 0].sum()], dtype=torch.float64)
+        self.mesh.assign(self.opt, self.box)
+        mesh = torch.from_numpy(np.concatenate([self.mesh.raw_mesh()[:, 0].copy(), [self.mesh.mode_sq]]))
+        q = self.QL
+        _, qlm, _ = r.ql_compute_cv(self.opt_ql, self.box, *self.nlist, q["rcut"], q["ron"], q["lmax"], 0, q["Ql_ref"], n_global=self.N)
+        ql = torch.from_numpy(np.concatenate([qlm.real, qlm.imag]))
+        en = torch.tensor([r.wrapper_energy(np.column_stack([np.zeros((len(self.ids), 3)), self.energy]), self.ext)], dtype=torch.float64)
+        return [lam, mesh, ql, en]
+
+    def force_pass(self, bufs, timestep):
+        r, q = self.ref, self.QL
+        lam, mesh, ql, en = [b.numpy() for b in bufs]
+        self.mesh.raw_mesh()[:, 0] = mesh[:-1]
+        self.mesh.set_mode_sq(mesh[-1])
+        n = len(ql) // 2
+        self.qlm = ql[:n] + 1j * ql[n:]
+        s_ql, _ = r.ql_from_qlm(q["lmax"], self.qlm, q["Ql_ref"], self.N)
+        self.cv = np.array([lam[0] / self.N, self.mesh.spectral(self.N), s_ql, en[0]])
+        self.bias = self.metad.update_bias(timestep, self.cv)
+        self.forces = [r.lamellar_forces(self.LV, self.opt, self.MODE, self.box, self.bias[0], n_global=self.N),
+                       self.mesh.forces(self.opt, self.box, self.bias[1], n_global=self.N),
+                       r.ql_compute_forces(self.opt_ql, self.box, *self.nlist, q["rcut"], q["ron"], q["lmax"], 0, q["Ql_ref"], self.qlm,
+                                           self.bias[2], n_global=self.N)[:len(self.ids)]]
+
+
+def _worker_cvset(rank, world, port, out):
+    _setup_paths()
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import mtd_ref
+        import util
+        from metadynamics.sharded import ShardedBiasStep
+        pos, Lc = util.fcc_lattice(4)
+        rng = np.random.default_rng(17)
+        pos = pos + rng.normal(0, 0.05, pos.shape)
+        n = len(pos)
+        types = (np.arange(n) % 2).astype(np.int32)
+        energy = rng.normal(-0.5, 0.1, n)
+        # single-rank values fix the grid ranges (identical on both ranks: same seeds)
+        full = np.arange(n)
+        probe = OracleCvSetBackend(pos, types, Lc, full, energy, 3.0, dict(sigma=[1, 1, 1, 1], cv_min=[0] * 4, cv_max=[1] * 4, num_points=[2] * 4))
+        probe.force_pass(probe.cv_pass(), 0)
+        s = probe.cv
+        grid = dict(sigma=[0.05, 0.1 * abs(s[1]), 0.02 * s[2], 2.0], cv_min=[s[0] - 0.5, 0.3 * s[1], 0.6 * s[2], s[3] - 20.0],
+                    cv_max=[s[0] + 0.6, 1.8 * s[1], 1.3 * s[2], s[3] + 27.0], num_points=[12, 10, 12, 10])
+        ids = np.where(pos[:, 0] < 0)[0] if rank == 0 else np.where(pos[:, 0] >= 0)[0]
+        be = OracleCvSetBackend(pos, types, Lc, ids, energy, 1.0 if rank == 0 else 2.0, grid)
+        step = ShardedBiasStep(be, dist)
+        single = OracleCvSetBackend(pos, types, Lc, full, energy, 3.0, grid)
+        ok = True
+        for t in range(3):
+            step.step(t)
+            single.force_pass(single.cv_pass(), t)
+            ok &= bool(np.allclose(be.cv, single.cv, rtol=1e-10, atol=1e-14))
+            ok &= bool(np.allclose(be.bias, single.bias, rtol=1e-6, atol=1e-9 * np.abs(single.bias).max()))
+            for c in range(3):
+                ref_f = single.forces[c][ids]
+                ok &= bool(np.abs(be.forces[c][:, :3] - ref_f[:, :3]).max() <= 1e-6 * np.abs(single.forces[c][:, :3]).max() + 1e-16)
+        ok &= float(np.abs(single.bias).max()) > 0
+        g = torch.from_numpy(be.metad.array("grid").copy())
+        gl = [torch.zeros_like(g) for _ in range(world)]
+        dist.all_gather(gl, g)
+        ok &= all(bool(torch.equal(gl[0], x)) for x in gl[1:])
+        out[rank] = ok
+    finally:
+        dist.destroy_process_group()
+
+
 def _run(worker):
     world = 2
     mgr = mp.Manager()
@@ -189,3 +293,8 @@ def test_sharded_particles_two_ranks():
 
 def test_multiple_walkers_two_ranks():
     _run(_worker_walkers)
+
+
+def test_sharded_cv_set_two_ranks():
+    """lamellar + mesh + Steinhardt (with ghosts) + wrapped energy: one all-reduce per CV buffer"""
+    _run(_worker_cvset)
