@@ -120,7 +120,7 @@ __global__ __launch_bounds__(CV_THREADS) void k_lamellar_mode_partials(const Lam
     }
 
 // ---------------------------------------------------------------------------------------------
-// out[c] = shift + scale * sum_b partials[b*stride + c]; wave w owns outputs c = w, w+4, ...
+// out[c] = shift + scale * sum_b partials[b*stride + c]; wave w of block g owns output c = 4 g + w
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_reduce_partials(const double *__restrict__ partials, const unsigned int n_partials,
                                                          const unsigned int stride, const unsigned int count,
@@ -128,13 +128,12 @@ __global__ __launch_bounds__(256) void k_reduce_partials(const double *__restric
     {
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    for (unsigned int c = wave; c < count; c += 4)
-        {
-        double v = 0.0;
-        for (unsigned int b = lane; b < n_partials; b += MTD_WAVE) v += partials[(size_t)b * stride + c];
-        v = wave_sum(v);
-        if (lane == 0) out[c] = shift + scale * v;
-        }
+    const unsigned int c = blockIdx.x * 4 + wave;
+    if (c >= count) return;
+    double v = 0.0;
+    for (unsigned int b = lane; b < n_partials; b += MTD_WAVE) v += partials[(size_t)b * stride + c];
+    v = wave_sum(v);
+    if (lane == 0) out[c] = shift + scale * v;
     }
 
 // ---------------------------------------------------------------------------------------------
@@ -303,7 +302,7 @@ int mtd_reduce_partials(const double *d_partials, unsigned int n_partials, unsig
                         unsigned int count, double scale, double shift, double *d_out, mtd_stream_t stream)
     {
     if (!d_partials || !d_out || count == 0) return MTD_ERR_INVALID_ARGUMENT;
-    k_reduce_partials<<<1, 256, 0, (hipStream_t)stream>>>(d_partials, n_partials, stride, count, scale, shift, d_out);
+    k_reduce_partials<<<(count + 3) / 4, 256, 0, (hipStream_t)stream>>>(d_partials, n_partials, stride, count, scale, shift, d_out);
     MTD_LAUNCH_CHECK();
     return MTD_SUCCESS;
     }

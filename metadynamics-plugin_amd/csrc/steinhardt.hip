@@ -4,15 +4,25 @@
 // spherical harmonics of spherical_harmonics.hpp:32-246 (fsph).  The reference has NO GPU implementation of this
 // CV (SURVEY §2.4 "new"): it runs a host loop that constructs a PointSPHEvaluator (five heap arrays) per pair.
 //
-// MI355X design (vector-ALU bound, ~7 kflop per pair in the force pass, not HBM bound):
-//   k_ql_accumulate   one thread per central particle; per pair the Y_lm(m >= 0) come from the same Jacobi
-//                     recurrence in registers (cos/sin of the angles from dx/r — no acos/atan2, no heap);
-//                     Q'_lm = sum f Y_lm kept in registers (28 complex at lmax = 6), reduced wave -> block in a
-//                     fixed order; negative m are conjugates, the Condon-Shortley phase is applied at the end
+// MI355X design (vector-ALU bound in fp64, not HBM bound):
+//   pair-parallel mapping: a block walks chunks of 16 consecutive central particles; the ~230 neighbour-list entries of a
+//                     chunk are spread one per thread (owner found by a 4-step search over the chunk's prefix counts in
+//                     LDS), so the waves stay ~90 % full whatever the per-particle neighbour counts are, and enough
+//                     waves exist to hide the fp64 dependency chains (one thread per particle ran at occupancy 1)
+//   k_ql_accumulate   per pair the real amplitudes A_lm(theta) (m >= 0) come from fsph's Jacobi recurrence in registers
+//                     (cos/sin of the angles from dx/r — no acos/atan2, no heap); Q'_lm += f A_lm e^{i m phi} is kept in
+//                     registers (28 complex at lmax = 6) and reduced wave -> block in a fixed order; negative m are
+//                     conjugates, the Condon-Shortley phase is applied at the end
 //   k_reduce_partials (lamellar.hip) -> Q'_lm ; [multi-GPU: all-reduce of (lmax+1)(lmax+2) doubles here]
 //   k_ql_finalize     full Q_lm table in the reference's order, third-law scaling, Q_l, CV value
-//   k_ql_forces       one thread per central particle, Q_lm broadcast from LDS, spherical-basis gradient of every
-//                     (l, m) term exactly as :287-321
+//   k_ql_forces       the spherical-basis gradient of :287-321 contracted BEFORE it is expanded: with
+//                     Y_lm = A_lm e^{i m phi}, dY/dtheta = (m cot A_lm + c_lm A_l,m+1) e^{i m phi}, dY/dphi = i m Y_lm and
+//                     z = e^{i m phi} conj(Q_lm) w_l, the pair force is -(alpha U + beta V + gamma W) with three scalars
+//                     U = sum A Re z, V = sum (dA/dtheta) Re z, W = -sum m A Im z and three real vectors
+//                     alpha = d f'/r, beta = (f/r) e_theta, gamma = (f/rho) e_phi; m < 0 terms equal their m > 0 partners
+//                     (Y_l,-m = (-1)^m conj Y_lm), so only m >= 0 is visited (weight 2), and degrees with Ql_ref[l] = 0
+//                     are skipped.  ~0.4 kflop per pair instead of ~4.5.  Per-particle sums over the pairs of a chunk in
+//                     a fixed order through LDS (deterministic, no atomics for full lists).
 // Double precision throughout.
 #include "mtd_device.hpp"
 
@@ -24,21 +34,37 @@ namespace
 
 using namespace mtd;
 
-constexpr int QL_THREADS = 128;
+constexpr int QL_THREADS = 256;
+constexpr int QL_PPB = 128;                     // central particles per chunk
+constexpr int QL_CAP = 2048;                    // pair slots staged in LDS per batch (3 doubles each = 48 KB)
 constexpr unsigned int QL_MAX_BLOCKS = 1024;
 
 template<int LMAX> struct QlArgs
     {
-    double lo[3], L[3], xy, xz, yz;
-    double rcutsq, ronsq, r_on, r_cut;
+    double lo[3], L[3], Linv[3], xy, xz, yz;
+    double rcutsq, ronsq, r_on, r_cut, inv_width;
     unsigned int lmax, type, N, n_global;
     int half_nlist, _pad;
-    // Jacobi recurrence prefactors (spherical_harmonics.hpp:151-175), [m][l] for l = 1..LMAX
-    double f0[LMAX + 1][LMAX + 1];
-    double f1[LMAX + 1][LMAX + 1];
-    double jac0[LMAX + 1];              // jacobi[m][0] = 1/sqrt(2) prod sqrt(1 + 1/2m) (:197-201)
     double ql_ref[LMAX + 1];
     };
+
+// Jacobi recurrence prefactors (spherical_harmonics.hpp:151-175) and jacobi[m][0] (:197-201).  They depend on (m, n) only,
+// so in the fully unrolled loops they fold to literals: no table in the kernel arguments, no scalar registers tied up
+// (a [m][n] table in the argument segment cost ~340 v_readlane per pair in spilled scalars)
+__device__ __forceinline__ double jac_f0(const int m, const int n)
+    {
+    return 2 * sqrt(1 + (m - 0.5) / n) * sqrt(1 - (m - 0.5) / (n + 2 * m));
+    }
+__device__ __forceinline__ double jac_f1(const int m, const int n)
+    {
+    return -sqrt(1.0 + 4.0 / (2 * n + 2 * m - 3)) * sqrt(1 - 1.0 / n) * sqrt(1.0 - 1.0 / (n + 2 * m));
+    }
+__device__ __forceinline__ double jac_0(const int m)
+    {
+    double v = 0.70710678118654752440084436210484903928483593768847;    // 1 / sqrt(2)
+    for (int k = 1; k <= m; ++k) v *= sqrt(1 + 1.0 / 2 / k);
+    return v;
+    }
 
 struct cplx
     {
@@ -52,114 +78,256 @@ __device__ __forceinline__ cplx cadd(cplx a, cplx b) { return {a.re + b.re, a.im
 template<int LMAX>
 __device__ __forceinline__ void min_image(const QlArgs<LMAX> &a, double &x, double &y, double &z)
     {
-    double img = rint(z / a.L[2]);
+    // HOOMD BoxDim::minImage: nearest image counts from the reciprocal box lengths
+    double img = rint(z * a.Linv[2]);
     z -= a.L[2] * img;
     y -= a.L[2] * a.yz * img;
     x -= a.L[2] * a.xz * img;
-    img = rint(y / a.L[1]);
+    img = rint(y * a.Linv[1]);
     y -= a.L[1] * img;
     x -= a.L[1] * a.xy * img;
-    x -= a.L[0] * rint(x / a.L[0]);
+    x -= a.L[0] * rint(x * a.Linv[0]);
     }
 
-template<int LMAX> __device__ __forceinline__ double f_smooth(const QlArgs<LMAX> &a, double rsq)          // :36-48
+// cos(pi x) and sin(pi x) for x in [0, 1] (the smoothing window): with y = x - 1/2, cos(pi x) = -sin(pi y) and
+// sin(pi x) = cos(pi y), |pi y| <= pi/2, Taylor series in z^2 to z^21 / z^20 (truncation < 3e-16); ~25 FMAs instead of
+// the ~80 instructions of the general-range library routine
+__device__ __forceinline__ void sincospi_unit(const double x, double &sn, double &cs)
     {
-    if (rsq <= a.ronsq) return 1.0;
-    if (rsq > a.rcutsq) return 0.0;
-    const double r = sqrt(rsq);
-    return 0.5 * (cospi((r - a.r_on) / (a.r_cut - a.r_on)) + 1.0);
+    const double z = M_PI * (x - 0.5), z2 = z * z;
+    double s = -1.0 / 51090942171709440000.0;          // -1/21!
+    s = s * z2 + 1.0 / 121645100408832000.0;           //  1/19!
+    s = s * z2 - 1.0 / 355687428096000.0;              // -1/17!
+    s = s * z2 + 1.0 / 1307674368000.0;                //  1/15!
+    s = s * z2 - 1.0 / 6227020800.0;                   // -1/13!
+    s = s * z2 + 1.0 / 39916800.0;                     //  1/11!
+    s = s * z2 - 1.0 / 362880.0;                       // -1/9!
+    s = s * z2 + 1.0 / 5040.0;                         //  1/7!
+    s = s * z2 - 1.0 / 120.0;                          // -1/5!
+    s = s * z2 + 1.0 / 6.0;                            //  1/3!
+    const double sin_z = z - z * z2 * s;
+    double c = 1.0 / 2432902008176640000.0;            //  1/20!
+    c = c * z2 - 1.0 / 6402373705728000.0;             // -1/18!
+    c = c * z2 + 1.0 / 20922789888000.0;               //  1/16!
+    c = c * z2 - 1.0 / 87178291200.0;                  // -1/14!
+    c = c * z2 + 1.0 / 479001600.0;                    //  1/12!
+    c = c * z2 - 1.0 / 3628800.0;                      // -1/10!
+    c = c * z2 + 1.0 / 40320.0;                        //  1/8!
+    c = c * z2 - 1.0 / 720.0;                          // -1/6!
+    c = c * z2 + 1.0 / 24.0;                           //  1/4!
+    c = c * z2 - 0.5;                                  // -1/2!
+    const double cos_z = 1.0 + z2 * c;
+    cs = -sin_z;
+    sn = cos_z;
     }
 
-template<int LMAX> __device__ __forceinline__ double fprime_smooth_divr(const QlArgs<LMAX> &a, double rsq)   // :50-60
+// smoothing function f (:36-48) and f'/r (:50-60); r = rsq * inv_r
+template<int LMAX>
+__device__ __forceinline__ void smoothing(const QlArgs<LMAX> &a, const double rsq, const double inv_r, double &f, double &fprime_divr)
     {
-    if (rsq <= a.ronsq || rsq > a.rcutsq) return 0.0;
-    const double r = sqrt(rsq);
-    return -(0.5 * M_PI) / r / (a.r_cut - a.r_on) * sinpi((r - a.r_on) / (a.r_cut - a.r_on));
-    }
-
-// Y'_lm (no Condon-Shortley phase) for 0 <= m <= l <= lmax at direction (dx,dy,dz)/r:
-// Y[m][l] = sin^m(theta) * jacobi[m][l-m] / sqrt(2 pi) * e^{i m phi}   (spherical_harmonics.hpp:78-93, 177-226)
-// SCALE: every Y is multiplied by `scale` and ADDED into Y[m][l] (accumulate = true) or stored (false)
-template<int LMAX, bool ACCUMULATE>
-__device__ __forceinline__ void ylm_table(const QlArgs<LMAX> &a, const double ct, const double st, const double cp, const double sp,
-                                          const double scale, cplx (&Y)[LMAX + 1][LMAX + 1])
-    {
-    const double inv_sqrt_2pi = 0.3989422804014326779399460599343818684758586311649;
-    double sinpow = 1.0;
-    cplx harm = {1.0, 0.0};                      // e^{i m phi}
-#pragma unroll
-    for (int m = 0; m <= LMAX; ++m)
+    f = 1.0;
+    fprime_divr = 0.0;
+    if (rsq > a.ronsq)
         {
-        if (m <= (int)a.lmax)
-            {
-            // jacobi recurrence in the degree n = l - m (:203-211)
-            double jm2 = 0.0, jm1 = a.jac0[m];
+        double sn, cs;
+        sincospi_unit((rsq * inv_r - a.r_on) * a.inv_width, sn, cs);
+        f = 0.5 * (cs + 1.0);
+        fprime_divr = -(0.5 * M_PI) * inv_r * a.inv_width * sn;
+        }
+    }
+
+// pair geometry shared by both passes: unit-vector trigonometry straight from the separation (theta = acos(dz/r),
+// phi = atan2(dy, dx) of :138-139 without the inverse functions)
+struct PairGeom
+    {
+    double dx, dy, dz, rsq, inv_r, inv_rho, ct, st, cp, sp;
+    };
+
+__device__ __forceinline__ PairGeom pair_geom(double dx, double dy, double dz, double rsq)
+    {
+    PairGeom g;
+    g.dx = dx; g.dy = dy; g.dz = dz; g.rsq = rsq;
+    g.inv_r = rsqrt(rsq);
+    const double rho2 = dx * dx + dy * dy;
+    const bool off_axis = rho2 > 0.0;
+    g.inv_rho = off_axis ? rsqrt(rho2) : INFINITY;      // on the z axis 1/(r sin theta) is inf like the reference
+    g.ct = dz * g.inv_r;
+    g.st = off_axis ? rho2 * g.inv_rho * g.inv_r : 0.0;
+    g.cp = off_axis ? dx * g.inv_rho : 1.0;                  // atan2(0, 0) = 0
+    g.sp = off_axis ? dy * g.inv_rho : 0.0;
+    return g;
+    }
+
+// column m of the raw amplitudes (no Condon-Shortley phase): col[l] = scale * jacobi[m][l-m], l = m..lmax, where the caller
+// passes scale = sin^m(theta) / sqrt(2 pi) (times f in the CV pass) (spherical_harmonics.hpp:78-93, 177-226); the
+// recurrence runs in the degree n = l - m (:203-211).  m is a compile-time constant in the unrolled callers.
+template<int LMAX>
+__device__ __forceinline__ void amplitude_column(const QlArgs<LMAX> &a, const int m, const double ct, const double scale,
+                                                 double (&col)[LMAX + 1])
+    {
+    double jm2 = 0.0, jm1 = jac_0(m);
 #pragma unroll
-            for (int n = 0; n + m <= LMAX; ++n)
+    for (int n = 0; n <= LMAX; ++n)
+        {
+        if (n + m <= LMAX)                       // degrees above the run-time lmax are computed too and never read: no selects
+            {
+            double j;
+            if (n == 0)
+                j = jac_0(m);
+            else if (n == 1)
+                j = ct * jac_f0(m, 1) * jm1;
+            else
+                j = ct * jac_f0(m, n) * jm1 + jac_f1(m, n) * jm2;
+            col[n + m] = scale * j;
+            jm2 = jm1;
+            jm1 = j;
+            }
+        }
+    }
+
+// chunk bookkeeping shared by both passes: the neighbour-list segments of QL_PPB consecutive central particles, flattened;
+// the separations of up to QL_CAP pairs are gathered into LDS first (phase 1: independent loads, many in flight per
+// thread), the fp64 arithmetic then runs on LDS operands only (phase 2)
+struct ChunkShared
+    {
+    unsigned int start[QL_PPB];       // head_list of the particle
+    unsigned int off[QL_PPB + 1];     // exclusive prefix of the neighbour counts inside the chunk
+    unsigned int wave_total[QL_PPB / MTD_WAVE];
+    double px[QL_PPB], py[QL_PPB], pz[QL_PPB];     // the central particles' own positions
+    double dx[QL_CAP], dy[QL_CAP], dz[QL_CAP];     // min-imaged separations r_i - r_j; excluded pairs carry an infinite dx
+    };
+
+template<typename S4, int LMAX>
+__device__ __forceinline__ void chunk_setup(const QlArgs<LMAX> &a, const S4 *__restrict__ postype,
+                                            const unsigned int *__restrict__ head_list, const unsigned int *__restrict__ n_neigh,
+                                            const unsigned int chunk, ChunkShared &cs)
+    {
+    __syncthreads();                                                             // previous chunk fully consumed
+    unsigned int incl = 0;
+    if (threadIdx.x < QL_PPB)
+        {
+        const unsigned int i = chunk * QL_PPB + threadIdx.x;
+        unsigned int st = 0, cnt = 0;
+        if (i < a.N)
+            {
+            const Particle pi = scalar4_traits<S4>::load(postype, i);
+            cs.px[threadIdx.x] = pi.x;
+            cs.py[threadIdx.x] = pi.y;
+            cs.pz[threadIdx.x] = pi.z;
+            if ((unsigned int)pi.type == a.type)                                 // :105
                 {
-                if (n + m <= (int)a.lmax)
-                    {
-                    double j;
-                    if (n == 0)
-                        j = a.jac0[m];
-                    else if (n == 1)
-                        j = ct * a.f0[m][1] * jm1;
-                    else
-                        j = ct * a.f0[m][n] * jm1 + a.f1[m][n] * jm2;
-                    const double leg = sinpow * j * inv_sqrt_2pi * scale;
-                    if (ACCUMULATE)
-                        {
-                        Y[m][n + m].re += leg * harm.re;
-                        Y[m][n + m].im += leg * harm.im;
-                        }
-                    else
-                        Y[m][n + m] = {leg * harm.re, leg * harm.im};
-                    jm2 = jm1;
-                    jm1 = j;
-                    }
+                st = head_list[i];
+                cnt = n_neigh[i];
                 }
             }
-        sinpow *= st;
-        harm = cmul(harm, {cp, sp});
+        cs.start[threadIdx.x] = st;
+        // inclusive scan of the counts inside each wave
+        incl = cnt;
+        const int lane = threadIdx.x & 63;
+#pragma unroll
+        for (int d = 1; d < MTD_WAVE; d <<= 1)
+            {
+            const unsigned int up = __shfl_up(incl, d, MTD_WAVE);
+            if (lane >= d) incl += up;
+            }
+        if (lane == 63) cs.wave_total[threadIdx.x >> 6] = incl;
         }
+    __syncthreads();
+    if (threadIdx.x < QL_PPB)
+        {
+        unsigned int base = 0;
+        for (unsigned int w = 0; w < (threadIdx.x >> 6); ++w) base += cs.wave_total[w];
+        cs.off[threadIdx.x + 1] = base + incl;
+        if (threadIdx.x == 0) cs.off[0] = 0;
+        }
+    __syncthreads();
+    }
+
+__device__ __forceinline__ unsigned int chunk_owner(const ChunkShared &cs, const unsigned int e)
+    {
+    unsigned int p = 0;
+#pragma unroll
+    for (unsigned int step = QL_PPB / 2; step > 0; step >>= 1)
+        if (cs.off[p + step] <= e) p += step;
+    return p;
+    }
+
+// phase 1: gather the separations of entries [base, base + QL_CAP) of the chunk into LDS
+template<typename S4, int LMAX>
+__device__ __forceinline__ void chunk_gather(const QlArgs<LMAX> &a, const S4 *__restrict__ postype,
+                                             const unsigned int *__restrict__ nlist, const unsigned int base, const unsigned int n,
+                                             ChunkShared &cs, unsigned int *s_j)
+    {
+#pragma unroll 4
+    for (unsigned int t = threadIdx.x; t < n; t += QL_THREADS)
+        {
+        const unsigned int e = base + t;
+        const unsigned int p = chunk_owner(cs, e);
+        const unsigned int j = nlist[cs.start[p] + (e - cs.off[p])];
+        const Particle pj = scalar4_traits<S4>::load(postype, j);
+        double dx = cs.px[p] - pj.x, dy = cs.py[p] - pj.y, dz = cs.pz[p] - pj.z;
+        min_image(a, dx, dy, dz);
+        if ((unsigned int)pj.type != a.type) dx = INFINITY;                    // :126 -> fails the cut-off test
+        cs.dx[t] = dx;
+        cs.dy[t] = dy;
+        cs.dz[t] = dz;
+        if (s_j) s_j[t] = j;
+        }
+    __syncthreads();
     }
 
 // ---- CV accumulation -------------------------------------------------------------------------------
 template<typename S4, int LMAX>
-__global__ __launch_bounds__(QL_THREADS) void k_ql_accumulate(const QlArgs<LMAX> a, const S4 *__restrict__ postype,
-                                                              const unsigned int *__restrict__ head_list,
-                                                              const unsigned int *__restrict__ n_neigh,
-                                                              const unsigned int *__restrict__ nlist, double *__restrict__ partials)
+__global__ __launch_bounds__(QL_THREADS, 2) void k_ql_accumulate(const QlArgs<LMAX> a, const S4 *__restrict__ postype,
+                                                                 const unsigned int *__restrict__ head_list,
+                                                                 const unsigned int *__restrict__ n_neigh,
+                                                                 const unsigned int *__restrict__ nlist, double *__restrict__ partials)
     {
     constexpr int NLM = (LMAX + 1) * (LMAX + 2) / 2;
     __shared__ double s_wave[QL_THREADS / MTD_WAVE][2 * NLM];
+    __shared__ ChunkShared cs;
     cplx Q[LMAX + 1][LMAX + 1];
 #pragma unroll
     for (int m = 0; m <= LMAX; ++m)
 #pragma unroll
         for (int l = 0; l <= LMAX; ++l) Q[m][l] = {0.0, 0.0};
 
-    for (unsigned int i = blockIdx.x * blockDim.x + threadIdx.x; i < a.N; i += gridDim.x * blockDim.x)
+    const unsigned int n_chunks = (a.N + QL_PPB - 1) / QL_PPB;
+    for (unsigned int chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x)
         {
-        const Particle pi = scalar4_traits<S4>::load(postype, i);
-        if ((unsigned int)pi.type != a.type) continue;                         // :105
-        const unsigned int head = head_list[i], size = n_neigh[i];
-        for (unsigned int k = 0; k < size; ++k)
+        chunk_setup<S4, LMAX>(a, postype, head_list, n_neigh, chunk, cs);
+        const unsigned int total = cs.off[QL_PPB];
+        for (unsigned int base = 0; base < total; base += QL_CAP)
             {
-            const unsigned int j = nlist[head + k];
-            const Particle pj = scalar4_traits<S4>::load(postype, j);
-            if ((unsigned int)pj.type != a.type) continue;                     // :126
-            double dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
-            min_image(a, dx, dy, dz);
-            const double rsq = dx * dx + dy * dy + dz * dz;
-            if (rsq <= a.rcutsq)
+            const unsigned int n = min(total - base, (unsigned int)QL_CAP);
+            if (base) __syncthreads();                                         // previous batch consumed
+            chunk_gather<S4, LMAX>(a, postype, nlist, base, n, cs, nullptr);
+            for (unsigned int t = threadIdx.x; t < n; t += QL_THREADS)
                 {
-                const double f = f_smooth(a, rsq);
-                const double r = sqrt(rsq);
-                const double rho = sqrt(dx * dx + dy * dy);
-                const double ct = dz / r, st = rho / r;                         // theta = acos(dz/r) (:138)
-                const double cp = rho > 0.0 ? dx / rho : 1.0, sp = rho > 0.0 ? dy / rho : 0.0;   // phi = atan2(dy,dx)
-                ylm_table<LMAX, true>(a, ct, st, cp, sp, f, Q);   // Q'_lm += f * Y_lm, straight from the recurrence
+                const double dx = cs.dx[t], dy = cs.dy[t], dz = cs.dz[t];
+                const double rsq = dx * dx + dy * dy + dz * dz;
+                if (!(rsq <= a.rcutsq)) continue;
+                const PairGeom g = pair_geom(dx, dy, dz, rsq);
+                double f, fprime_divr;
+                smoothing(a, rsq, g.inv_r, f, fprime_divr);
+                // Q'_lm += f * Y'_lm, column by column
+                double sinpow = f * 0.3989422804014326779399460599343818684758586311649;   // 1 / sqrt(2 pi)
+                cplx harm = {1.0, 0.0};                                        // e^{i m phi}
+#pragma unroll
+                for (int m = 0; m <= LMAX; ++m)
+                    {
+                    double col[LMAX + 1];
+                    amplitude_column<LMAX>(a, m, g.ct, 1.0, col);
+                    const double hr = sinpow * harm.re, hi = sinpow * harm.im;
+#pragma unroll
+                    for (int l = m; l <= LMAX; ++l)
+                        {
+                        Q[m][l].re += col[l] * hr;
+                        Q[m][l].im += col[l] * hi;
+                        }
+                    sinpow *= g.st;
+                    harm = cmul(harm, {g.cp, g.sp});
+                    }
                 }
             }
         }
@@ -230,117 +398,156 @@ __global__ void k_ql_finalize(const QlArgs<LMAX> a, const double *__restrict__ q
 
 // ---- forces ----------------------------------------------------------------------------------------------
 template<typename S4, int LMAX, bool HALF>
-__global__ __launch_bounds__(QL_THREADS) void k_ql_forces(const QlArgs<LMAX> a, const S4 *__restrict__ postype,
-                                                          const unsigned int *__restrict__ head_list,
-                                                          const unsigned int *__restrict__ n_neigh,
-                                                          const unsigned int *__restrict__ nlist, const double *__restrict__ qlm_full,
-                                                          S4 *__restrict__ force, const double *__restrict__ d_bias, const double bias_host)
+__global__ __launch_bounds__(QL_THREADS, 2) void k_ql_forces(const QlArgs<LMAX> a, const S4 *__restrict__ postype,
+                                                             const unsigned int *__restrict__ head_list,
+                                                             const unsigned int *__restrict__ n_neigh,
+                                                             const unsigned int *__restrict__ nlist, const double *__restrict__ qlm_full,
+                                                             S4 *__restrict__ force, const double *__restrict__ d_bias, const double bias_host)
     {
     typedef typename scalar4_traits<S4>::scalar scalar;
-    constexpr int NFULL = (LMAX + 1) * (LMAX + 1);
-    __shared__ double s_q[2 * NFULL];
-    for (unsigned int q = threadIdx.x; q < 2 * (a.lmax + 1) * (a.lmax + 1); q += blockDim.x) s_q[q] = qlm_full[q];
-    __syncthreads();
+    constexpr int NLM = (LMAX + 1) * (LMAX + 2) / 2;
+    __shared__ double s_qw[2 * NLM];                 // w_l (2 or 4) conj(Q_lm), m >= 0, index l(l+1)/2 + m
+    __shared__ ChunkShared cs;
+    __shared__ unsigned int s_j[HALF ? QL_CAP : 1];
     const double bias = d_bias ? *d_bias : bias_host;
     const double ng = (double)a.n_global;
-
-    for (unsigned int i = blockIdx.x * blockDim.x + threadIdx.x; i < a.N; i += gridDim.x * blockDim.x)
+    unsigned int active_l = 0;
+#pragma unroll
+    for (int l = 0; l <= LMAX; ++l)
+        if (l <= (int)a.lmax && a.ql_ref[l] != 0.0) active_l |= 1u << l;
+    for (unsigned int q = threadIdx.x; q < (unsigned int)NLM; q += blockDim.x)
         {
-        const Particle pi = scalar4_traits<S4>::load(postype, i);
-        double Fx = 0.0, Fy = 0.0, Fz = 0.0;
-        if ((unsigned int)pi.type == a.type)
+        // (l, m) of the packed index
+        int l = 0;
+        while ((l + 1) * (l + 2) / 2 <= (int)q) ++l;
+        const int m = (int)q - l * (l + 1) / 2;
+        double re = 0.0, im = 0.0;
+        if (l <= (int)a.lmax)
             {
-            const unsigned int head = head_list[i], size = n_neigh[i];
-            for (unsigned int k = 0; k < size; ++k)
+            const double w = bias * (4.0 * M_PI / (2 * l + 1)) / (ng * ng) * a.ql_ref[l] * (m > 0 ? 4.0 : 2.0);   // :316-321
+            const int n = l * l + m;                                             // reference order: m = 0..l, then -1..-l
+            re = w * qlm_full[2 * n];
+            im = -w * qlm_full[2 * n + 1];
+            }
+        s_qw[2 * q] = re;
+        s_qw[2 * q + 1] = im;
+        }
+    // chunk_setup's first barrier publishes s_qw
+
+    const unsigned int n_chunks = (a.N + QL_PPB - 1) / QL_PPB;
+    for (unsigned int chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x)
+        {
+        chunk_setup<S4, LMAX>(a, postype, head_list, n_neigh, chunk, cs);
+        const unsigned int total = cs.off[QL_PPB];
+        double Fx = 0.0, Fy = 0.0, Fz = 0.0;                                     // thread p < QL_PPB: running force of particle p
+        for (unsigned int base = 0; base < total; base += QL_CAP)
+            {
+            const unsigned int n = min(total - base, (unsigned int)QL_CAP);
+            if (base) __syncthreads();
+            chunk_gather<S4, LMAX>(a, postype, nlist, base, n, cs, HALF ? s_j : nullptr);
+            for (unsigned int t = threadIdx.x; t < n; t += QL_THREADS)
                 {
-                const unsigned int j = nlist[head + k];
-                const Particle pj = scalar4_traits<S4>::load(postype, j);
-                if ((unsigned int)pj.type != a.type) continue;
-                double dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z;
-                min_image(a, dx, dy, dz);
+                const double dx = cs.dx[t], dy = cs.dy[t], dz = cs.dz[t];
                 const double rsq = dx * dx + dy * dy + dz * dz;
-                if (!(rsq <= a.rcutsq)) continue;
-                const double r = sqrt(rsq);
-                const double rho = sqrt(dx * dx + dy * dy);
-                const double ct = dz / r, st = rho / r;
-                const double cp = rho > 0.0 ? dx / rho : 1.0, sp = rho > 0.0 ? dy / rho : 0.0;
-                const double e_theta[3] = {ct * cp, ct * sp, -st};               // :288
-                const double e_phi[3] = {-sp, cp, 0.0};
-                const double d[3] = {dx, dy, dz};
-                const double cot = ct / st;                                      // m / tan(theta) (:305); theta = 0 -> inf like the reference
-                const cplx emiphi = {cp, -sp};                                   // exp(-i phi)
-                const double fprime_divr = fprime_smooth_divr(a, rsq);
-                const double f = f_smooth(a, rsq);
-                cplx Y[LMAX + 1][LMAX + 1];
-                ylm_table<LMAX, false>(a, ct, st, cp, sp, 1.0, Y);
                 double fpx = 0.0, fpy = 0.0, fpz = 0.0;
-                int n = 0;
-#pragma unroll
-                for (int l = 0; l <= LMAX; ++l)
+                if (rsq <= a.rcutsq)
                     {
-                    if (l <= (int)a.lmax)
+                    const PairGeom g = pair_geom(dx, dy, dz, rsq);
+                    double f, fprime_divr;
+                    smoothing(a, rsq, g.inv_r, f, fprime_divr);
+                    const double cot = g.dz * g.inv_rho;                         // m / tan(theta) (:305); theta = 0 -> inf like the reference
+                    double U = 0.0, V = 0.0, W = 0.0;
+                    // ascending m; the terms of order m need column m + 1 as well, so they run one step late
+                    double prev[LMAX + 1], cur[LMAX + 1];
+                    double sinpow = 0.3989422804014326779399460599343818684758586311649;         // 1 / sqrt(2 pi)
+                    cplx harm = {1.0, 0.0}, harm_prev = {1.0, 0.0};
+#pragma unroll
+                    for (int mm = 0; mm <= LMAX + 1; ++mm)
                         {
-                        double del[3] = {0.0, 0.0, 0.0};
-#pragma unroll
-                        for (int p = 0; p < 2 * l + 1; ++p)
+                        if (mm <= LMAX)                                          // Condon-Shortley phase for odd m (:150, :303-304)
+                            amplitude_column<LMAX>(a, mm, g.ct, (mm % 2) ? -sinpow : sinpow, cur);
+                        if (mm >= 1)
                             {
-                            const int m = (p <= l) ? p : (l - p);
-                            const int am = m < 0 ? -m : m;
-                            // Ylm_pp[n]: raw fsph value; Ylm = phase * Ylm_pp[n] (:303-304)
-                            cplx raw = Y[am][l];
-                            if (m < 0) raw = cconj(raw);
-                            const double phase = (m > 0 && (m % 2)) ? -1.0 : 1.0;
-                            const cplx Ylm = cscale(raw, phase);
-                            cplx dth = cscale(Ylm, (double)m * cot);               // (m / tan theta) * Ylm
-                            if (m < l)
-                                {
-                                // Ylm_pp[m_plus_one] (:308): the raw entry of m+1 (for m = -1: m+1 = 0)
-                                const int mp = m + 1;
-                                const int amp = mp < 0 ? -mp : mp;
-                                cplx rawp = Y[amp][l];
-                                if (mp < 0) rawp = cconj(rawp);
-                                const double phase_p = (mp > 0 && (mp % 2)) ? -1.0 : 1.0;
-                                const double c = phase_p * sqrt((double)((l - m) * (l + m + 1)));
-                                dth = cadd(dth, cscale(cmul(emiphi, rawp), c));
-                                }
-                            const cplx dph = {-(double)m * Ylm.im, (double)m * Ylm.re};   // i m Ylm (:312)
-                            const cplx qc = {s_q[2 * n], -s_q[2 * n + 1]};                 // conj(Qlm[n])
+                            const int m = mm - 1;
 #pragma unroll
-                            for (int c3 = 0; c3 < 3; ++c3)
+                            for (int l = m; l <= LMAX; ++l)
                                 {
-                                cplx t = cscale(Ylm, d[c3] * fprime_divr);
-                                t = cadd(t, cscale(dth, f / r * e_theta[c3]));
-                                t = cadd(t, cscale(dph, f * e_phi[c3] / (r * st)));
-                                const cplx tq = cmul(t, qc);
-                                del[c3] += 2.0 * tq.re;                                     // :316
+                                if (active_l & (1u << l))                        // degrees with Ql_ref[l] != 0 (and l <= lmax)
+                                    {
+                                    const int idx = l * (l + 1) / 2 + m;
+                                    const double qr = s_qw[2 * idx], qi = s_qw[2 * idx + 1];
+                                    const double zr = harm_prev.re * qr - harm_prev.im * qi;
+                                    const double zi = harm_prev.re * qi + harm_prev.im * qr;
+                                    const double A = prev[l];
+                                    // dA/dtheta: m cot A_lm + sqrt((l-m)(l+m+1)) A_l,m+1 (:305-309); column m+1 is `cur` (0 beyond lmax)
+                                    double B = (double)m * cot * A;
+                                    if (l > m && mm <= LMAX) B += sqrt((double)((l - m) * (l + m + 1))) * cur[l];
+                                    U += A * zr;
+                                    V += B * zr;
+                                    W -= (double)m * A * zi;                     // Re(i m Y z) (:312)
+                                    }
                                 }
-                            ++n;
                             }
-                        const double norm = (4.0 * M_PI / (2 * l + 1)) / (ng * ng);        // :319
-                        fpx -= bias * del[0] * norm * a.ql_ref[l];                          // :321
-                        fpy -= bias * del[1] * norm * a.ql_ref[l];
-                        fpz -= bias * del[2] * norm * a.ql_ref[l];
+#pragma unroll
+                        for (int l = 0; l <= LMAX; ++l) prev[l] = cur[l];
+                        harm_prev = harm;
+                        sinpow *= g.st;
+                        harm = cmul(harm, {g.cp, g.sp});
+                        }
+                    const double e_theta[3] = {g.ct * g.cp, g.ct * g.sp, -g.st};                 // :288
+                    const double e_phi[3] = {-g.sp, g.cp, 0.0};
+                    const double fa = fprime_divr * U, fb = f * g.inv_r * V, fc = f * g.inv_rho * W;   // 1/(r sin theta) = 1/rho
+                    fpx = -(fa * g.dx + fb * e_theta[0] + fc * e_phi[0]);
+                    fpy = -(fa * g.dy + fb * e_theta[1] + fc * e_phi[1]);
+                    fpz = -(fa * g.dz + fb * e_theta[2] + fc * e_phi[2]);
+                    if (HALF)                                                                    // :328-333
+                        {
+                        const unsigned int j = s_j[t];
+                        if (j < a.N)
+                            {
+                            scalar *fj = (scalar *)&force[j];
+                            atomicAdd(fj + 0, (scalar)(-fpx));
+                            atomicAdd(fj + 1, (scalar)(-fpy));
+                            atomicAdd(fj + 2, (scalar)(-fpz));
+                            }
                         }
                     }
-                Fx += fpx; Fy += fpy; Fz += fpz;
-                if (HALF && j < a.N)                                                        // :328-333
+                // the pair force replaces the separation in its own slot
+                cs.dx[t] = fpx;
+                cs.dy[t] = fpy;
+                cs.dz[t] = fpz;
+                }
+            __syncthreads();
+            // per-particle sums over this batch of pairs, in list order
+            if (threadIdx.x < QL_PPB)
+                {
+                const unsigned int lo = cs.off[threadIdx.x] > base ? cs.off[threadIdx.x] - base : 0u;
+                unsigned int hi = cs.off[threadIdx.x + 1] > base ? cs.off[threadIdx.x + 1] - base : 0u;
+                if (hi > n) hi = n;
+                for (unsigned int t = lo; t < hi; ++t)
                     {
-                    scalar *fj = (scalar *)&force[j];
-                    atomicAdd(fj + 0, (scalar)(-fpx));
-                    atomicAdd(fj + 1, (scalar)(-fpy));
-                    atomicAdd(fj + 2, (scalar)(-fpz));
+                    Fx += cs.dx[t];
+                    Fy += cs.dy[t];
+                    Fz += cs.dz[t];
                     }
                 }
             }
-        if (HALF)
+        if (threadIdx.x < QL_PPB)
             {
-            scalar *fi = (scalar *)&force[i];
-            atomicAdd(fi + 0, (scalar)Fx);
-            atomicAdd(fi + 1, (scalar)Fy);
-            atomicAdd(fi + 2, (scalar)Fz);
+            const unsigned int i = chunk * QL_PPB + threadIdx.x;
+            if (i < a.N)
+                {
+                if (HALF)
+                    {
+                    scalar *fi = (scalar *)&force[i];
+                    atomicAdd(fi + 0, (scalar)Fx);
+                    atomicAdd(fi + 1, (scalar)Fy);
+                    atomicAdd(fi + 2, (scalar)Fz);
+                    }
+                else
+                    force[i] = scalar4_traits<S4>::make((scalar)Fx, (scalar)Fy, (scalar)Fz, (scalar)0);
+                }
             }
-        else
-            force[i] = scalar4_traits<S4>::make((scalar)Fx, (scalar)Fy, (scalar)Fz, (scalar)0);
         }
     }
 
@@ -361,25 +568,18 @@ int fill_args(QlArgs<LMAX> &a, unsigned int N, const mtd_box *box, double rcut, 
     a.ronsq = ron * ron;
     a.r_on = std::sqrt(a.ronsq);
     a.r_cut = std::sqrt(a.rcutsq);
+    a.inv_width = 1.0 / (a.r_cut - a.r_on);
+    for (int i = 0; i < 3; ++i) a.Linv[i] = 1.0 / box->L[i];
     a.lmax = lmax; a.type = type; a.N = N; a.n_global = n_global; a.half_nlist = half;
-    // evaluatePrefactors (spherical_harmonics.hpp:151-175) for the RUNTIME lmax; jacobi[m][0] (:197-201)
-    for (unsigned int m = 0; m <= lmax; ++m)
-        {
-        for (unsigned int l = 1; l <= lmax; ++l) a.f0[m][l] = 2 * std::sqrt(1 + (m - 0.5) / l) * std::sqrt(1 - (m - 0.5) / (l + 2 * m));
-        a.f1[m][1] = 0;
-        for (unsigned int l = 2; l <= lmax; ++l)
-            a.f1[m][l] = -std::sqrt(1.0 + 4.0 / (2 * l + 2 * m - 3)) * std::sqrt(1 - 1.0 / l) * std::sqrt(1.0 - 1.0 / (l + 2 * m));
-        a.jac0[m] = m > 0 ? a.jac0[m - 1] * std::sqrt(1 + 1.0 / 2 / m) : 1 / std::sqrt(2.0);
-        }
     for (unsigned int l = 0; l <= lmax; ++l) a.ql_ref[l] = ql_ref[l];
     return MTD_SUCCESS;
     }
 
 unsigned int ql_blocks(unsigned int N)
     {
-    unsigned int b = (N + QL_THREADS - 1) / QL_THREADS;
+    unsigned int b = (N + QL_PPB - 1) / QL_PPB;
     if (b < 1) b = 1;
-    if (b > QL_MAX_BLOCKS) b = QL_MAX_BLOCKS;
+    if (b > 512) b = 512;                      // 2 resident blocks per CU (LDS: 48 KB pair slots each)
     return b;
     }
 
