@@ -8,12 +8,16 @@
 // final-reduce launches (:510-541, :771-885), texture-bound force gather (:566-754).
 //
 // MI355X design: single rank, no ghost cells (the multi-GPU plan replicates the mesh).
-//   1 k_mesh_count      cell of every particle, per-cell counts, block sums of mode^2
-//   2 scan (3 tiny kernels)  exclusive scan of the counts -> cell starts
-//   3 k_mesh_fill       particle ids into their cell's slots (atomic cursor)
-//   4 k_mesh_sort       per cell: ids sorted ascending (=> bitwise reproducible sums), (shift, mode) packed
-//   5 k_mesh_gather     one thread per mesh cell sums the TSC weights of the particles in its 27 neighbour
-//                       cells: no atomics on the mesh, no scratch, every mesh cell written exactly once
+//   1 k_mesh_bin        cell of every particle and its arrival slot in that cell (ONE returning atomic per particle),
+//                       block sums of mode^2
+//   2 scan (2 kernels)  exclusive scan of the counts -> cell starts; the counters are cleared for the next call
+//   3 k_mesh_place      (shift, mode) record, id and cell of every particle written to start[cell] + slot
+//   4 k_mesh_sortfix    cells holding >= 2 particles: records ordered by particle id (=> bitwise reproducible sums)
+//   5 k_mesh_gather     a block owns a 16x8x8 tile of mesh cells: the records of the tile + one halo layer are staged in
+//                       LDS, then every thread sums the TSC weights of the particles of its cells' 27 neighbour cells from
+//                       LDS (the Poisson-distributed cell counts make this loop divergent — in LDS that costs ALU slots,
+//                       from global memory it cost 316 us of load latency): no atomics on the mesh, no scratch, every
+//                       mesh cell written exactly once
 //   6 k_fft_lines x3    unnormalised DFT, one pass per axis, lines staged in LDS in [pos][line] layout
 //                       (16 adjacent lines per block so strided axes still move 256-B segments)
 //   7 k_mesh_spectral   f = F/N, G = f(|f|^2 - I^2 sum mode^2 / 2N^2), block sums of the CV integrand
@@ -48,6 +52,16 @@ __device__ __forceinline__ double tsc(double x)                       // :457-46
     if (xsq <= 1.0 / 4.0) return 3.0 / 4.0 - xsq;
     if (xsq <= 9.0 / 4.0) return 1.0 / 2.0 * (3.0 / 2.0 - xabs) * (3.0 / 2.0 - xabs);
     return 0.0;
+    }
+
+// TSC weight of a particle with in-cell shift s (mesh units, |s| <= 1/2) on the cell at offset i in {-1, 0, 1}:
+// tsc(s - i) without the branches: 3/4 - s^2 (i = 0), (1/2 + s)^2 / 2 (i = +1), (1/2 - s)^2 / 2 (i = -1)
+__device__ __forceinline__ double tsc_cell(const double s, const int i)
+    {
+    if (!(fabs(s) <= 0.5000001)) return tsc(s - i);            // out-of-box particle clamped into the mesh
+    if (i == 0) return 0.75 - s * s;
+    const double t = 0.5 + (i > 0 ? s : -s);
+    return 0.5 * t * t;
     }
 
 __device__ __forceinline__ double tsc_deriv(double x)                 // :470-483 (copysignf: float |x|, Q9)
@@ -119,11 +133,12 @@ __device__ __forceinline__ int wrap(int i, int n)
     return i;
     }
 
-// ---- 1. cell ids, counts, sum of mode^2 ---------------------------------------------------------
+// ---- 1. cell ids, arrival slots, sum of mode^2 ----------------------------------------------------
 template<typename S4>
-__global__ __launch_bounds__(256) void k_mesh_count(const MeshGeom g, const S4 *__restrict__ postype, const unsigned int N,
-                                                    const double *__restrict__ mode, unsigned int *__restrict__ cell_of,
-                                                    unsigned int *__restrict__ count, double *__restrict__ modesq_partials)
+__global__ __launch_bounds__(256) void k_mesh_bin(const MeshGeom g, const S4 *__restrict__ postype, const unsigned int N,
+                                                  const double *__restrict__ mode, unsigned int *__restrict__ cell_of,
+                                                  unsigned int *__restrict__ slot_of, unsigned int *__restrict__ count,
+                                                  double *__restrict__ modesq_partials)
     {
     __shared__ double s_red[16];
     double msq = 0.0;
@@ -135,7 +150,7 @@ __global__ __launch_bounds__(256) void k_mesh_count(const MeshGeom g, const S4 *
         locate(g, p, ix, iy, iz, sx, sy, sz);
         const unsigned int c = ix + g.nx * (iy + g.ny * iz);
         cell_of[i] = c;
-        atomicAdd(&count[c], 1u);
+        slot_of[i] = atomicAdd(&count[c], 1u);
         const double a = mode[p.type];
         msq += a * a;
         }
@@ -178,124 +193,219 @@ __global__ __launch_bounds__(256) void k_scan_tiles(const unsigned int *__restri
     if (threadIdx.x == 255) tile_sums[blockIdx.x] = wave_off + incl;
     }
 
-__global__ __launch_bounds__(256) void k_scan_sums(unsigned int *__restrict__ tile_sums, const unsigned int n_tiles)
+// second level: every block sums the tile totals in front of its tile itself (n_tiles <= 2^20 values, L2 resident),
+// adds the offset, and clears the counters it covers for the next call
+__global__ __launch_bounds__(256) void k_scan_finish(unsigned int *__restrict__ out, const unsigned int *__restrict__ tile_sums,
+                                                     unsigned int *__restrict__ count, const unsigned int n, const unsigned int total)
     {
-    // one block, serial over chunks of 256 tiles (n_tiles <= 2^21 / 1024 * ... small)
     __shared__ unsigned int s_wave[4];
-    __shared__ unsigned int s_carry;
-    if (threadIdx.x == 0) s_carry = 0;
-    __syncthreads();
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (unsigned int b0 = 0; b0 < n_tiles; b0 += 256)
-        {
-        const unsigned int i = b0 + threadIdx.x;
-        const unsigned int t = i < n_tiles ? tile_sums[i] : 0u;
-        unsigned int incl = t;
+    const unsigned int first = blockIdx.x * blockDim.x;
+    const unsigned int tile = first / SCAN_TILE;
+    unsigned int v = 0;
+    for (unsigned int t = threadIdx.x; t < tile; t += blockDim.x) v += tile_sums[t];
 #pragma unroll
-        for (int off = 1; off < 64; off <<= 1)
-            {
-            const unsigned int o = __shfl_up(incl, off, 64);
-            if (lane >= off) incl += o;
-            }
-        if (lane == 63) s_wave[wave] = incl;
-        __syncthreads();
-        unsigned int wave_off = s_carry;
-        for (int w = 0; w < wave; ++w) wave_off += s_wave[w];
-        if (i < n_tiles) tile_sums[i] = wave_off + incl - t;
-        __syncthreads();
-        if (threadIdx.x == 255) s_carry = wave_off + incl;
-        __syncthreads();
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    if ((threadIdx.x & 63) == 0) s_wave[threadIdx.x >> 6] = v;
+    __syncthreads();
+    const unsigned int prefix = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+    const unsigned int i = first + threadIdx.x;
+    if (i < n)
+        {
+        out[i] += prefix;
+        count[i] = 0;
         }
-    }
-
-__global__ __launch_bounds__(256) void k_scan_add(unsigned int *__restrict__ out, const unsigned int *__restrict__ tile_sums,
-                                                  const unsigned int n, const unsigned int total)
-    {
-    const unsigned int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out[i] += tile_sums[i / SCAN_TILE];
     if (i == 0) out[n] = total;
     }
 
-// ---- 3. fill: particle ids into their cell's slots ------------------------------------------------
-__global__ __launch_bounds__(256) void k_mesh_fill(const unsigned int *__restrict__ cell_of, const unsigned int N,
-                                                   const unsigned int *__restrict__ start, unsigned int *__restrict__ cursor,
-                                                   unsigned int *__restrict__ ids)
+// ---- 3. place: record, id and cell of every particle at start[cell] + slot ----------------------------
+template<typename S4>
+__global__ __launch_bounds__(256) void k_mesh_place(const MeshGeom g, const S4 *__restrict__ postype, const unsigned int N,
+                                                    const double *__restrict__ mode, const unsigned int *__restrict__ cell_of,
+                                                    const unsigned int *__restrict__ slot_of, const unsigned int *__restrict__ start,
+                                                    unsigned int *__restrict__ ids, double4 *__restrict__ packed,
+                                                    unsigned int *__restrict__ cell_sorted)
     {
     for (unsigned int i = blockIdx.x * blockDim.x + threadIdx.x; i < N; i += gridDim.x * blockDim.x)
         {
+        const Particle p = scalar4_traits<S4>::load(postype, i);
+        int ix, iy, iz;
+        double sx, sy, sz;
+        locate(g, p, ix, iy, iz, sx, sy, sz);
         const unsigned int c = cell_of[i];
-        const unsigned int slot = atomicAdd(&cursor[c], 1u);
-        ids[start[c] + slot] = i;
+        const unsigned int dst = start[c] + slot_of[i];
+        packed[dst] = make_double4(sx, sy, sz, mode[p.type]);
+        ids[dst] = i;
+        cell_sorted[dst] = c;
         }
     }
 
-// ---- 4. per cell: sort ids ascending (deterministic order), pack (shift, mode) ----------------------
-template<typename S4>
-__global__ __launch_bounds__(256) void k_mesh_sort(const MeshGeom g, const S4 *__restrict__ postype, const double *__restrict__ mode,
-                                                   const unsigned int *__restrict__ start, unsigned int *__restrict__ ids,
-                                                   double4 *__restrict__ packed, unsigned int *__restrict__ cell_sorted)
+// ---- 4. cells with >= 2 particles: order by particle id (the arrival order of step 1 is not reproducible) ----
+__global__ __launch_bounds__(256) void k_mesh_sortfix(const unsigned int n_cells, const unsigned int *__restrict__ start,
+                                                      unsigned int *__restrict__ ids, double4 *__restrict__ packed)
     {
     const unsigned int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= g.n_cells) return;
+    if (c >= n_cells) return;
     const unsigned int b = start[c], e = start[c + 1];
     for (unsigned int i = b + 1; i < e; ++i)          // insertion sort: cells hold O(1) particles
         {
         const unsigned int key = ids[i];
+        const double4 rec = packed[i];
         unsigned int j = i;
         while (j > b && ids[j - 1] > key)
             {
             ids[j] = ids[j - 1];
+            packed[j] = packed[j - 1];
             --j;
             }
         ids[j] = key;
-        }
-    for (unsigned int i = b; i < e; ++i)
-        {
-        const Particle p = scalar4_traits<S4>::load(postype, ids[i]);
-        int ix, iy, iz;
-        double sx, sy, sz;
-        locate(g, p, ix, iy, iz, sx, sy, sz);
-        packed[i] = make_double4(sx, sy, sz, mode[p.type]);
-        cell_sorted[i] = c;
+        packed[j] = rec;
         }
     }
 
-// ---- 5. gather: mesh[c] = sum over particles of the 27 neighbour cells -----------------------------
-// Cells are x-fastest, so for a fixed (j,k) the three source cells cx-1, cx, cx+1 own ONE contiguous range of the
-// sorted particle list (except across the periodic wrap in x): 9 ranges per cell instead of 27 cell look-ups.
-__device__ __forceinline__ double gather_range(const double4 *__restrict__ packed, unsigned int b, unsigned int e, int i, int j,
-                                               int k, double acc)
-    {
-    for (unsigned int q = b; q < e; ++q)
-        {
-        const double4 pk = packed[q];
-        acc += pk.w * (tsc(pk.x - i) * tsc(pk.y - j) * tsc(pk.z - k));
-        }
-    return acc;
-    }
+// ---- 5. gather: mesh[c] = sum over the particles of the 27 neighbour cells, tile by tile from LDS ----------
+constexpr int GT_X = 16, GT_Y = 8, GT_Z = 8;                       // output tile (clipped to the mesh)
+constexpr int GT_HCELLS = (GT_X + 2) * (GT_Y + 2) * (GT_Z + 2);     // with one halo layer: 1800
+constexpr int GT_CAP = 1408;                                        // records staged in LDS (44 KB); denser tiles read global memory
 
-__global__ __launch_bounds__(256) void k_mesh_gather(const MeshGeom g, const unsigned int *__restrict__ start,
-                                                     const double4 *__restrict__ packed, double *__restrict__ rho)
+struct GatherTiling
     {
-    const unsigned int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= g.n_cells) return;
-    const int cz = c / (g.nx * g.ny);
-    const int cy = (c - cz * g.nx * g.ny) / g.nx;
-    const int cx = c % g.nx;
+    unsigned int tx, ty, tz;          // tile dimensions
+    unsigned int ntx, nty, ntz;       // tiles per axis
+    };
+
+constexpr int GT_THREADS = GT_X * GT_Y * GT_Z;                      // one thread per output cell: 16 waves hide the LDS latency
+                                                                    // of the divergent per-cell loops
+
+__global__ __launch_bounds__(GT_THREADS) void k_mesh_gather(const MeshGeom g, const GatherTiling tl, const unsigned int *__restrict__ start,
+                                                            const double4 *__restrict__ packed, double *__restrict__ rho)
+    {
+    __shared__ unsigned int s_off[GT_HCELLS + 1];      // first staged record of every halo'd cell
+    __shared__ unsigned int s_gb[GT_HCELLS];           // global begin of the cell's records
+    __shared__ unsigned int s_wave[GT_THREADS / 64];
+    __shared__ double4 s_rec[GT_CAP];
+
+    const unsigned int t_id = blockIdx.x;
+    const unsigned int tix = t_id % tl.ntx, tiy = (t_id / tl.ntx) % tl.nty, tiz = t_id / (tl.ntx * tl.nty);
+    const int x0 = tix * tl.tx, y0 = tiy * tl.ty, z0 = tiz * tl.tz;
+    const unsigned int HX = tl.tx + 2, HY = tl.ty + 2, HZ = tl.tz + 2;
+    const unsigned int HC = HX * HY * HZ;
+
+    // counts of the halo'd cells; thread t owns the halo'd cells 2t and 2t+1
+    unsigned int cnt[2], tsum = 0;
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+        {
+        const unsigned int hc = threadIdx.x * 2 + q;
+        cnt[q] = 0;
+        if (hc < HC)
+            {
+            const int hx = hc % HX, hy = (hc / HX) % HY, hz = hc / (HX * HY);
+            int gx = x0 + hx - 1, gy = y0 + hy - 1, gz = z0 + hz - 1;
+            gx = gx < 0 ? gx + (int)g.nx : (gx >= (int)g.nx ? gx - (int)g.nx : gx);
+            gy = gy < 0 ? gy + (int)g.ny : (gy >= (int)g.ny ? gy - (int)g.ny : gy);
+            gz = gz < 0 ? gz + (int)g.nz : (gz >= (int)g.nz ? gz - (int)g.nz : gz);
+            const unsigned int gc = gx + g.nx * (gy + g.ny * gz);
+            const unsigned int b = start[gc];
+            cnt[q] = start[gc + 1] - b;
+            s_gb[hc] = b;
+            }
+        tsum += cnt[q];
+        }
+    // block exclusive scan of the per-thread sums
+    unsigned int incl = tsum;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1)
+        {
+        const unsigned int o = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += o;
+        }
+    if (lane == 63) s_wave[wave] = incl;
+    __syncthreads();
+    unsigned int excl = incl - tsum, total = 0;
+#pragma unroll
+    for (int w = 0; w < GT_THREADS / 64; ++w)
+        {
+        if (w < wave) excl += s_wave[w];
+        total += s_wave[w];
+        }
+    const bool in_lds = total <= (unsigned int)GT_CAP;           // block-uniform
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+        {
+        const unsigned int hc = threadIdx.x * 2 + q;
+        if (hc < HC)
+            {
+            s_off[hc] = excl;
+            excl += cnt[q];
+            }
+        }
+    if (threadIdx.x == 0) s_off[HC] = total;
+    __syncthreads();
+    if (in_lds)
+        {
+        // flat copy: staged record q belongs to the halo'd cell found by bisection over s_off
+        for (unsigned int q = threadIdx.x; q < total; q += GT_THREADS)
+            {
+            unsigned int lo = 0, hi = HC;                        // largest lo with s_off[lo] <= q
+            while (hi - lo > 1)
+                {
+                const unsigned int mid = (lo + hi) >> 1;
+                if (s_off[mid] <= q)
+                    lo = mid;
+                else
+                    hi = mid;
+                }
+            s_rec[q] = packed[s_gb[lo] + (q - s_off[lo])];
+            }
+        __syncthreads();
+        }
+
+    const unsigned int lx = threadIdx.x % GT_X, ly = (threadIdx.x / GT_X) % GT_Y, lz = threadIdx.x / (GT_X * GT_Y);
+    if (lx >= tl.tx || ly >= tl.ty || lz >= tl.tz) return;
     double acc = 0.0;
     // this cell receives from the particle cell at offset (-i,-j,-k) with dx = shift - (i,j,k); fixed loop order
+#pragma unroll
     for (int k = -1; k <= 1; ++k)
+#pragma unroll
         for (int j = -1; j <= 1; ++j)
             {
-            const int syc = wrap(cy - j, (int)g.ny), szc = wrap(cz - k, (int)g.nz);
-            const unsigned int row = g.nx * (syc + g.ny * szc);
-            // source x cells: cx+1 (i=-1), cx (i=0), cx-1 (i=+1)
-            const unsigned int xm = (unsigned int)wrap(cx - 1, (int)g.nx), x0 = (unsigned int)cx, xp = (unsigned int)wrap(cx + 1, (int)g.nx);
-            acc = gather_range(packed, start[row + xm], start[row + xm + 1], 1, j, k, acc);
-            acc = gather_range(packed, start[row + x0], start[row + x0 + 1], 0, j, k, acc);
-            acc = gather_range(packed, start[row + xp], start[row + xp + 1], -1, j, k, acc);
+            // halo'd coordinates of the source row: (ly + 1 - j, lz + 1 - k); its x cells lx .. lx+2 (= i = +1, 0, -1) sit next to
+            // each other in the staged order
+            const unsigned int h0 = HX * ((ly + 1 - j) + HY * (lz + 1 - k)) + lx;
+            const unsigned int b0 = s_off[h0], b1 = s_off[h0 + 1], b2 = s_off[h0 + 2], b3 = s_off[h0 + 3];
+            if (in_lds)
+                {
+                for (unsigned int q = b0; q < b3; ++q)
+                    {
+                    const double4 pk = s_rec[q];
+                    const int i = q < b1 ? 1 : (q < b2 ? 0 : -1);
+                    acc += pk.w * (tsc_cell(pk.x, i) * tsc_cell(pk.y, j) * tsc_cell(pk.z, k));
+                    }
+                }
+            else
+                {
+                // dense tile: same order, records straight from global memory (the three cells need not be adjacent there
+                // when the row wraps in x)
+                const unsigned int n0 = b1 - b0, n1 = b2 - b1, n2 = b3 - b2;
+                for (unsigned int r = 0; r < n0; ++r)
+                    {
+                    const double4 pk = packed[s_gb[h0] + r];
+                    acc += pk.w * (tsc_cell(pk.x, 1) * tsc_cell(pk.y, j) * tsc_cell(pk.z, k));
+                    }
+                for (unsigned int r = 0; r < n1; ++r)
+                    {
+                    const double4 pk = packed[s_gb[h0 + 1] + r];
+                    acc += pk.w * (tsc_cell(pk.x, 0) * tsc_cell(pk.y, j) * tsc_cell(pk.z, k));
+                    }
+                for (unsigned int r = 0; r < n2; ++r)
+                    {
+                    const double4 pk = packed[s_gb[h0 + 2] + r];
+                    acc += pk.w * (tsc_cell(pk.x, -1) * tsc_cell(pk.y, j) * tsc_cell(pk.z, k));
+                    }
+                }
             }
-    rho[c] = acc;
+    rho[(x0 + lx) + g.nx * ((y0 + ly) + g.ny * (z0 + lz))] = acc;
     }
 
 // ---- 6/8. DFT of lines staged in LDS ---------------------------------------------------------------
@@ -511,12 +621,13 @@ __global__ void k_zero_u32(unsigned int *p, unsigned int n)
     if (i < n) p[i] = 0;
     }
 
-__global__ void k_sum_partials(const double *__restrict__ partials, unsigned int n, double *out)
+__global__ __launch_bounds__(256) void k_sum_partials(const double *__restrict__ partials, unsigned int n, double *out)
     {
-    // one wave, fixed order
+    // one block, fixed order
+    __shared__ double s_red[16];
     double v = 0.0;
-    for (unsigned int b = threadIdx.x; b < n; b += 64) v += partials[b];
-    v = wave_sum(v);
+    for (unsigned int b = threadIdx.x; b < n; b += 256) v += partials[b];
+    v = block_sum(v, s_red);
     if (threadIdx.x == 0) *out = v;
     }
 
@@ -538,7 +649,7 @@ struct mtd_mesh
     double *d_mode, *d_rho, *d_inv, *d_modesq_partials, *d_mode_sq, *d_cv_partials;
     double2 *d_f, *d_g, *d_tw[3];
     double4 *d_packed;
-    unsigned int *d_cell_of, *d_count, *d_start, *d_ids, *d_tile_sums, *d_cell_sorted;
+    unsigned int *d_cell_of, *d_slot_of, *d_count, *d_start, *d_ids, *d_tile_sums, *d_cell_sorted;
     unsigned int n_last;   // particle count of the last compute_cv (the sorted list the force pass walks)
     unsigned int n_cv_partials, n_count_blocks;
     };
@@ -624,7 +735,7 @@ int mtd_mesh_create(mtd_mesh **out, unsigned int nx, unsigned int ny, unsigned i
     m->max_particles = max_particles;
     m->bug_compat = 1;
     const size_t M = m->M, N = max_particles;
-    m->n_count_blocks = 1024;
+    m->n_count_blocks = 4096;
     m->n_cv_partials = (m->M + 255) / 256;
     const unsigned int n_tiles = (m->M + SCAN_TILE - 1) / SCAN_TILE;
     auto al = [](size_t b) { return (b + 255) / 256 * 256; };
@@ -635,7 +746,7 @@ int mtd_mesh_create(mtd_mesh **out, unsigned int nx, unsigned int ny, unsigned i
                  o_tw2 = take(sizeof(double2) * nz), o_packed = take(sizeof(double4) * N), o_cell = take(sizeof(unsigned int) * N),
                  o_count = take(sizeof(unsigned int) * (M + 1)), o_start = take(sizeof(unsigned int) * (M + 1)),
                  o_ids = take(sizeof(unsigned int) * N), o_tiles = take(sizeof(unsigned int) * n_tiles),
-                 o_inv = take(sizeof(double) * M), o_csort = take(sizeof(unsigned int) * N);
+                 o_inv = take(sizeof(double) * M), o_csort = take(sizeof(unsigned int) * N), o_slot = take(sizeof(unsigned int) * N);
     hipError_t e = hipMalloc(&m->slab, off);
     if (e != hipSuccess)
         {
@@ -652,6 +763,7 @@ int mtd_mesh_create(mtd_mesh **out, unsigned int nx, unsigned int ny, unsigned i
     m->d_tile_sums = (unsigned int *)(p + o_tiles);
     m->d_inv = (double *)(p + o_inv);
     m->d_cell_sorted = (unsigned int *)(p + o_csort);
+    m->d_slot_of = (unsigned int *)(p + o_slot);
     e = hipMemset(m->slab, 0, off);
     if (e == hipSuccess) e = hipMemcpy(m->d_mode, mode, sizeof(double) * n_types, hipMemcpyHostToDevice);
     // twiddles exp(-2 pi i j / n), j < n/2, in double on the host
@@ -705,31 +817,31 @@ int mtd_mesh_assign(mtd_mesh *m, unsigned int n_particles, const void *d_postype
     const unsigned int cell_blocks = (M + 255) / 256;
     const unsigned int n_tiles = (M + SCAN_TILE - 1) / SCAN_TILE;
 
-    k_zero_u32<<<(M + 1 + 255) / 256, 256, 0, s>>>(m->d_count, M + 1);
-    MTD_LAUNCH_CHECK();
+    // the counters are zero on entry: cleared at creation and by k_scan_finish of the previous call
     if (dtype == MTD_F32)
-        k_mesh_count<float4><<<m->n_count_blocks, 256, 0, s>>>(g, (const float4 *)d_postype, N, m->d_mode, m->d_cell_of, m->d_count, m->d_modesq_partials);
+        k_mesh_bin<float4><<<m->n_count_blocks, 256, 0, s>>>(g, (const float4 *)d_postype, N, m->d_mode, m->d_cell_of, m->d_slot_of, m->d_count, m->d_modesq_partials);
     else
-        k_mesh_count<double4><<<m->n_count_blocks, 256, 0, s>>>(g, (const double4 *)d_postype, N, m->d_mode, m->d_cell_of, m->d_count, m->d_modesq_partials);
+        k_mesh_bin<double4><<<m->n_count_blocks, 256, 0, s>>>(g, (const double4 *)d_postype, N, m->d_mode, m->d_cell_of, m->d_slot_of, m->d_count, m->d_modesq_partials);
     MTD_LAUNCH_CHECK();
-    k_sum_partials<<<1, 64, 0, s>>>(m->d_modesq_partials, m->n_count_blocks, m->d_mode_sq);   // m_mode_sq (:622), fixed order
+    k_sum_partials<<<1, 256, 0, s>>>(m->d_modesq_partials, m->n_count_blocks, m->d_mode_sq);   // m_mode_sq (:622), fixed order
     MTD_LAUNCH_CHECK();
     k_scan_tiles<<<n_tiles, 256, 0, s>>>(m->d_count, m->d_start, m->d_tile_sums, M);
     MTD_LAUNCH_CHECK();
-    k_scan_sums<<<1, 256, 0, s>>>(m->d_tile_sums, n_tiles);
-    MTD_LAUNCH_CHECK();
-    k_scan_add<<<cell_blocks, 256, 0, s>>>(m->d_start, m->d_tile_sums, M, N);
-    MTD_LAUNCH_CHECK();
-    k_zero_u32<<<cell_blocks, 256, 0, s>>>(m->d_count, M);                                      // reused as the fill cursor
-    MTD_LAUNCH_CHECK();
-    k_mesh_fill<<<m->n_count_blocks, 256, 0, s>>>(m->d_cell_of, N, m->d_start, m->d_count, m->d_ids);
+    k_scan_finish<<<cell_blocks, 256, 0, s>>>(m->d_start, m->d_tile_sums, m->d_count, M, N);
     MTD_LAUNCH_CHECK();
     if (dtype == MTD_F32)
-        k_mesh_sort<float4><<<cell_blocks, 256, 0, s>>>(g, (const float4 *)d_postype, m->d_mode, m->d_start, m->d_ids, m->d_packed, m->d_cell_sorted);
+        k_mesh_place<float4><<<m->n_count_blocks, 256, 0, s>>>(g, (const float4 *)d_postype, N, m->d_mode, m->d_cell_of, m->d_slot_of, m->d_start, m->d_ids, m->d_packed, m->d_cell_sorted);
     else
-        k_mesh_sort<double4><<<cell_blocks, 256, 0, s>>>(g, (const double4 *)d_postype, m->d_mode, m->d_start, m->d_ids, m->d_packed, m->d_cell_sorted);
+        k_mesh_place<double4><<<m->n_count_blocks, 256, 0, s>>>(g, (const double4 *)d_postype, N, m->d_mode, m->d_cell_of, m->d_slot_of, m->d_start, m->d_ids, m->d_packed, m->d_cell_sorted);
     MTD_LAUNCH_CHECK();
-    k_mesh_gather<<<cell_blocks, 256, 0, s>>>(g, m->d_start, m->d_packed, m->d_rho);
+    k_mesh_sortfix<<<cell_blocks, 256, 0, s>>>(M, m->d_start, m->d_ids, m->d_packed);
+    MTD_LAUNCH_CHECK();
+    GatherTiling tl;
+    tl.tx = m->nx < (unsigned int)GT_X ? m->nx : GT_X;
+    tl.ty = m->ny < (unsigned int)GT_Y ? m->ny : GT_Y;
+    tl.tz = m->nz < (unsigned int)GT_Z ? m->nz : GT_Z;
+    tl.ntx = m->nx / tl.tx; tl.nty = m->ny / tl.ty; tl.ntz = m->nz / tl.tz;
+    k_mesh_gather<<<tl.ntx * tl.nty * tl.ntz, GT_THREADS, 0, s>>>(g, tl, m->d_start, m->d_packed, m->d_rho);
     MTD_LAUNCH_CHECK();
     m->n_last = N;
     return MTD_SUCCESS;
