@@ -264,6 +264,20 @@ int mtd_mesh_spectral(mtd_mesh *m, const mtd_box *box, unsigned int n_global, co
 int mtd_mesh_forces(mtd_mesh *m, unsigned int n_particles, const void *d_postype, void *d_force, int dtype,
                     const mtd_box *box, unsigned int n_global, const double *d_bias, double bias_host, mtd_stream_t stream);
 
+/* setTable (OrderParameterMesh.cc:148-189): convolution kernel K(k) and its derivative on n equidistant points of
+ * [k_min, k_max].  Like the reference, K itself is stored and never applied to the mesh; K' enters the virial. */
+int mtd_mesh_set_table(mtd_mesh *m, const double *K, const double *d_K, unsigned int n, double k_min, double k_max);
+int mtd_mesh_set_use_table(mtd_mesh *m, int use_table);
+
+/* computeQmax (:1108-1179) on the Fourier mesh of the last compute_cv / spectral call (SYNCHRONISES):
+ * out[0..2] = wave vector of the cell with the largest |f|^2 (first cell wins ties, DC bin included), out[3] = that
+ * amplitude times N_global — the log quantities qx_max, qy_max, qz_max, sq_max. */
+int mtd_mesh_qmax(mtd_mesh *m, const mtd_box *box, unsigned int n_global, double *out, mtd_stream_t stream);
+
+/* computeVirial (:970-1050) (SYNCHRONISES): virial[6] (xx, xy, xz, yy, yz, zz) = bias * sum_{k != 0} |f|^4 / N^2 *
+ * K'(|k|) / (2 |k|) * k_a k_b — identically zero without a table in use, exactly like the reference. */
+int mtd_mesh_virial(mtd_mesh *m, const mtd_box *box, unsigned int n_global, double bias, double *virial, mtd_stream_t stream);
+
 /* raw arrays for parity tests (SYNCHRONISES): which = 0 real mesh double[M]; 1 fourier_mesh (normalised) complex double[M];
  * 3 Re(inv_fourier_mesh) double[M] (the imaginary part is never used, OrderParameterMesh.cc:851-857); 7 sum of mode^2 */
 int mtd_mesh_get_array(mtd_mesh *m, int which, void *host_out, mtd_stream_t stream);

@@ -615,6 +615,112 @@ __global__ __launch_bounds__(256) void k_mesh_forces(const MeshGeom g, const uns
         }
     }
 
+// ---- 10. log quantities and virial ---------------------------------------------------------
+// Miller indices (:417-422) and wave vector k = n_x b1 + n_y b2 + n_z b3 with b_i = 2 pi * reciprocal rows of the box
+__device__ __forceinline__ void wave_vector(const MeshGeom &g, const unsigned int cell, double &kx, double &ky, double &kz)
+    {
+    const unsigned int wz = cell / (g.nx * g.ny);
+    const unsigned int wy = (cell - wz * g.nx * g.ny) / g.nx;
+    const unsigned int wx = cell % g.nx;
+    int n0 = (int)wx, n1 = (int)wy, n2 = (int)wz;
+    if (n0 >= (int)(g.nx / 2 + g.nx % 2)) n0 -= (int)g.nx;
+    if (n1 >= (int)(g.ny / 2 + g.ny % 2)) n1 -= (int)g.ny;
+    if (n2 >= (int)(g.nz / 2 + g.nz % 2)) n2 -= (int)g.nz;
+    const double tp = 2.0 * M_PI;
+    kx = tp * (n0 * g.binv[0][0] + n1 * g.binv[1][0] + n2 * g.binv[2][0]);
+    ky = tp * (n0 * g.binv[0][1] + n1 * g.binv[1][1] + n2 * g.binv[2][1]);
+    kz = tp * (n0 * g.binv[0][2] + n1 * g.binv[1][2] + n2 * g.binv[2][2]);
+    }
+
+// computeQmax (:1108-1179): the cell with the largest |f|^2 (DC bin included like the reference), first index wins ties
+__global__ __launch_bounds__(256) void k_mesh_argmax(const double2 *__restrict__ fmesh, const unsigned int n, double *__restrict__ out_val,
+                                                     unsigned int *__restrict__ out_idx)
+    {
+    __shared__ double s_v[4];
+    __shared__ unsigned int s_i[4];
+    double best = 0.0;
+    unsigned int bi = 0xffffffffu;                    // "no cell yet": the reference keeps q_max = 0 when no amplitude exceeds 0
+    for (unsigned int k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x)
+        {
+        const double2 f = fmesh[k];
+        const double a = f.x * f.x + f.y * f.y;
+        if (a > best)                                  // ascending k per thread: strict > keeps the first
+            {
+            best = a;
+            bi = k;
+            }
+        }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1)
+        {
+        const double ov = __shfl_xor(best, off, 64);
+        const unsigned int oi = __shfl_xor(bi, off, 64);
+        if (ov > best || (ov == best && oi < bi))
+            {
+            best = ov;
+            bi = oi;
+            }
+        }
+    if ((threadIdx.x & 63) == 0)
+        {
+        s_v[threadIdx.x >> 6] = best;
+        s_i[threadIdx.x >> 6] = bi;
+        }
+    __syncthreads();
+    if (threadIdx.x == 0)
+        {
+        for (int w = 1; w < 4; ++w)
+            if (s_v[w] > best || (s_v[w] == best && s_i[w] < bi))
+                {
+                best = s_v[w];
+                bi = s_i[w];
+                }
+        out_val[blockIdx.x] = best;
+        out_idx[blockIdx.x] = bi;
+        }
+    }
+
+// computeVirial (:970-1050): sum over k != 0 of |f|^4 / N^2 * K'(|k|) / (2 |k|) * k_a k_b with K' from the derivative table
+// (zero outside [k_min, k_max) and without a table); six block partial sums, fixed order
+__global__ __launch_bounds__(256) void k_mesh_virial(const MeshGeom g, const double2 *__restrict__ fmesh, const double n_global,
+                                                     const double *__restrict__ table_d, const double k_min, const double k_max,
+                                                     const double delta_k, const int use_table, double *__restrict__ partials)
+    {
+    __shared__ double s_red[16];
+    double v[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    for (unsigned int k = blockIdx.x * blockDim.x + threadIdx.x; k < g.n_cells; k += gridDim.x * blockDim.x)
+        {
+        if (k == 0) continue;                                           // exclude DC bin (:1003-1005)
+        double kx, ky, kz;
+        wave_vector(g, k, kx, ky, kz);
+        const double knorm = sqrt(kx * kx + ky * ky + kz * kz);
+        double val_D = 0.0;
+        if (use_table && knorm >= k_min && knorm < k_max)               // :1018-1030
+            {
+            const double value_f = (knorm - k_min) / delta_k;
+            const unsigned int value_i = (unsigned int)value_f;
+            const double dK0 = table_d[value_i], dK1 = table_d[value_i + 1];
+            val_D = dK0 + (value_f - (double)value_i) * (dK1 - dK0);
+            }
+        const double kfac = 1.0 / 2.0 / knorm * val_D;
+        const double2 f = fmesh[k];
+        const double a = f.x * f.x + f.y * f.y;
+        const double rhog = a * (a / n_global) / n_global;             // :1034-1035 (f is already F / N: the reference divides again)
+        v[0] += rhog * kfac * kx * kx;
+        v[1] += rhog * kfac * kx * ky;
+        v[2] += rhog * kfac * kx * kz;
+        v[3] += rhog * kfac * ky * ky;
+        v[4] += rhog * kfac * ky * kz;
+        v[5] += rhog * kfac * kz * kz;
+        }
+#pragma unroll
+    for (int c = 0; c < 6; ++c)
+        {
+        const double r = block_sum(v[c], s_red);
+        if (threadIdx.x == 0) partials[blockIdx.x * 6 + c] = r;
+        }
+    }
+
 __global__ void k_zero_u32(unsigned int *p, unsigned int n)
     {
     const unsigned int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -651,6 +757,11 @@ struct mtd_mesh
     double4 *d_packed;
     unsigned int *d_cell_of, *d_slot_of, *d_count, *d_start, *d_ids, *d_tile_sums, *d_cell_sorted;
     unsigned int n_last;   // particle count of the last compute_cv (the sorted list the force pass walks)
+    // convolution-kernel table (setTable, :148-189): K is stored and never applied (Q7); K' enters the virial
+    double *d_table, *d_table_d, *d_log_scratch;
+    unsigned int n_table;
+    double k_min, k_max, delta_k;
+    int use_table;
     unsigned int n_cv_partials, n_count_blocks;
     };
 
@@ -792,6 +903,8 @@ int mtd_mesh_create(mtd_mesh **out, unsigned int nx, unsigned int ny, unsigned i
 int mtd_mesh_destroy(mtd_mesh *m)
     {
     if (!m) return MTD_SUCCESS;
+    if (m->d_table) (void)hipFree(m->d_table);
+    if (m->d_log_scratch) (void)hipFree(m->d_log_scratch);
     hipError_t e = hipFree(m->slab);
     delete m;
     return (int)e;
@@ -904,6 +1017,103 @@ int mtd_mesh_forces(mtd_mesh *m, unsigned int n_particles, const void *d_postype
     else
         k_mesh_forces<double4><<<blocks, 256, 0, s>>>(g, n_particles, m->d_ids, m->d_cell_sorted, m->d_packed, m->d_inv, (double4 *)d_force, d_bias, bias_host, two_over_n);
     MTD_LAUNCH_CHECK();
+    return MTD_SUCCESS;
+    }
+
+int mtd_mesh_set_table(mtd_mesh *m, const double *K, const double *d_K, unsigned int n, double k_min, double k_max)
+    {
+    if (!m || !K || !d_K || n < 2) return MTD_ERR_INVALID_ARGUMENT;
+    if (k_min < 0 || k_max < 0 || k_max <= k_min) return MTD_ERR_INVALID_ARGUMENT;       // :153-158
+    if (m->d_table) MTD_HIP_TRY(hipFree(m->d_table));
+    m->d_table = nullptr;
+    MTD_HIP_TRY(hipMalloc((void **)&m->d_table, sizeof(double) * 2 * n));
+    m->d_table_d = m->d_table + n;
+    MTD_HIP_TRY(hipMemcpy(m->d_table, K, sizeof(double) * n, hipMemcpyHostToDevice));
+    MTD_HIP_TRY(hipMemcpy(m->d_table_d, d_K, sizeof(double) * n, hipMemcpyHostToDevice));
+    m->n_table = n;
+    m->k_min = k_min;
+    m->k_max = k_max;
+    m->delta_k = (k_max - k_min) / (double)(n - 1);                                       // :169
+    return MTD_SUCCESS;
+    }
+
+int mtd_mesh_set_use_table(mtd_mesh *m, int use_table)
+    {
+    if (!m) return MTD_ERR_INVALID_ARGUMENT;
+    if (use_table && !m->d_table) return MTD_ERR_INVALID_ARGUMENT;
+    m->use_table = use_table ? 1 : 0;
+    return MTD_SUCCESS;
+    }
+
+static int log_scratch(mtd_mesh *m)
+    {
+    if (!m->d_log_scratch) MTD_HIP_TRY(hipMalloc((void **)&m->d_log_scratch, sizeof(double) * 8 * 256));
+    return MTD_SUCCESS;
+    }
+
+int mtd_mesh_qmax(mtd_mesh *m, const mtd_box *box, unsigned int n_global, double *out, mtd_stream_t stream)
+    {
+    if (!m || !out || n_global == 0) return MTD_ERR_INVALID_ARGUMENT;
+    MeshGeom g;
+    int rc = fill_geom(g, m, box);
+    if (rc) return rc;
+    rc = log_scratch(m);
+    if (rc) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    const unsigned int blocks = 256;
+    double *d_val = m->d_log_scratch;
+    unsigned int *d_idx = (unsigned int *)(m->d_log_scratch + 256);
+    k_mesh_argmax<<<blocks, 256, 0, s>>>(m->d_f, m->M, d_val, d_idx);
+    MTD_LAUNCH_CHECK();
+    double val[256];
+    unsigned int idx[256];
+    MTD_HIP_TRY(hipMemcpyAsync(val, d_val, sizeof(val), hipMemcpyDeviceToHost, s));
+    MTD_HIP_TRY(hipMemcpyAsync(idx, d_idx, sizeof(idx), hipMemcpyDeviceToHost, s));
+    MTD_HIP_TRY(hipStreamSynchronize(s));
+    double best = 0.0;
+    unsigned int bi = 0xffffffffu;
+    for (unsigned int b = 0; b < blocks; ++b)
+        if (val[b] > best || (val[b] == best && idx[b] < bi))
+            {
+            best = val[b];
+            bi = idx[b];
+            }
+    out[0] = out[1] = out[2] = 0.0;
+    if (bi != 0xffffffffu && best > 0.0)
+        {
+        const unsigned int wz = bi / (m->nx * m->ny), wy = (bi - wz * m->nx * m->ny) / m->nx, wx = bi % m->nx;
+        int n0 = (int)wx, n1 = (int)wy, n2 = (int)wz;
+        if (n0 >= (int)(m->nx / 2 + m->nx % 2)) n0 -= (int)m->nx;
+        if (n1 >= (int)(m->ny / 2 + m->ny % 2)) n1 -= (int)m->ny;
+        if (n2 >= (int)(m->nz / 2 + m->nz % 2)) n2 -= (int)m->nz;
+        for (int d = 0; d < 3; ++d) out[d] = 2.0 * M_PI * (n0 * g.binv[0][d] + n1 * g.binv[1][d] + n2 * g.binv[2][d]);
+        }
+    out[3] = best * (double)n_global;                                                      // :1174-1178
+    return MTD_SUCCESS;
+    }
+
+int mtd_mesh_virial(mtd_mesh *m, const mtd_box *box, unsigned int n_global, double bias, double *virial, mtd_stream_t stream)
+    {
+    if (!m || !virial || n_global == 0) return MTD_ERR_INVALID_ARGUMENT;
+    MeshGeom g;
+    int rc = fill_geom(g, m, box);
+    if (rc) return rc;
+    rc = log_scratch(m);
+    if (rc) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    const unsigned int blocks = 256;
+    k_mesh_virial<<<blocks, 256, 0, s>>>(g, m->d_f, (double)n_global, m->d_table_d, m->k_min, m->k_max, m->delta_k,
+                                         m->use_table && m->d_table_d, m->d_log_scratch);
+    MTD_LAUNCH_CHECK();
+    double part[256 * 6];
+    MTD_HIP_TRY(hipMemcpyAsync(part, m->d_log_scratch, sizeof(part), hipMemcpyDeviceToHost, s));
+    MTD_HIP_TRY(hipStreamSynchronize(s));
+    for (int c = 0; c < 6; ++c)
+        {
+        double v = 0.0;
+        for (unsigned int b = 0; b < blocks; ++b) v += part[b * 6 + c];
+        virial[c] = bias * v;                                                              // :1046-1047
+        }
     return MTD_SUCCESS;
     }
 

@@ -241,7 +241,7 @@ OrderParameterMeshGPU::OrderParameterMeshGPU(std::shared_ptr<SystemDefinition> s
                                              unsigned int nz, std::vector<double> mode, std::vector<int3> zero_modes)
     : CollectiveVariable(sysdef, "mesh"), m_mesh(nullptr), m_mode(mode), m_zero_modes(zero_modes), m_k_min(0.0), m_k_max(0.0),
       m_delta_k(0.0), m_use_table(false), m_is_first_step(true), m_partials(nullptr), m_n_partials(0), m_cv_last_updated(0),
-      m_cv(0.0)
+      m_cv(0.0), m_q_max_last_computed(0), m_q_max{0.0, 0.0, 0.0}, m_sq_max(0.0)
     {
     if (mode.size() != m_pdata->getNTypes()) throw std::runtime_error("Error setting up cv.mesh");   // OrderParameterMesh.cc:44-49
     int rc = mtd_mesh_create(&m_mesh, nx, ny, nz, mode.data(), (unsigned int)mode.size(), m_pdata->getN());
@@ -272,6 +272,57 @@ void OrderParameterMeshGPU::setTable(const std::vector<double> &K, const std::ve
     m_delta_k = (kmax - kmin) / (double)(K.size() - 1);
     m_table = K;
     m_table_d = d_K;
+    mtd_check(mtd_mesh_set_table(m_mesh, K.data(), d_K.data(), (unsigned int)K.size(), kmin, kmax), "mtd_mesh_set_table");
+    }
+
+void OrderParameterMeshGPU::setUseTable(bool use_table)
+    {
+    if (use_table && m_table.empty()) throw std::runtime_error("cv.mesh: set_kernel() before use_table=True");
+    m_use_table = use_table;
+    mtd_check(mtd_mesh_set_use_table(m_mesh, use_table ? 1 : 0), "mtd_mesh_set_use_table");
+    }
+
+// :1108-1179
+void OrderParameterMeshGPU::computeQmax(unsigned int timestep)
+    {
+    enqueueCV(timestep);                                               // compute Fourier grid (:1111)
+    if (timestep && m_q_max_last_computed == timestep) return;         // :1113
+    m_q_max_last_computed = timestep;
+    const mtd_box box = m_pdata->getGlobalBox().toMtd();
+    double out[4];
+    mtd_check(mtd_mesh_qmax(m_mesh, &box, m_pdata->getNGlobal(), out, m_exec_conf->getStream()), "mtd_mesh_qmax");
+    m_q_max[0] = out[0]; m_q_max[1] = out[1]; m_q_max[2] = out[2];
+    m_sq_max = out[3];
+    }
+
+// :1077-1106
+double OrderParameterMeshGPU::getLogValue(const std::string &quantity, unsigned int timestep)
+    {
+    if (quantity == "cv_mesh") return getCurrentValue(timestep);
+    if (quantity == "qx_max" || quantity == "qy_max" || quantity == "qz_max" || quantity == "sq_max")
+        {
+        computeQmax(timestep);
+        if (quantity == "qx_max") return m_q_max[0];
+        if (quantity == "qy_max") return m_q_max[1];
+        if (quantity == "qz_max") return m_q_max[2];
+        return m_sq_max;
+        }
+    return CollectiveVariable::getLogValue(quantity, timestep);
+    }
+
+// :970-1050 — needs the host value of the bias factor (the reference multiplies on the host too)
+void OrderParameterMeshGPU::computeVirial()
+    {
+    double bias = m_bias;
+    if (m_bias_device)
+        {
+        m_exec_conf->sync();
+        hip_check(hipMemcpy(&bias, m_bias_device, sizeof(double), hipMemcpyDeviceToHost), "bias read-back");
+        }
+    const mtd_box box = m_pdata->getGlobalBox().toMtd();
+    double v[6];
+    mtd_check(mtd_mesh_virial(m_mesh, &box, m_pdata->getNGlobal(), bias, v, m_exec_conf->getStream()), "mtd_mesh_virial");
+    for (unsigned int i = 0; i < 6; ++i) m_external_virial[i] = v[i];
     }
 
 void OrderParameterMeshGPU::enqueueCV(unsigned int timestep)
@@ -301,8 +352,7 @@ double OrderParameterMeshGPU::getCurrentValue(unsigned int timestep)
     return m_cv;
     }
 
-// OrderParameterMesh.cc:1052-1075 (virial: SURVEY §8f row N3, not built: external virial left at zero like the
-// reference without pressure flags, :1069-1072)
+// OrderParameterMesh.cc:1052-1075
 void OrderParameterMeshGPU::computeBiasForces(unsigned int timestep)
     {
     if (m_is_first_step || m_cv_last_updated != timestep) enqueueCV(timestep);   // :1055-1056
@@ -310,7 +360,10 @@ void OrderParameterMeshGPU::computeBiasForces(unsigned int timestep)
     mtd_check(mtd_mesh_forces(m_mesh, m_pdata->getN(), m_pdata->positionsPtr(), m_force.data(), m_pdata->getDtype(), &box,
                               m_pdata->getNGlobal(), m_bias_device, m_bias, m_exec_conf->getStream()),
               "mtd_mesh_forces");
-    for (unsigned int i = 0; i < 6; ++i) m_external_virial[i] = 0.0;
+    if (m_pdata->getPressureFlag())                                    // :1062-1067 (pdata_flag::pressure_tensor / isotropic_virial)
+        computeVirial();
+    else
+        for (unsigned int i = 0; i < 6; ++i) m_external_virial[i] = 0.0;
     }
 
 // ------------------------------------------------------------------------------------------------

@@ -175,23 +175,23 @@ class OrderParameterMeshGPU : public CollectiveVariable
         void computeBiasForces(unsigned int timestep) override;        // OrderParameterMesh.cc:1052-1075
         //! convolution-kernel table: stored like the reference, which never applies it to the mesh (Q7)
         void setTable(const std::vector<double> &K, const std::vector<double> &d_K, double kmin, double kmax);   // :148-189
-        void setUseTable(bool use_table) { m_use_table = use_table; }
+        void setUseTable(bool use_table);                             // OrderParameterMesh.h:60-63
         //! this build: false = interpolation function as intended instead of the reference's unsigned division (Q6)
         void setBugCompatible(bool on);
         std::vector<std::string> getProvidedLogQuantities() override
             {
             auto l = CollectiveVariable::getProvidedLogQuantities();
-            l.push_back("cv_mesh");
+            for (const char *n : {"cv_mesh", "qx_max", "qy_max", "qz_max", "sq_max"}) l.push_back(n);   // OrderParameterMesh.cc:118-122
             return l;
             }
-        double getLogValue(const std::string &quantity, unsigned int timestep) override
-            {
-            if (quantity == "cv_mesh") return getCurrentValue(timestep);
-            return CollectiveVariable::getLogValue(quantity, timestep);
-            }
+        double getLogValue(const std::string &quantity, unsigned int timestep) override;   // :1077-1106
 
     private:
         void enqueueCV(unsigned int timestep);
+        void computeQmax(unsigned int timestep);                      // :1108-1179
+        void computeVirial();                                         // :970-1050
+        unsigned int m_q_max_last_computed;
+        double m_q_max[3], m_sq_max;
         mtd_mesh *m_mesh;
         std::vector<double> m_mode;
         std::vector<int3> m_zero_modes;          // stored and never read, like the reference (OrderParameterMesh.cc:59-63)

@@ -127,7 +127,7 @@ class ParticleData
     {
     public:
         ParticleData(unsigned int N, int dtype, const std::vector<std::string> &type_names, const BoxDim &box)
-            : m_N(N), m_N_global(N), m_dtype(dtype), m_type_names(type_names), m_box(box), m_external_energy(0.0), m_virial_pitch(N)
+            : m_N(N), m_N_global(N), m_dtype(dtype), m_type_names(type_names), m_box(box), m_external_energy(0.0), m_pressure_flag(false), m_virial_pitch(N)
             {
             if (dtype != MTD_F32 && dtype != MTD_F64) throw std::runtime_error("ParticleData: dtype must be MTD_F32 or MTD_F64");
             m_external_virial.fill(0.0);
@@ -154,6 +154,9 @@ class ParticleData
         unsigned int getNetVirialPitch() const { return m_virial_pitch; }
         double getExternalEnergy() const { return m_external_energy; }
         void setExternalEnergy(double e) { m_external_energy = e; }
+        //! PDataFlags pressure_tensor / isotropic_virial: set when an integrator or logger needs the virial
+        bool getPressureFlag() const { return m_pressure_flag; }
+        void setPressureFlag(bool f) { m_pressure_flag = f; }
         double getExternalVirial(unsigned int i) const { return m_external_virial.at(i); }
         void setExternalVirial(unsigned int i, double v) { m_external_virial.at(i) = v; }
         //! use caller-owned device memory for the positions (e.g. a torch tensor), no copy
@@ -167,6 +170,7 @@ class ParticleData
         BoxDim m_box;
         DeviceBuffer m_postype, m_net_force, m_net_torque, m_net_virial;
         double m_external_energy;
+        bool m_pressure_flag;
         std::array<double, 6> m_external_virial;
         unsigned int m_virial_pitch;
         void *m_borrowed_pos = nullptr;

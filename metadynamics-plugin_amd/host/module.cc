@@ -133,6 +133,8 @@ PYBIND11_MODULE(_metadynamics, m)
         .def("getNetVirial", [](ParticleData &p) { return download_scalar_array(p.getNetVirial(), p.getDtype(), {6, (ssize_t)p.getNetVirialPitch()}); })
         .def("getExternalEnergy", &ParticleData::getExternalEnergy)
         .def("setExternalEnergy", &ParticleData::setExternalEnergy)
+        .def("getPressureFlag", &ParticleData::getPressureFlag)
+        .def("setPressureFlag", &ParticleData::setPressureFlag)
         .def("getExternalVirial", &ParticleData::getExternalVirial)
         .def("setExternalVirial", &ParticleData::setExternalVirial);
 

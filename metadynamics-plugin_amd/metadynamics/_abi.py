@@ -132,6 +132,10 @@ _SIGNATURES = {
     "mtd_mesh_destroy": (C.c_int, [_vp]),
     "mtd_mesh_set_bug_compat": (C.c_int, [_vp, C.c_int]),
     "mtd_mesh_num_cells": (C.c_uint, [_vp]),
+    "mtd_mesh_set_table": (C.c_int, [_vp, _dp, _dp, C.c_uint, C.c_double, C.c_double]),
+    "mtd_mesh_set_use_table": (C.c_int, [_vp, C.c_int]),
+    "mtd_mesh_qmax": (C.c_int, [_vp, C.POINTER(Box), C.c_uint, _dp, _vp]),
+    "mtd_mesh_virial": (C.c_int, [_vp, C.POINTER(Box), C.c_uint, C.c_double, _dp, _vp]),
     "mtd_mesh_assign": (C.c_int, [_vp, C.c_uint, _vp, C.c_int, C.POINTER(Box), _vp]),
     "mtd_mesh_exchange_buffer": (C.c_int, [_vp, C.POINTER(_vp), C.POINTER(C.c_size_t)]),
     "mtd_mesh_spectral": (C.c_int, [_vp, C.POINTER(Box), C.c_uint, C.POINTER(_vp), _up, _vp]),

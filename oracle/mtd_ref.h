@@ -133,6 +133,12 @@ void ref_mesh_destroy(ref_mesh *m);
 void ref_mesh_set_bug_compat(ref_mesh *m, int on);
 /* getCurrentValue (OrderParameterMesh.cc:925-968): assignParticles -> FFT -> updateMeshes -> iFFT -> computeCV */
 double ref_mesh_cv(ref_mesh *m, unsigned int N, const double *postype, const ref_box *box, unsigned int N_global);
+/* convolution kernel table (setTable :148-189; K is stored in inf_f and never applied, Q7), q_max log quantities (:1108-1179),
+ * virial (:970-1050, nonzero only with a table in use) — all on the Fourier mesh of the last ref_mesh_cv */
+int ref_mesh_set_table(ref_mesh *m, const double *K, const double *d_K, unsigned int n, double kmin, double kmax);
+void ref_mesh_set_use_table(ref_mesh *m, int on);
+void ref_mesh_qmax(const ref_mesh *m, unsigned int N_global, double *out /*qx,qy,qz,sq_max*/);
+void ref_mesh_virial(const ref_mesh *m, unsigned int N_global, double bias, double *virial /*6*/);
 /* halves of ref_mesh_cv for particle-sharded checks: spread one shard; (sum mesh + mode_sq over shards); spectral part */
 void ref_mesh_assign(ref_mesh *m, unsigned int N, const double *postype, const ref_box *box);
 void ref_mesh_set_mode_sq(ref_mesh *m, double mode_sq);

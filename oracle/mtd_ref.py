@@ -147,6 +147,14 @@ def _bind_optional(L):
         L.ref_mesh_array.argtypes = [C.c_void_p, C.c_int]
         L.ref_mesh_mode_sq.restype = C.c_double
         L.ref_mesh_mode_sq.argtypes = [C.c_void_p]
+        L.ref_mesh_set_table.restype = C.c_int
+        L.ref_mesh_set_table.argtypes = [C.c_void_p, _dp, _dp, C.c_uint, C.c_double, C.c_double]
+        L.ref_mesh_set_use_table.restype = None
+        L.ref_mesh_set_use_table.argtypes = [C.c_void_p, C.c_int]
+        L.ref_mesh_qmax.restype = None
+        L.ref_mesh_qmax.argtypes = [C.c_void_p, C.c_uint, _dp]
+        L.ref_mesh_virial.restype = None
+        L.ref_mesh_virial.argtypes = [C.c_void_p, C.c_uint, C.c_double, _dp]
         L.ref_mesh_assign.restype = None
         L.ref_mesh_assign.argtypes = [C.c_void_p, C.c_uint, _dp, C.POINTER(Box)]
         L.ref_mesh_set_mode_sq.restype = None
@@ -451,6 +459,25 @@ class Mesh:
         out = np.zeros((pt.shape[0], 4), dtype=np.float64)
         lib().ref_mesh_forces(self._h, pt.shape[0], _d(pt), C.byref(box), pt.shape[0] if n_global is None else int(n_global),
                               float(bias), _d(out))
+        return out
+
+    def set_table(self, K, dK, kmin, kmax):
+        k = np.ascontiguousarray(K, dtype=np.float64)
+        d = np.ascontiguousarray(dK, dtype=np.float64)
+        if lib().ref_mesh_set_table(self._h, _d(k), _d(d), len(k), float(kmin), float(kmax)):
+            raise RuntimeError("Error setting up OrderParameterMesh")
+
+    def set_use_table(self, on):
+        lib().ref_mesh_set_use_table(self._h, int(bool(on)))
+
+    def qmax(self, n_global):
+        out = np.zeros(4)
+        lib().ref_mesh_qmax(self._h, int(n_global), _d(out))
+        return out
+
+    def virial(self, n_global, bias):
+        out = np.zeros(6)
+        lib().ref_mesh_virial(self._h, int(n_global), float(bias), _d(out))
         return out
 
     def assign(self, postype, box):

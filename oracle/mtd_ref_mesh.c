@@ -29,6 +29,11 @@ struct ref_mesh
     cpx *mesh, *fourier_mesh, *fourier_mesh_G, *inv_fourier_mesh;
     double *inf_f, *interpolation_f, *k;
     double mode_sq, cv;
+    /* convolution kernel table (setTable :148-189) */
+    double *table, *table_d;
+    unsigned int n_table;
+    double k_min, k_max, delta_k;
+    int use_table;
     };
 
 /* ---------------------------------------------------------------- BoxDim pieces */
@@ -200,6 +205,7 @@ void ref_mesh_destroy(ref_mesh *m)
     if (!m) return;
     free(m->mode); free(m->mesh); free(m->fourier_mesh); free(m->fourier_mesh_G); free(m->inv_fourier_mesh);
     free(m->inf_f); free(m->interpolation_f); free(m->k);
+    free(m->table); free(m->table_d);
     free(m);
     }
 
@@ -244,7 +250,17 @@ static void compute_influence_function(ref_mesh *m, const ref_box *global_box)
         if (n[1] >= (int)(gy / 2 + gy % 2)) n[1] -= (int)gy;
         if (n[2] >= (int)(gz / 2 + gz % 2)) n[2] -= (int)gz;
         for (int c = 0; c < 3; c++) m->k[3 * (size_t)cell_idx + c] = n[0] * b1[c] + n[1] * b2[c] + n[2] * b3[c];
-        m->inf_f[cell_idx] = 1.0;
+        double val = 1.0;
+        const double *kv = m->k + 3 * (size_t)cell_idx;
+        double knorm = sqrt(kv[0] * kv[0] + kv[1] * kv[1] + kv[2] * kv[2]);
+        if (m->use_table && knorm >= m->k_min && knorm < m->k_max)    /* :431-443; stored, never applied to the mesh (Q7) */
+            {
+            double value_f = (knorm - m->k_min) / m->delta_k;
+            unsigned int value_i = (unsigned int)value_f;
+            double K0 = m->table[value_i], K1 = m->table[value_i + 1];
+            val = K0 + (value_f - (double)value_i) * (K1 - K0);
+            }
+        m->inf_f[cell_idx] = val;
         double kH[3];
         if (m->bug_compat)
             {
@@ -388,6 +404,76 @@ double ref_mesh_spectral(ref_mesh *m, unsigned int N_global)
     update_meshes(m, N_global);
     m->cv = compute_cv(m, N_global);
     return m->cv;
+    }
+
+/* setTable :148-189 (returns 0, or -1 where the reference throws) and setUseTable */
+int ref_mesh_set_table(ref_mesh *m, const double *K, const double *d_K, unsigned int n, double kmin, double kmax)
+    {
+    if (kmin < 0 || kmax < 0 || kmax <= kmin) return -1;
+    free(m->table); free(m->table_d);
+    m->table = (double *)malloc(sizeof(double) * n);
+    m->table_d = (double *)malloc(sizeof(double) * n);
+    memcpy(m->table, K, sizeof(double) * n);
+    memcpy(m->table_d, d_K, sizeof(double) * n);
+    m->n_table = n;
+    m->k_min = kmin;
+    m->k_max = kmax;
+    m->delta_k = (kmax - kmin) / (double)(n - 1);
+    m->initialized = 0;
+    return 0;
+    }
+
+void ref_mesh_set_use_table(ref_mesh *m, int on) { m->use_table = on; m->initialized = 0; }
+
+/* computeQmax :1108-1179 on the Fourier mesh of the last ref_mesh_cv: out = (qx, qy, qz, sq_max) */
+void ref_mesh_qmax(const ref_mesh *m, unsigned int N_global, double *out)
+    {
+    double max_amplitude = 0.0;
+    double q_max[3] = { 0.0, 0.0, 0.0 };
+    for (unsigned int kidx = 0; kidx < m->n_cells; ++kidx)
+        {
+        double a = m->fourier_mesh[kidx].r * m->fourier_mesh[kidx].r + m->fourier_mesh[kidx].i * m->fourier_mesh[kidx].i;
+        if (a > max_amplitude)
+            {
+            for (int c = 0; c < 3; c++) q_max[c] = m->k[3 * (size_t)kidx + c];
+            max_amplitude = a;
+            }
+        }
+    out[0] = q_max[0]; out[1] = q_max[1]; out[2] = q_max[2];
+    out[3] = max_amplitude * (double)N_global;
+    }
+
+/* computeVirial :970-1050: virial[6] = bias * sum over k != 0 */
+void ref_mesh_virial(const ref_mesh *m, unsigned int N_global, double bias, double *virial)
+    {
+    for (int i = 0; i < 6; ++i) virial[i] = 0.0;
+    for (unsigned int kidx = 0; kidx < m->n_cells; ++kidx)
+        {
+        if (kidx == 0) continue;                                      /* exclude DC bin */
+        cpx fourier = m->fourier_mesh[kidx];
+        const double *k = m->k + 3 * (size_t)kidx;
+        double ksq = k[0] * k[0] + k[1] * k[1] + k[2] * k[2];
+        double knorm = sqrt(ksq);
+        double kfac = 1.0 / 2.0 / knorm;
+        double val_D = 0.0;
+        if (m->use_table && knorm >= m->k_min && knorm < m->k_max)
+            {
+            double value_f = (knorm - m->k_min) / m->delta_k;
+            unsigned int value_i = (unsigned int)value_f;
+            double dK0 = m->table_d[value_i], dK1 = m->table_d[value_i + 1];
+            val_D = dK0 + (value_f - (double)value_i) * (dK1 - dK0);
+            }
+        kfac *= val_D;
+        double val = (fourier.r * fourier.r + fourier.i * fourier.i) / (double)N_global;
+        double rhog = (fourier.r * fourier.r + fourier.i * fourier.i) * val / (double)N_global;
+        virial[0] += rhog * kfac * k[0] * k[0];
+        virial[1] += rhog * kfac * k[0] * k[1];
+        virial[2] += rhog * kfac * k[0] * k[2];
+        virial[3] += rhog * kfac * k[1] * k[1];
+        virial[4] += rhog * kfac * k[1] * k[2];
+        virial[5] += rhog * kfac * k[2] * k[2];
+        }
+    for (int i = 0; i < 6; ++i) virial[i] = bias * virial[i];
     }
 
 /* interpolateForces, :749-864 (after getCurrentValue of the same snapshot) */

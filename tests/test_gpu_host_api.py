@@ -384,3 +384,48 @@ def test_adaptive_gaussians_through_api(api, ref):
     assert np.allclose(meta.cpp_integrator.getBiasFactors(), b, rtol=1e-6, atol=1e-9 * np.abs(b).max())
     t_now = context.current.system.getCurrentTimeStep()
     assert meta.cpp_integrator.getLogValue("det_sigma", t_now) == pytest.approx(g.sigma_determinant, rel=1e-6)
+
+
+def test_mesh_log_quantities_and_virial_through_api(api, ref):
+    """cv.mesh log quantities qx_max..sq_max (OrderParameterMesh.cc:1077-1179), set_kernel / use_table (cv.py:423-466)
+    and the external virial under the pressure flag (:1062-1072)"""
+    context, cv, integrate = api
+    N, L = 8000, 20.0
+    pos, types = util.snapshot_random(N, L, seed=21, modulated=True, dtype=np.float64)
+    context.initialize(pos, types, ["A", "B"], L, dtype=np.float64)
+    integrate.mode_metadynamics(dt=0.005, stride=1)
+    mesh = cv.mesh(nx=16, mode={"A": 1.0, "B": -1.0})
+    assert set(["cv_mesh", "qx_max", "qy_max", "qz_max", "sq_max"]) <= set(mesh.cpp_force.getProvidedLogQuantities())
+    rbox = ref.Box.make(L)
+    opt = util.oracle_postype(pos, types)
+    r = ref.Mesh(16, 16, 16, [1.0, -1.0])
+    s_ref = r.cv(opt, rbox)
+    q_ref = r.qmax(N)
+    got_q = np.array([mesh.cpp_force.getLogValue(n, 1) for n in ("qx_max", "qy_max", "qz_max")])
+    assert np.abs(q_ref[:3]).max() > 0                               # defined up to the sign (|f(k)| = |f(-k)|)
+    assert np.allclose(got_q, q_ref[:3], rtol=1e-10, atol=1e-13) or np.allclose(got_q, -q_ref[:3], rtol=1e-10, atol=1e-13)
+    assert mesh.cpp_force.getLogValue("sq_max", 1) == pytest.approx(q_ref[3], rel=1e-10)
+    assert mesh.cpp_force.getLogValue("cv_mesh", 1) == pytest.approx(s_ref, rel=1e-9)
+    with pytest.raises(RuntimeError):
+        mesh.set_params(use_table=True)                               # no kernel set yet
+
+    def kernel(k, kmin, kmax, a):
+        return np.exp(-a * k * k), -2 * a * k * np.exp(-a * k * k)
+
+    mesh.set_kernel(kernel, 0.3, 6.0, 40, coeff=dict(a=0.1))
+    mesh.set_params(use_table=True, umbrella="harmonic", kappa=3.0, cv0=0.5 * s_ref)
+    pdata = context.current.system_definition.getParticleData()
+    context.run(1)
+    assert [mesh.cpp_force.getExternalVirial(i) for i in range(6)] == [0.0] * 6      # pressure flag not set (:1069-1072)
+    pdata.setPressureFlag(True)
+    context.run(1)
+    kt = np.linspace(0.3, 6.0, 40)
+    K, dK = kernel(kt, 0.3, 6.0, 0.1)
+    r.set_table(K, dK, 0.3, 6.0)
+    r.set_use_table(True)
+    r.cv(opt, rbox)
+    bias = 3.0 * (s_ref - 0.5 * s_ref)                                # harmonic umbrella dU/ds (CollectiveVariable.cc:43-50)
+    v_ref = r.virial(N, bias)
+    got = np.array([mesh.cpp_force.getExternalVirial(i) for i in range(6)])
+    assert np.abs(v_ref).max() > 0
+    assert np.allclose(got, v_ref, rtol=1e-8, atol=1e-11 * np.abs(v_ref).max())

@@ -159,3 +159,54 @@ def test_mesh_config3_size(abi, ref):
         assert np.abs(F[sl, :3] - F_ref[:, :3]).max() <= 1e-5 * np.abs(F_ref[:, :3]).max()
     finally:
         g.close()
+
+
+@pytest.mark.parametrize("tilt", [{}, dict(xy=0.1, xz=-0.05, yz=0.2)])
+def test_qmax_virial_table(abi, ref, tilt):
+    """q_max / sq_max log quantities (OrderParameterMesh.cc:1108-1179), convolution-kernel table
+    (:148-189) and the virial (:970-1050) vs the oracle, incl. a triclinic box"""
+    lib = abi.load()
+    N, L = 20000, 16.0
+    rng = np.random.default_rng(77)
+    f = rng.random((N, 3))                                            # fractional coordinates: inside the (tilted) box
+    a1 = np.array([L, 0, 0]); a2 = np.array([tilt.get("xy", 0) * L, L, 0])
+    a3 = np.array([tilt.get("xz", 0) * L, tilt.get("yz", 0) * L, L])
+    pos = -0.5 * L + f[:, :1] * a1 + f[:, 1:2] * a2 + f[:, 2:3] * a3
+    types = (np.sin(2 * np.pi * 3 * f[:, 2]) > 0).astype(np.int32)    # a density wave along the third reciprocal vector
+    box, rbox = abi.Box.make(L, **tilt), ref.Box.make(L, **tilt)
+    mode = [1.0, -1.0]
+    m = GpuMesh(abi, (32, 16, 32), mode, N)
+    r = ref.Mesh(32, 16, 32, mode)
+    d_pos = torch.from_numpy(util.pack_postype(pos, types, np.float64)).cuda()
+    pt = util.oracle_postype(pos, types)
+    s_gpu, s_ref = m.cv(d_pos, abi.MTD_F64, box, N), r.cv(pt, rbox)
+    assert s_gpu == pytest.approx(s_ref, rel=1e-9)
+    out = np.zeros(4)
+    abi.check(lib.mtd_mesh_qmax(m.h, C.byref(box), N, out.ctypes.data_as(C.POINTER(C.c_double)), None))
+    q_ref = r.qmax(N)
+    # |f(k)| = |f(-k)| for a real mesh: which of the two cells holds the (rounding-level) larger value depends on the FFT's
+    # summation order, in the reference as well — the wave vector is defined up to its sign
+    assert np.abs(q_ref[:3]).max() > 0
+    assert np.allclose(out[:3], q_ref[:3], rtol=1e-12, atol=1e-13) or np.allclose(out[:3], -q_ref[:3], rtol=1e-12, atol=1e-13)
+    assert out[3] == pytest.approx(q_ref[3], rel=1e-10)
+
+    vir = np.ones(6)
+    abi.check(lib.mtd_mesh_virial(m.h, C.byref(box), N, 0.8, vir.ctypes.data_as(C.POINTER(C.c_double)), None))
+    assert np.all(vir == 0.0) and np.all(r.virial(N, 0.8) == 0.0)          # no table in use
+    # a smooth kernel on a window that cuts through the populated k range (some cells outside [kmin, kmax))
+    npts, kmin, kmax = 48, 0.5, 9.0
+    kt = np.linspace(kmin, kmax, npts)
+    K, dK = np.exp(-0.1 * kt ** 2), -0.2 * kt * np.exp(-0.1 * kt ** 2)
+    abi.check(lib.mtd_mesh_set_table(m.h, util.dbl_array(K), util.dbl_array(dK), npts, kmin, kmax))
+    abi.check(lib.mtd_mesh_set_use_table(m.h, 1))
+    r.set_table(K, dK, kmin, kmax)
+    r.set_use_table(True)
+    # K is stored and never applied (Q7): the CV does not change
+    assert m.cv(d_pos, abi.MTD_F64, box, N) == pytest.approx(s_gpu, rel=1e-14)
+    assert r.cv(pt, rbox) == pytest.approx(s_ref, rel=1e-14)
+    abi.check(lib.mtd_mesh_virial(m.h, C.byref(box), N, 0.8, vir.ctypes.data_as(C.POINTER(C.c_double)), None))
+    v_ref = r.virial(N, 0.8)
+    assert np.abs(v_ref).max() > 0
+    assert np.allclose(vir, v_ref, rtol=1e-9, atol=1e-12 * np.abs(v_ref).max())
+    assert lib.mtd_mesh_set_table(m.h, util.dbl_array(K), util.dbl_array(dK), npts, 2.0, 1.0) == -1   # MTD_ERR_INVALID_ARGUMENT
+    m.close()

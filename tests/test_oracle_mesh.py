@@ -96,3 +96,56 @@ def test_mesh_uniform_lattice_has_zero_cv_modes(ref):
     s = m.cv(ref.as_postype(pos, np.zeros(len(pos), dtype=int)), ref.Box.make(L))
     assert abs(s) < 1e-25
     assert np.allclose(m.array("mesh").real, 1.0)
+
+
+def test_qmax_and_virial_kat(ref):
+    """computeQmax / computeVirial (OrderParameterMesh.cc:1108-1179, 970-1050): a density wave along (2,0,1) puts the
+    largest amplitude at that wave vector (or its mirror image, whichever cell comes first); the virial vanishes without a
+    table and equals the k-space sum with K'(k) = const when a table is in use"""
+    N, L = 4000, 10.0
+    rng = np.random.default_rng(8)
+    pos = rng.random((N, 3)) * L - L / 2
+    q = 2 * np.pi / L * np.array([2, 0, 1])
+    keep = rng.random(N) < 0.5 * (1 + 0.9 * np.cos(pos @ q))
+    pos = pos[keep]
+    n = len(pos)
+    pt = np.column_stack([pos, np.zeros(n)])
+    box = ref.Box.make(L)
+    m = ref.Mesh(16, 16, 16, [1.0])
+    m.set_bug_compat(False)
+    m.cv(pt, box)
+    qx, qy, qz, sq = m.qmax(n)
+    # the DC bin (k = 0) holds (sum a / N)^2 = 1, the largest amplitude of all: the reference does not exclude it
+    assert (qx, qy, qz) == (0.0, 0.0, 0.0) and sq == pytest.approx(n, rel=1e-12)
+    # with a symmetric mode set the DC bin is empty and the modulation wins
+    types = (np.arange(n) % 2).astype(np.float64)
+    wave = np.cos(pos @ q) > 0
+    pt2 = np.column_stack([pos, np.where(wave, 0.0, 1.0)])
+    m2 = ref.Mesh(16, 16, 16, [1.0, -1.0])
+    m2.set_bug_compat(False)
+    m2.cv(pt2, box)
+    got = np.array(m2.qmax(n)[:3])
+    assert np.allclose(np.abs(got), np.abs(q), atol=1e-12) and np.allclose(got, q) | np.allclose(got, -q)
+    f = m2.array("fourier_mesh")
+    assert m2.qmax(n)[3] == pytest.approx((np.abs(f) ** 2).max() * n, rel=1e-12)
+
+    assert np.all(m2.virial(n, 0.7) == 0.0)                      # no table: K' = 0 (:1015-1032)
+    kk = m2.array("k")
+    knorm = np.sqrt((kk ** 2).sum(-1))
+    kmax = knorm.max() * 1.01
+    npts = 64
+    ktab = np.linspace(0.0, kmax, npts)
+    m2.set_table(np.ones(npts), 0.3 * ktab, 0.0, kmax)          # K' = 0.3 k, linear: the table interpolation is exact
+    m2.set_use_table(True)
+    m2.cv(pt2, box)
+    v = m2.virial(n, 0.7)
+    a = np.abs(m2.array("fourier_mesh")) ** 2
+    rhog = a * a / n / n
+    w = np.where(knorm > 0, rhog * 0.3 * 0.5, 0.0)               # kfac = K'/(2k) = 0.15
+    w.flat[0] = 0.0
+    expect = 0.7 * np.array([(w * kk[..., 0] * kk[..., 0]).sum(), (w * kk[..., 0] * kk[..., 1]).sum(), (w * kk[..., 0] * kk[..., 2]).sum(),
+                             (w * kk[..., 1] * kk[..., 1]).sum(), (w * kk[..., 1] * kk[..., 2]).sum(), (w * kk[..., 2] * kk[..., 2]).sum()])
+    assert np.allclose(v, expect, rtol=1e-10, atol=1e-14 * np.abs(expect).max())
+    assert v[0] > 0 and v[5] > 0
+    with pytest.raises(RuntimeError):
+        m2.set_table(np.ones(4), np.ones(4), 2.0, 1.0)           # kmax <= kmin (:153-158)
