@@ -43,14 +43,16 @@ __global__ __launch_bounds__(CV_THREADS) void k_lamellar_cv_partials(const LamKA
     __shared__ float s_coeff[MTD_MAX_CV * MTD_MAX_TYPES];
     __shared__ double s_wave[(CV_THREADS / MTD_WAVE) * NCV];
     __shared__ ModeTables s_mt;
+    RawGroup<S4, CV_UNROLL> first;
+    lam_load_group<S4, CV_UNROLL>(postype, N, blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x, first);
     load_coeff(a, s_coeff);
-    load_modes(a, s_mt, false);
+    load_modes_cv(a, s_mt);
     __syncthreads();
     float acc[NCV];
 #pragma unroll
     for (int c = 0; c < NCV; ++c) acc[c] = 0.0f;
     lam_cv_accumulate<S4, NCV, FAST, CV_UNROLL>(a, postype, N, blockIdx.x * blockDim.x + threadIdx.x,
-                                                gridDim.x * blockDim.x, s_coeff, s_mt, acc);
+                                                gridDim.x * blockDim.x, s_coeff, s_mt, first, acc);
     lam_cv_block_reduce<NCV>(acc, s_wave, partials, blockIdx.x);
     }
 
@@ -256,6 +258,35 @@ int fill_kargs(LamKArgs &k, const mtd_lamellar_set *set, const mtd_box *box)
             }
     for (unsigned int c = 0; c < set->n_cv; ++c)
         for (unsigned int t = 0; t < set->n_types; ++t) k.coeff[c][t] = (float)set->coeff[c][t];
+    // CV pass: fold every second harmonic 2(h,k,l) into its fundamental (h,k,l) of the same CV (cos 2x = 2 cos^2 x - 1).
+    // One level only: a folded mode does not take a harmonic of its own, and every mode is folded at most once.
+    static const bool fold = env_uint("MTD_LAM_FOLD_HARMONICS", 1) != 0;
+    for (unsigned int c = 0; c < set->n_cv; ++c)
+        {
+        bool folded[MTD_MAX_MODES] = {false};
+        for (unsigned int m = set->first[c]; fold && m < set->first[c + 1]; ++m)
+            {
+            if (folded[m] || k.h[m].w != 0.0f) continue;
+            const int *hm = set->hkl[m];
+            if (hm[0] == 0 && hm[1] == 0 && hm[2] == 0) continue;
+            for (unsigned int j = set->first[c]; j < set->first[c + 1]; ++j)
+                {
+                const int *hj = set->hkl[j];
+                if (j != m && !folded[j] && k.h[j].w == 0.0f && hj[0] == 2 * hm[0] && hj[1] == 2 * hm[1] && hj[2] == 2 * hm[2])
+                    {
+                    k.h[m].w = 1.0f;
+                    folded[j] = true;
+                    break;
+                    }
+                }
+            }
+        unsigned int n = 0;
+        for (unsigned int m = set->first[c]; m < set->first[c + 1]; ++m)
+            if (!folded[m]) k.corder[set->first[c] + n++] = (unsigned char)m;
+        k.nact[c] = (unsigned char)n;
+        for (unsigned int m = set->first[c]; m < set->first[c + 1]; ++m)       // the rest of the CV's slots: harmless duplicates
+            if (folded[m]) k.corder[set->first[c] + n++] = (unsigned char)m;
+        }
     return MTD_SUCCESS;
     }
 

@@ -20,7 +20,10 @@ struct LamKArgs
     unsigned int n_cv, n_modes, n_types, _pad;
     unsigned int first[MTD_MAX_CV + 1];
     unsigned int _pad2[3];
-    float4 h[MTD_MAX_MODES];                  // Miller indices (h, k, l, 0)
+    float4 h[MTD_MAX_MODES];                  // Miller indices (h, k, l, fold): fold = 1 when the mode 2(h,k,l) of the same CV is
+                                              // folded into this one by the CV pass, else 0
+    unsigned char corder[MTD_MAX_MODES];      // CV pass: the modes of CV c it visits are corder[first[c] .. first[c] + nact[c])
+    unsigned char nact[MTD_MAX_CV];           // (second harmonics folded into their fundamental are left out)
     float4 q[MTD_MAX_MODES];                  // Cartesian wave vectors with 2*pi (qx, qy, qz, 0)
     float coeff[MTD_MAX_CV][MTD_MAX_TYPES];
     };
@@ -80,25 +83,71 @@ __device__ __forceinline__ void load_modes(const LamKArgs &a, ModeTables &t, con
         }
     }
 
+// CV pass: the visited modes of every CV, gathered into a dense list at [first[c], first[c] + nact[c])
+__device__ __forceinline__ void load_modes_cv(const LamKArgs &a, ModeTables &t)
+    {
+    for (unsigned int k = threadIdx.x; k < a.n_modes; k += blockDim.x) t.h[k] = a.h[a.corder[k]];
+    }
+
 // acc[c] += sum over this thread's particles of a_c(type_j) sum_k cos(q_k . r_j)
-// thread `tid` of `n_threads` walks particles tid, tid + n_threads, ... in groups of U.
+// thread `tid` of `n_threads` walks particles tid, tid + n_threads, ... in groups of U (even).
+// Two things keep this pass off the instruction-issue limit it otherwise sits on (M = 16 modes: 36 issue cycles per
+// particle-mode, ~3.7 us per 10^6 particles):
+//  * particles are handled two at a time in <2 x float> lanes, so the phase and the sums are v_pk_mul / v_pk_fma / v_pk_add
+//    (one instruction per two particles; v_fract / v_cos have no packed form);
+//  * a mode whose Miller indices are exactly twice those of another mode of the same CV (second harmonics, half of a typical
+//    lamellar mode set) costs one packed fma instead of a phase + fract + cos: cos 2x = 2 cos^2 x - 1.
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+// raw particle records of one group (U particles of this thread), loaded without being looked at: the loads can be in
+// flight while something else happens (mode tables being staged, the previous group being summed)
+template<typename S4, int U> struct RawGroup
+    {
+    S4 v[U];
+    };
+
+template<typename S4, int U>
+__device__ __forceinline__ void lam_load_group(const S4 *__restrict__ postype, const unsigned int N, const unsigned int base,
+                                               const unsigned int n_threads, RawGroup<S4, U> &g)
+    {
+    if (N == 0) return;                       // nothing to read (postype may be NULL): the caller's loop does not run either
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+        {
+        const unsigned int i = base + u * n_threads;
+        g.v[u] = postype[i < N ? i : N - 1];  // out-of-range slots re-read the last particle and are masked by ok[]
+        }
+    }
+
+// `first` holds the group at base = tid (lam_load_group, issued by the caller before it staged the tables); every further
+// group is requested before the current one is summed, so only the very first memory round trip of the launch is exposed
+// (measured: 2.6 us per exposed round trip, more than summing a group)
 template<typename S4, int NCV, bool FAST, int U>
 __device__ __forceinline__ void lam_cv_accumulate(const LamKArgs &a, const S4 *__restrict__ postype, const unsigned int N,
                                                   const unsigned int tid, const unsigned int n_threads,
-                                                  const float *s_coeff, const ModeTables &mt, float (&acc)[NCV])
+                                                  const float *s_coeff, const ModeTables &mt, RawGroup<S4, U> cur,
+                                                  float (&acc)[NCV])
     {
+    static_assert(U % 2 == 0, "particles are processed in pairs");
+    constexpr int P = U / 2;
     for (unsigned int base = tid; base < N; base += U * n_threads)
         {
-        float g0[U], g1[U], g2[U];
+        const unsigned int next = base + U * n_threads;
+        RawGroup<S4, U> nxt = cur;
+        if (next < N) lam_load_group<S4, U>(postype, N, next, n_threads, nxt);
+        v2f g0[P], g1[P], g2[P];
         int type[U];
         bool ok[U];
 #pragma unroll
         for (int u = 0; u < U; ++u)
             {
-            const unsigned int i = base + u * n_threads;
-            ok[u] = i < N;
-            const Particle p = scalar4_traits<S4>::load(postype, ok[u] ? i : base);
-            project(a, p, g0[u], g1[u], g2[u]);
+            ok[u] = base + u * n_threads < N;
+            const Particle p = scalar4_traits<S4>::unpack(cur.v[u]);
+            float x0, x1, x2;
+            project(a, p, x0, x1, x2);
+            g0[u / 2][u % 2] = x0;
+            g1[u / 2][u % 2] = x1;
+            g2[u / 2][u % 2] = x2;
             type[u] = p.type;
             }
 #pragma unroll
@@ -106,25 +155,34 @@ __device__ __forceinline__ void lam_cv_accumulate(const LamKArgs &a, const S4 *_
             {
             if (c < (int)a.n_cv)
                 {
-                float sum[U];
+                v2f sum[P];
 #pragma unroll
-                for (int u = 0; u < U; ++u) sum[u] = 0.0f;
-                const unsigned int k1 = a.first[c + 1];
+                for (int q = 0; q < P; ++q) sum[q] = (v2f)(0.0f);
+                const unsigned int k1 = a.first[c] + a.nact[c];
 #pragma unroll 4
                 for (unsigned int k = a.first[c]; k < k1; ++k)
                     {
-                    const float4 h = mt.h[k];
+                    const float4 h = mt.h[k];                         // staged by load_modes_cv: dense, fold flag in w
 #pragma unroll
-                    for (int u = 0; u < U; ++u) sum[u] += cos2pi<FAST>(h.x * g0[u] + h.y * g1[u] + h.z * g2[u]);
+                    for (int q = 0; q < P; ++q)
+                        {
+                        const v2f t = h.x * g0[q] + h.y * g1[q] + h.z * g2[q];
+                        v2f cs;
+                        cs.x = cos2pi<FAST>(t.x);
+                        cs.y = cos2pi<FAST>(t.y);
+                        sum[q] += cs;
+                        sum[q] += h.w * ((cs * cs) * 2.0f - 1.0f);    // the second harmonic of this mode when folded (w = 1), branch-free
+                        }
                     }
 #pragma unroll
                 for (int u = 0; u < U; ++u)
                     {
                     const float w = ok[u] ? s_coeff[c * MTD_MAX_TYPES + type[u]] : 0.0f;
-                    acc[c] += w * sum[u];
+                    acc[c] += w * sum[u / 2][u % 2];
                     }
                 }
             }
+        cur = nxt;
         }
     }
 

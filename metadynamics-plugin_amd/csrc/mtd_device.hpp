@@ -72,28 +72,28 @@ template<typename S4> struct scalar4_traits;
 template<> struct scalar4_traits<float4>
     {
     typedef float scalar;
-    static __device__ __forceinline__ Particle load(const float4 *p, unsigned int i)
+    static __device__ __forceinline__ Particle unpack(const float4 v)
         {
-        float4 v = p[i];
         Particle r;
         r.x = v.x; r.y = v.y; r.z = v.z;
         r.type = __float_as_int(v.w);
         return r;
         }
+    static __device__ __forceinline__ Particle load(const float4 *p, unsigned int i) { return unpack(p[i]); }
     static __device__ __forceinline__ float4 make(float x, float y, float z, float w) { return make_float4(x, y, z, w); }
     };
 
 template<> struct scalar4_traits<double4>
     {
     typedef double scalar;
-    static __device__ __forceinline__ Particle load(const double4 *p, unsigned int i)
+    static __device__ __forceinline__ Particle unpack(const double4 v)
         {
-        double4 v = p[i];
         Particle r;
         r.x = v.x; r.y = v.y; r.z = v.z;
         r.type = __double2loint(v.w); // HOOMD __scalar_as_int for double builds: low word
         return r;
         }
+    static __device__ __forceinline__ Particle load(const double4 *p, unsigned int i) { return unpack(p[i]); }
     static __device__ __forceinline__ double4 make(double x, double y, double z, double w) { return make_double4(x, y, z, w); }
     };
 
