@@ -521,9 +521,9 @@ __global__ __launch_bounds__(256) void k_mesh_spectral(const MeshGeom g, double2
                                                        const int bug_compat, double *__restrict__ cv_partials)
     {
     __shared__ double s_red[16];
-    const unsigned int k = blockIdx.x * blockDim.x + threadIdx.x;
     double term = 0.0;
-    if (k < g.n_cells)
+    // grid-stride: at most 1024 partial sums for the consumer (k_prepare / the chain) to add up, whatever the mesh size
+    for (unsigned int k = blockIdx.x * blockDim.x + threadIdx.x; k < g.n_cells; k += gridDim.x * blockDim.x)
         {
         const unsigned int wz = k / (g.nx * g.ny);
         const unsigned int wy = (k - wz * g.nx * g.ny) / g.nx;
@@ -555,7 +555,7 @@ __global__ __launch_bounds__(256) void k_mesh_spectral(const MeshGeom g, double2
         fmesh[k] = f;
         gmesh[k] = G;
         if (k != 0)                                                    // exclude the DC bin (:889-894)
-            term = (G.x * f.x + G.y * f.y) - 0.5 * val * I * I * (*mode_sq) / n_global / n_global;
+            term += (G.x * f.x + G.y * f.y) - 0.5 * val * I * I * (*mode_sq) / n_global / n_global;
         }
     term = block_sum(term, s_red);
     if (threadIdx.x == 0) cv_partials[blockIdx.x] = term;
@@ -848,6 +848,7 @@ int mtd_mesh_create(mtd_mesh **out, unsigned int nx, unsigned int ny, unsigned i
     const size_t M = m->M, N = max_particles;
     m->n_count_blocks = 4096;
     m->n_cv_partials = (m->M + 255) / 256;
+    if (m->n_cv_partials > 1024) m->n_cv_partials = 1024;
     const unsigned int n_tiles = (m->M + SCAN_TILE - 1) / SCAN_TILE;
     auto al = [](size_t b) { return (b + 255) / 256 * 256; };
     size_t off = 0;

@@ -189,6 +189,12 @@ class steinhardt(_collective_variable):
         self.cpp_force = _metadynamics.SteinhardtQl(context.current.system_definition, float(r_cut), float(r_on), int(lmax),
                                                     nlist.cpp_nlist, type_list.index(type), [float(q) for q in Ql_ref], suffix)
 
+    def get_rcut(self):
+        """cv.py:603-617: the cut-off this CV asks of the neighbour list, by type pair — only (type, type) interacts.
+        (The reference body refers to an undefined ``nl``; this returns the plain dict it was building.)"""
+        names = context.current.type_names
+        return {(a, b): (self.r_cut if a == b == self.type else -1.0) for i, a in enumerate(names) for b in names[i:]}
+
 
 class nlist_cell(object):
     """Stand-in for ``hoomd.md.nlist.cell``: HOOMD's NeighborList is not part of the plugin.  The list is built on the host
@@ -235,3 +241,14 @@ class wrap(_collective_variable):
         self.force = force
         self.cpp_force = _metadynamics.CollectiveWrapper(context.current.system_definition, force.cpp_force, name)
         self.log = force.log
+
+    # cv.py:531-537 call themselves recursively and name an undefined ``force``; the evident intent is kept
+    def disable(self, log=False):
+        self.enabled = False
+        self.log = log
+        self.force.enabled = False
+        self.force.log = log
+
+    def enable(self):
+        self.enabled = True
+        self.force.enabled = True
