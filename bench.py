@@ -52,6 +52,8 @@ def parse():
     ap.add_argument("--driver", choices=["host", "abi"], default=None,
                     help="host: metadynamics.integrate API, C++ run loop (default at N=1); abi: C-ABI calls from Python "
                          "(default for N>1, where torch.distributed carries the all-reduce)")
+    ap.add_argument("--dtype", choices=["f32", "f64"], default="f32",
+                    help="Scalar of the particle arrays (HOOMD single / double precision build); headline: f32 as in BASELINE.json")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=4)
     return ap.parse_args()
@@ -60,7 +62,7 @@ def parse():
 class Engine:
     """The hot path through the C-ABI, device resident (metadynamics.sharded.HipLamellarBackend)."""
 
-    def __init__(self, n_local, n_global, rank, seed, stride, fast_trig, dist=None, path="fused"):
+    def __init__(self, n_local, n_global, rank, seed, stride, fast_trig, dist=None, path="fused", dtype=np.float32):
         from metadynamics.sharded import HipLamellarBackend, ShardedBiasStep
         self.dist = dist
         L = BOX_L * (n_global / N_PER_GPU) ** (1.0 / 3.0)  # constant density (config 4: L = 200 at 8e6)
@@ -71,7 +73,7 @@ class Engine:
             pos, types = pos[sl].copy(), types[sl].copy()
         self.pos_np, self.types_np, self.L = pos, types, L
         cvs = [(util.CV1_VECTORS, util.MODE_AB), (util.CV2_VECTORS, util.MODE_AB)]
-        d_pos = torch.from_numpy(util.pack_postype(pos, types, np.float32)).cuda()
+        d_pos = torch.from_numpy(util.pack_postype(pos.astype(dtype), types, dtype)).cuda()
         self.be = HipLamellarBackend(cvs, d_pos, n_global, L, GRID, W, DELTA_T, T, stride, "well_tempered",
                                      fast_trig=bool(fast_trig), fused=(path == "fused"))
         self.sharded = ShardedBiasStep(self.be, dist) if dist is not None else None
@@ -116,11 +118,11 @@ class HostEngine:
     """The same workload through the reference-shaped API: metadynamics.cv / metadynamics.integrate over the C++
     host classes; the step loop is System::run in C++ (what HOOMD's run loop does)."""
 
-    def __init__(self, n, seed, stride, fast_trig, path):
+    def __init__(self, n, seed, stride, fast_trig, path, dtype=np.float32):
         from metadynamics import context, cv, integrate
         pos, types = util.snapshot_random(n, BOX_L, seed=seed, dtype=np.float32)
         self.pos_np, self.types_np, self.L = pos, types, BOX_L
-        self.ctx = context.initialize(pos, types, ["A", "B"], BOX_L, dtype=np.float32)
+        self.ctx = context.initialize(pos, types, ["A", "B"], BOX_L, dtype=dtype)
         self.meta = integrate.mode_metadynamics(dt=0.005, stride=stride, mode="well_tempered", W=W, deltaT=DELTA_T, T=T)
         self.cvs = []
         for i, vecs in enumerate((util.CV1_VECTORS, util.CV2_VECTORS)):
@@ -189,11 +191,12 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    np_dtype = np.float32 if args.dtype == "f32" else np.float64
     # the event-bracketed pass over the dominant kernel always goes through the C-ABI backend (same kernels)
     eng = Engine(n_local, n_global, rank, seed=12345 if world == 1 else 12346, stride=args.stride,
-                 fast_trig=args.fast_trig, dist=dist, path=args.path)
+                 fast_trig=args.fast_trig, dist=dist, path=args.path, dtype=np_dtype)
     if driver == "host":
-        host = HostEngine(n_local, 12345, args.stride, args.fast_trig, args.path)
+        host = HostEngine(n_local, 12345, args.stride, args.fast_trig, args.path, dtype=np_dtype)
         host.run(max(args.warmup - 1, 0))
         barrier()
         t0 = time.perf_counter()
@@ -236,7 +239,11 @@ def main():
     ev_overhead_us = float(np.median([a.elapsed_time(b) for a, b in empty]) * 1e3)
     raw = np.array([a.elapsed_time(b) for a, b in eng.ev]) * 1e3
     force_us = float(np.median(raw) - ev_overhead_us)
-    force_us_mean = float(np.mean(raw) - ev_overhead_us)
+    # average over the launches; a sample more than 3x the median is a stall of the queue (clock ramp, host jitter between the
+    # two records), not a kernel duration: such samples are dropped and counted
+    keep = raw <= 3.0 * np.median(raw)
+    n_stalls = int((~keep).sum())
+    force_us_mean = float(np.mean(raw[keep]) - ev_overhead_us)
     eng.ev = None
 
     if rank == 0:
@@ -245,7 +252,8 @@ def main():
         # dominant kernel's algorithmic bytes per launch: read Scalar4 positions + write one Scalar4
         # force per CV (48 B/particle); the fused kernel also carries the first grid pass of the deposit
         # (per cell: 8 B dV written, 8+8 B reweighted r/w, 4 B hist_delta read)
-        force_bytes = n_local * (16 + 2 * 16)
+        scalar4 = 16 if args.dtype == "f32" else 32
+        force_bytes = n_local * (scalar4 + 2 * scalar4)
         if args.path == "fused" and args.stride == 1:
             force_bytes += 256 * 256 * 28
         achieved = force_bytes / (force_us_mean * 1e-6) / 1e9
@@ -267,7 +275,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": args.dtype,
             "data": "synthetic",
             "config": {"workload": "1xMI355X: 10^6 particles, 2 lamellar CVs (8 Fourier modes each), 256^2 bias grid, well-tempered"
                        if world == 1 else "%dxMI355X: %d particles sharded, 2 lamellar CVs, RCCL all-reduce of CV sums, replicated 256^2 grid" % (world, n_global),
@@ -277,7 +285,8 @@ def main():
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_source": "profiles/r1/pmc_summary.json (rocprofv3 --pmc passes of this command)" if traffic else None,
                          "algorithmic_bytes_per_launch": force_bytes, "avg_launch_us": force_us_mean,
-                         "median_launch_us": force_us, "event_pair_overhead_us": ev_overhead_us},
+                         "median_launch_us": force_us, "event_pair_overhead_us": ev_overhead_us,
+                         "launches_timed": int(keep.sum()), "stalled_samples_dropped": n_stalls},
             "state": st,
         }
         if not args.no_cpu_baseline:
