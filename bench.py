@@ -75,7 +75,8 @@ class Engine:
         cvs = [(util.CV1_VECTORS, util.MODE_AB), (util.CV2_VECTORS, util.MODE_AB)]
         d_pos = torch.from_numpy(util.pack_postype(pos.astype(dtype), types, dtype)).cuda()
         self.be = HipLamellarBackend(cvs, d_pos, n_global, L, GRID, W, DELTA_T, T, stride, "well_tempered",
-                                     fast_trig=bool(fast_trig), fused=(path == "fused"))
+                                     fast_trig=bool(fast_trig), fused=(path == "fused"),
+                                     exchange="partials")   # equal shards: the block partial sums travel (no reduce launch)
         self.sharded = ShardedBiasStep(self.be, dist) if dist is not None else None
         self.t = 0
         self.ev = None
@@ -173,11 +174,19 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)" % args.gpus)
     dist = None
+    # rehearsal of the N>1 code path on a one-GPU box: MTD_BENCH_REHEARSAL=1 puts every rank on cuda:0 and carries the
+    # all-reduce with gloo (RCCL refuses two ranks on one device); numbers from such a run mean nothing
+    rehearsal = os.environ.get("MTD_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     n_local = args.particles
     n_global = n_local * world
@@ -289,7 +298,7 @@ def main():
                          "launches_timed": int(keep.sum()), "stalled_samples_dropped": n_stalls},
             "state": st,
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:
             pos, types = eng.pos_np, eng.types_np
             v, dt = cpu_baseline(pos, types, eng.L, args.cpu_steps)
             out["cpu_baseline"] = {"value": v, "unit": "particle-CV-evals/s", "cores": 1, "kind": "port",

@@ -299,8 +299,9 @@ class HipLamellarBackend:
     """The fused two-launch lamellar bias step on one GPU (C ABI of libmtd_hip.so)."""
 
     def __init__(self, cvs, d_postype, n_global, box_L, grid, W, T_shift, T, stride, mode="well_tempered",
-                 fast_trig=True, fused=True):
+                 fast_trig=True, fused=True, exchange="sums"):
         import torch
+        self.exchange = exchange
         from . import _abi
         self._abi, self._torch = _abi, torch
         self.lib = lib = _abi.load()
@@ -349,9 +350,16 @@ class HipLamellarBackend:
             abi.check(lib.mtd_lamellar_cv_partials(C.byref(self.lset), self.N, self.d_pos.data_ptr(), self.dt,
                                                    C.byref(self.box), self.scratch.data_ptr(), C.byref(self.n_part), None))
 
-    def cv_pass(self):
-        """local per-CV sums as a device tensor (what the ranks all-reduce)"""
+    def cv_pass(self, reduce_locally=None):
+        """what the ranks all-reduce, as a device tensor: the n_cv local sums (``exchange="sums"``, any shard sizes) or the
+        block partial sums themselves (``exchange="partials"``: n_blocks x n_cv doubles, 4 KB at the headline config — as
+        cheap to all-reduce as 16 bytes and it saves the reduce launch; launch B then adds up the reduced rows exactly as
+        on one GPU.  Every rank must hold the same number of particles, so that the launch geometry — the row count — agrees)"""
         self.cv_partials()
+        if reduce_locally is None:
+            reduce_locally = self.exchange != "partials"
+        if not reduce_locally:
+            return self.scratch[: self.n_part.value * self.n_cv]
         self._abi.check(self.lib.mtd_reduce_partials(self.scratch.data_ptr(), self.n_part.value, self.n_cv, self.n_cv,
                                                      1.0, 0.0, self.cv_sum.data_ptr(), None))
         return self.cv_sum
@@ -360,7 +368,7 @@ class HipLamellarBackend:
     def force_pass(self, sums, timestep):
         """sums: None -> single GPU, read the block partial sums directly; else the (all-reduced) n_cv sums"""
         abi, lib = self._abi, self.lib
-        if sums is None:
+        if sums is None or sums.data_ptr() == self.scratch.data_ptr():
             self._set_sources(self.scratch.data_ptr(), self.n_part.value)
         else:
             self._set_sources(sums.data_ptr(), 1)

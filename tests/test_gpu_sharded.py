@@ -90,6 +90,48 @@ def test_two_shards_lamellar_mesh_energy(abi, ref, dtype):
         be.close()
 
 
+@pytest.mark.parametrize("reduce_locally", [False, True])
+def test_two_shards_fused_lamellar(abi, ref, reduce_locally):
+    """the fused two-launch step sharded over two backends (what bench.py --gpus N runs): launch A per shard, the block
+    partial sums (or the n_cv local sums) summed across the shards, launch B per shard with N_global"""
+    from metadynamics import sharded
+    N, L = 30000, 24.0
+    pos, types = util.snapshot_random(N, L, seed=41, modulated=True, dtype=np.float32)
+    cvs = [(util.CV1_VECTORS, util.MODE_AB), (util.CV2_VECTORS, util.MODE_AB)]
+    grid = dict(sigma=[0.05, 0.05], cv_min=[-1.0, -1.0], cv_max=[1.0, 1.0], num_points=[64, 48])
+    cut = N // 2 if not reduce_locally else 17000          # exchanging block partials needs equal shards
+
+    def make(sl):
+        dp = _dev_postype(pos[sl], types[sl], np.float32)
+        return sharded.HipLamellarBackend(cvs, dp, N, L, grid, 1.0, 7.0, 1.0, 1, "well_tempered", fast_trig=True, fused=True)
+
+    single, a, b = make(slice(0, N)), make(slice(0, cut)), make(slice(cut, N))
+    rbox = ref.Box.make(L)
+    opt = util.oracle_postype(pos, types)
+    s_ref = [ref.lamellar_cv(v, opt, m, rbox) for v, m in cvs]
+    g = ref.Metad(grid["sigma"], grid["cv_min"], grid["cv_max"], grid["num_points"], **dict(KW))
+    for t in range(4):
+        single.step_single(t)
+        sa, sb = a.cv_pass(reduce_locally), b.cv_pass(reduce_locally)
+        assert sa.numel() == sb.numel()                       # same block count on every shard (equal launch geometry)
+        _allreduce_by_hand([sa], [sb])
+        a.force_pass(sa, t)
+        b.force_pass(sb, t)
+        bias = g.update_bias(t, s_ref)
+    torch.cuda.synchronize()
+    st, sta, stb = single.state(), a.state(), b.state()
+    assert sta["cv"] == stb["cv"] and sta["bias"] == stb["bias"]
+    assert np.allclose(sta["cv"], s_ref, rtol=1e-6) and np.allclose(st["cv"], s_ref, rtol=1e-6)
+    assert np.allclose(sta["bias"], bias, rtol=1e-4, atol=1e-6 * np.abs(bias).max())
+    assert sta["num_gaussians"] == st["num_gaussians"] == 4
+    for c in range(2):
+        fs = single.forces[c].cpu().numpy()
+        f2 = torch.cat([a.forces[c], b.forces[c]]).cpu().numpy()
+        assert np.abs(f2[:, :3] - fs[:, :3]).max() <= 2e-5 * np.abs(fs[:, :3]).max()
+    for be in (single, a, b):
+        be.close()
+
+
 def test_two_shards_steinhardt_with_ghosts(abi, ref):
     """Q_l over two spatial slabs: each shard stores its own particles first and the other slab's particles as ghosts;
     the exchange is the Q'_lm sums"""
