@@ -523,30 +523,38 @@ __device__ __forceinline__ double tsc_fourier(double x)              // :487-511
 // it), G never exists in HBM in k-space, and three of the nine sweeps over the mesh (z-pass write, spectral read + write,
 // inverse z-pass read) disappear.  Forward: decimation in time (bit-reversed load, natural order out); inverse: decimation in
 // frequency on the natural-order G (bit-reversed order out, undone by the store address) — no second LDS buffer.
-__device__ __forceinline__ double interpolation_function(const MeshGeom &g, const unsigned int wx, const unsigned int wy,
-                                                         const unsigned int wz, const int bug_compat)
+// The interpolation function I(k) = T(k_x) T(k_y) T(k_z) (:448-449) depends on the mesh dimensions only: its three
+// factors are tabulated once (nx + ny + nz doubles).  In bug-compatible mode the argument of sin() is ~1e9 for every negative
+// Miller index (Q6), i.e. the slow argument-reduction path of the library sine — per cell and per step that was a third
+// of the spectral pass.
+__global__ void k_interp_tables(const unsigned int nx, const unsigned int ny, const unsigned int nz, const int bug_compat,
+                                double *__restrict__ itab)
     {
-    int n0 = (int)wx, n1 = (int)wy, n2 = (int)wz;
-    if (n0 >= (int)(g.nx / 2 + g.nx % 2)) n0 -= (int)g.nx;         // Miller indices :417-422
-    if (n1 >= (int)(g.ny / 2 + g.ny % 2)) n1 -= (int)g.ny;
-    if (n2 >= (int)(g.nz / 2 + g.nz % 2)) n2 -= (int)g.nz;
-    if (bug_compat)
+    const unsigned int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nx + ny + nz) return;
+    unsigned int dim = nx, w = i;
+    if (i >= nx + ny)
         {
-        // :448 int / unsigned => unsigned division (Q6): the quotient is 0 for n >= 0 and ~2^32/dim otherwise
-        const double kx = (M_PI * 2.0) * (double)((unsigned int)n0 / g.nx);
-        const double ky = (M_PI * 2.0) * (double)((unsigned int)n1 / g.ny);
-        const double kz = (M_PI * 2.0) * (double)((unsigned int)n2 / g.nz);
-        return tsc_fourier(kx) * tsc_fourier(ky) * tsc_fourier(kz);
+        dim = nz;
+        w = i - nx - ny;
         }
-    return tsc_fourier((M_PI * 2.0) * ((double)n0 / g.nx)) * tsc_fourier((M_PI * 2.0) * ((double)n1 / g.ny))
-           * tsc_fourier((M_PI * 2.0) * ((double)n2 / g.nz));
+    else if (i >= nx)
+        {
+        dim = ny;
+        w = i - nx;
+        }
+    int n = (int)w;
+    if (n >= (int)(dim / 2 + dim % 2)) n -= (int)dim;              // Miller index :417-422
+    // :448 int / unsigned => unsigned division (Q6): the quotient is 0 for n >= 0 and ~2^32/dim otherwise
+    const double kH = bug_compat ? (M_PI * 2.0) * (double)((unsigned int)n / dim) : (M_PI * 2.0) * ((double)n / dim);
+    itab[i] = tsc_fourier(kH);
     }
 
 __global__ __launch_bounds__(FFT_THREADS) void k_fft_z_spectral(const MeshGeom g, double2 *__restrict__ fmesh, double2 *__restrict__ gmesh,
                                                                 const double2 *__restrict__ twiddle, const unsigned int log2n,
                                                                 const unsigned int tile, const unsigned int tiles_per_row,
                                                                 const double *__restrict__ mode_sq, const double n_global,
-                                                                const int bug_compat, double *__restrict__ cv_partials)
+                                                                const double *__restrict__ itab, double *__restrict__ cv_partials)
     {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ double s_red[16];
@@ -592,7 +600,7 @@ __global__ __launch_bounds__(FFT_THREADS) void k_fft_z_spectral(const MeshGeom g
         {
         const unsigned int p = idx / tile, t = idx % tile;             // p = k_z index
         const unsigned int wx = x_first + t;
-        const double I = interpolation_function(g, wx, wy, p, bug_compat);
+        const double I = itab[wx] * itab[g.nx + wy] * itab[g.nx + g.ny + p];
         double2 f = s[p * tile + t];
         f.x /= n_global;
         f.y /= n_global;
@@ -834,7 +842,7 @@ struct mtd_mesh
     unsigned int *d_cell_of, *d_slot_of, *d_count, *d_start, *d_ids, *d_tile_sums, *d_cell_sorted;
     unsigned int n_last;   // particle count of the last compute_cv (the sorted list the force pass walks)
     // convolution-kernel table (setTable, :148-189): K is stored and never applied (Q7); K' enters the virial
-    double *d_table, *d_table_d, *d_log_scratch;
+    double *d_table, *d_table_d, *d_log_scratch, *d_itab;
     unsigned int n_table;
     double k_min, k_max, delta_k;
     int use_table;
@@ -956,7 +964,8 @@ int mtd_mesh_create(mtd_mesh **out, unsigned int nx, unsigned int ny, unsigned i
                  o_tw2 = take(sizeof(double2) * nz), o_packed = take(sizeof(double4) * N), o_cell = take(sizeof(unsigned int) * N),
                  o_count = take(sizeof(unsigned int) * (M + 1)), o_start = take(sizeof(unsigned int) * (M + 1)),
                  o_ids = take(sizeof(unsigned int) * N), o_tiles = take(sizeof(unsigned int) * n_tiles),
-                 o_inv = take(sizeof(double) * M), o_csort = take(sizeof(unsigned int) * N), o_slot = take(sizeof(unsigned int) * N);
+                 o_inv = take(sizeof(double) * M), o_csort = take(sizeof(unsigned int) * N), o_slot = take(sizeof(unsigned int) * N),
+                 o_itab = take(sizeof(double) * (nx + ny + nz));
     hipError_t e = hipMalloc(&m->slab, off);
     if (e != hipSuccess)
         {
@@ -974,6 +983,7 @@ int mtd_mesh_create(mtd_mesh **out, unsigned int nx, unsigned int ny, unsigned i
     m->d_inv = (double *)(p + o_inv);
     m->d_cell_sorted = (unsigned int *)(p + o_csort);
     m->d_slot_of = (unsigned int *)(p + o_slot);
+    m->d_itab = (double *)(p + o_itab);
     e = hipMemset(m->slab, 0, off);
     if (e == hipSuccess) e = hipMemcpy(m->d_mode, mode, sizeof(double) * n_types, hipMemcpyHostToDevice);
     // twiddles exp(-2 pi i j / n), j < n/2, in double on the host
@@ -989,6 +999,15 @@ int mtd_mesh_create(mtd_mesh **out, unsigned int nx, unsigned int ny, unsigned i
             }
         e = hipMemcpy(m->d_tw[a], tw.data(), sizeof(double) * tw.size(), hipMemcpyHostToDevice);
         }
+    if (e != hipSuccess)
+        {
+        (void)hipFree(m->slab);
+        delete m;
+        return (int)e;
+        }
+    k_interp_tables<<<(nx + ny + nz + 255) / 256, 256>>>(nx, ny, nz, m->bug_compat, m->d_itab);
+    e = hipGetLastError();
+    if (e == hipSuccess) e = hipDeviceSynchronize();
     if (e != hipSuccess)
         {
         (void)hipFree(m->slab);
@@ -1013,6 +1032,9 @@ int mtd_mesh_set_bug_compat(mtd_mesh *m, int on)
     {
     if (!m) return MTD_ERR_INVALID_ARGUMENT;
     m->bug_compat = on ? 1 : 0;
+    k_interp_tables<<<(m->nx + m->ny + m->nz + 255) / 256, 256>>>(m->nx, m->ny, m->nz, m->bug_compat, m->d_itab);
+    MTD_LAUNCH_CHECK();
+    MTD_HIP_TRY(hipDeviceSynchronize());
     return MTD_SUCCESS;
     }
 
@@ -1079,7 +1101,7 @@ int mtd_mesh_spectral(mtd_mesh *m, const mtd_box *box, unsigned int n_global, co
     if (rc) return rc;
     const FftPass pz = fft_z_pass(m);
     k_fft_z_spectral<<<pz.n_blocks, FFT_THREADS, (size_t)pz.n * pz.tile * sizeof(double2), s>>>(
-        g, m->d_f, m->d_g, pz.tw, ilog2(pz.n), pz.tile, pz.tiles_per_row, m->d_mode_sq, (double)n_global, m->bug_compat, m->d_cv_partials);
+        g, m->d_f, m->d_g, pz.tw, ilog2(pz.n), pz.tile, pz.tiles_per_row, m->d_mode_sq, (double)n_global, m->d_itab, m->d_cv_partials);
     MTD_LAUNCH_CHECK();
     rc = launch_fft3d(m, nullptr, m->d_g, m->d_inv, 1, 0x3, s);          // y, x; Re(inv) lands in its own array
     if (rc) return rc;
