@@ -42,7 +42,7 @@ using namespace mtd;
 struct MeshGeom
     {
     unsigned int nx, ny, nz, n_cells;
-    double lo[3], L[3], xy, xz, yz;      // box (local == global: single rank)
+    double lo[3], L[3], Linv[3], xy, xz, yz;   // box (local == global: single rank); Linv = 1 / L
     double binv[3][3];                    // reciprocal rows without 2 pi (force pass, :761-769)
     };
 
@@ -84,9 +84,9 @@ __device__ __forceinline__ void make_fraction(const MeshGeom &g, double x, doubl
     double dx = x - g.lo[0], dy = y - g.lo[1], dz = z - g.lo[2];
     dx -= (g.xz - g.yz * g.xy) * dz + g.xy * dy;
     dy -= g.yz * dz;
-    fx = dx / g.L[0];
-    fy = dy / g.L[1];
-    fz = dz / g.L[2];
+    fx = dx * g.Linv[0];
+    fy = dy * g.Linv[1];
+    fz = dz * g.Linv[2];
     }
 
 // cell (ix,iy,iz) and in-cell shift (mesh units) of a particle — :540-573 == :784-812
@@ -105,21 +105,22 @@ __device__ __forceinline__ void locate(const MeshGeom &g, const Particle &p, int
     ix = min(max(ix, 0), (int)g.nx - 1);
     iy = min(max(iy, 0), (int)g.ny - 1);
     iz = min(max(iz, 0), (int)g.nz - 1);
-    const double cfx = ((double)ix + 0.5) / g.nx, cfy = ((double)iy + 0.5) / g.ny, cfz = ((double)iz + 0.5) / g.nz;
+    // mesh dimensions are powers of two: the divisions by nx, ny, nz are exact multiplications
+    const double cfx = ((double)ix + 0.5) * (1.0 / g.nx), cfy = ((double)iy + 0.5) * (1.0 / g.ny), cfz = ((double)iz + 0.5) * (1.0 / g.nz);
     // makeCoordinates(cell centre)
     const double cx = g.lo[0] + cfx * g.L[0] + cfy * g.xy * g.L[1] + cfz * g.xz * g.L[2];
     const double cy = g.lo[1] + cfy * g.L[1] + cfz * g.yz * g.L[2];
     const double cz = g.lo[2] + cfz * g.L[2];
     double wx = p.x - cx, wy = p.y - cy, wz = p.z - cz;
     // minImage
-    double img = rint(wz / g.L[2]);
+    double img = rint(wz * g.Linv[2]);              // HOOMD BoxDim::minImage works with the reciprocal lengths too
     wz -= g.L[2] * img;
     wy -= g.L[2] * g.yz * img;
     wx -= g.L[2] * g.xz * img;
-    img = rint(wy / g.L[1]);
+    img = rint(wy * g.Linv[1]);
     wy -= g.L[1] * img;
     wx -= g.L[1] * g.xy * img;
-    wx -= g.L[0] * rint(wx / g.L[0]);
+    wx -= g.L[0] * rint(wx * g.Linv[0]);
     double sfx, sfy, sfz;
     make_fraction(g, wx + g.lo[0], wy + g.lo[1], wz + g.lo[2], sfx, sfy, sfz);
     sx = sfx * g.nx;
@@ -861,6 +862,7 @@ int fill_geom(MeshGeom &g, const mtd_mesh *m, const mtd_box *box)
         {
         g.lo[i] = box->lo[i];
         g.L[i] = box->L[i];
+        g.Linv[i] = 1.0 / box->L[i];
         }
     g.xy = box->xy; g.xz = box->xz; g.yz = box->yz;
     reciprocal_rows(*box, g.binv);
