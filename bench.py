@@ -143,7 +143,7 @@ class HostEngine:
         t = self.ctx.system.getCurrentTimeStep()
         integ = self.meta.cpp_integrator
         return dict(cv=[c.cpp_force.getCurrentValue(t) for c in self.cvs], V=integ.getLogValue("bias", t),
-                    w=integ.getLogValue("weight", t), fused=integ.usedFusedPath())
+                    w=integ.getLogValue("weight", t), num_gaussians=integ.getNumGaussians(), fused=integ.usedFusedPath())
 
 
 def cpu_baseline(pos, types, L, steps):
@@ -163,6 +163,21 @@ def cpu_baseline(pos, types, L, steps):
             mtd_ref.lamellar_forces(v, opt, m, rbox, b[c])
     dt = time.perf_counter() - t0
     return pos.shape[0] * len(cvs) * steps / dt, dt
+
+
+def self_check(st, stride):
+    """The grid engine of the oracle, driven with the CV values the device reports (the particles do not move, so they are
+    the same every step), deposits the same number of hills; V(s) and the reweighting factor w(s) after thousands of
+    deposits must agree with the device's.  Checker only: nothing here is timed."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import mtd_ref
+    r = mtd_ref.Metad(W=W, T_shift=DELTA_T, T=T, stride=1, mode="well_tempered", **GRID)
+    n = int(st["num_gaussians"])
+    for t in range(n):
+        r.update_bias(t, st["cv"])
+    v_ref, w_ref = r.curr_bias, r.curr_weight
+    return {"hills": n, "V_oracle": v_ref, "w_oracle": w_ref,
+            "V_rel_err": abs(st["V"] - v_ref) / max(abs(v_ref), 1e-300), "w_rel_err": abs(st["w"] - w_ref) / max(abs(w_ref), 1e-300)}
 
 
 def main():
@@ -298,6 +313,8 @@ def main():
                          "launches_timed": int(keep.sum()), "stalled_samples_dropped": n_stalls},
             "state": st,
         }
+        if not args.no_cpu_baseline and world == 1 and st.get("num_gaussians") and args.stride == 1:
+            out["self_check"] = self_check(st, args.stride)
         if not args.no_cpu_baseline and world == 1:
             pos, types = eng.pos_np, eng.types_np
             v, dt = cpu_baseline(pos, types, eng.L, args.cpu_steps)

@@ -936,6 +936,13 @@ std::vector<double> IntegratorMetaDynamics::getBiasFactors()
     return b;
     }
 
+unsigned int IntegratorMetaDynamics::getNumGaussians()
+    {
+    unsigned int n = 0;
+    if (m_engine) mtd_check(mtd_metad_get_state(m_engine, nullptr, nullptr, nullptr, nullptr, &n, nullptr, m_exec_conf->getStream()), "mtd_metad_get_state");
+    return n;
+    }
+
 // :817-829
 void IntegratorMetaDynamics::dumpGrid(const std::string &filename1, const std::string &filename2, unsigned int period)
     {

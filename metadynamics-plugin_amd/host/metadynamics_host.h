@@ -321,6 +321,8 @@ class IntegratorMetaDynamics
         void setAdaptive(bool adaptive) { m_adaptive = adaptive; }   // IntegratorMetaDynamics.h:248-251
         //! the inverse width matrix of the last deposit (row major n_cv x n_cv)
         std::vector<double> getSigmaInv() const { return m_sigma_inv; }
+        //! hills deposited so far (m_num_gaussians, IntegratorMetaDynamics.cc:440)
+        unsigned int getNumGaussians();
         void setSigmaG(double sigma_g) { m_sigma_g = sigma_g; }
         void setMultipleWalkers(bool multiple) { m_multiple_walkers = multiple; }
         void resetHistogram();                                         // :1195-1203

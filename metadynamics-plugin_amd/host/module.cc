@@ -251,6 +251,7 @@ PYBIND11_MODULE(_metadynamics, m)
         .def("setAdaptive", &IntegratorMetaDynamics::setAdaptive)
         .def("setSigmaG", &IntegratorMetaDynamics::setSigmaG)
         .def("getSigmaInv", &IntegratorMetaDynamics::getSigmaInv)
+        .def("getNumGaussians", &IntegratorMetaDynamics::getNumGaussians)
         .def("resetHistogram", &IntegratorMetaDynamics::resetHistogram)
         .def("setMultipleWalkers", &IntegratorMetaDynamics::setMultipleWalkers)
         // HOOMD Integrator interface used by System / analyze.log
