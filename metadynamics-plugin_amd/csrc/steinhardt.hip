@@ -35,8 +35,10 @@ namespace
 using namespace mtd;
 
 constexpr int QL_THREADS = 256;
-constexpr int QL_PPB = 128;                     // central particles per chunk
-constexpr int QL_CAP = 2048;                    // pair slots staged in LDS per batch (3 doubles each = 48 KB)
+// chunk geometry {central particles per chunk, pair slots staged in LDS per batch (3 doubles each)}: the CV pass runs four
+// blocks per CU (24 KB each), the force pass two (its registers allow no more) with larger chunks to amortise the set-up
+constexpr int QL_ACC_PPB = 64, QL_ACC_CAP = 1024;
+constexpr int QL_FRC_PPB = 128, QL_FRC_CAP = 2048;
 constexpr unsigned int QL_MAX_BLOCKS = 1024;
 
 template<int LMAX> struct QlArgs
@@ -188,20 +190,22 @@ __device__ __forceinline__ void amplitude_column(const QlArgs<LMAX> &a, const in
 // chunk bookkeeping shared by both passes: the neighbour-list segments of QL_PPB consecutive central particles, flattened;
 // the separations of up to QL_CAP pairs are gathered into LDS first (phase 1: independent loads, many in flight per
 // thread), the fp64 arithmetic then runs on LDS operands only (phase 2)
-struct ChunkShared
+template<int PPB, int CAP> struct ChunkShared
     {
-    unsigned int start[QL_PPB];       // head_list of the particle
-    unsigned int off[QL_PPB + 1];     // exclusive prefix of the neighbour counts inside the chunk
-    unsigned int wave_total[QL_PPB / MTD_WAVE];
-    double px[QL_PPB], py[QL_PPB], pz[QL_PPB];     // the central particles' own positions
-    double dx[QL_CAP], dy[QL_CAP], dz[QL_CAP];     // min-imaged separations r_i - r_j; excluded pairs carry an infinite dx
+    static constexpr int ppb = PPB, cap = CAP;
+    unsigned int start[PPB];          // head_list of the particle
+    unsigned int off[PPB + 1];        // exclusive prefix of the neighbour counts inside the chunk
+    unsigned int wave_total[PPB / MTD_WAVE];
+    double px[PPB], py[PPB], pz[PPB];              // the central particles' own positions
+    double dx[CAP], dy[CAP], dz[CAP];              // min-imaged separations r_i - r_j; excluded pairs carry an infinite dx
     };
 
-template<typename S4, int LMAX>
+template<typename S4, int LMAX, typename CS>
 __device__ __forceinline__ void chunk_setup(const QlArgs<LMAX> &a, const S4 *__restrict__ postype,
                                             const unsigned int *__restrict__ head_list, const unsigned int *__restrict__ n_neigh,
-                                            const unsigned int chunk, ChunkShared &cs)
+                                            const unsigned int chunk, CS &cs)
     {
+    constexpr int QL_PPB = CS::ppb;
     __syncthreads();                                                             // previous chunk fully consumed
     unsigned int incl = 0;
     if (threadIdx.x < QL_PPB)
@@ -243,8 +247,9 @@ __device__ __forceinline__ void chunk_setup(const QlArgs<LMAX> &a, const S4 *__r
     __syncthreads();
     }
 
-__device__ __forceinline__ unsigned int chunk_owner(const ChunkShared &cs, const unsigned int e)
+template<typename CS> __device__ __forceinline__ unsigned int chunk_owner(const CS &cs, const unsigned int e)
     {
+    constexpr int QL_PPB = CS::ppb;
     unsigned int p = 0;
 #pragma unroll
     for (unsigned int step = QL_PPB / 2; step > 0; step >>= 1)
@@ -253,10 +258,10 @@ __device__ __forceinline__ unsigned int chunk_owner(const ChunkShared &cs, const
     }
 
 // phase 1: gather the separations of entries [base, base + QL_CAP) of the chunk into LDS
-template<typename S4, int LMAX>
+template<typename S4, int LMAX, typename CS>
 __device__ __forceinline__ void chunk_gather(const QlArgs<LMAX> &a, const S4 *__restrict__ postype,
                                              const unsigned int *__restrict__ nlist, const unsigned int base, const unsigned int n,
-                                             ChunkShared &cs, unsigned int *s_j)
+                                             CS &cs, unsigned int *s_j)
     {
 #pragma unroll 4
     for (unsigned int t = threadIdx.x; t < n; t += QL_THREADS)
@@ -277,21 +282,86 @@ __device__ __forceinline__ void chunk_gather(const QlArgs<LMAX> &a, const S4 *__
     }
 
 // ---- CV accumulation -------------------------------------------------------------------------------
-template<typename S4, int LMAX>
-__global__ __launch_bounds__(QL_THREADS, 2) void k_ql_accumulate(const QlArgs<LMAX> a, const S4 *__restrict__ postype,
-                                                                 const unsigned int *__restrict__ head_list,
-                                                                 const unsigned int *__restrict__ n_neigh,
-                                                                 const unsigned int *__restrict__ nlist, double *__restrict__ partials)
+// The 28 complex accumulators (lmax = 6) alone are 112 VGPRs: with everything else that is two waves per SIMD, and the fp64
+// dependency chains of the recurrence are then exposed.  So the orders m are split between two ROLES (even / odd waves of
+// the block): every pair is visited once per role (the geometry twice — cheap next to the recurrence), each role keeps half
+// of the accumulators, and four waves per SIMD fit.
+__host__ __device__ constexpr bool ql_role_has(const int m, const int role) { return ((m % 4 == 0 || m % 4 == 3) ? 0 : 1) == role; }
+
+typedef ChunkShared<QL_ACC_PPB, QL_ACC_CAP> AccChunk;
+typedef ChunkShared<QL_FRC_PPB, QL_FRC_CAP> FrcChunk;
+
+template<int LMAX, int ROLE>
+__device__ __forceinline__ void ql_accumulate_pairs(const QlArgs<LMAX> &a, const AccChunk &cs, const unsigned int n,
+                                                    const unsigned int first, cplx (&Q)[LMAX + 1][LMAX + 1])
     {
-    constexpr int NLM = (LMAX + 1) * (LMAX + 2) / 2;
-    __shared__ double s_wave[QL_THREADS / MTD_WAVE][2 * NLM];
-    __shared__ ChunkShared cs;
+    for (unsigned int t = first; t < n; t += QL_THREADS / 2)
+        {
+        const double dx = cs.dx[t], dy = cs.dy[t], dz = cs.dz[t];
+        const double rsq = dx * dx + dy * dy + dz * dz;
+        if (!(rsq <= a.rcutsq)) continue;
+        const PairGeom g = pair_geom(dx, dy, dz, rsq);
+        double f, fprime_divr;
+        smoothing(a, rsq, g.inv_r, f, fprime_divr);
+        // Q'_lm += f * Y'_lm, column by column
+        double sinpow = f * 0.3989422804014326779399460599343818684758586311649;   // 1 / sqrt(2 pi)
+        cplx harm = {1.0, 0.0};                                                    // e^{i m phi}
+#pragma unroll
+        for (int m = 0; m <= LMAX; ++m)
+            {
+            if (ql_role_has(m, ROLE))
+                {
+                double col[LMAX + 1];
+                amplitude_column<LMAX>(a, m, g.ct, 1.0, col);
+                const double hr = sinpow * harm.re, hi = sinpow * harm.im;
+#pragma unroll
+                for (int l = m; l <= LMAX; ++l)
+                    {
+                    Q[m][l].re += col[l] * hr;
+                    Q[m][l].im += col[l] * hi;
+                    }
+                }
+            sinpow *= g.st;
+            harm = cmul(harm, {g.cp, g.sp});
+            }
+        }
+    }
+
+template<int LMAX, int ROLE>
+__device__ __forceinline__ void ql_wave_reduce(const cplx (&Q)[LMAX + 1][LMAX + 1], double *s_row)
+    {
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int l = 0; l <= LMAX; ++l)
+#pragma unroll
+        for (int m = 0; m <= l; ++m)
+            if (ql_role_has(m, ROLE))
+                {
+                const int idx = l * (l + 1) / 2 + m;
+                const double re = wave_sum(Q[m][l].re), im = wave_sum(Q[m][l].im);
+                if (lane == 0)
+                    {
+                    s_row[2 * idx] = re;
+                    s_row[2 * idx + 1] = im;
+                    }
+                }
+    }
+
+// the whole chunk loop of one role, with its own accumulators: the two instantiations sit in the two arms of a wave-uniform
+// branch, so their registers overlap (one shared Q array would keep all 28 entries live in both)
+template<typename S4, int LMAX, int ROLE>
+__device__ __forceinline__ void ql_accumulate_role(const QlArgs<LMAX> &a, const S4 *__restrict__ postype,
+                                                   const unsigned int *__restrict__ head_list, const unsigned int *__restrict__ n_neigh,
+                                                   const unsigned int *__restrict__ nlist, AccChunk &cs, double *s_row)
+    {
+    constexpr int QL_PPB = QL_ACC_PPB, QL_CAP = QL_ACC_CAP;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned int first = (wave >> 1) * MTD_WAVE + lane;       // this thread's first pair slot within its role
     cplx Q[LMAX + 1][LMAX + 1];
 #pragma unroll
     for (int m = 0; m <= LMAX; ++m)
 #pragma unroll
         for (int l = 0; l <= LMAX; ++l) Q[m][l] = {0.0, 0.0};
-
     const unsigned int n_chunks = (a.N + QL_PPB - 1) / QL_PPB;
     for (unsigned int chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x)
         {
@@ -302,50 +372,30 @@ __global__ __launch_bounds__(QL_THREADS, 2) void k_ql_accumulate(const QlArgs<LM
             const unsigned int n = min(total - base, (unsigned int)QL_CAP);
             if (base) __syncthreads();                                         // previous batch consumed
             chunk_gather<S4, LMAX>(a, postype, nlist, base, n, cs, nullptr);
-            for (unsigned int t = threadIdx.x; t < n; t += QL_THREADS)
-                {
-                const double dx = cs.dx[t], dy = cs.dy[t], dz = cs.dz[t];
-                const double rsq = dx * dx + dy * dy + dz * dz;
-                if (!(rsq <= a.rcutsq)) continue;
-                const PairGeom g = pair_geom(dx, dy, dz, rsq);
-                double f, fprime_divr;
-                smoothing(a, rsq, g.inv_r, f, fprime_divr);
-                // Q'_lm += f * Y'_lm, column by column
-                double sinpow = f * 0.3989422804014326779399460599343818684758586311649;   // 1 / sqrt(2 pi)
-                cplx harm = {1.0, 0.0};                                        // e^{i m phi}
-#pragma unroll
-                for (int m = 0; m <= LMAX; ++m)
-                    {
-                    double col[LMAX + 1];
-                    amplitude_column<LMAX>(a, m, g.ct, 1.0, col);
-                    const double hr = sinpow * harm.re, hi = sinpow * harm.im;
-#pragma unroll
-                    for (int l = m; l <= LMAX; ++l)
-                        {
-                        Q[m][l].re += col[l] * hr;
-                        Q[m][l].im += col[l] * hi;
-                        }
-                    sinpow *= g.st;
-                    harm = cmul(harm, {g.cp, g.sp});
-                    }
-                }
+            ql_accumulate_pairs<LMAX, ROLE>(a, cs, n, first, Q);
             }
         }
+    // every wave owns the (l, m) entries of its role; the other entries of its row stay zero (cleared at entry, published by
+    // the barriers of the chunk loop)
+    ql_wave_reduce<LMAX, ROLE>(Q, s_row);
+    }
 
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-    for (int l = 0; l <= LMAX; ++l)
-#pragma unroll
-        for (int m = 0; m <= l; ++m)
-            {
-            const int idx = l * (l + 1) / 2 + m;
-            const double re = wave_sum(Q[m][l].re), im = wave_sum(Q[m][l].im);
-            if (lane == 0)
-                {
-                s_wave[wave][2 * idx] = re;
-                s_wave[wave][2 * idx + 1] = im;
-                }
-            }
+template<typename S4, int LMAX>
+__global__ __launch_bounds__(QL_THREADS, (LMAX <= 6 ? 4 : 2)) void k_ql_accumulate(const QlArgs<LMAX> a, const S4 *__restrict__ postype,
+                                                                 const unsigned int *__restrict__ head_list,
+                                                                 const unsigned int *__restrict__ n_neigh,
+                                                                 const unsigned int *__restrict__ nlist, double *__restrict__ partials)
+    {
+    constexpr int NLM = (LMAX + 1) * (LMAX + 2) / 2;
+    __shared__ double s_wave[QL_THREADS / MTD_WAVE][2 * NLM];
+    __shared__ AccChunk cs;
+    const int wave = threadIdx.x >> 6;
+    for (unsigned int q = threadIdx.x; q < (QL_THREADS / MTD_WAVE) * 2 * NLM; q += QL_THREADS) (&s_wave[0][0])[q] = 0.0;
+    // both arms run the same sequence of block barriers (the chunk loop depends on blockIdx and N only)
+    if (wave & 1)
+        ql_accumulate_role<S4, LMAX, 1>(a, postype, head_list, n_neigh, nlist, cs, s_wave[wave]);
+    else
+        ql_accumulate_role<S4, LMAX, 0>(a, postype, head_list, n_neigh, nlist, cs, s_wave[wave]);
     __syncthreads();
     const unsigned int n_out = (a.lmax + 1) * (a.lmax + 2);     // 2 * n_lm of the RUNTIME lmax (same (l,m) order)
     for (unsigned int q = threadIdx.x; q < n_out; q += blockDim.x)
@@ -406,8 +456,9 @@ __global__ __launch_bounds__(QL_THREADS, 2) void k_ql_forces(const QlArgs<LMAX> 
     {
     typedef typename scalar4_traits<S4>::scalar scalar;
     constexpr int NLM = (LMAX + 1) * (LMAX + 2) / 2;
+    constexpr int QL_PPB = QL_FRC_PPB, QL_CAP = QL_FRC_CAP;
     __shared__ double s_qw[2 * NLM];                 // w_l (2 or 4) conj(Q_lm), m >= 0, index l(l+1)/2 + m
-    __shared__ ChunkShared cs;
+    __shared__ FrcChunk cs;
     __shared__ unsigned int s_j[HALF ? QL_CAP : 1];
     const double bias = d_bias ? *d_bias : bias_host;
     const double ng = (double)a.n_global;
@@ -449,6 +500,7 @@ __global__ __launch_bounds__(QL_THREADS, 2) void k_ql_forces(const QlArgs<LMAX> 
                 {
                 const double dx = cs.dx[t], dy = cs.dy[t], dz = cs.dz[t];
                 const double rsq = dx * dx + dy * dy + dz * dz;
+                const unsigned int opaque0 = t >> 31;
                 double fpx = 0.0, fpy = 0.0, fpz = 0.0;
                 if (rsq <= a.rcutsq)
                     {
@@ -475,7 +527,9 @@ __global__ __launch_bounds__(QL_THREADS, 2) void k_ql_forces(const QlArgs<LMAX> 
                                 if (active_l & (1u << l))                        // degrees with Ql_ref[l] != 0 (and l <= lmax)
                                     {
                                     const int idx = l * (l + 1) / 2 + m;
-                                    const double qr = s_qw[2 * idx], qi = s_qw[2 * idx + 1];
+                                    // `opaque0` (always 0, but derived from the pair slot) keeps these reads inside the pair
+                                    // loop: hoisted, the loop-invariant table takes ~110 registers and costs a wave per SIMD
+                                    const double qr = s_qw[2 * idx + opaque0], qi = s_qw[2 * idx + 1 + opaque0];
                                     const double zr = harm_prev.re * qr - harm_prev.im * qi;
                                     const double zi = harm_prev.re * qi + harm_prev.im * qr;
                                     const double A = prev[l];
@@ -575,11 +629,11 @@ int fill_args(QlArgs<LMAX> &a, unsigned int N, const mtd_box *box, double rcut, 
     return MTD_SUCCESS;
     }
 
-unsigned int ql_blocks(unsigned int N)
+unsigned int ql_blocks(unsigned int N, int ppb, unsigned int resident)
     {
-    unsigned int b = (N + QL_PPB - 1) / QL_PPB;
+    unsigned int b = (N + ppb - 1) / ppb;
     if (b < 1) b = 1;
-    if (b > 512) b = 512;                      // 2 resident blocks per CU (LDS: 48 KB pair slots each)
+    if (b > resident) b = resident;            // every block resident at once: 4 per CU in the CV pass, 2 in the force pass
     return b;
     }
 
@@ -601,7 +655,7 @@ int accumulate_impl(unsigned int N, const void *d_postype, int dtype, const mtd_
         MTD_LAUNCH_CHECK();
         return MTD_SUCCESS;
         }
-    const unsigned int blocks = ql_blocks(N);
+    const unsigned int blocks = ql_blocks(N, QL_ACC_PPB, 1024);
     const unsigned int n_out = (lmax + 1) * (lmax + 2);
     if (dtype == MTD_F32)
         k_ql_accumulate<float4, LMAX><<<blocks, QL_THREADS, 0, s>>>(a, (const float4 *)d_postype, d_head, d_nneigh, d_nlist, d_partials);
@@ -626,7 +680,7 @@ int forces_impl(unsigned int N, const void *d_postype, void *d_force, int dtype,
     QlArgs<LMAX> a;
     int rc = fill_args<LMAX>(a, N, box, rcut, ron, lmax, type, ql_ref, n_global, half);
     if (rc) return rc;
-    const unsigned int blocks = ql_blocks(N);
+    const unsigned int blocks = ql_blocks(N, QL_FRC_PPB, 512);
     const size_t s4 = dtype == MTD_F32 ? sizeof(float4) : sizeof(double4);
     if (half) MTD_HIP_TRY(hipMemsetAsync(d_force, 0, s4 * N, s));            // memset of :236, the pair terms are then added atomically
     if (dtype == MTD_F32)
