@@ -224,8 +224,7 @@ template<typename S4>
 __global__ __launch_bounds__(256) void k_mesh_place(const MeshGeom g, const S4 *__restrict__ postype, const unsigned int N,
                                                     const double *__restrict__ mode, const unsigned int *__restrict__ cell_of,
                                                     const unsigned int *__restrict__ slot_of, const unsigned int *__restrict__ start,
-                                                    unsigned int *__restrict__ ids, double4 *__restrict__ packed,
-                                                    unsigned int *__restrict__ cell_sorted)
+                                                    uint2 *__restrict__ idcell, double4 *__restrict__ packed)
     {
     for (unsigned int i = blockIdx.x * blockDim.x + threadIdx.x; i < N; i += gridDim.x * blockDim.x)
         {
@@ -236,30 +235,29 @@ __global__ __launch_bounds__(256) void k_mesh_place(const MeshGeom g, const S4 *
         const unsigned int c = cell_of[i];
         const unsigned int dst = start[c] + slot_of[i];
         packed[dst] = make_double4(sx, sy, sz, mode[p.type]);
-        ids[dst] = i;
-        cell_sorted[dst] = c;
+        idcell[dst] = make_uint2(i, c);                 // one 8-byte scattered store instead of two 4-byte ones
         }
     }
 
 // ---- 4. cells with >= 2 particles: order by particle id (the arrival order of step 1 is not reproducible) ----
 __global__ __launch_bounds__(256) void k_mesh_sortfix(const unsigned int n_cells, const unsigned int *__restrict__ start,
-                                                      unsigned int *__restrict__ ids, double4 *__restrict__ packed)
+                                                      uint2 *__restrict__ idcell, double4 *__restrict__ packed)
     {
     const unsigned int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= n_cells) return;
     const unsigned int b = start[c], e = start[c + 1];
     for (unsigned int i = b + 1; i < e; ++i)          // insertion sort: cells hold O(1) particles
         {
-        const unsigned int key = ids[i];
+        const uint2 key = idcell[i];
         const double4 rec = packed[i];
         unsigned int j = i;
-        while (j > b && ids[j - 1] > key)
+        while (j > b && idcell[j - 1].x > key.x)
             {
-            ids[j] = ids[j - 1];
+            idcell[j] = idcell[j - 1];
             packed[j] = packed[j - 1];
             --j;
             }
-        ids[j] = key;
+        idcell[j] = key;
         packed[j] = rec;
         }
     }
@@ -651,8 +649,8 @@ __global__ __launch_bounds__(FFT_THREADS) void k_fft_z_spectral(const MeshGeom g
 // 27 uncoalesced gathers), shift and mode come from the packed records (no second locate()), the force is written to
 // the particle's original index.
 template<typename S4>
-__global__ __launch_bounds__(256) void k_mesh_forces(const MeshGeom g, const unsigned int N, const unsigned int *__restrict__ ids,
-                                                     const unsigned int *__restrict__ cell_sorted, const double4 *__restrict__ packed,
+__global__ __launch_bounds__(256) void k_mesh_forces(const MeshGeom g, const unsigned int N, const uint2 *__restrict__ idcell,
+                                                     const double4 *__restrict__ packed,
                                                      const double *__restrict__ inv, S4 *__restrict__ force,
                                                      const double *__restrict__ d_bias, const double bias_host, const double two_over_n)
     {
@@ -661,7 +659,8 @@ __global__ __launch_bounds__(256) void k_mesh_forces(const MeshGeom g, const uns
     for (unsigned int q = blockIdx.x * blockDim.x + threadIdx.x; q < N; q += gridDim.x * blockDim.x)
         {
         const double4 pk = packed[q];
-        const unsigned int c = cell_sorted[q];
+        const uint2 ic = idcell[q];
+        const unsigned int c = ic.y;
         const int iz = c / (g.nx * g.ny);
         const int iy = (c - iz * g.nx * g.ny) / g.nx;
         const int ix = c % g.nx;
@@ -696,7 +695,7 @@ __global__ __launch_bounds__(256) void k_mesh_forces(const MeshGeom g, const uns
         const double fx = (c1 * g.binv[0][0] + c2 * g.binv[1][0] + c3 * g.binv[2][0]) * s;
         const double fy = (c1 * g.binv[0][1] + c2 * g.binv[1][1] + c3 * g.binv[2][1]) * s;
         const double fz = (c1 * g.binv[0][2] + c2 * g.binv[1][2] + c3 * g.binv[2][2]) * s;
-        force[ids[q]] = scalar4_traits<S4>::make((scalar)fx, (scalar)fy, (scalar)fz, (scalar)0);
+        force[ic.x] = scalar4_traits<S4>::make((scalar)fx, (scalar)fy, (scalar)fz, (scalar)0);
         }
     }
 
@@ -840,7 +839,8 @@ struct mtd_mesh
     double *d_mode, *d_rho, *d_inv, *d_modesq_partials, *d_mode_sq, *d_cv_partials;
     double2 *d_f, *d_g, *d_tw[3];
     double4 *d_packed;
-    unsigned int *d_cell_of, *d_slot_of, *d_count, *d_start, *d_ids, *d_tile_sums, *d_cell_sorted;
+    unsigned int *d_cell_of, *d_slot_of, *d_count, *d_start, *d_tile_sums;
+    uint2 *d_idcell;           // (particle id, cell) of every sorted slot
     unsigned int n_last;   // particle count of the last compute_cv (the sorted list the force pass walks)
     // convolution-kernel table (setTable, :148-189): K is stored and never applied (Q7); K' enters the virial
     double *d_table, *d_table_d, *d_log_scratch, *d_itab;
@@ -965,8 +965,8 @@ int mtd_mesh_create(mtd_mesh **out, unsigned int nx, unsigned int ny, unsigned i
                  o_g = take(sizeof(double2) * M), o_tw0 = take(sizeof(double2) * nx), o_tw1 = take(sizeof(double2) * ny),
                  o_tw2 = take(sizeof(double2) * nz), o_packed = take(sizeof(double4) * N), o_cell = take(sizeof(unsigned int) * N),
                  o_count = take(sizeof(unsigned int) * (M + 1)), o_start = take(sizeof(unsigned int) * (M + 1)),
-                 o_ids = take(sizeof(unsigned int) * N), o_tiles = take(sizeof(unsigned int) * n_tiles),
-                 o_inv = take(sizeof(double) * M), o_csort = take(sizeof(unsigned int) * N), o_slot = take(sizeof(unsigned int) * N),
+                 o_ids = take(sizeof(uint2) * N), o_tiles = take(sizeof(unsigned int) * n_tiles),
+                 o_inv = take(sizeof(double) * M), o_slot = take(sizeof(unsigned int) * N),
                  o_itab = take(sizeof(double) * (nx + ny + nz));
     hipError_t e = hipMalloc(&m->slab, off);
     if (e != hipSuccess)
@@ -980,10 +980,9 @@ int mtd_mesh_create(mtd_mesh **out, unsigned int nx, unsigned int ny, unsigned i
     m->d_cv_partials = (double *)(p + o_cvp); m->d_f = (double2 *)(p + o_f);
     m->d_g = (double2 *)(p + o_g); m->d_tw[0] = (double2 *)(p + o_tw0); m->d_tw[1] = (double2 *)(p + o_tw1);
     m->d_tw[2] = (double2 *)(p + o_tw2); m->d_packed = (double4 *)(p + o_packed); m->d_cell_of = (unsigned int *)(p + o_cell);
-    m->d_count = (unsigned int *)(p + o_count); m->d_start = (unsigned int *)(p + o_start); m->d_ids = (unsigned int *)(p + o_ids);
+    m->d_count = (unsigned int *)(p + o_count); m->d_start = (unsigned int *)(p + o_start); m->d_idcell = (uint2 *)(p + o_ids);
     m->d_tile_sums = (unsigned int *)(p + o_tiles);
     m->d_inv = (double *)(p + o_inv);
-    m->d_cell_sorted = (unsigned int *)(p + o_csort);
     m->d_slot_of = (unsigned int *)(p + o_slot);
     m->d_itab = (double *)(p + o_itab);
     e = hipMemset(m->slab, 0, off);
@@ -1066,11 +1065,11 @@ int mtd_mesh_assign(mtd_mesh *m, unsigned int n_particles, const void *d_postype
     k_scan_finish<<<cell_blocks, 256, 0, s>>>(m->d_start, m->d_tile_sums, m->d_count, M, N);
     MTD_LAUNCH_CHECK();
     if (dtype == MTD_F32)
-        k_mesh_place<float4><<<m->n_count_blocks, 256, 0, s>>>(g, (const float4 *)d_postype, N, m->d_mode, m->d_cell_of, m->d_slot_of, m->d_start, m->d_ids, m->d_packed, m->d_cell_sorted);
+        k_mesh_place<float4><<<m->n_count_blocks, 256, 0, s>>>(g, (const float4 *)d_postype, N, m->d_mode, m->d_cell_of, m->d_slot_of, m->d_start, m->d_idcell, m->d_packed);
     else
-        k_mesh_place<double4><<<m->n_count_blocks, 256, 0, s>>>(g, (const double4 *)d_postype, N, m->d_mode, m->d_cell_of, m->d_slot_of, m->d_start, m->d_ids, m->d_packed, m->d_cell_sorted);
+        k_mesh_place<double4><<<m->n_count_blocks, 256, 0, s>>>(g, (const double4 *)d_postype, N, m->d_mode, m->d_cell_of, m->d_slot_of, m->d_start, m->d_idcell, m->d_packed);
     MTD_LAUNCH_CHECK();
-    k_mesh_sortfix<<<cell_blocks, 256, 0, s>>>(M, m->d_start, m->d_ids, m->d_packed);
+    k_mesh_sortfix<<<cell_blocks, 256, 0, s>>>(M, m->d_start, m->d_idcell, m->d_packed);
     MTD_LAUNCH_CHECK();
     GatherTiling tl;
     tl.tx = m->nx < (unsigned int)GT_X ? m->nx : GT_X;
@@ -1138,9 +1137,9 @@ int mtd_mesh_forces(mtd_mesh *m, unsigned int n_particles, const void *d_postype
     if (n_particles != m->n_last) return MTD_ERR_INVALID_ARGUMENT;
     (void)d_postype;
     if (dtype == MTD_F32)
-        k_mesh_forces<float4><<<blocks, 256, 0, s>>>(g, n_particles, m->d_ids, m->d_cell_sorted, m->d_packed, m->d_inv, (float4 *)d_force, d_bias, bias_host, two_over_n);
+        k_mesh_forces<float4><<<blocks, 256, 0, s>>>(g, n_particles, m->d_idcell, m->d_packed, m->d_inv, (float4 *)d_force, d_bias, bias_host, two_over_n);
     else
-        k_mesh_forces<double4><<<blocks, 256, 0, s>>>(g, n_particles, m->d_ids, m->d_cell_sorted, m->d_packed, m->d_inv, (double4 *)d_force, d_bias, bias_host, two_over_n);
+        k_mesh_forces<double4><<<blocks, 256, 0, s>>>(g, n_particles, m->d_idcell, m->d_packed, m->d_inv, (double4 *)d_force, d_bias, bias_host, two_over_n);
     MTD_LAUNCH_CHECK();
     return MTD_SUCCESS;
     }
