@@ -42,6 +42,7 @@ using namespace mtd;
 struct MeshGeom
     {
     unsigned int nx, ny, nz, n_cells;
+    unsigned int hxp;                          // row pitch of the half-spectrum arrays (k_x = 0 .. nx/2 stored, then padding)
     double lo[3], L[3], Linv[3], xy, xz, yz;   // box (local == global: single rank); Linv = 1 / L
     double binv[3][3];                    // reciprocal rows without 2 pi (force pass, :761-769)
     };
@@ -516,6 +517,86 @@ __device__ __forceinline__ double tsc_fourier(double x)              // :487-511
     return sinc * sinc * sinc;
     }
 
+// ---- 6a / 8c. x lines, real <-> half spectrum ----------------------------------------------------------------
+// The mesh is real, so its transform is Hermitian: F(-k) = conj F(k).  Only k_x = 0 .. nx/2 is kept (rows of pitch hxp,
+// padded so that the y and z passes still move aligned tiles); everything downstream of the x pass — two line passes, the
+// fused z pass, the inverse passes — touches ~56 % of the full-spectrum bytes.  The real part of the inverse transform that
+// interpolateForces reads (:851-857) is the inverse of the Hermitian part of G, which the spectral step forms directly.
+// LDS layout [p][tile] as in k_fft_lines; `tile` adjacent x lines per block.
+__device__ __forceinline__ void fft_stages_dit(double2 *s, const double2 *__restrict__ twiddle, const unsigned int n,
+                                               const unsigned int tile, const int inverse)
+    {
+    const unsigned int half_total = (n / 2) * tile;
+    for (unsigned int len = 2; len <= n; len <<= 1)
+        {
+        const unsigned int half = len >> 1;
+        const unsigned int tw_step = n / len;
+        for (unsigned int idx = threadIdx.x; idx < half_total; idx += FFT_THREADS)
+            {
+            const unsigned int t = idx % tile;
+            const unsigned int bf = idx / tile;
+            const unsigned int grp = bf / half, j = bf % half;
+            const unsigned int i0 = grp * len + j, i1 = i0 + half;
+            double2 w = twiddle[j * tw_step];                // exp(-2 pi i j / len)
+            if (inverse) w.y = -w.y;
+            const double2 u = s[i0 * tile + t], v = s[i1 * tile + t];
+            const double2 tv = make_double2(v.x * w.x - v.y * w.y, v.x * w.y + v.y * w.x);
+            s[i0 * tile + t] = make_double2(u.x + tv.x, u.y + tv.y);
+            s[i1 * tile + t] = make_double2(u.x - tv.x, u.y - tv.y);
+            }
+        __syncthreads();
+        }
+    }
+
+__global__ __launch_bounds__(FFT_THREADS) void k_fft_x_r2c(const double *__restrict__ real_in, double2 *__restrict__ half_out,
+                                                           const double2 *__restrict__ twiddle, const unsigned int n,
+                                                           const unsigned int log2n, const unsigned int tile, const unsigned int hxp)
+    {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double2 *s = (double2 *)smem;
+    const size_t line0 = (size_t)blockIdx.x * tile;
+    const unsigned int total = n * tile;
+    for (unsigned int idx = threadIdx.x; idx < total; idx += FFT_THREADS)
+        {
+        const unsigned int t = idx / n, p = idx % n;
+        const unsigned int pr = __brev(p) >> (32 - log2n);
+        s[pr * tile + t] = make_double2(real_in[(line0 + t) * n + p], 0.0);
+        }
+    __syncthreads();
+    fft_stages_dit(s, twiddle, n, tile, 0);
+    const unsigned int hx = n / 2 + 1;
+    for (unsigned int idx = threadIdx.x; idx < hx * tile; idx += FFT_THREADS)
+        {
+        const unsigned int t = idx / hx, p = idx % hx;
+        half_out[(line0 + t) * hxp + p] = s[p * tile + t];
+        }
+    }
+
+__global__ __launch_bounds__(FFT_THREADS) void k_fft_x_c2r(const double2 *__restrict__ half_in, double *__restrict__ real_out,
+                                                           const double2 *__restrict__ twiddle, const unsigned int n,
+                                                           const unsigned int log2n, const unsigned int tile, const unsigned int hxp)
+    {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double2 *s = (double2 *)smem;
+    const size_t line0 = (size_t)blockIdx.x * tile;
+    const unsigned int hx = n / 2 + 1;
+    for (unsigned int idx = threadIdx.x; idx < hx * tile; idx += FFT_THREADS)
+        {
+        const unsigned int t = idx / hx, p = idx % hx;
+        const double2 v = half_in[(line0 + t) * hxp + p];
+        s[(__brev(p) >> (32 - log2n)) * tile + t] = v;
+        if (p != 0 && p != n / 2)                                    // the other half of the line by Hermitian symmetry
+            s[(__brev(n - p) >> (32 - log2n)) * tile + t] = make_double2(v.x, -v.y);
+        }
+    __syncthreads();
+    fft_stages_dit(s, twiddle, n, tile, 1);
+    for (unsigned int idx = threadIdx.x; idx < n * tile; idx += FFT_THREADS)
+        {
+        const unsigned int t = idx / n, p = idx % n;
+        real_out[(line0 + t) * n + p] = s[p * tile + t].x;          // interpolateForces only reads Re(inv) (:851-857)
+        }
+    }
+
 // ---- 6c+7+8a. z lines: forward transform, spectral step, inverse transform — one pass ----------------------
 // The last forward pass, updateMeshes/computeCV and the first inverse pass all work on complete z lines, so they share one
 // staging of the lines in LDS: the Fourier mesh is written once (f, normalised: the log quantities and the virial read
@@ -559,11 +640,12 @@ __global__ __launch_bounds__(FFT_THREADS) void k_fft_z_spectral(const MeshGeom g
     __shared__ double s_red[16];
     double2 *s = (double2 *)smem;
     const unsigned int n = g.nz;
-    const unsigned int plane = g.nx * g.ny;
+    const unsigned int plane = g.hxp * g.ny;                             // half-spectrum arrays: rows of pitch hxp
     const unsigned int wy = blockIdx.x / tiles_per_row;                  // row = y index
     const unsigned int x_first = (blockIdx.x % tiles_per_row) * tile;
-    const size_t base = (size_t)wy * g.nx + x_first;
+    const size_t base = (size_t)wy * g.hxp + x_first;
     const unsigned int total = n * tile;
+    const unsigned int nxh = g.nx / 2;
 
     for (unsigned int idx = threadIdx.x; idx < total; idx += FFT_THREADS)
         {
@@ -592,26 +674,43 @@ __global__ __launch_bounds__(FFT_THREADS) void k_fft_z_spectral(const MeshGeom g
         __syncthreads();
         }
 
-    // spectral step in place: updateMeshes :697-712 + computeCV :896-905
+    // spectral step in place: updateMeshes :697-712 + computeCV :896-905 on the stored half of the spectrum.
+    // f(-k) = conj f(k), so the cell -k (not stored for 0 < k_x < nx/2) has the same |f|^2 and its own interpolation factor
+    // I(-k) (they differ in bug-compatible mode, Q6).  Stored for the inverse transform: the Hermitian part
+    // G_H(k) = (G(k) + conj G(-k)) / 2 = f (|f|^2 - (I(k)^2 + I(-k)^2) / 2 * sum mode^2 / 2 N^2), whose inverse is Re(inv).
     double term = 0.0;
     const double msq = *mode_sq;
     for (unsigned int idx = threadIdx.x; idx < total; idx += FFT_THREADS)
         {
         const unsigned int p = idx / tile, t = idx % tile;             // p = k_z index
         const unsigned int wx = x_first + t;
+        if (wx > nxh)                                                  // padding column of the half-spectrum rows
+            {
+            s[p * tile + t] = make_double2(0.0, 0.0);
+            fmesh[base + t + (size_t)p * plane] = make_double2(0.0, 0.0);
+            continue;
+            }
         const double I = itab[wx] * itab[g.nx + wy] * itab[g.nx + g.ny + p];
+        const unsigned int mx = (g.nx - wx) % g.nx, my = (g.ny - wy) % g.ny, mz = (g.nz - p) % g.nz;
+        const double Im = itab[mx] * itab[g.nx + my] * itab[g.nx + g.ny + mz];
         double2 f = s[p * tile + t];
         f.x /= n_global;
         f.y /= n_global;
         const double val = f.x * f.x + f.y * f.y;
-        const double diagonal_term = 0.5 * I * I * msq / n_global / n_global;
+        const double diagonal_term = 0.5 * (0.5 * (I * I + Im * Im)) * msq / n_global / n_global;
         double2 G = make_double2(f.x * val, f.y * val);
         G.x -= f.x * diagonal_term;
         G.y -= f.y * diagonal_term;
         fmesh[base + t + (size_t)p * plane] = f;
         s[p * tile + t] = G;
         if (wx != 0 || wy != 0 || p != 0)                              // exclude the DC bin (:889-894)
-            term += (G.x * f.x + G.y * f.y) - 0.5 * val * I * I * msq / n_global / n_global;
+            {
+            // Re(G f*) - |f|^2 I^2 sum mode^2 / 2 N^2 (:896-905) = |f|^4 - I^2 |f|^2 sum mode^2 / N^2 for the cell itself ...
+            double tk = val * val - val * (I * I) * msq / n_global / n_global;
+            // ... plus the same for its mirror image when that one is not stored
+            if (wx != 0 && wx != nxh) tk += val * val - val * (Im * Im) * msq / n_global / n_global;
+            term += tk;
+            }
         }
     __syncthreads();
 
@@ -716,19 +815,27 @@ __device__ __forceinline__ void wave_vector(const MeshGeom &g, const unsigned in
     kz = tp * (n0 * g.binv[0][2] + n1 * g.binv[1][2] + n2 * g.binv[2][2]);
     }
 
-// computeQmax (:1108-1179): the cell with the largest |f|^2 (DC bin included like the reference), first index wins ties
-__global__ __launch_bounds__(256) void k_mesh_argmax(const double2 *__restrict__ fmesh, const unsigned int n, double *__restrict__ out_val,
+// computeQmax (:1108-1179): the cell with the largest |f|^2 (DC bin included like the reference), first index wins ties.
+// On the stored half of the spectrum a cell stands for itself and for its mirror image -k (same |f|^2): the candidate
+// index is the smaller of the two FULL-mesh linear indices, which is the cell the reference's strict `>` scan keeps.
+__global__ __launch_bounds__(256) void k_mesh_argmax(const MeshGeom g, const double2 *__restrict__ fmesh, double *__restrict__ out_val,
                                                      unsigned int *__restrict__ out_idx)
     {
     __shared__ double s_v[4];
     __shared__ unsigned int s_i[4];
     double best = 0.0;
     unsigned int bi = 0xffffffffu;                    // "no cell yet": the reference keeps q_max = 0 when no amplitude exceeds 0
-    for (unsigned int k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x)
+    const unsigned int hx = g.nx / 2 + 1;
+    const unsigned int n_half = hx * g.ny * g.nz;
+    for (unsigned int h = blockIdx.x * blockDim.x + threadIdx.x; h < n_half; h += gridDim.x * blockDim.x)
         {
-        const double2 f = fmesh[k];
+        const unsigned int wx = h % hx, wy = (h / hx) % g.ny, wz = h / (hx * g.ny);
+        const double2 f = fmesh[wx + (size_t)g.hxp * (wy + (size_t)g.ny * wz)];
         const double a = f.x * f.x + f.y * f.y;
-        if (a > best)                                  // ascending k per thread: strict > keeps the first
+        const unsigned int mx = (g.nx - wx) % g.nx, my = (g.ny - wy) % g.ny, mz = (g.nz - wz) % g.nz;
+        const unsigned int k0 = wx + g.nx * (wy + g.ny * wz), k1 = mx + g.nx * (my + g.ny * mz);
+        const unsigned int k = k0 < k1 ? k0 : k1;
+        if (a > best || (a == best && a > 0.0 && k < bi))
             {
             best = a;
             bi = k;
@@ -772,30 +879,42 @@ __global__ __launch_bounds__(256) void k_mesh_virial(const MeshGeom g, const dou
     {
     __shared__ double s_red[16];
     double v[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-    for (unsigned int k = blockIdx.x * blockDim.x + threadIdx.x; k < g.n_cells; k += gridDim.x * blockDim.x)
+    const unsigned int hx = g.nx / 2 + 1;
+    const unsigned int n_half = hx * g.ny * g.nz;
+    for (unsigned int h = blockIdx.x * blockDim.x + threadIdx.x; h < n_half; h += gridDim.x * blockDim.x)
         {
+        const unsigned int wx = h % hx, wy = (h / hx) % g.ny, wz = h / (hx * g.ny);
+        const unsigned int k = wx + g.nx * (wy + g.ny * wz);            // full-mesh index of the stored cell
         if (k == 0) continue;                                           // exclude DC bin (:1003-1005)
-        double kx, ky, kz;
-        wave_vector(g, k, kx, ky, kz);
-        const double knorm = sqrt(kx * kx + ky * ky + kz * kz);
-        double val_D = 0.0;
-        if (use_table && knorm >= k_min && knorm < k_max)               // :1018-1030
-            {
-            const double value_f = (knorm - k_min) / delta_k;
-            const unsigned int value_i = (unsigned int)value_f;
-            const double dK0 = table_d[value_i], dK1 = table_d[value_i + 1];
-            val_D = dK0 + (value_f - (double)value_i) * (dK1 - dK0);
-            }
-        const double kfac = 1.0 / 2.0 / knorm * val_D;
-        const double2 f = fmesh[k];
+        const double2 f = fmesh[wx + (size_t)g.hxp * (wy + (size_t)g.ny * wz)];
         const double a = f.x * f.x + f.y * f.y;
         const double rhog = a * (a / n_global) / n_global;             // :1034-1035 (f is already F / N: the reference divides again)
-        v[0] += rhog * kfac * kx * kx;
-        v[1] += rhog * kfac * kx * ky;
-        v[2] += rhog * kfac * kx * kz;
-        v[3] += rhog * kfac * ky * ky;
-        v[4] += rhog * kfac * ky * kz;
-        v[5] += rhog * kfac * kz * kz;
+        // the stored cell, then its mirror image when that one is not stored: same |f|^2, but its OWN wave vector — on the
+        // Nyquist planes of y and z the Miller index of the mirror cell is not the negative one (both are -n/2)
+        const unsigned int mx = (g.nx - wx) % g.nx, my = (g.ny - wy) % g.ny, mz = (g.nz - wz) % g.nz;
+        const unsigned int cells[2] = {k, mx + g.nx * (my + g.ny * mz)};
+        const int n_terms = (wx != 0 && wx != g.nx / 2) ? 2 : 1;
+        for (int term = 0; term < n_terms; ++term)
+            {
+            double kx, ky, kz;
+            wave_vector(g, cells[term], kx, ky, kz);
+            const double knorm = sqrt(kx * kx + ky * ky + kz * kz);
+            double val_D = 0.0;
+            if (use_table && knorm >= k_min && knorm < k_max)           // :1018-1030
+                {
+                const double value_f = (knorm - k_min) / delta_k;
+                const unsigned int value_i = (unsigned int)value_f;
+                const double dK0 = table_d[value_i], dK1 = table_d[value_i + 1];
+                val_D = dK0 + (value_f - (double)value_i) * (dK1 - dK0);
+                }
+            const double kfac = 1.0 / 2.0 / knorm * val_D;
+            v[0] += rhog * kfac * kx * kx;
+            v[1] += rhog * kfac * kx * ky;
+            v[2] += rhog * kfac * kx * kz;
+            v[3] += rhog * kfac * ky * ky;
+            v[4] += rhog * kfac * ky * kz;
+            v[5] += rhog * kfac * kz * kz;
+            }
         }
 #pragma unroll
     for (int c = 0; c < 6; ++c)
@@ -834,6 +953,7 @@ unsigned int ilog2(unsigned int n)
 struct mtd_mesh
     {
     unsigned int nx, ny, nz, M, n_types, max_particles;
+    unsigned int hxp;          // row pitch of the half-spectrum arrays d_f, d_g (nx/2 + 1 rounded up)
     int bug_compat;
     void *slab;
     double *d_mode, *d_rho, *d_inv, *d_modesq_partials, *d_mode_sq, *d_cv_partials;
@@ -858,6 +978,7 @@ int fill_geom(MeshGeom &g, const mtd_mesh *m, const mtd_box *box)
     if (!box || !(box->L[0] > 0.0) || !(box->L[1] > 0.0) || !(box->L[2] > 0.0)) return MTD_ERR_INVALID_ARGUMENT;
     std::memset(&g, 0, sizeof(g));
     g.nx = m->nx; g.ny = m->ny; g.nz = m->nz; g.n_cells = m->M;
+    g.hxp = m->hxp;
     for (int i = 0; i < 3; ++i)
         {
         g.lo[i] = box->lo[i];
@@ -881,55 +1002,29 @@ unsigned int fft_tile_for(unsigned int n, unsigned int lines)
     return t;
     }
 
+// geometry of the line passes over the half-spectrum arrays (rows of pitch hxp along x)
+FftPass fft_y_pass(const mtd_mesh *m)
+    {
+    FftPass py;
+    py.n = m->ny; py.tile = fft_tile_for(m->ny, m->hxp); py.elem_stride = m->hxp; py.line_stride = 1; py.tiles_per_row = m->hxp / py.tile;
+    py.row_stride = m->hxp * m->ny; py.n_blocks = py.tiles_per_row * m->nz; py.p_fastest = 0; py.tw = m->d_tw[1];
+    return py;
+    }
+
 FftPass fft_z_pass(const mtd_mesh *m)
     {
     FftPass pz;
-    pz.n = m->nz; pz.tile = fft_tile_for(m->nz, m->nx); pz.elem_stride = m->nx * m->ny; pz.line_stride = 1; pz.tiles_per_row = m->nx / pz.tile;
-    pz.row_stride = m->nx; pz.n_blocks = pz.tiles_per_row * m->ny; pz.p_fastest = 0; pz.tw = m->d_tw[2];
+    pz.n = m->nz; pz.tile = fft_tile_for(m->nz, m->hxp); pz.elem_stride = m->hxp * m->ny; pz.line_stride = 1; pz.tiles_per_row = m->hxp / pz.tile;
+    pz.row_stride = m->hxp; pz.n_blocks = pz.tiles_per_row * m->ny; pz.p_fastest = 0; pz.tw = m->d_tw[2];
     return pz;
     }
 
-int launch_fft3d(const mtd_mesh *m, const double *real_in, double2 *data, double *real_out, int inverse, unsigned int axes, hipStream_t s)
+int launch_fft_y(const mtd_mesh *m, double2 *data, int inverse, hipStream_t s)
     {
-    const unsigned int nx = m->nx, ny = m->ny, nz = m->nz;
-    // x lines: contiguous; tile = as many lines as keep <= 64 KB of LDS, p fastest for coalescing
-    typedef FftPass Pass;
-    auto tile_for = fft_tile_for;
-    Pass px, py, pz;
-    // X: all ny*nz lines form one "row"; tile adjacent lines
-    px.n = nx; px.tile = tile_for(nx, ny * nz); px.elem_stride = 1; px.line_stride = nx; px.tiles_per_row = (ny * nz) / px.tile;
-    px.row_stride = 0; px.n_blocks = px.tiles_per_row; px.p_fastest = 1; px.tw = m->d_tw[0];
-    // Y: for each z (row), tiles of adjacent x
-    py.n = ny; py.tile = tile_for(ny, nx); py.elem_stride = nx; py.line_stride = 1; py.tiles_per_row = nx / py.tile;
-    py.row_stride = nx * ny; py.n_blocks = py.tiles_per_row * nz; py.p_fastest = 0; py.tw = m->d_tw[1];
-    // Z: for each y (row), tiles of adjacent x
-    pz.n = nz; pz.tile = tile_for(nz, nx); pz.elem_stride = nx * ny; pz.line_stride = 1; pz.tiles_per_row = nx / pz.tile;
-    pz.row_stride = nx; pz.n_blocks = pz.tiles_per_row * ny; pz.p_fastest = 0; pz.tw = m->d_tw[2];
-    const Pass passes[3] = {px, py, pz};
-    int last = -1;
-    for (int o = 0; o < 3; ++o)
-        {
-        const int a = inverse ? 2 - o : o;
-        if (axes & (1u << a)) last = a;
-        }
-    for (int o = 0; o < 3; ++o)
-        {
-        const int a = inverse ? 2 - o : o;
-        if (!(axes & (1u << a))) continue;
-        const Pass &p = passes[a];
-        const size_t lds = (size_t)p.n * p.tile * sizeof(double2);
-        if (p.n == 1) continue;
-        if (a == 0 && real_in)
-            k_fft_lines<true, false><<<p.n_blocks, FFT_THREADS, lds, s>>>(real_in, data, nullptr, p.tw, p.n, ilog2(p.n), p.tile, p.elem_stride,
-                                                                           p.line_stride, p.tiles_per_row, p.row_stride, inverse, p.p_fastest);
-        else if (a == last && real_out)
-            k_fft_lines<false, true><<<p.n_blocks, FFT_THREADS, lds, s>>>(nullptr, data, real_out, p.tw, p.n, ilog2(p.n), p.tile, p.elem_stride,
-                                                                           p.line_stride, p.tiles_per_row, p.row_stride, inverse, p.p_fastest);
-        else
-            k_fft_lines<false, false><<<p.n_blocks, FFT_THREADS, lds, s>>>(nullptr, data, nullptr, p.tw, p.n, ilog2(p.n), p.tile, p.elem_stride,
-                                                                            p.line_stride, p.tiles_per_row, p.row_stride, inverse, p.p_fastest);
-        MTD_LAUNCH_CHECK();
-        }
+    const FftPass p = fft_y_pass(m);
+    k_fft_lines<false, false><<<p.n_blocks, FFT_THREADS, (size_t)p.n * p.tile * sizeof(double2), s>>>(
+        nullptr, data, nullptr, p.tw, p.n, ilog2(p.n), p.tile, p.elem_stride, p.line_stride, p.tiles_per_row, p.row_stride, inverse, p.p_fastest);
+    MTD_LAUNCH_CHECK();
     return MTD_SUCCESS;
     }
 
@@ -956,13 +1051,18 @@ int mtd_mesh_create(mtd_mesh **out, unsigned int nx, unsigned int ny, unsigned i
     m->bug_compat = 1;
     const size_t M = m->M, N = max_particles;
     m->n_count_blocks = 4096;
+    {
+    const unsigned int hx = nx / 2 + 1, unit = nx < 8 ? nx : 8;
+    m->hxp = (hx + unit - 1) / unit * unit;                    // 72 at nx = 128
+    }
+    const size_t MH = (size_t)m->hxp * ny * nz;
     m->n_cv_partials = fft_z_pass(m).n_blocks;                 // one partial sum per block of the fused z pass
     const unsigned int n_tiles = (m->M + SCAN_TILE - 1) / SCAN_TILE;
     auto al = [](size_t b) { return (b + 255) / 256 * 256; };
     size_t off = 0;
     auto take = [&](size_t b) { size_t o = off; off += al(b); return o; };
-    const size_t o_mode = take(sizeof(double) * n_types), o_rho = take(sizeof(double) * (M + 1)), o_msqp = take(sizeof(double) * m->n_count_blocks), o_cvp = take(sizeof(double) * m->n_cv_partials), o_f = take(sizeof(double2) * M),
-                 o_g = take(sizeof(double2) * M), o_tw0 = take(sizeof(double2) * nx), o_tw1 = take(sizeof(double2) * ny),
+    const size_t o_mode = take(sizeof(double) * n_types), o_rho = take(sizeof(double) * (M + 1)), o_msqp = take(sizeof(double) * m->n_count_blocks), o_cvp = take(sizeof(double) * m->n_cv_partials), o_f = take(sizeof(double2) * MH),
+                 o_g = take(sizeof(double2) * MH), o_tw0 = take(sizeof(double2) * nx), o_tw1 = take(sizeof(double2) * ny),
                  o_tw2 = take(sizeof(double2) * nz), o_packed = take(sizeof(double4) * N), o_cell = take(sizeof(unsigned int) * N),
                  o_count = take(sizeof(unsigned int) * (M + 1)), o_start = take(sizeof(unsigned int) * (M + 1)),
                  o_ids = take(sizeof(uint2) * N), o_tiles = take(sizeof(unsigned int) * n_tiles),
@@ -1098,14 +1198,20 @@ int mtd_mesh_spectral(mtd_mesh *m, const mtd_box *box, unsigned int n_global, co
     int rc = fill_geom(g, m, box);
     if (rc) return rc;
     hipStream_t s = (hipStream_t)stream;
-    rc = launch_fft3d(m, m->d_rho, m->d_f, nullptr, 0, 0x3, s);          // x (real input), y
+    const unsigned int x_tile = fft_tile_for(m->nx, m->ny * m->nz), x_blocks = (m->ny * m->nz) / x_tile;
+    const size_t x_lds = (size_t)m->nx * x_tile * sizeof(double2);
+    k_fft_x_r2c<<<x_blocks, FFT_THREADS, x_lds, s>>>(m->d_rho, m->d_f, m->d_tw[0], m->nx, ilog2(m->nx), x_tile, m->hxp);
+    MTD_LAUNCH_CHECK();
+    rc = launch_fft_y(m, m->d_f, 0, s);
     if (rc) return rc;
     const FftPass pz = fft_z_pass(m);
     k_fft_z_spectral<<<pz.n_blocks, FFT_THREADS, (size_t)pz.n * pz.tile * sizeof(double2), s>>>(
         g, m->d_f, m->d_g, pz.tw, ilog2(pz.n), pz.tile, pz.tiles_per_row, m->d_mode_sq, (double)n_global, m->d_itab, m->d_cv_partials);
     MTD_LAUNCH_CHECK();
-    rc = launch_fft3d(m, nullptr, m->d_g, m->d_inv, 1, 0x3, s);          // y, x; Re(inv) lands in its own array
+    rc = launch_fft_y(m, m->d_g, 1, s);
     if (rc) return rc;
+    k_fft_x_c2r<<<x_blocks, FFT_THREADS, x_lds, s>>>(m->d_g, m->d_inv, m->d_tw[0], m->nx, ilog2(m->nx), x_tile, m->hxp);   // Re(inv)
+    MTD_LAUNCH_CHECK();
     *d_partials = m->d_cv_partials;
     *n_partials = m->n_cv_partials;
     return MTD_SUCCESS;
@@ -1187,7 +1293,7 @@ int mtd_mesh_qmax(mtd_mesh *m, const mtd_box *box, unsigned int n_global, double
     const unsigned int blocks = 256;
     double *d_val = m->d_log_scratch;
     unsigned int *d_idx = (unsigned int *)(m->d_log_scratch + 256);
-    k_mesh_argmax<<<blocks, 256, 0, s>>>(m->d_f, m->M, d_val, d_idx);
+    k_mesh_argmax<<<blocks, 256, 0, s>>>(g, m->d_f, d_val, d_idx);
     MTD_LAUNCH_CHECK();
     double val[256];
     unsigned int idx[256];
@@ -1249,7 +1355,30 @@ int mtd_mesh_get_array(mtd_mesh *m, int which, void *host_out, mtd_stream_t stre
     switch (which)
         {
         case 0: src = m->d_rho; bytes = sizeof(double) * m->M; break;            // real mesh (assignParticles)
-        case 1: src = m->d_f; bytes = sizeof(double2) * m->M; break;             // fourier_mesh, normalised
+        case 1:                                                                  // fourier_mesh, normalised: full mesh from the stored half
+            {
+            const size_t MH = (size_t)m->hxp * m->ny * m->nz;
+            std::vector<double2> half(MH);
+            MTD_HIP_TRY(hipMemcpyAsync(half.data(), m->d_f, sizeof(double2) * MH, hipMemcpyDeviceToHost, (hipStream_t)stream));
+            MTD_HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+            double2 *out = (double2 *)host_out;
+            for (unsigned int wz = 0; wz < m->nz; ++wz)
+                for (unsigned int wy = 0; wy < m->ny; ++wy)
+                    for (unsigned int wx = 0; wx < m->nx; ++wx)
+                        {
+                        double2 v;
+                        if (wx <= m->nx / 2)
+                            v = half[wx + (size_t)m->hxp * (wy + (size_t)m->ny * wz)];
+                        else
+                            {
+                            const unsigned int mx = m->nx - wx, my = (m->ny - wy) % m->ny, mz = (m->nz - wz) % m->nz;
+                            v = half[mx + (size_t)m->hxp * (my + (size_t)m->ny * mz)];
+                            v.y = -v.y;
+                            }
+                        out[wx + (size_t)m->nx * (wy + (size_t)m->ny * wz)] = v;
+                        }
+            return MTD_SUCCESS;
+            }
         case 3: src = m->d_inv; bytes = sizeof(double) * m->M; break;            // Re(inv_fourier_mesh), real double[M]
         case 7: src = m->d_mode_sq; bytes = sizeof(double); break;
         default: return MTD_ERR_INVALID_ARGUMENT;

@@ -207,6 +207,8 @@ def test_qmax_virial_table(abi, ref, tilt):
     abi.check(lib.mtd_mesh_virial(m.h, C.byref(box), N, 0.8, vir.ctypes.data_as(C.POINTER(C.c_double)), None))
     v_ref = r.virial(N, 0.8)
     assert np.abs(v_ref).max() > 0
-    assert np.allclose(vir, v_ref, rtol=1e-9, atol=1e-12 * np.abs(v_ref).max())
+    # components that vanish by symmetry are sums of cancelling terms (rounding noise, summation-order dependent): the
+    # absolute tolerance is set by the largest component
+    assert np.allclose(vir, v_ref, rtol=1e-9, atol=1e-9 * np.abs(v_ref).max())
     assert lib.mtd_mesh_set_table(m.h, util.dbl_array(K), util.dbl_array(dK), npts, 2.0, 1.0) == -1   # MTD_ERR_INVALID_ARGUMENT
     m.close()
