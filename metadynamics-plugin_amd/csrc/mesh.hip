@@ -18,11 +18,12 @@
 //                       LDS (the Poisson-distributed cell counts make this loop divergent — in LDS that costs ALU slots,
 //                       from global memory it cost 316 us of load latency): no atomics on the mesh, no scratch, every
 //                       mesh cell written exactly once
-//   6 k_fft_lines x2    unnormalised DFT along x (real input) and y, lines staged in LDS in [pos][line] layout
-//                       (16 adjacent lines per block so strided axes still move 256-B segments)
-//   7 k_fft_z_spectral  z lines: forward transform, f = F/N, G = f(|f|^2 - I^2 sum mode^2 / 2N^2), block sums of the CV
-//                       integrand, inverse transform — one staging in LDS for all three
-//   8 k_fft_lines x2    inverse along y and x (real part only out)
+//   6 k_fft_x_r2c       unnormalised DFT along x of the real mesh, only k_x = 0 .. nx/2 kept (half spectrum, padded rows);
+//     k_fft_lines       along y; lines staged in LDS in [pos][line] layout (adjacent lines per block so strided axes
+//                       still move 128-B segments)
+//   7 k_fft_z_spectral  z lines: forward transform, f = F/N, Hermitian part of G = f(|f|^2 - I^2 sum mode^2 / 2N^2), block
+//                       sums of the CV integrand (stored cell + mirror cell), inverse transform — one staging in LDS
+//   8 k_fft_lines       inverse along y; k_fft_x_c2r inverse along x (other half of the line by symmetry, real part out)
 //   9 k_mesh_forces     per particle: 27 reads of Re(inv) with TSC' x TSC x TSC weights
 // Everything is double precision: the CV is quartic in the Fourier amplitudes, fp32 meshes cannot hold
 // 1e-6 on it.  Mesh sizes must be powers of two (the reference's own multi-rank restriction,
