@@ -925,12 +925,6 @@ __global__ __launch_bounds__(256) void k_mesh_virial(const MeshGeom g, const dou
         }
     }
 
-__global__ void k_zero_u32(unsigned int *p, unsigned int n)
-    {
-    const unsigned int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) p[i] = 0;
-    }
-
 __global__ __launch_bounds__(256) void k_sum_partials(const double *__restrict__ partials, unsigned int n, double *out)
     {
     // one block, fixed order

@@ -75,7 +75,6 @@ struct cplx
 __device__ __forceinline__ cplx cmul(cplx a, cplx b) { return {a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re}; }
 __device__ __forceinline__ cplx cconj(cplx a) { return {a.re, -a.im}; }
 __device__ __forceinline__ cplx cscale(cplx a, double s) { return {a.re * s, a.im * s}; }
-__device__ __forceinline__ cplx cadd(cplx a, cplx b) { return {a.re + b.re, a.im + b.im}; }
 
 template<int LMAX>
 __device__ __forceinline__ void min_image(const QlArgs<LMAX> &a, double &x, double &y, double &z)
