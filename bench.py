@@ -165,6 +165,19 @@ def cpu_baseline(pos, types, L, steps):
     return pos.shape[0] * len(cvs) * steps / dt, dt
 
 
+def host_cores():
+    """CPU cores this process may actually use: the affinity mask capped by the cgroup CPU quota (a 256-thread host can
+    hand a container 16)."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = max(1, min(n, int(float(quota) / float(period) + 0.5)))
+    except Exception:
+        pass
+    return n
+
+
 def self_check(st, stride):
     """The grid engine of the oracle, driven with the CV values the device reports (the particles do not move, so they are
     the same every step), deposits the same number of hills; V(s) and the reweighting factor w(s) after thousands of
@@ -320,6 +333,21 @@ def main():
             v, dt = cpu_baseline(pos, types, eng.L, args.cpu_steps)
             out["cpu_baseline"] = {"value": v, "unit": "particle-CV-evals/s", "cores": 1, "kind": "port",
                                    "sample": "%d full steps of the same 10^6-particle workload (%.1f s) with the oracle's C restatement, gcc -O2, double" % (args.cpu_steps, dt)}
+            # informational: the same loops with OpenMP over the particles on every host core ("idealised multi-rank";
+            # the reference itself has no threading, one MPI rank per core is its only parallelism)
+            try:
+                import mtd_ref
+                n_thr = host_cores()
+                os.environ["OMP_NUM_THREADS"] = str(n_thr)              # read by libgomp when the OpenMP build is loaded
+                mtd_ref.use_openmp(True)
+                cpu_baseline(pos, types, eng.L, 1)                      # thread pool start-up
+                v2, dt2 = cpu_baseline(pos, types, eng.L, 4 * args.cpu_steps)
+                out["cpu_baseline_all_cores"] = {"value": v2, "unit": "particle-CV-evals/s", "cores": n_thr, "kind": "port",
+                                                 "sample": "%d steps (%.1f s), OpenMP over particles" % (4 * args.cpu_steps, dt2)}
+            except Exception as e:                                      # never let the informational leg break the bench line
+                out["cpu_baseline_all_cores"] = {"error": str(e)}
+            finally:
+                mtd_ref.use_openmp(False)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

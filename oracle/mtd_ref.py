@@ -57,14 +57,26 @@ def _i(a):
 
 
 _lib = None
+_OMP_LIB_PATH = os.path.join(_HERE, "_build", "libmtd_ref_omp.so")
+_use_omp = False
+
+
+def use_openmp(enable):
+    """bench.py only: switch to the build with OpenMP over the particles of the lamellar loops (the "all cores" CPU
+    baseline).  The checker used by the tests is always the serial build."""
+    global _lib, _use_omp
+    if bool(enable) != _use_omp:
+        _use_omp = bool(enable)
+        _lib = None
 
 
 def lib():
     global _lib
     if _lib is None:
-        if not os.path.exists(_LIB_PATH):
-            build()
-        L = C.CDLL(_LIB_PATH)
+        path = _OMP_LIB_PATH if _use_omp else _LIB_PATH
+        if not os.path.exists(path):
+            build(force=_use_omp)
+        L = C.CDLL(path)
         L.ref_index_get.restype = C.c_uint
         L.ref_index_get.argtypes = [C.c_uint, _up, _up]
         L.ref_index_coords.restype = None

@@ -49,15 +49,21 @@ void ref_lamellar_fourier_modes(unsigned int n_wave, const int *lattice, unsigne
             q[c] = b1[c] * (double)lattice[3 * k + 0] + b2[c] * (double)lattice[3 * k + 1]
                    + b3[c] * (double)lattice[3 * k + 2];
 
+        double re = 0.0, im = 0.0;
+#ifdef REF_OMP   /* libmtd_ref_omp.so only: the "idealised multi-rank" CPU baseline of bench.py; the checker is serial */
+#pragma omp parallel for reduction(+ : re, im) schedule(static)
+#endif
         for (unsigned int idx = 0; idx < N; idx++)
             {
             const double *p = postype + 4 * idx;
             unsigned int type = (unsigned int)p[3];                   /* __scalar_as_int(postype.w) */
             double a = mode[type];
             double dotproduct = q[0] * p[0] + q[1] * p[1] + q[2] * p[2];
-            modes_out[2 * k + 0] += a * cos(dotproduct);              /* .cc:175 */
-            modes_out[2 * k + 1] += a * sin(dotproduct);              /* .cc:176 */
+            re += a * cos(dotproduct);                                /* .cc:175 */
+            im += a * sin(dotproduct);                                /* .cc:176 */
             }
+        modes_out[2 * k + 0] = re;
+        modes_out[2 * k + 1] = im;
         }
     }
 
@@ -80,6 +86,9 @@ void ref_lamellar_forces(unsigned int n_wave, const int *lattice, unsigned int N
     reciprocal(global_box, b1, b2, b3);
     double denom = (double)N_global;
 
+#ifdef REF_OMP
+#pragma omp parallel for schedule(static)
+#endif
     for (unsigned int idx = 0; idx < N; idx++)
         {
         const double *p = postype + 4 * idx;
