@@ -58,10 +58,11 @@ __device__ __forceinline__ double tsc(double x)                       // :457-46
     }
 
 // TSC weight of a particle with in-cell shift s (mesh units, |s| <= 1/2) on the cell at offset i in {-1, 0, 1}:
-// tsc(s - i) without the branches: 3/4 - s^2 (i = 0), (1/2 + s)^2 / 2 (i = +1), (1/2 - s)^2 / 2 (i = -1)
+// tsc(s - i) without the branches: 3/4 - s^2 (i = 0), (1/2 + s)^2 / 2 (i = +1), (1/2 - s)^2 / 2 (i = -1).
+// Valid for |s| <= 1/2 only: the gather checks the staged records once per tile and takes the general tsc() for a tile
+// that holds a particle outside the box (clamped cell, large shift) — per record visit that check cost a quarter of the loop.
 __device__ __forceinline__ double tsc_cell(const double s, const int i)
     {
-    if (!(fabs(s) <= 0.5000001)) return tsc(s - i);            // out-of-box particle clamped into the mesh
     if (i == 0) return 0.75 - s * s;
     const double t = 0.5 + (i > 0 ? s : -s);
     return 0.5 * t * t;
@@ -265,9 +266,10 @@ __global__ __launch_bounds__(256) void k_mesh_sortfix(const unsigned int n_cells
     }
 
 // ---- 5. gather: mesh[c] = sum over the particles of the 27 neighbour cells, tile by tile from LDS ----------
-constexpr int GT_X = 16, GT_Y = 8, GT_Z = 8;                       // output tile (clipped to the mesh)
-constexpr int GT_HCELLS = (GT_X + 2) * (GT_Y + 2) * (GT_Z + 2);     // with one halo layer: 1800
-constexpr int GT_CAP = 1408;                                        // records staged in LDS (44 KB); denser tiles read global memory
+constexpr int GT_X = 16, GT_Y = 8, GT_Z = 4;                       // output tile (clipped to the mesh)
+constexpr int GT_HCELLS = (GT_X + 2) * (GT_Y + 2) * (GT_Z + 2);     // with one halo layer: 1080
+constexpr int GT_CAP = 832;                                         // records staged in LDS (26 KB); denser tiles read global memory
+constexpr int GT_CPT = (GT_HCELLS + GT_X * GT_Y * GT_Z - 1) / (GT_X * GT_Y * GT_Z);   // halo'd cells per thread in the staging
 
 struct GatherTiling
     {
@@ -285,19 +287,21 @@ __global__ __launch_bounds__(GT_THREADS) void k_mesh_gather(const MeshGeom g, co
     __shared__ unsigned int s_gb[GT_HCELLS];           // global begin of the cell's records
     __shared__ unsigned int s_wave[GT_THREADS / 64];
     __shared__ double4 s_rec[GT_CAP];
+    __shared__ int s_general;                          // the tile holds a record with |shift| > 1/2: general tsc() for this tile
 
+    if (threadIdx.x == 0) s_general = 0;
     const unsigned int t_id = blockIdx.x;
     const unsigned int tix = t_id % tl.ntx, tiy = (t_id / tl.ntx) % tl.nty, tiz = t_id / (tl.ntx * tl.nty);
     const int x0 = tix * tl.tx, y0 = tiy * tl.ty, z0 = tiz * tl.tz;
     const unsigned int HX = tl.tx + 2, HY = tl.ty + 2, HZ = tl.tz + 2;
     const unsigned int HC = HX * HY * HZ;
 
-    // counts of the halo'd cells; thread t owns the halo'd cells 2t and 2t+1
-    unsigned int cnt[2], tsum = 0;
+    // counts of the halo'd cells; thread t owns GT_CPT consecutive halo'd cells
+    unsigned int cnt[GT_CPT], tsum = 0;
 #pragma unroll
-    for (int q = 0; q < 2; ++q)
+    for (int q = 0; q < GT_CPT; ++q)
         {
-        const unsigned int hc = threadIdx.x * 2 + q;
+        const unsigned int hc = threadIdx.x * GT_CPT + q;
         cnt[q] = 0;
         if (hc < HC)
             {
@@ -333,9 +337,9 @@ __global__ __launch_bounds__(GT_THREADS) void k_mesh_gather(const MeshGeom g, co
         }
     const bool in_lds = total <= (unsigned int)GT_CAP;           // block-uniform
 #pragma unroll
-    for (int q = 0; q < 2; ++q)
+    for (int q = 0; q < GT_CPT; ++q)
         {
-        const unsigned int hc = threadIdx.x * 2 + q;
+        const unsigned int hc = threadIdx.x * GT_CPT + q;
         if (hc < HC)
             {
             s_off[hc] = excl;
@@ -358,10 +362,13 @@ __global__ __launch_bounds__(GT_THREADS) void k_mesh_gather(const MeshGeom g, co
                 else
                     hi = mid;
                 }
-            s_rec[q] = packed[s_gb[lo] + (q - s_off[lo])];
+            const double4 rec = packed[s_gb[lo] + (q - s_off[lo])];
+            s_rec[q] = rec;
+            if (!(fabs(rec.x) <= 0.5000001 && fabs(rec.y) <= 0.5000001 && fabs(rec.z) <= 0.5000001)) s_general = 1;
             }
         __syncthreads();
         }
+    const bool fast = in_lds && !s_general;                      // block-uniform
 
     const unsigned int lx = threadIdx.x % GT_X, ly = (threadIdx.x / GT_X) % GT_Y, lz = threadIdx.x / (GT_X * GT_Y);
     if (lx >= tl.tx || ly >= tl.ty || lz >= tl.tz) return;
@@ -376,7 +383,7 @@ __global__ __launch_bounds__(GT_THREADS) void k_mesh_gather(const MeshGeom g, co
             // each other in the staged order
             const unsigned int h0 = HX * ((ly + 1 - j) + HY * (lz + 1 - k)) + lx;
             const unsigned int b0 = s_off[h0], b1 = s_off[h0 + 1], b2 = s_off[h0 + 2], b3 = s_off[h0 + 3];
-            if (in_lds)
+            if (fast)
                 {
                 for (unsigned int q = b0; q < b3; ++q)
                     {
@@ -387,23 +394,17 @@ __global__ __launch_bounds__(GT_THREADS) void k_mesh_gather(const MeshGeom g, co
                 }
             else
                 {
-                // dense tile: same order, records straight from global memory (the three cells need not be adjacent there
-                // when the row wraps in x)
-                const unsigned int n0 = b1 - b0, n1 = b2 - b1, n2 = b3 - b2;
-                for (unsigned int r = 0; r < n0; ++r)
+                // dense tile (records straight from global memory; the three cells need not be adjacent there when the row
+                // wraps in x) or a tile with an out-of-box particle: same order, general TSC weights
+                for (int i = 1; i >= -1; --i)
                     {
-                    const double4 pk = packed[s_gb[h0] + r];
-                    acc += pk.w * (tsc_cell(pk.x, 1) * tsc_cell(pk.y, j) * tsc_cell(pk.z, k));
-                    }
-                for (unsigned int r = 0; r < n1; ++r)
-                    {
-                    const double4 pk = packed[s_gb[h0 + 1] + r];
-                    acc += pk.w * (tsc_cell(pk.x, 0) * tsc_cell(pk.y, j) * tsc_cell(pk.z, k));
-                    }
-                for (unsigned int r = 0; r < n2; ++r)
-                    {
-                    const double4 pk = packed[s_gb[h0 + 2] + r];
-                    acc += pk.w * (tsc_cell(pk.x, -1) * tsc_cell(pk.y, j) * tsc_cell(pk.z, k));
+                    const unsigned int h = h0 + (1 - i);
+                    const unsigned int n = s_off[h + 1] - s_off[h];
+                    for (unsigned int r = 0; r < n; ++r)
+                        {
+                        const double4 pk = in_lds ? s_rec[s_off[h] + r] : packed[s_gb[h] + r];
+                        acc += pk.w * (tsc(pk.x - i) * tsc(pk.y - j) * tsc(pk.z - k));
+                        }
                     }
                 }
             }
