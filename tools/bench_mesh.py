@@ -10,6 +10,8 @@ from metadynamics import context, cv, integrate
 N, L = 1_000_000, 100.0
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 pos, types = util.snapshot_random(N, L, seed=12345, modulated=True, dtype=np.float32)
+pos = (np.mod(pos.astype(np.float64) + L / 2, L) - L / 2).astype(np.float32)   # an MD engine keeps its particles wrapped into the box
+pos[pos >= L / 2] = -L / 2
 context.initialize(pos, types, ["A", "B"], L, dtype=np.float32)
 meta = integrate.mode_metadynamics(dt=0.005, stride=1, mode="well_tempered", W=1.0, deltaT=7.0, T=1.0)
 lam = cv.lamellar(sigma=0.02, mode=dict(A=1.0, B=-1.0), lattice_vectors=util.CV1_VECTORS)
