@@ -13,7 +13,7 @@
 //   2 scan (2 kernels)  exclusive scan of the counts -> cell starts; the counters are cleared for the next call
 //   3 k_mesh_place      (shift, mode) record, id and cell of every particle written to start[cell] + slot
 //   4 k_mesh_sortfix    cells holding >= 2 particles: records ordered by particle id (=> bitwise reproducible sums)
-//   5 k_mesh_gather     a block owns a 16x8x8 tile of mesh cells: the records of the tile + one halo layer are staged in
+//   5 k_mesh_gather     a block owns a 16x8x4 tile of mesh cells: the records of the tile + one halo layer are staged in
 //                       LDS, then every thread sums the TSC weights of the particles of its cells' 27 neighbour cells from
 //                       LDS (the Poisson-distributed cell counts make this loop divergent — in LDS that costs ALU slots,
 //                       from global memory it cost 316 us of load latency): no atomics on the mesh, no scratch, every
@@ -277,7 +277,7 @@ struct GatherTiling
     unsigned int ntx, nty, ntz;       // tiles per axis
     };
 
-constexpr int GT_THREADS = GT_X * GT_Y * GT_Z;                      // one thread per output cell: 16 waves hide the LDS latency
+constexpr int GT_THREADS = GT_X * GT_Y * GT_Z;                      // one thread per output cell: 8 waves per block, four blocks per CU hide the LDS latency
                                                                     // of the divergent per-cell loops
 
 __global__ __launch_bounds__(GT_THREADS) void k_mesh_gather(const MeshGeom g, const GatherTiling tl, const unsigned int *__restrict__ start,
