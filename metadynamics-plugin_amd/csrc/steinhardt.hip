@@ -407,42 +407,55 @@ __global__ __launch_bounds__(QL_THREADS, (LMAX <= 6 ? 4 : 2)) void k_ql_accumula
 
 // ---- finalize: full Q_lm table (reference order), Q_l, CV --------------------------------------------
 template<int LMAX>
-__global__ void k_ql_finalize(const QlArgs<LMAX> a, const double *__restrict__ qprime, double *__restrict__ qlm_full,
-                              double *__restrict__ ql, double *__restrict__ value)
+__global__ __launch_bounds__(256) void k_ql_finalize(const QlArgs<LMAX> a, const double *__restrict__ qprime,
+                                                     double *__restrict__ qlm_full, double *__restrict__ ql, double *__restrict__ value)
     {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    // one thread per entry of the full table (<= 169 at lmax = 12), the sums over m and l in the serial order of the reference
+    __shared__ double s_sq[(LMAX + 1) * (LMAX + 1)];
+    __shared__ double s_ql[LMAX + 1];
     const double ng = (double)a.n_global;
-    unsigned int n = 0;
-    double val = 0.0;
-    for (int l = 0; l <= (int)a.lmax; ++l)
+    const unsigned int n = threadIdx.x;
+    const unsigned int count = (a.lmax + 1) * (a.lmax + 1);
+    if (n < count)
         {
-        double Ql = 0.0;
-        for (int p = 0; p < 2 * l + 1; ++p)
+        int l = 0;
+        while ((l + 1) * (l + 1) <= (int)n) ++l;
+        const int p = (int)n - l * l;
+        const int m = (p <= l) ? p : (l - p);
+        const int am = m < 0 ? -m : m;
+        const int idx = l * (l + 1) / 2 + am;
+        cplx q = {qprime[2 * idx], qprime[2 * idx + 1]};
+        if (m < 0) q = cconj(q);                                            // fsph negative m: conjugate, phase +1
+        if (m > 0 && (m % 2)) q = cscale(q, -1.0);                          // Condon-Shortley (:150)
+        if (a.half_nlist)                                                   // :173-179
             {
-            const int m = (p <= l) ? p : (l - p);
-            const int am = m < 0 ? -m : m;
-            const int idx = l * (l + 1) / 2 + am;
-            cplx q = {qprime[2 * idx], qprime[2 * idx + 1]};
-            if (m < 0) q = cconj(q);                                            // fsph negative m: conjugate, phase +1
-            if (m > 0 && (m % 2)) q = cscale(q, -1.0);                          // Condon-Shortley (:150)
-            if (a.half_nlist)                                                   // :173-179
-                {
-                if (l % 2 == 0)
-                    q = cscale(q, 2.0);
-                else
-                    q = {0.0, 0.0};
-                }
-            qlm_full[2 * n] = q.re;
-            qlm_full[2 * n + 1] = q.im;
-            double sq = q.re * q.re + q.im * q.im;
-            sq *= (4.0 * M_PI / (2 * l + 1)) / (ng * ng);                       // nc = 1 (:182)
-            Ql += sq;
-            ++n;
+            if (l % 2 == 0)
+                q = cscale(q, 2.0);
+            else
+                q = {0.0, 0.0};
             }
-        ql[l] = Ql;
-        val += a.ql_ref[l] * Ql;                                                // :190-194
+        qlm_full[2 * n] = q.re;
+        qlm_full[2 * n + 1] = q.im;
+        double sq = q.re * q.re + q.im * q.im;
+        sq *= (4.0 * M_PI / (2 * l + 1)) / (ng * ng);                       // nc = 1 (:182)
+        s_sq[n] = sq;
         }
-    *value = val;
+    __syncthreads();
+    if (threadIdx.x <= a.lmax)
+        {
+        const int l = threadIdx.x;
+        double Ql = 0.0;
+        for (int p = 0; p < 2 * l + 1; ++p) Ql += s_sq[l * l + p];
+        ql[l] = Ql;
+        s_ql[l] = Ql;
+        }
+    __syncthreads();
+    if (threadIdx.x == 0)
+        {
+        double val = 0.0;
+        for (int l = 0; l <= (int)a.lmax; ++l) val += a.ql_ref[l] * s_ql[l];   // :190-194
+        *value = val;
+        }
     }
 
 // ---- forces ----------------------------------------------------------------------------------------------
@@ -650,7 +663,7 @@ int accumulate_impl(unsigned int N, const void *d_postype, int dtype, const mtd_
     if (rc) return rc;
     if (!accumulate)
         {
-        k_ql_finalize<LMAX><<<1, 64, 0, s>>>(a, d_qprime, d_qlm, d_ql, d_value);
+        k_ql_finalize<LMAX><<<1, 256, 0, s>>>(a, d_qprime, d_qlm, d_ql, d_value);
         MTD_LAUNCH_CHECK();
         return MTD_SUCCESS;
         }
@@ -665,7 +678,7 @@ int accumulate_impl(unsigned int N, const void *d_postype, int dtype, const mtd_
     rc = mtd_reduce_partials(d_partials, blocks, n_out, n_out, 1.0, 0.0, d_qprime, (mtd_stream_t)s);
     if (rc) return rc;
     if (!finalize) return MTD_SUCCESS;
-    k_ql_finalize<LMAX><<<1, 64, 0, s>>>(a, d_qprime, d_qlm, d_ql, d_value);
+    k_ql_finalize<LMAX><<<1, 256, 0, s>>>(a, d_qprime, d_qlm, d_ql, d_value);
     MTD_LAUNCH_CHECK();
     return MTD_SUCCESS;
     }
