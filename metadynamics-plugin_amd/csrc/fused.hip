@@ -47,6 +47,7 @@ extern "C" int mtd_debug_read_stamps(unsigned long long *host)
 #include "metad_host.hpp"
 
 #include <cstdlib>
+#include <cstring>
 
 namespace
 {
@@ -156,7 +157,7 @@ __global__ __launch_bounds__(FF_THREADS, 4) void k_fused_force(const LamKArgs a,
                 s_wcoef[i] = (cv < a.n_cv) ? (float)((double)a.coeff[cv][i % MTD_MAX_TYPES] * b * two_over_n) : 0.0f;
                 }
         }
-    else if (!grid_block)
+    else if (!grid_block && N)                      // N == 0: the grid engine on its own (mtd_metad_update_bias), no particles
         {
         lam_force_unscaled<S4, NCV, FAST, FF_U>(a, postype, N, first, stride, s_mt, R);
         if (GROUPS > 1) lam_force_unscaled<S4, NCV, FAST, FF_U>(a, postype, N, first1, stride, s_mt, R1);
@@ -211,7 +212,7 @@ __global__ __launch_bounds__(FF_THREADS, 4) void k_fused_force(const LamKArgs a,
             }
         MTD_STAMP(20, blockIdx.x == 0 && threadIdx.x == 0);
         }
-    else if (wave != 0)
+    else if (wave != 0 && N)
         {
         lam_force_store<S4, NCV, FF_U>(a, out, first, stride, s_wcoef, R);
         if (GROUPS > 1) lam_force_store<S4, NCV, FF_U>(a, out, first1, stride, s_wcoef, R1);
@@ -457,3 +458,34 @@ int mtd_fused_force_pass(mtd_metad *m, const mtd_lamellar_set *set, unsigned int
     }
 
 } // extern "C"
+
+namespace mtd
+{
+// The grid engine on its own in the fused form (any CV set with <= 3 collective variables whose values arrive through
+// mtd_metad_set_cv_source / set_cv_value): the deferred pass of the previous deposit, then ONE launch for the chain
+// (CV values -> V_old -> scale -> closed-form dV/ds) and the first grid pass — instead of k_prepare, k_reweight1, k_apply,
+// k_evaluate, four dependent launches of ~5 us latency each.
+int fused_grid_step(mtd_metad *m, unsigned int timestep, hipStream_t s)
+    {
+    if (m->cfg.n_cv > (unsigned int)CHAIN_MAX_CV) return MTD_ERR_UNSUPPORTED;
+    int rc = metad_flush(m, s);
+    if (rc) return rc;
+    LamKArgs k;
+    std::memset(&k, 0, sizeof(k));
+    k.n_cv = m->cfg.n_cv;
+    ForcePtrs out;
+    for (unsigned int c = 0; c < MTD_MAX_CV; ++c) out.f[c] = nullptr;
+    const int dep = (m->add_bias && (timestep % m->stride == 0)) ? 1 : 0;
+    const unsigned int n_grid = dep ? m->cfg.n_gblocks : 0;
+    const unsigned int grid = n_grid ? n_grid : 1;                  // still one block to publish the scalars
+    switch (m->cfg.n_cv)
+        {
+        case 1: k_fused_force<float4, 1, true, 1><<<grid, FF_THREADS, 0, s>>>(k, nullptr, out, 0, 0.0, m->cfg, dep, n_grid); break;
+        case 2: k_fused_force<float4, 2, true, 1><<<grid, FF_THREADS, 0, s>>>(k, nullptr, out, 0, 0.0, m->cfg, dep, n_grid); break;
+        default: k_fused_force<float4, 3, true, 1><<<grid, FF_THREADS, 0, s>>>(k, nullptr, out, 0, 0.0, m->cfg, dep, n_grid); break;
+        }
+    MTD_LAUNCH_CHECK();
+    m->pending_apply = dep;
+    return MTD_SUCCESS;
+    }
+} // namespace mtd

@@ -23,6 +23,8 @@
 
 #include "metad_host.hpp"
 
+#include <cstdlib>
+
 namespace
 {
 
@@ -464,6 +466,8 @@ int mtd_metad_update_phase_b(mtd_metad *m, int deposited, mtd_stream_t stream)
 int mtd_metad_update_bias(mtd_metad *m, unsigned int timestep, mtd_stream_t stream)
     {
     if (!m) return MTD_ERR_INVALID_ARGUMENT;
+    static const bool four_launches = std::getenv("MTD_METAD_FOUR_LAUNCHES") != nullptr;    // diagnostic: the plain sequence
+    if (m->cfg.n_cv <= 3 && !four_launches) return mtd::fused_grid_step(m, timestep, (hipStream_t)stream);
     { int frc = mtd::metad_flush(m, (hipStream_t)stream); if (frc) return frc; }
     hipStream_t s = (hipStream_t)stream;
     const int dep = (m->add_bias && (timestep % m->stride == 0)) ? 1 : 0;

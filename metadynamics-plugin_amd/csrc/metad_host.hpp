@@ -18,4 +18,6 @@ namespace mtd
 {
 // run the deferred k_apply if one is pending (called by every entry point that reads or updates the grid)
 int metad_flush(mtd_metad *m, hipStream_t s);
+// fused.hip: deferred apply + one launch for the whole update (n_cv <= 3), MTD_ERR_UNSUPPORTED otherwise
+int fused_grid_step(mtd_metad *m, unsigned int timestep, hipStream_t s);
 }
