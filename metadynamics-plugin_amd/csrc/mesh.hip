@@ -26,8 +26,8 @@
 //   8 k_fft_lines       inverse along y; k_fft_x_c2r inverse along x (other half of the line by symmetry, real part out)
 //   9 k_mesh_forces     per particle: 27 reads of Re(inv) with TSC' x TSC x TSC weights
 // Everything is double precision: the CV is quartic in the Fourier amplitudes, fp32 meshes cannot hold
-// 1e-6 on it.  Mesh sizes must be powers of two (the reference's own multi-rank restriction,
-// OrderParameterMesh.cc:74-79); other sizes return MTD_ERR_UNSUPPORTED.
+// 1e-6 on it.  Mesh sizes: 4 ... 256 per axis (any, direct transform in LDS for lengths that are not powers of two), or a
+// power of two up to 1024 (radix-2 stages); other sizes return MTD_ERR_UNSUPPORTED.
 #include "mtd_device.hpp"
 
 #include <cmath>
@@ -372,6 +372,7 @@ __global__ __launch_bounds__(GT_THREADS) void k_mesh_gather(const MeshGeom g, co
 
     const unsigned int lx = threadIdx.x % GT_X, ly = (threadIdx.x / GT_X) % GT_Y, lz = threadIdx.x / (GT_X * GT_Y);
     if (lx >= tl.tx || ly >= tl.ty || lz >= tl.tz) return;
+    if (x0 + lx >= g.nx || y0 + ly >= g.ny || z0 + lz >= g.nz) return;       // partial tile at the edge of the mesh
     double acc = 0.0;
     // this cell receives from the particle cell at offset (-i,-j,-k) with dx = shift - (i,j,k); fixed loop order
 #pragma unroll
@@ -416,6 +417,38 @@ __global__ __launch_bounds__(GT_THREADS) void k_mesh_gather(const MeshGeom g, co
 // LDS layout [p][tile] (consecutive lines in consecutive 16-B slots: conflict-free butterflies).
 constexpr int FFT_THREADS = 256;
 
+// Line lengths that are not powers of two (log2n == 0 marks them) take a direct O(n^2) DFT in LDS from buffer `in` to
+// buffer `out` (natural order both): n <= 256, so a pass costs n^2 per line — tens of microseconds on this machine, and
+// any mesh size the reference accepts (kiss_fft / cuFFT take arbitrary n) works.  twiddle[j] = exp(-2 pi i j / n), j < n.
+__device__ __forceinline__ void dft_direct(const double2 *in, double2 *out, const double2 *__restrict__ twiddle, const unsigned int n,
+                                           const unsigned int tile, const int inverse)
+    {
+    for (unsigned int idx = threadIdx.x; idx < n * tile; idx += FFT_THREADS)
+        {
+        const unsigned int k = idx / tile, t = idx % tile;
+        double re = 0.0, im = 0.0;
+        unsigned int r = 0;                                      // (p * k) mod n
+        for (unsigned int p = 0; p < n; ++p)
+            {
+            double2 w = twiddle[r];
+            if (inverse) w.y = -w.y;
+            const double2 v = in[p * tile + t];
+            re += v.x * w.x - v.y * w.y;
+            im += v.x * w.y + v.y * w.x;
+            r += k;
+            if (r >= n) r -= n;
+            }
+        out[k * tile + t] = make_double2(re, im);
+        }
+    __syncthreads();
+    }
+
+// LDS slot of line position p at load time: bit-reversed for the radix-2 path (decimation in time), natural otherwise
+__device__ __forceinline__ unsigned int lds_slot(const unsigned int p, const unsigned int log2n)
+    {
+    return log2n ? (__brev(p) >> (32 - log2n)) : p;
+    }
+
 template<bool REAL_INPUT, bool REAL_OUTPUT>
 __global__ __launch_bounds__(FFT_THREADS) void k_fft_lines(const double *__restrict__ real_in, double2 *__restrict__ data,
                                                            double *__restrict__ real_out,
@@ -453,13 +486,17 @@ __global__ __launch_bounds__(FFT_THREADS) void k_fft_lines(const double *__restr
             v = make_double2(real_in[a], 0.0);
         else
             v = data[a];
-        const unsigned int pr = __brev(p) >> (32 - log2n);
-        s[pr * tile + t] = v;
+        s[lds_slot(p, log2n) * tile + t] = v;
         }
     __syncthreads();
 
+    if (!log2n)
+        {
+        dft_direct(s, s + total, twiddle, n, tile, inverse);
+        s += total;                                              // the result buffer
+        }
     const unsigned int half_total = (n / 2) * tile;
-    for (unsigned int len = 2, stage = 1; len <= n; len <<= 1, ++stage)
+    for (unsigned int len = 2, stage = 1; log2n && len <= n; len <<= 1, ++stage)
         {
         const unsigned int half = len >> 1;
         const unsigned int tw_step = n / len;
@@ -550,6 +587,19 @@ __device__ __forceinline__ void fft_stages_dit(double2 *s, const double2 *__rest
         }
     }
 
+// radix-2 stages in place, or the direct transform into the second buffer; returns the buffer that holds the result
+__device__ __forceinline__ double2 *lds_transform(double2 *s, const double2 *__restrict__ twiddle, const unsigned int n,
+                                                  const unsigned int log2n, const unsigned int tile, const int inverse)
+    {
+    if (log2n)
+        {
+        fft_stages_dit(s, twiddle, n, tile, inverse);
+        return s;
+        }
+    dft_direct(s, s + n * tile, twiddle, n, tile, inverse);
+    return s + n * tile;
+    }
+
 __global__ __launch_bounds__(FFT_THREADS) void k_fft_x_r2c(const double *__restrict__ real_in, double2 *__restrict__ half_out,
                                                            const double2 *__restrict__ twiddle, const unsigned int n,
                                                            const unsigned int log2n, const unsigned int tile, const unsigned int hxp)
@@ -561,11 +611,10 @@ __global__ __launch_bounds__(FFT_THREADS) void k_fft_x_r2c(const double *__restr
     for (unsigned int idx = threadIdx.x; idx < total; idx += FFT_THREADS)
         {
         const unsigned int t = idx / n, p = idx % n;
-        const unsigned int pr = __brev(p) >> (32 - log2n);
-        s[pr * tile + t] = make_double2(real_in[(line0 + t) * n + p], 0.0);
+        s[lds_slot(p, log2n) * tile + t] = make_double2(real_in[(line0 + t) * n + p], 0.0);
         }
     __syncthreads();
-    fft_stages_dit(s, twiddle, n, tile, 0);
+    s = lds_transform(s, twiddle, n, log2n, tile, 0);
     const unsigned int hx = n / 2 + 1;
     for (unsigned int idx = threadIdx.x; idx < hx * tile; idx += FFT_THREADS)
         {
@@ -586,12 +635,12 @@ __global__ __launch_bounds__(FFT_THREADS) void k_fft_x_c2r(const double2 *__rest
         {
         const unsigned int t = idx / hx, p = idx % hx;
         const double2 v = half_in[(line0 + t) * hxp + p];
-        s[(__brev(p) >> (32 - log2n)) * tile + t] = v;
-        if (p != 0 && p != n / 2)                                    // the other half of the line by Hermitian symmetry
-            s[(__brev(n - p) >> (32 - log2n)) * tile + t] = make_double2(v.x, -v.y);
+        s[lds_slot(p, log2n) * tile + t] = v;
+        if (p != 0 && 2 * p != n)                                    // the other half of the line by Hermitian symmetry
+            s[lds_slot(n - p, log2n) * tile + t] = make_double2(v.x, -v.y);
         }
     __syncthreads();
-    fft_stages_dit(s, twiddle, n, tile, 1);
+    s = lds_transform(s, twiddle, n, log2n, tile, 1);
     for (unsigned int idx = threadIdx.x; idx < n * tile; idx += FFT_THREADS)
         {
         const unsigned int t = idx / n, p = idx % n;
@@ -652,12 +701,17 @@ __global__ __launch_bounds__(FFT_THREADS) void k_fft_z_spectral(const MeshGeom g
     for (unsigned int idx = threadIdx.x; idx < total; idx += FFT_THREADS)
         {
         const unsigned int p = idx / tile, t = idx % tile;
-        const unsigned int pr = __brev(p) >> (32 - log2n);
-        s[pr * tile + t] = fmesh[base + t + (size_t)p * plane];
+        s[lds_slot(p, log2n) * tile + t] = fmesh[base + t + (size_t)p * plane];
         }
     __syncthreads();
+    double2 *const s_first = s;
+    if (!log2n)
+        {
+        dft_direct(s, s + total, twiddle, n, tile, 0);               // forward, natural order, into the second buffer
+        s += total;
+        }
     const unsigned int half_total = (n / 2) * tile;
-    for (unsigned int len = 2; len <= n; len <<= 1)                      // forward, decimation in time
+    for (unsigned int len = 2; log2n && len <= n; len <<= 1)             // forward, decimation in time
         {
         const unsigned int half = len >> 1;
         const unsigned int tw_step = n / len;
@@ -709,14 +763,20 @@ __global__ __launch_bounds__(FFT_THREADS) void k_fft_z_spectral(const MeshGeom g
             {
             // Re(G f*) - |f|^2 I^2 sum mode^2 / 2 N^2 (:896-905) = |f|^4 - I^2 |f|^2 sum mode^2 / N^2 for the cell itself ...
             double tk = val * val - val * (I * I) * msq / n_global / n_global;
-            // ... plus the same for its mirror image when that one is not stored
-            if (wx != 0 && wx != nxh) tk += val * val - val * (Im * Im) * msq / n_global / n_global;
+            // ... plus the same for its mirror image when that one is not stored (k_x = 0 and, for even nx, nx/2 mirror
+            // into their own plane)
+            if (wx != 0 && 2 * wx != g.nx) tk += val * val - val * (Im * Im) * msq / n_global / n_global;
             term += tk;
             }
         }
     __syncthreads();
 
-    for (unsigned int len = n; len >= 2; len >>= 1)                      // inverse, decimation in frequency
+    if (!log2n)
+        {
+        dft_direct(s, s_first, twiddle, n, tile, 1);                 // inverse, natural order, back into the first buffer
+        s = s_first;
+        }
+    for (unsigned int len = n; log2n && len >= 2; len >>= 1)             // inverse, decimation in frequency
         {
         const unsigned int half = len >> 1;
         const unsigned int tw_step = n / len;
@@ -737,8 +797,8 @@ __global__ __launch_bounds__(FFT_THREADS) void k_fft_z_spectral(const MeshGeom g
         }
     for (unsigned int idx = threadIdx.x; idx < total; idx += FFT_THREADS)
         {
-        const unsigned int q = idx / tile, t = idx % tile;             // LDS slot q holds position z = bitrev(q)
-        const unsigned int z = __brev(q) >> (32 - log2n);
+        const unsigned int q = idx / tile, t = idx % tile;             // LDS slot q holds position z = bitrev(q) (radix-2 path)
+        const unsigned int z = lds_slot(q, log2n);
         gmesh[base + t + (size_t)z * plane] = s[q * tile + t];
         }
     term = block_sum(term, s_red);
@@ -895,7 +955,7 @@ __global__ __launch_bounds__(256) void k_mesh_virial(const MeshGeom g, const dou
         // Nyquist planes of y and z the Miller index of the mirror cell is not the negative one (both are -n/2)
         const unsigned int mx = (g.nx - wx) % g.nx, my = (g.ny - wy) % g.ny, mz = (g.nz - wz) % g.nz;
         const unsigned int cells[2] = {k, mx + g.nx * (my + g.ny * mz)};
-        const int n_terms = (wx != 0 && wx != g.nx / 2) ? 2 : 1;
+        const int n_terms = (wx != 0 && 2 * wx != g.nx) ? 2 : 1;
         for (int term = 0; term < n_terms; ++term)
             {
             double kx, ky, kz;
@@ -937,12 +997,17 @@ __global__ __launch_bounds__(256) void k_sum_partials(const double *__restrict__
     }
 
 bool is_pow2(unsigned int n) { return n && !(n & (n - 1)); }
+// log2 of a power of two, 0 otherwise (the kernels take 0 as "direct DFT, natural order")
 unsigned int ilog2(unsigned int n)
     {
+    if (!is_pow2(n)) return 0;
     unsigned int l = 0;
     while ((1u << l) < n) ++l;
     return l;
     }
+
+// dynamic LDS of a line pass: one buffer of n * tile elements, two for the direct transform
+size_t fft_lds_bytes(unsigned int n, unsigned int tile) { return (size_t)n * tile * sizeof(double2) * (is_pow2(n) ? 1 : 2); }
 
 } // namespace
 
@@ -993,7 +1058,7 @@ struct FftPass { unsigned int n, tile, elem_stride, line_stride, tiles_per_row, 
 unsigned int fft_tile_for(unsigned int n, unsigned int lines)
     {
     unsigned int t = 16;
-    while (t > 1 && (size_t)n * t * sizeof(double2) > 64 * 1024) t >>= 1;
+    while (t > 1 && fft_lds_bytes(n, t) > 64 * 1024) t >>= 1;
     while (t > 1 && lines % t) t >>= 1;
     return t;
     }
@@ -1018,7 +1083,7 @@ FftPass fft_z_pass(const mtd_mesh *m)
 int launch_fft_y(const mtd_mesh *m, double2 *data, int inverse, hipStream_t s)
     {
     const FftPass p = fft_y_pass(m);
-    k_fft_lines<false, false><<<p.n_blocks, FFT_THREADS, (size_t)p.n * p.tile * sizeof(double2), s>>>(
+    k_fft_lines<false, false><<<p.n_blocks, FFT_THREADS, fft_lds_bytes(p.n, p.tile), s>>>(
         nullptr, data, nullptr, p.tw, p.n, ilog2(p.n), p.tile, p.elem_stride, p.line_stride, p.tiles_per_row, p.row_stride, inverse, p.p_fastest);
     MTD_LAUNCH_CHECK();
     return MTD_SUCCESS;
@@ -1033,9 +1098,10 @@ int mtd_mesh_create(mtd_mesh **out, unsigned int nx, unsigned int ny, unsigned i
     {
     if (!out || !mode || n_types == 0) return MTD_ERR_INVALID_ARGUMENT;
     if (nx == 0 || ny == 0 || nz == 0) return MTD_ERR_INVALID_ARGUMENT;
-    // power-of-two meshes of at least 4 cells per axis (3x3x3 stencils must not alias), <= 1024 per axis
-    if (!is_pow2(nx) || !is_pow2(ny) || !is_pow2(nz) || nx < 4 || ny < 4 || nz < 4 || nx > 1024 || ny > 1024 || nz > 1024)
-        return MTD_ERR_UNSUPPORTED;
+    // at least 4 cells per axis (3x3x3 stencils must not alias); powers of two up to 1024 take the radix-2 transforms, any
+    // other size up to 256 the direct one
+    for (unsigned int n : {nx, ny, nz})
+        if (n < 4 || n > 1024 || (!is_pow2(n) && n > 256)) return MTD_ERR_UNSUPPORTED;
     const unsigned long long M64 = (unsigned long long)nx * ny * nz;
     if (M64 > (1ull << 30)) return MTD_ERR_UNSUPPORTED;
     mtd_mesh *m = new (std::nothrow) mtd_mesh();
@@ -1083,12 +1149,12 @@ int mtd_mesh_create(mtd_mesh **out, unsigned int nx, unsigned int ny, unsigned i
     m->d_itab = (double *)(p + o_itab);
     e = hipMemset(m->slab, 0, off);
     if (e == hipSuccess) e = hipMemcpy(m->d_mode, mode, sizeof(double) * n_types, hipMemcpyHostToDevice);
-    // twiddles exp(-2 pi i j / n), j < n/2, in double on the host
+    // twiddles exp(-2 pi i j / n), j < n (the radix-2 stages use the first half), in double on the host
     const unsigned int dims[3] = {nx, ny, nz};
     for (int a = 0; a < 3 && e == hipSuccess; ++a)
         {
         std::vector<double> tw(2 * (size_t)dims[a], 0.0);
-        for (unsigned int j = 0; j < dims[a] / 2; ++j)
+        for (unsigned int j = 0; j < dims[a]; ++j)
             {
             const double ang = -2.0 * M_PI * (double)j / (double)dims[a];
             tw[2 * j] = std::cos(ang);
@@ -1171,7 +1237,7 @@ int mtd_mesh_assign(mtd_mesh *m, unsigned int n_particles, const void *d_postype
     tl.tx = m->nx < (unsigned int)GT_X ? m->nx : GT_X;
     tl.ty = m->ny < (unsigned int)GT_Y ? m->ny : GT_Y;
     tl.tz = m->nz < (unsigned int)GT_Z ? m->nz : GT_Z;
-    tl.ntx = m->nx / tl.tx; tl.nty = m->ny / tl.ty; tl.ntz = m->nz / tl.tz;
+    tl.ntx = (m->nx + tl.tx - 1) / tl.tx; tl.nty = (m->ny + tl.ty - 1) / tl.ty; tl.ntz = (m->nz + tl.tz - 1) / tl.tz;   // edge tiles may be partial
     k_mesh_gather<<<tl.ntx * tl.nty * tl.ntz, GT_THREADS, 0, s>>>(g, tl, m->d_start, m->d_packed, m->d_rho);
     MTD_LAUNCH_CHECK();
     m->n_last = N;
@@ -1195,13 +1261,13 @@ int mtd_mesh_spectral(mtd_mesh *m, const mtd_box *box, unsigned int n_global, co
     if (rc) return rc;
     hipStream_t s = (hipStream_t)stream;
     const unsigned int x_tile = fft_tile_for(m->nx, m->ny * m->nz), x_blocks = (m->ny * m->nz) / x_tile;
-    const size_t x_lds = (size_t)m->nx * x_tile * sizeof(double2);
+    const size_t x_lds = fft_lds_bytes(m->nx, x_tile);
     k_fft_x_r2c<<<x_blocks, FFT_THREADS, x_lds, s>>>(m->d_rho, m->d_f, m->d_tw[0], m->nx, ilog2(m->nx), x_tile, m->hxp);
     MTD_LAUNCH_CHECK();
     rc = launch_fft_y(m, m->d_f, 0, s);
     if (rc) return rc;
     const FftPass pz = fft_z_pass(m);
-    k_fft_z_spectral<<<pz.n_blocks, FFT_THREADS, (size_t)pz.n * pz.tile * sizeof(double2), s>>>(
+    k_fft_z_spectral<<<pz.n_blocks, FFT_THREADS, fft_lds_bytes(pz.n, pz.tile), s>>>(
         g, m->d_f, m->d_g, pz.tw, ilog2(pz.n), pz.tile, pz.tiles_per_row, m->d_mode_sq, (double)n_global, m->d_itab, m->d_cv_partials);
     MTD_LAUNCH_CHECK();
     rc = launch_fft_y(m, m->d_g, 1, s);

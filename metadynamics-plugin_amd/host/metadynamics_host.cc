@@ -246,7 +246,7 @@ OrderParameterMeshGPU::OrderParameterMeshGPU(std::shared_ptr<SystemDefinition> s
     if (mode.size() != m_pdata->getNTypes()) throw std::runtime_error("Error setting up cv.mesh");   // OrderParameterMesh.cc:44-49
     int rc = mtd_mesh_create(&m_mesh, nx, ny, nz, mode.data(), (unsigned int)mode.size(), m_pdata->getN());
     if (rc == MTD_ERR_UNSUPPORTED)
-        throw std::runtime_error("cv.mesh: the number of mesh points along every direction must be a power of two in [4, 1024]");
+        throw std::runtime_error("cv.mesh: mesh points per direction: 4 ... 256, or a power of two up to 1024");
     mtd_check(rc, "mtd_mesh_create");
     m_cv_dev.resize(sizeof(double));
     }

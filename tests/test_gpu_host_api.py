@@ -264,7 +264,7 @@ def test_mesh_cv_with_umbrella_through_api(api, ref):
     F_ref = ref.lamellar_forces(util.CV1_VECTORS, opt, util.MODE_AB, rbox, b[0])
     assert np.abs(F[:, :3] - F_ref[:, :3]).max() <= 1e-5 * np.abs(F_ref[:, :3]).max()
     with pytest.raises(RuntimeError):
-        cv.mesh(nx=12, mode={"A": 1.0, "B": -1.0})            # not a power of two
+        cv.mesh(nx=300, mode={"A": 1.0, "B": -1.0})           # neither <= 256 nor a power of two
 
 
 def test_steinhardt_through_api(api, ref):

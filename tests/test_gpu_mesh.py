@@ -60,7 +60,9 @@ class GpuMesh:
 
 
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
-@pytest.mark.parametrize("dims,tilt", [((8, 8, 8), {}), ((16, 8, 32), dict(xy=0.2, xz=-0.1, yz=0.15)), ((32, 32, 32), {})])
+@pytest.mark.parametrize("dims,tilt", [((8, 8, 8), {}), ((16, 8, 32), dict(xy=0.2, xz=-0.1, yz=0.15)), ((32, 32, 32), {}),
+                                       # sizes that are not powers of two (direct transforms, partial gather tiles, odd lengths)
+                                       ((12, 20, 6), dict(xy=0.1, xz=0.05, yz=-0.2)), ((5, 7, 9), {}), ((48, 16, 36), {})])
 def test_mesh_cv_and_forces(abi, ref, dtype, dims, tilt):
     N = 6007
     Ls = (9.0, 7.5, 11.0)
@@ -132,7 +134,9 @@ def test_mesh_edge_cases(abi, ref):
     finally:
         g.close()
     h = C.c_void_p()
-    assert lib.mtd_mesh_create(C.byref(h), 12, 8, 8, util.dbl_array([1.0]), 1, 10) == -2   # not a power of two
+    assert lib.mtd_mesh_create(C.byref(h), 300, 8, 8, util.dbl_array([1.0]), 1, 10) == -2  # not a power of two and > 256
+    assert lib.mtd_mesh_create(C.byref(h), 2048, 8, 8, util.dbl_array([1.0]), 1, 10) == -2
+    assert lib.mtd_mesh_create(C.byref(h), 3, 8, 8, util.dbl_array([1.0]), 1, 10) == -2    # 3x3x3 stencils would alias
     assert lib.mtd_mesh_create(C.byref(h), 8, 8, 0, util.dbl_array([1.0]), 1, 10) == -1
 
 
