@@ -235,7 +235,7 @@ int mtd_fused_force_pass(mtd_metad *m, const mtd_lamellar_set *set, unsigned int
 typedef struct mtd_mesh mtd_mesh; /* opaque; owns the meshes, the cell list and the FFT twiddles */
 
 /* OrderParameterMesh constructor + setupMesh + initializeFFT (OrderParameterMesh.cc:18-122, 191-229, 263-342).
- * mode: host double[n_types].  Mesh sizes must be powers of two in [4, 1024] (MTD_ERR_UNSUPPORTED otherwise). */
+ * mode: host double[n_types].  Mesh points per axis: 4 ... 256 (any), or a power of two up to 1024 (MTD_ERR_UNSUPPORTED otherwise). */
 int mtd_mesh_create(mtd_mesh **out, unsigned int nx, unsigned int ny, unsigned int nz, const double *mode,
                     unsigned int n_types, unsigned int max_particles);
 int mtd_mesh_destroy(mtd_mesh *m);
