@@ -108,6 +108,8 @@ constexpr int FF_U = 4;        // particles per register group
 template<typename S4, int NCV> struct ff_groups { static constexpr int value = 1; };
 template<> struct ff_groups<float4, 1> { static constexpr int value = 2; };
 template<> struct ff_groups<float4, 2> { static constexpr int value = 2; };
+template<> struct ff_groups<double4, 1> { static constexpr int value = 2; };
+template<> struct ff_groups<double4, 2> { static constexpr int value = 2; };
 
 template<typename S4, int NCV, bool FAST, int GROUPS>
 __global__ __launch_bounds__(FF_THREADS, 4) void k_fused_force(const LamKArgs a, const S4 *__restrict__ postype, const ForcePtrs out,
@@ -413,7 +415,7 @@ int mtd_fused_force_pass(mtd_metad *m, const mtd_lamellar_set *set, unsigned int
     static const bool force_general = std::getenv("MTD_FUSED_GENERAL") != nullptr;
     if (set->n_cv <= (unsigned int)CHAIN_MAX_CV && !force_general)
         {
-        const unsigned int groups = (dtype == MTD_F32 && set->n_cv <= 2) ? 2 : 1;
+        const unsigned int groups = (set->n_cv <= 2) ? 2 : 1;
         unsigned int fblocks = (n_particles + FF_STREAM_THREADS * FF_U * groups - 1) / (FF_STREAM_THREADS * FF_U * groups);
         if (fblocks == 0 && n_grid == 0) fblocks = 1;               // still one block to publish the scalars
         const unsigned int grid = n_grid + fblocks;
