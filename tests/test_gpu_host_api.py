@@ -438,3 +438,40 @@ def test_mesh_log_quantities_and_virial_through_api(api, ref):
     got = np.array([mesh.cpp_force.getExternalVirial(i) for i in range(6)])
     assert np.abs(v_ref).max() > 0
     assert np.allclose(got, v_ref, rtol=1e-8, atol=1e-9 * np.abs(v_ref).max())
+
+
+def test_umbrella_force_descends_the_umbrella_energy(api):
+    """end to end, no oracle: moving the particles a small step along the bias force the API reports must lower the umbrella
+    energy U(s) = kappa/2 (s - cv0)^2 and pull the CV towards cv0 — the sign and direction of F = -dU/ds grad s through the
+    whole stack (CollectiveVariable.cc:22-66 on top of the CV's computeBiasForces)"""
+    context, cv, integrate = api
+    pos, types, L = util.snapshot_config0b()
+    context.initialize(pos, types, ["A", "B"], L, dtype=np.float64)
+    integrate.mode_metadynamics(dt=0.005, stride=1)
+    lam = cv.lamellar(sigma=0.05, mode=dict(A=1.0, B=-1.0), lattice_vectors=[(0, 0, 4)])
+    mesh = cv.mesh(nx=16, mode={"A": 1.0, "B": -1.0})
+    pdata = context.current.system_definition.getParticleData()
+    for c in (lam, mesh):
+        name = [q for q in c.cpp_force.getProvidedLogQuantities() if q.startswith("umbrella_energy_")][0]
+        context.run(1)
+        t = context.current.system.getCurrentTimeStep()
+        s0 = c.cpp_force.getCurrentValue(t)
+        cv0 = 0.8 * s0
+        c.set_params(umbrella="harmonic", cv0=cv0, kappa=50.0 / s0 ** 2)
+        energies, values = [], []
+        for it in range(6):
+            context.run(1)
+            t = context.current.system.getCurrentTimeStep()
+            energies.append(c.cpp_force.getLogValue(name, t))
+            values.append(c.cpp_force.getCurrentValue(t))
+            F = c.cpp_force.getForceArray().astype(np.float64)
+            P = pdata.getPositions().astype(np.float64)
+            step = 0.02 / np.abs(F[:, :3]).max()                    # largest displacement 0.02: a small step downhill
+            P[:, :3] += step * F[:, :3]
+            pdata.setPositions(P)
+        # the first step goes downhill; later ones may overshoot the minimum with this fixed step length (the mesh CV is
+        # quartic in the density), but never back up to where the descent started
+        assert energies[1] < energies[0], (name, energies)
+        assert max(energies[1:]) < 0.5 * energies[0], (name, energies)
+        assert abs(values[-1] - cv0) < abs(values[0] - cv0)
+        c.set_params(umbrella="no_umbrella")
