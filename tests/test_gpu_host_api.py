@@ -472,6 +472,6 @@ def test_umbrella_force_descends_the_umbrella_energy(api):
         # the first step goes downhill; later ones may overshoot the minimum with this fixed step length (the mesh CV is
         # quartic in the density), but never back up to where the descent started
         assert energies[1] < energies[0], (name, energies)
-        assert max(energies[1:]) < 0.5 * energies[0], (name, energies)
+        assert max(energies[1:]) < energies[0] and min(energies) < 0.2 * energies[0], (name, energies)
         assert abs(values[-1] - cv0) < abs(values[0] - cv0)
         c.set_params(umbrella="no_umbrella")
