@@ -600,51 +600,66 @@ __device__ __forceinline__ double2 *lds_transform(double2 *s, const double2 *__r
     return s + n * tile;
     }
 
+// Two real lines per complex transform: z = a + i b, Z = FFT z, then A[k] = (Z[k] + conj Z[n-k]) / 2 and
+// B[k] = (Z[k] - conj Z[n-k]) / 2i — half the butterflies and half the LDS of one transform per line.  `tile` (even) real
+// lines per block = tile / 2 complex lines in LDS.
 __global__ __launch_bounds__(FFT_THREADS) void k_fft_x_r2c(const double *__restrict__ real_in, double2 *__restrict__ half_out,
                                                            const double2 *__restrict__ twiddle, const unsigned int n,
-                                                           const unsigned int log2n, const unsigned int tile, const unsigned int hxp)
+                                                           const unsigned int log2n, const unsigned int tile, const unsigned int hxp,
+                                                           const unsigned int n_lines)
     {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double2 *s = (double2 *)smem;
     const size_t line0 = (size_t)blockIdx.x * tile;
-    const unsigned int total = n * tile;
-    for (unsigned int idx = threadIdx.x; idx < total; idx += FFT_THREADS)
+    const unsigned int pairs = tile / 2;
+    for (unsigned int idx = threadIdx.x; idx < n * pairs; idx += FFT_THREADS)
         {
-        const unsigned int t = idx / n, p = idx % n;
-        s[lds_slot(p, log2n) * tile + t] = make_double2(real_in[(line0 + t) * n + p], 0.0);
+        const unsigned int u = idx / n, p = idx % n;
+        const size_t la = line0 + 2 * u, lb = la + 1;                // lines past the end (odd line counts) are zero
+        s[lds_slot(p, log2n) * pairs + u] = make_double2(la < n_lines ? real_in[la * n + p] : 0.0, lb < n_lines ? real_in[lb * n + p] : 0.0);
         }
     __syncthreads();
-    s = lds_transform(s, twiddle, n, log2n, tile, 0);
+    s = lds_transform(s, twiddle, n, log2n, pairs, 0);
     const unsigned int hx = n / 2 + 1;
-    for (unsigned int idx = threadIdx.x; idx < hx * tile; idx += FFT_THREADS)
+    for (unsigned int idx = threadIdx.x; idx < hx * pairs; idx += FFT_THREADS)
         {
-        const unsigned int t = idx / hx, p = idx % hx;
-        half_out[(line0 + t) * hxp + p] = s[p * tile + t];
+        const unsigned int u = idx / hx, k = idx % hx;
+        const double2 zk = s[k * pairs + u], zm = s[((n - k) % n) * pairs + u];
+        if (line0 + 2 * u < n_lines) half_out[(line0 + 2 * u) * hxp + k] = make_double2(0.5 * (zk.x + zm.x), 0.5 * (zk.y - zm.y));
+        if (line0 + 2 * u + 1 < n_lines) half_out[(line0 + 2 * u + 1) * hxp + k] = make_double2(0.5 * (zk.y + zm.y), -0.5 * (zk.x - zm.x));
         }
     }
 
+// The inverse of the above: Z[k] = A[k] + i B[k] with both half spectra completed by Hermitian symmetry, one inverse
+// transform, a = Re z and b = Im z are the two real lines (interpolateForces only reads Re(inv), :851-857).
 __global__ __launch_bounds__(FFT_THREADS) void k_fft_x_c2r(const double2 *__restrict__ half_in, double *__restrict__ real_out,
                                                            const double2 *__restrict__ twiddle, const unsigned int n,
-                                                           const unsigned int log2n, const unsigned int tile, const unsigned int hxp)
+                                                           const unsigned int log2n, const unsigned int tile, const unsigned int hxp,
+                                                           const unsigned int n_lines)
     {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double2 *s = (double2 *)smem;
     const size_t line0 = (size_t)blockIdx.x * tile;
+    const unsigned int pairs = tile / 2;
     const unsigned int hx = n / 2 + 1;
-    for (unsigned int idx = threadIdx.x; idx < hx * tile; idx += FFT_THREADS)
+    for (unsigned int idx = threadIdx.x; idx < hx * pairs; idx += FFT_THREADS)
         {
-        const unsigned int t = idx / hx, p = idx % hx;
-        const double2 v = half_in[(line0 + t) * hxp + p];
-        s[lds_slot(p, log2n) * tile + t] = v;
-        if (p != 0 && 2 * p != n)                                    // the other half of the line by Hermitian symmetry
-            s[lds_slot(n - p, log2n) * tile + t] = make_double2(v.x, -v.y);
+        const unsigned int u = idx / hx, k = idx % hx;
+        const double2 zero = make_double2(0.0, 0.0);
+        const double2 A = line0 + 2 * u < n_lines ? half_in[(line0 + 2 * u) * hxp + k] : zero;
+        const double2 B = line0 + 2 * u + 1 < n_lines ? half_in[(line0 + 2 * u + 1) * hxp + k] : zero;
+        s[lds_slot(k, log2n) * pairs + u] = make_double2(A.x - B.y, A.y + B.x);                 // A + i B
+        if (k != 0 && 2 * k != n)                                                                 // conj A + i conj B at n - k
+            s[lds_slot(n - k, log2n) * pairs + u] = make_double2(A.x + B.y, -A.y + B.x);
         }
     __syncthreads();
-    s = lds_transform(s, twiddle, n, log2n, tile, 1);
-    for (unsigned int idx = threadIdx.x; idx < n * tile; idx += FFT_THREADS)
+    s = lds_transform(s, twiddle, n, log2n, pairs, 1);
+    for (unsigned int idx = threadIdx.x; idx < n * pairs; idx += FFT_THREADS)
         {
-        const unsigned int t = idx / n, p = idx % n;
-        real_out[(line0 + t) * n + p] = s[p * tile + t].x;          // interpolateForces only reads Re(inv) (:851-857)
+        const unsigned int u = idx / n, p = idx % n;
+        const double2 z = s[p * pairs + u];
+        if (line0 + 2 * u < n_lines) real_out[(line0 + 2 * u) * n + p] = z.x;
+        if (line0 + 2 * u + 1 < n_lines) real_out[(line0 + 2 * u + 1) * n + p] = z.y;
         }
     }
 
@@ -1260,9 +1275,13 @@ int mtd_mesh_spectral(mtd_mesh *m, const mtd_box *box, unsigned int n_global, co
     int rc = fill_geom(g, m, box);
     if (rc) return rc;
     hipStream_t s = (hipStream_t)stream;
-    const unsigned int x_tile = fft_tile_for(m->nx, m->ny * m->nz), x_blocks = (m->ny * m->nz) / x_tile;
-    const size_t x_lds = fft_lds_bytes(m->nx, x_tile);
-    k_fft_x_r2c<<<x_blocks, FFT_THREADS, x_lds, s>>>(m->d_rho, m->d_f, m->d_tw[0], m->nx, ilog2(m->nx), x_tile, m->hxp);
+    // x passes: two real lines per complex transform, `x_tile` real lines per block (the last block may run short)
+    const unsigned int n_lines = m->ny * m->nz;
+    unsigned int x_pairs = 16;
+    while (x_pairs > 1 && fft_lds_bytes(m->nx, x_pairs) > 64 * 1024) x_pairs >>= 1;
+    const unsigned int x_tile = 2 * x_pairs, x_blocks = (n_lines + x_tile - 1) / x_tile;
+    const size_t x_lds = fft_lds_bytes(m->nx, x_pairs);
+    k_fft_x_r2c<<<x_blocks, FFT_THREADS, x_lds, s>>>(m->d_rho, m->d_f, m->d_tw[0], m->nx, ilog2(m->nx), x_tile, m->hxp, n_lines);
     MTD_LAUNCH_CHECK();
     rc = launch_fft_y(m, m->d_f, 0, s);
     if (rc) return rc;
@@ -1272,7 +1291,7 @@ int mtd_mesh_spectral(mtd_mesh *m, const mtd_box *box, unsigned int n_global, co
     MTD_LAUNCH_CHECK();
     rc = launch_fft_y(m, m->d_g, 1, s);
     if (rc) return rc;
-    k_fft_x_c2r<<<x_blocks, FFT_THREADS, x_lds, s>>>(m->d_g, m->d_inv, m->d_tw[0], m->nx, ilog2(m->nx), x_tile, m->hxp);   // Re(inv)
+    k_fft_x_c2r<<<x_blocks, FFT_THREADS, x_lds, s>>>(m->d_g, m->d_inv, m->d_tw[0], m->nx, ilog2(m->nx), x_tile, m->hxp, n_lines);   // Re(inv)
     MTD_LAUNCH_CHECK();
     *d_partials = m->d_cv_partials;
     *n_partials = m->n_cv_partials;
