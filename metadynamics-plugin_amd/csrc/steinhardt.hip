@@ -35,10 +35,10 @@ namespace
 using namespace mtd;
 
 constexpr int QL_THREADS = 256;
-// chunk geometry {central particles per chunk, pair slots staged in LDS per batch (3 doubles each)}: the CV pass runs four
-// blocks per CU (24 KB each), the force pass two (its registers allow no more) with larger chunks to amortise the set-up
+// chunk geometry {central particles per chunk, pair slots staged in LDS per batch (3 doubles each = 24 KB)}: the CV pass
+// runs four blocks per CU, the force pass three (140 VGPRs)
 constexpr int QL_ACC_PPB = 64, QL_ACC_CAP = 1024;
-constexpr int QL_FRC_PPB = 128, QL_FRC_CAP = 2048;
+constexpr int QL_FRC_PPB = 64, QL_FRC_CAP = 1024;
 constexpr unsigned int QL_MAX_BLOCKS = 1024;
 
 template<int LMAX> struct QlArgs
@@ -460,7 +460,7 @@ __global__ __launch_bounds__(256) void k_ql_finalize(const QlArgs<LMAX> a, const
 
 // ---- forces ----------------------------------------------------------------------------------------------
 template<typename S4, int LMAX, bool HALF>
-__global__ __launch_bounds__(QL_THREADS, 2) void k_ql_forces(const QlArgs<LMAX> a, const S4 *__restrict__ postype,
+__global__ __launch_bounds__(QL_THREADS, (LMAX <= 6 ? 4 : 2)) void k_ql_forces(const QlArgs<LMAX> a, const S4 *__restrict__ postype,
                                                              const unsigned int *__restrict__ head_list,
                                                              const unsigned int *__restrict__ n_neigh,
                                                              const unsigned int *__restrict__ nlist, const double *__restrict__ qlm_full,
@@ -559,7 +559,8 @@ __global__ __launch_bounds__(QL_THREADS, 2) void k_ql_forces(const QlArgs<LMAX> 
                         harm_prev = harm;
                         sinpow *= g.st;
                         harm = cmul(harm, {g.cp, g.sp});
-                        }
+                        __builtin_amdgcn_sched_barrier(0);           // keep the orders m in sequence: interleaved by the
+                        }                                            // scheduler they need ~250 VGPRs instead of ~140
                     const double e_theta[3] = {g.ct * g.cp, g.ct * g.sp, -g.st};                 // :288
                     const double e_phi[3] = {-g.sp, g.cp, 0.0};
                     const double fa = fprime_divr * U, fb = f * g.inv_r * V, fc = f * g.inv_rho * W;   // 1/(r sin theta) = 1/rho
@@ -692,7 +693,7 @@ int forces_impl(unsigned int N, const void *d_postype, void *d_force, int dtype,
     QlArgs<LMAX> a;
     int rc = fill_args<LMAX>(a, N, box, rcut, ron, lmax, type, ql_ref, n_global, half);
     if (rc) return rc;
-    const unsigned int blocks = ql_blocks(N, QL_FRC_PPB, 512);
+    const unsigned int blocks = ql_blocks(N, QL_FRC_PPB, 1024);
     const size_t s4 = dtype == MTD_F32 ? sizeof(float4) : sizeof(double4);
     if (half) MTD_HIP_TRY(hipMemsetAsync(d_force, 0, s4 * N, s));            // memset of :236, the pair terms are then added atomically
     if (dtype == MTD_F32)
