@@ -208,13 +208,16 @@ def main():
     if rehearsal:
         local_rank = 0
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    # MTD_BENCH_FORCE_DIST=1: take the N>1 code path (RCCL process group, all-reduce per step) with a single rank — the
+    # host-side cost of that path can then be measured on a one-GPU box
+    if world > 1 or os.environ.get("MTD_BENCH_FORCE_DIST") == "1":
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         if rehearsal:
-            dist.init_process_group("gloo")
+            dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     n_local = args.particles
     n_global = n_local * world
