@@ -203,9 +203,9 @@ __global__ __launch_bounds__(256) void k_scan_tiles(const unsigned int *__restri
 __global__ __launch_bounds__(256) void k_scan_finish(unsigned int *__restrict__ out, const unsigned int *__restrict__ tile_sums,
                                                      unsigned int *__restrict__ count, const unsigned int n, const unsigned int total)
     {
+    // one block per tile of SCAN_TILE cells (four per thread): the prefix of the tile totals is summed once per tile
     __shared__ unsigned int s_wave[4];
-    const unsigned int first = blockIdx.x * blockDim.x;
-    const unsigned int tile = first / SCAN_TILE;
+    const unsigned int tile = blockIdx.x;
     unsigned int v = 0;
     for (unsigned int t = threadIdx.x; t < tile; t += blockDim.x) v += tile_sums[t];
 #pragma unroll
@@ -213,13 +213,17 @@ __global__ __launch_bounds__(256) void k_scan_finish(unsigned int *__restrict__ 
     if ((threadIdx.x & 63) == 0) s_wave[threadIdx.x >> 6] = v;
     __syncthreads();
     const unsigned int prefix = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
-    const unsigned int i = first + threadIdx.x;
-    if (i < n)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
         {
-        out[i] += prefix;
-        count[i] = 0;
+        const unsigned int i = tile * SCAN_TILE + j * 256 + threadIdx.x;
+        if (i < n)
+            {
+            out[i] += prefix;
+            count[i] = 0;
+            }
         }
-    if (i == 0) out[n] = total;
+    if (tile == 0 && threadIdx.x == 0) out[n] = total;
     }
 
 // ---- 3. place: record, id and cell of every particle at start[cell] + slot ----------------------------
@@ -1239,7 +1243,7 @@ int mtd_mesh_assign(mtd_mesh *m, unsigned int n_particles, const void *d_postype
     MTD_LAUNCH_CHECK();
     k_scan_tiles<<<n_tiles, 256, 0, s>>>(m->d_count, m->d_start, m->d_tile_sums, M);
     MTD_LAUNCH_CHECK();
-    k_scan_finish<<<cell_blocks, 256, 0, s>>>(m->d_start, m->d_tile_sums, m->d_count, M, N);
+    k_scan_finish<<<n_tiles, 256, 0, s>>>(m->d_start, m->d_tile_sums, m->d_count, M, N);
     MTD_LAUNCH_CHECK();
     if (dtype == MTD_F32)
         k_mesh_place<float4><<<m->n_count_blocks, 256, 0, s>>>(g, (const float4 *)d_postype, N, m->d_mode, m->d_cell_of, m->d_slot_of, m->d_start, m->d_idcell, m->d_packed);
