@@ -167,9 +167,22 @@ __global__ __launch_bounds__(256) void k_mesh_bin(const MeshGeom g, const S4 *__
 constexpr unsigned int SCAN_TILE = 1024;
 
 __global__ __launch_bounds__(256) void k_scan_tiles(const unsigned int *__restrict__ in, unsigned int *__restrict__ out,
-                                                    unsigned int *__restrict__ tile_sums, const unsigned int n)
+                                                    unsigned int *__restrict__ tile_sums, const unsigned int n,
+                                                    const double *__restrict__ modesq_partials, const unsigned int n_partials,
+                                                    double *__restrict__ mode_sq)
     {
     __shared__ unsigned int s_wave[4];
+    if (blockIdx.x * SCAN_TILE >= n)
+        {
+        // one extra block rides along: m_mode_sq (:622) = the block sums of k_mesh_bin added up in a fixed order — a launch
+        // of its own cost ~5 us of pure latency in the step's chain of small kernels
+        __shared__ double s_red[16];
+        double v = 0.0;
+        for (unsigned int b = threadIdx.x; b < n_partials; b += 256) v += modesq_partials[b];
+        v = block_sum(v, s_red);
+        if (threadIdx.x == 0) *mode_sq = v;
+        return;
+        }
     const unsigned int base = blockIdx.x * SCAN_TILE + threadIdx.x * 4;
     unsigned int v[4];
 #pragma unroll
@@ -1005,16 +1018,6 @@ __global__ __launch_bounds__(256) void k_mesh_virial(const MeshGeom g, const dou
         }
     }
 
-__global__ __launch_bounds__(256) void k_sum_partials(const double *__restrict__ partials, unsigned int n, double *out)
-    {
-    // one block, fixed order
-    __shared__ double s_red[16];
-    double v = 0.0;
-    for (unsigned int b = threadIdx.x; b < n; b += 256) v += partials[b];
-    v = block_sum(v, s_red);
-    if (threadIdx.x == 0) *out = v;
-    }
-
 bool is_pow2(unsigned int n) { return n && !(n & (n - 1)); }
 // log2 of a power of two, 0 otherwise (the kernels take 0 as "direct DFT, natural order")
 unsigned int ilog2(unsigned int n)
@@ -1239,9 +1242,7 @@ int mtd_mesh_assign(mtd_mesh *m, unsigned int n_particles, const void *d_postype
     else
         k_mesh_bin<double4><<<m->n_count_blocks, 256, 0, s>>>(g, (const double4 *)d_postype, N, m->d_mode, m->d_cell_of, m->d_slot_of, m->d_count, m->d_modesq_partials);
     MTD_LAUNCH_CHECK();
-    k_sum_partials<<<1, 256, 0, s>>>(m->d_modesq_partials, m->n_count_blocks, m->d_mode_sq);   // m_mode_sq (:622), fixed order
-    MTD_LAUNCH_CHECK();
-    k_scan_tiles<<<n_tiles, 256, 0, s>>>(m->d_count, m->d_start, m->d_tile_sums, M);
+    k_scan_tiles<<<n_tiles + 1, 256, 0, s>>>(m->d_count, m->d_start, m->d_tile_sums, M, m->d_modesq_partials, m->n_count_blocks, m->d_mode_sq);
     MTD_LAUNCH_CHECK();
     k_scan_finish<<<n_tiles, 256, 0, s>>>(m->d_start, m->d_tile_sums, m->d_count, M, N);
     MTD_LAUNCH_CHECK();
