@@ -58,7 +58,10 @@ def noisy_fcc(n, sigma=0.05, seed=777):
 
 
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
-@pytest.mark.parametrize("lmax,Ql_ref", [(6, [0, 0, 0, 0, 1, 0, 1]), (4, [0.2, 0, 1.0, 0.5, 1.0]), (8, [0, 0, 0, 0, 1, 0, 1, 0, 0.5])])
+@pytest.mark.parametrize("lmax,Ql_ref", [(6, [0, 0, 0, 0, 1, 0, 1]), (4, [0.2, 0, 1.0, 0.5, 1.0]), (8, [0, 0, 0, 0, 1, 0, 1, 0, 0.5]),
+                                         # run-time lmax below the compiled table size (2 -> 4, 5 -> 6, 10 -> 12) and the largest one
+                                         (2, [0.5, 0.3, 1.0]), (5, [0, 0, 0.2, 0, 1, 0.7]), (10, [0] * 10 + [1.0]),
+                                         (12, [0, 0, 0, 0, 1, 0, 1, 0, 0, 0, 0.5, 0, 0.25])])
 @pytest.mark.parametrize("half", [False, True])
 def test_ql_parity(abi, ref, dtype, lmax, Ql_ref, half):
     pos, L = noisy_fcc(5)
