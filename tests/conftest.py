@@ -33,6 +33,21 @@ def pytest_collection_modifyitems(config, items):
             item.add_marker(skip)
 
 
+def _ensure_built():
+    """The shared objects are build products (git-ignored): build them when a fresh checkout has none yet."""
+    lib = os.path.join(ROOT, "metadynamics-plugin_amd", "lib", "libmtd_hip.so")
+    mod_dir = os.path.join(ROOT, "metadynamics-plugin_amd", "metadynamics")
+    have_mod = any(f.startswith("_metadynamics") and f.endswith(".so") for f in os.listdir(mod_dir))
+    if not (os.path.exists(lib) and have_mod):
+        import __graft_entry__
+        __graft_entry__.build()
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _built():
+    _ensure_built()
+
+
 @pytest.fixture(scope="session")
 def abi():
     from metadynamics import _abi

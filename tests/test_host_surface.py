@@ -1,0 +1,82 @@
+"""CPU: the pybind11 module and the Python API present the reference's surface — class names, methods,
+enums, constructor arity — and the pure host logic that needs no device (box maths, argument validation in Python).
+Nothing here touches the GPU: objects that allocate device memory are not constructed."""
+import inspect
+
+import numpy as np
+import pytest
+
+
+@pytest.fixture(scope="module")
+def mod():
+    from metadynamics import _metadynamics
+    return _metadynamics
+
+
+def test_module_classes_and_methods(mod):
+    # module `_metadynamics` (module.cc:23-41 of the reference)
+    for cls in ("CollectiveVariable", "IntegratorMetaDynamics", "LamellarOrderParameterGPU", "OrderParameterMeshGPU",
+                "WellTemperedEnsemble", "CollectiveWrapper", "SteinhardtQl", "AspectRatio", "Density", "std_vector_int3"):
+        assert hasattr(mod, cls), cls
+    # IntegratorMetaDynamics.cc:1315-1349
+    for meth in ("registerCollectiveVariable", "removeAllVariables", "isInitialized", "setGrid", "dumpGrid", "restartFromGridFile",
+                 "setAddHills", "setMode", "setStride", "setAdaptive", "setSigmaG", "resetHistogram", "setMultipleWalkers"):
+        assert hasattr(mod.IntegratorMetaDynamics, meth), meth
+    assert {"standard", "well_tempered"} <= set(mod.IntegratorMetaDynamics.mode.__members__)
+    # CollectiveVariable.cc:109-130
+    for meth in ("getCurrentValue", "setUmbrella", "setKappa", "setWidthFlat", "setMinimum", "setScale", "requiresNetForce"):
+        assert hasattr(mod.CollectiveVariable, meth), meth
+    assert {"no_umbrella", "linear", "harmonic", "wall", "gaussian"} <= set(mod.CollectiveVariable.umbrella.__members__)
+    # OrderParameterMesh.cc:1181-1193
+    for meth in ("setTable", "setUseTable"):
+        assert hasattr(mod.OrderParameterMeshGPU, meth), meth
+    # every CV class derives from CollectiveVariable, which derives from ForceCompute (CollectiveVariable.h:32)
+    for cls in ("LamellarOrderParameterGPU", "OrderParameterMeshGPU", "WellTemperedEnsemble", "CollectiveWrapper", "SteinhardtQl",
+                "AspectRatio", "Density"):
+        assert issubclass(getattr(mod, cls), mod.CollectiveVariable)
+    assert issubclass(mod.CollectiveVariable, mod.ForceCompute)
+
+
+def test_python_api_signatures():
+    """metadynamics.cv / metadynamics.integrate: argument names and defaults of the reference (cv.py, integrate.py)"""
+    from metadynamics import cv, integrate
+
+    def params(f):
+        return [(n, p.default) for n, p in inspect.signature(f).parameters.items() if n != "self"]
+
+    E = inspect.Parameter.empty
+    assert params(cv.lamellar.__init__) == [("mode", E), ("lattice_vectors", E), ("name", None), ("sigma", 1.0)]
+    assert params(cv.mesh.__init__) == [("mode", E), ("nx", E), ("ny", None), ("nz", None), ("name", None), ("sigma", 1.0),
+                                         ("zero_modes", None)]
+    assert params(cv.steinhardt.__init__) == [("r_cut", E), ("r_on", E), ("lmax", E), ("Ql_ref", E), ("nlist", E), ("type", E),
+                                               ("name", None), ("sigma", 1.0)]
+    assert params(cv.potential_energy.__init__) == [("sigma", 1.0)]
+    assert params(cv.wrap.__init__) == [("force", E), ("sigma", 1.0)]
+    assert params(cv.aspect_ratio.__init__) == [("dir1", E), ("dir2", E), ("name", ""), ("sigma", 1.0)]
+    assert params(cv.density.__init__) == [("group", None), ("sigma", 1.0)]
+    assert params(cv._collective_variable.set_grid) == [("cv_min", E), ("cv_max", E), ("num_points", E)]
+    assert [n for n, _ in params(cv._collective_variable.set_params)] == ["sigma", "kappa", "cv0", "umbrella", "width_flat", "scale",
+                                                                          "reweight"]
+    assert params(integrate.mode_metadynamics.__init__) == [("dt", E), ("stride", E), ("mode", "standard"), ("W", 1.0), ("deltaT", 1.0),
+                                                            ("T", 1.0), ("filename", ""), ("overwrite", False), ("add_hills", True)]
+    assert params(integrate.mode_metadynamics.dump_grid) == [("filename1", E), ("filename2", ""), ("period", 0)]
+    assert [n for n, _ in params(integrate.mode_metadynamics.set_params)] == ["add_hills", "mode", "stride", "adaptive", "sigma_g",
+                                                                              "multiple_walkers"]
+    for meth in ("restart_from_grid", "reset_histogram", "update_forces"):
+        assert hasattr(integrate.mode_metadynamics, meth)
+
+
+def test_boxdim_host_maths(mod, ref):
+    """BoxDim stand-in vs the oracle's box CVs (AspectRatio.cc:24-57, Density.cc:20-27): plain host arithmetic"""
+    b = mod.BoxDim(3.0, 4.0, 6.0)
+    assert tuple(b.getL()) == (3.0, 4.0, 6.0)
+    s = b.scale(0.5)
+    assert tuple(s.getL()) == (1.5, 2.0, 3.0)
+    rbox = ref.Box.make([3.0, 4.0, 6.0])
+    assert ref.aspect_ratio(rbox, 0, 1) == pytest.approx(3.0 / 4.0)
+    assert ref.density(rbox, 36) == pytest.approx(36 / 72.0)
+    # pack_postype: type id bit-cast into w like HOOMD's __scalar_as_int
+    p = mod.pack_postype(np.array([[1.0, 2.0, 3.0]]), np.array([5], dtype=np.int32), mod.MTD_F32)
+    assert p.dtype == np.float32 and p.view(np.int32)[0, 3] == 5
+    p = mod.pack_postype(np.array([[1.0, 2.0, 3.0]]), np.array([7], dtype=np.int32), mod.MTD_F64)
+    assert p.dtype == np.float64 and p.view(np.int32)[0, 6] == 7       # low word of w
