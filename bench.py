@@ -78,6 +78,15 @@ class Engine:
                                      fast_trig=bool(fast_trig), fused=(path == "fused"),
                                      exchange="partials")   # equal shards: the block partial sums travel (no reduce launch)
         self.sharded = ShardedBiasStep(self.be, dist) if dist is not None else None
+        self.exchange = None
+        if dist is not None:
+            # the n_cv sums of a step travel through the xGMI mailbox (direct stores between the GPUs, no collective call);
+            # RCCL all-reduce of the block partial sums if the mailbox cannot be set up on this node
+            from metadynamics import xgmi
+            box = xgmi.connect(dist, max_doubles=8)
+            if box is not None:
+                self.be.attach_mailbox(box)
+            self.exchange = "xgmi-mailbox" if box is not None else ("rccl" if dist.get_backend() == "nccl" else dist.get_backend())
         self.t = 0
         self.ev = None
 
@@ -90,7 +99,7 @@ class Engine:
                 be.step_single(self.t)         # launch A, launch B
         else:
             # same step with the dominant kernel bracketed by events on the launch stream
-            if self.sharded is not None:
+            if self.sharded is not None and be.mailbox is None:
                 sums = be.cv_pass()
                 self.dist.all_reduce(sums)
             else:
@@ -254,10 +263,15 @@ def main():
         barrier()
         elapsed = time.perf_counter() - t0
         if dist is not None:
-            tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+            tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             elapsed = float(tt.item())
         st = eng.state()
+    mailbox_timeouts = None
+    if eng.be.mailbox is not None:
+        tt = torch.tensor([eng.be.mailbox.timeouts()], dtype=torch.int64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        mailbox_timeouts = int(tt.item())
 
     # dominant kernel (force pass): per-launch durations from HIP events on the launch stream, over the same
     # loop.  An event pair costs the command processor two extra barrier packets; that fixed overhead is
@@ -318,7 +332,7 @@ def main():
             "dtype": args.dtype,
             "data": "synthetic",
             "config": {"workload": "1xMI355X: 10^6 particles, 2 lamellar CVs (8 Fourier modes each), 256^2 bias grid, well-tempered"
-                       if world == 1 else "%dxMI355X: %d particles sharded, 2 lamellar CVs, RCCL all-reduce of CV sums, replicated 256^2 grid" % (world, n_global),
+                       if world == 1 else "%dxMI355X: %d particles sharded, 2 lamellar CVs, all-reduce of the CV sums (%s), replicated 256^2 grid" % (world, n_global, eng.exchange),
                        "particles_per_gpu": n_local, "n_cv": 2, "modes_per_cv": 8, "grid": "256x256",
                        "stride": args.stride, "fast_trig": int(args.fast_trig), "path": args.path, "driver": driver},
             "roofline": {"bound": "hbm", "kernel": "k_fused_force" if args.path == "fused" else "k_lamellar_forces", "achieved": achieved, "peak": HBM_PEAK_GBS,
@@ -329,6 +343,10 @@ def main():
                          "launches_timed": int(keep.sum()), "stalled_samples_dropped": n_stalls},
             "state": st,
         }
+        if eng.exchange is not None:
+            out["config"]["exchange"] = eng.exchange
+            if mailbox_timeouts is not None:
+                out["config"]["mailbox_timeouts"] = mailbox_timeouts
         if not args.no_cpu_baseline and world == 1 and st.get("num_gaussians") and args.stride == 1:
             out["self_check"] = self_check(st, args.stride)
         if not args.no_cpu_baseline and world == 1:

@@ -226,6 +226,43 @@ int mtd_fused_force_pass(mtd_metad *m, const mtd_lamellar_set *set, unsigned int
                          unsigned int timestep, mtd_stream_t stream);
 
 /* ================================================================================================
+ * xGMI mailbox: all-reduce (sum) of a few doubles between the GPUs of one node, one process per GPU
+ * replaces the host-staged MPI_Allreduce of the per-step CV sums (LamellarOrderParameterGPU.cc:69-77,
+ * SteinhardtQl.cc:183-191, WellTemperedEnsemble.cc:57-63) without a collective-library call on the
+ * critical path: every rank's kernels store their values straight into the peers' mailboxes over xGMI
+ * (hipIpc-mapped uncached device memory) and poll their own.  Large buffers (replicated mesh, packed
+ * walker deltas) stay on RCCL.  Every wait is bounded: a peer that never arrives is a counted timeout
+ * (MTD_COMM_TIMEOUT_MS, default 2000), not a hang.
+ * ============================================================================================== */
+
+#define MTD_COMM_MAX_RANKS 8     /* the GPUs of one node */
+#define MTD_COMM_HANDLE_BYTES 64 /* sizeof(hipIpcMemHandle_t) */
+
+typedef struct mtd_comm mtd_comm; /* opaque; owns this rank's mailbox and the mappings of the peers' */
+
+/* max_doubles: largest message (per rank) in doubles, <= 4096.  SYNCHRONISES (allocation + clear). */
+int mtd_comm_create(mtd_comm **out, unsigned int rank, unsigned int world, unsigned int max_doubles);
+/* the IPC handle of this rank's mailbox (MTD_COMM_HANDLE_BYTES bytes) for the caller's control plane to gather */
+int mtd_comm_handle(mtd_comm *c, void *out_handle);
+/* handles: world * MTD_COMM_HANDLE_BYTES bytes in rank order (the own entry is ignored).  world == 1 needs no connect. */
+int mtd_comm_connect(mtd_comm *c, const void *handles);
+/* d_values[0..n) <- sum over ranks, added up in rank order (the same bits on every rank).  Every rank must issue the
+ * same sequence of exchanges (this call and the fused step's) on its comm. */
+int mtd_comm_allreduce_small(mtd_comm *c, double *d_values, unsigned int n, mtd_stream_t stream);
+/* number of timed-out waits so far; SYNCHRONISES the stream */
+int mtd_comm_status(mtd_comm *c, unsigned int *timeouts, mtd_stream_t stream);
+unsigned int mtd_comm_world(const mtd_comm *c);
+unsigned int mtd_comm_rank(const mtd_comm *c);
+int mtd_comm_destroy(mtd_comm *c);
+
+/* Particle-sharded fused step: with a comm attached, mtd_fused_cv_pass's last block to finish adds up the block
+ * partial sums of this rank and sends the n_cv totals to every rank, and mtd_fused_force_pass's scalar chain takes
+ * s_c = scale_c * (sum over ranks) + shift_c from the mailbox instead of the registered partial sums (scale / shift
+ * as registered with mtd_metad_set_cv_source): still two launches per step, no collective call.  n_cv <= 3.
+ * comm == NULL detaches. */
+int mtd_metad_set_comm(mtd_metad *m, mtd_comm *comm);
+
+/* ================================================================================================
  * Particle-mesh order parameter (cv.mesh)
  * replaces OrderParameterMeshGPU.cuh:9-109 (gpu_bin_particles, gpu_assign_binned_particles_to_mesh,
  * gpu_update_meshes, gpu_compute_cv, gpu_compute_forces, gpu_compute_mode_sq) and the cuFFT plans of

@@ -1,0 +1,204 @@
+// comm.hip — xGMI mailbox: all-reduce (sum) of a few doubles between the GPUs of one node.
+//
+// Replaces, for the small per-step messages of the sharded bias step, the reference's host-staged
+// MPI_Allreduce (LamellarOrderParameterGPU.cc:69-77; SteinhardtQl.cc:183-191; WellTemperedEnsemble.cc:57-63) and a
+// library all-reduce: one process per GPU, every rank allocates a mailbox (uncached device memory), exports it with
+// hipIpcGetMemHandle, the handles travel once through the caller's control plane (torch.distributed / MPI), every
+// rank maps its peers' mailboxes and from then on kernels store into them directly over xGMI.  Large buffers (the
+// replicated mesh, the packed walker deltas) stay on RCCL.
+//
+// Protocol and bounds: comm_device.hpp.
+#include "comm_host.hpp"
+
+#include <cstdlib>
+#include <cstring>
+#include <new>
+
+namespace
+{
+
+using namespace mtd;
+
+constexpr int AR_THREADS = 256;
+
+// Stand-alone all-reduce of n doubles in place (one block): send, poll, sum in rank order.
+__global__ __launch_bounds__(AR_THREADS) void k_comm_allreduce(const CommK k, double *__restrict__ values, const unsigned int n)
+    {
+    extern __shared__ unsigned int s_half[];            // world * 2n halves
+    const unsigned int nw = 2 * n;
+    for (unsigned int i = threadIdx.x; i < k.world * nw; i += AR_THREADS)
+        {
+        const unsigned int dst = i / nw, w = i % nw;
+        const double x = values[w >> 1];
+        comm_send_word(k, dst, w, (w & 1) ? dbl_hi(x) : dbl_lo(x));
+        }
+    for (unsigned int i = threadIdx.x; i < k.world * nw; i += AR_THREADS)
+        s_half[i] = comm_recv_word(k, i / nw, i % nw);
+    __syncthreads();
+    for (unsigned int j = threadIdx.x; j < n; j += AR_THREADS)
+        {
+        double t = 0.0;
+        for (unsigned int r = 0; r < k.world; ++r)
+            t += __hiloint2double((int)s_half[r * nw + 2 * j + 1], (int)s_half[r * nw + 2 * j]);
+        values[j] = t;
+        }
+    }
+
+unsigned long long env_timeout_ticks()
+    {
+    const char *e = std::getenv("MTD_COMM_TIMEOUT_MS");
+    double ms = 2000.0;
+    if (e && *e) ms = std::atof(e);
+    if (!(ms > 0.0)) ms = 2000.0;
+    return (unsigned long long)(ms * 1.0e5);            // wall_clock64: 100 MHz
+    }
+
+} // namespace
+
+namespace mtd
+{
+
+int comm_next(mtd_comm *c, CommK &k)
+    {
+    if (!c || !c->connected) return MTD_ERR_INVALID_ARGUMENT;
+    c->seq = (c->seq == 0xffffffffu) ? 1u : c->seq + 1u;
+    k = c->k;
+    k.seq = c->seq;
+    return MTD_SUCCESS;
+    }
+
+int comm_current(const mtd_comm *c, CommK &k)
+    {
+    if (!c || !c->connected || c->seq == 0) return MTD_ERR_INVALID_ARGUMENT;
+    k = c->k;
+    k.seq = c->seq;
+    return MTD_SUCCESS;
+    }
+
+} // namespace mtd
+
+extern "C" {
+
+int mtd_comm_create(mtd_comm **out, unsigned int rank, unsigned int world, unsigned int max_doubles)
+    {
+    if (!out || world == 0 || world > MTD_COMM_MAX_RANKS || rank >= world || max_doubles == 0 || max_doubles > 4096)
+        return MTD_ERR_INVALID_ARGUMENT;
+    mtd_comm *c = new (std::nothrow) mtd_comm;
+    if (!c) return (int)hipErrorOutOfMemory;
+    std::memset(c, 0, sizeof(*c));
+    c->k.rank = rank;
+    c->k.world = world;
+    c->k.words_per_rank = 2 * max_doubles;
+    c->k.timeout_ticks = env_timeout_ticks();
+    c->max_doubles = max_doubles;
+    c->bytes = sizeof(unsigned long long) * 2 * world * c->k.words_per_rank;
+    // uncached device memory: peers' stores and this GPU's polling loads must not sit in a non-coherent L2
+    hipError_t e = hipExtMallocWithFlags(&c->local, c->bytes, hipDeviceMallocUncached);
+    if (e != hipSuccess)
+        {
+        (void)hipGetLastError();
+        e = hipExtMallocWithFlags(&c->local, c->bytes, hipDeviceMallocFinegrained);
+        }
+    if (e != hipSuccess)
+        {
+        (void)hipGetLastError();
+        delete c;
+        return (int)e;
+        }
+    void *aux = nullptr;
+    const size_t aux_bytes = 64 + sizeof(unsigned long long) * COMM_LL_BLOCKS * 2 * COMM_LL_DOUBLES;
+    e = hipMalloc(&aux, aux_bytes);
+    if (e == hipSuccess) e = hipMemset(aux, 0, aux_bytes);
+    if (e == hipSuccess) e = hipMemset(c->local, 0, c->bytes);
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e != hipSuccess)
+        {
+        if (aux) (void)hipFree(aux);
+        (void)hipFree(c->local);
+        delete c;
+        return (int)e;
+        }
+    c->k.err = (unsigned int *)aux;
+    c->k.ll = (unsigned long long *)((char *)aux + 64);
+    c->k.box[rank] = (unsigned long long *)c->local;
+    if (world == 1) c->connected = 1;
+    *out = c;
+    return MTD_SUCCESS;
+    }
+
+int mtd_comm_handle(mtd_comm *c, void *out_handle)
+    {
+    if (!c || !out_handle) return MTD_ERR_INVALID_ARGUMENT;
+    static_assert(sizeof(hipIpcMemHandle_t) == MTD_COMM_HANDLE_BYTES, "hipIpcMemHandle_t is 64 bytes");
+    hipIpcMemHandle_t h;
+    MTD_HIP_TRY(hipIpcGetMemHandle(&h, c->local));
+    std::memcpy(out_handle, &h, sizeof(h));
+    return MTD_SUCCESS;
+    }
+
+int mtd_comm_connect(mtd_comm *c, const void *handles)
+    {
+    if (!c || !handles) return MTD_ERR_INVALID_ARGUMENT;
+    if (c->connected) return MTD_SUCCESS;
+    for (unsigned int r = 0; r < c->k.world; ++r)
+        {
+        if (r == c->k.rank) continue;
+        hipIpcMemHandle_t h;
+        std::memcpy(&h, (const char *)handles + (size_t)r * MTD_COMM_HANDLE_BYTES, sizeof(h));
+        void *p = nullptr;
+        hipError_t e = hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess);
+        if (e != hipSuccess)
+            {
+            (void)hipGetLastError();
+            for (unsigned int q = 0; q < r; ++q)
+                if (q != c->k.rank && c->k.box[q])
+                    {
+                    (void)hipIpcCloseMemHandle(c->k.box[q]);
+                    c->k.box[q] = nullptr;
+                    }
+            return (int)e;
+            }
+        c->k.box[r] = (unsigned long long *)p;
+        }
+    c->connected = 1;
+    return MTD_SUCCESS;
+    }
+
+int mtd_comm_allreduce_small(mtd_comm *c, double *d_values, unsigned int n, mtd_stream_t stream)
+    {
+    if (!c || !d_values || n == 0 || n > c->max_doubles) return MTD_ERR_INVALID_ARGUMENT;
+    CommK k;
+    int rc = comm_next(c, k);
+    if (rc) return rc;
+    const size_t lds = sizeof(unsigned int) * 2 * n * k.world;
+    if (lds > 60000) return MTD_ERR_UNSUPPORTED;
+    k_comm_allreduce<<<1, AR_THREADS, lds, (hipStream_t)stream>>>(k, d_values, n);
+    MTD_LAUNCH_CHECK();
+    return MTD_SUCCESS;
+    }
+
+int mtd_comm_status(mtd_comm *c, unsigned int *timeouts, mtd_stream_t stream)
+    {
+    if (!c || !timeouts) return MTD_ERR_INVALID_ARGUMENT;
+    hipStream_t s = (hipStream_t)stream;
+    MTD_HIP_TRY(hipMemcpyAsync(timeouts, c->k.err, sizeof(unsigned int), hipMemcpyDeviceToHost, s));
+    MTD_HIP_TRY(hipStreamSynchronize(s));
+    return MTD_SUCCESS;
+    }
+
+unsigned int mtd_comm_world(const mtd_comm *c) { return c ? c->k.world : 0; }
+unsigned int mtd_comm_rank(const mtd_comm *c) { return c ? c->k.rank : 0; }
+
+int mtd_comm_destroy(mtd_comm *c)
+    {
+    if (!c) return MTD_SUCCESS;
+    (void)hipDeviceSynchronize();
+    for (unsigned int r = 0; r < c->k.world; ++r)
+        if (r != c->k.rank && c->k.box[r]) (void)hipIpcCloseMemHandle(c->k.box[r]);
+    if (c->k.err) (void)hipFree(c->k.err);
+    if (c->local) (void)hipFree(c->local);
+    delete c;
+    return MTD_SUCCESS;
+    }
+
+} // extern "C"

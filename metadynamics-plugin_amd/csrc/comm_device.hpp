@@ -1,0 +1,171 @@
+// comm_device.hpp — device side of the xGMI mailbox (comm.hip): all-reduce of a few doubles between the GPUs of one
+// node without a collective library call on the critical path.
+//
+// The reference reduces its Fourier-mode sums with a host-staged MPI_Allreduce (LamellarOrderParameterGPU.cc:69-77:
+// D2H copy, MPI, host sum).  On MI355X the exchanged payload of the lamellar step is n_cv doubles; a library
+// all-reduce costs a stream hop and a kernel of its own (measured ~8 us with one rank, before any link latency)
+// against ~22 us for the whole step.  Here every rank owns a small mailbox in its HBM that all peers have mapped
+// (hipIpcOpenMemHandle); a sender stores its values straight into every peer's mailbox over the xGMI links and the
+// consumer kernel polls its LOCAL mailbox.
+//
+// Wire format ("LL": data and flag travel in one 8-byte store, which the fabric delivers atomically, so no fence and
+// no second round trip is needed): a double is split in two 32-bit halves, each stored as one 64-bit word
+// { half, seq }.  A word is valid for exchange number `seq` when its upper half equals seq.  seq is never 0 (the
+// mailbox starts zeroed).  Slots are double-buffered by the parity of seq: a peer can run at most one exchange ahead
+// of a rank that has not yet read (its exchange seq+1 completes only after this rank's send seq+1, which is ordered
+// after this rank's read of seq on the stream), so two buffers suffice.
+//
+// Every poll loop is bounded (wall clock, 100 MHz): on a timeout the kernel counts an error and goes on with whatever
+// it read — it never hangs; mtd_comm_status reports the count.
+#pragma once
+
+#include "mtd_device.hpp"
+
+namespace mtd
+{
+
+constexpr int COMM_MAX_RANKS = MTD_COMM_MAX_RANKS;
+
+struct CommK
+    {
+    unsigned long long *box[COMM_MAX_RANKS];   // mailbox of every rank as mapped in THIS process (box[rank] is local)
+    unsigned int rank, world;
+    unsigned int seq;                           // exchange number of this launch (never 0)
+    unsigned int words_per_rank;                // 2 * max_doubles
+    unsigned long long *ll;                     // local: block sums of the sending launch in the same wire format, [block][2 * n]
+    unsigned int *err;                          // timeouts seen (local)
+    unsigned long long timeout_ticks;           // wall_clock64 ticks (100 MHz)
+    };
+
+__device__ __forceinline__ unsigned long long *comm_slot(const CommK &k, unsigned int owner, unsigned int from)
+    {
+    return k.box[owner] + ((size_t)(k.seq & 1u) * k.world + from) * k.words_per_rank;
+    }
+
+// one word of this rank's payload into the mailbox of rank `dst`
+__device__ __forceinline__ void comm_send_word(const CommK &k, unsigned int dst, unsigned int w, unsigned int half)
+    {
+    const unsigned long long word = ((unsigned long long)k.seq << 32) | (unsigned long long)half;
+    __hip_atomic_store(comm_slot(k, dst, k.rank) + w, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+
+// word `w` of rank `src`'s payload from the LOCAL mailbox; spins until it carries this exchange's number
+__device__ __forceinline__ unsigned int comm_recv_word(const CommK &k, unsigned int src, unsigned int w)
+    {
+    const unsigned long long *p = comm_slot(k, k.rank, src) + w;
+    unsigned long long word = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if ((unsigned int)(word >> 32) != k.seq)
+        {
+        const unsigned long long t0 = wall_clock64();
+        for (;;)
+            {
+            __builtin_amdgcn_s_sleep(1);
+            word = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            if ((unsigned int)(word >> 32) == k.seq) break;
+            if (wall_clock64() - t0 > k.timeout_ticks)
+                {
+                atomicAdd(k.err, 1u);
+                break;
+                }
+            }
+        }
+    return (unsigned int)word;
+    }
+
+// The same wire format inside one GPU (block -> collector block of the same launch): agent-scope stores and loads go
+// past the non-coherent caches, no fence, no atomic, one memory round trip between the last store and the collector.
+__device__ __forceinline__ void ll_store(unsigned long long *p, unsigned int seq, double v)
+    {
+    __hip_atomic_store(p, ((unsigned long long)seq << 32) | (unsigned int)__double2loint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(p + 1, ((unsigned long long)seq << 32) | (unsigned int)__double2hiint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+
+// Collector side, ONE wave: lane l adds up the NS sums of blocks l, l + 64, ... (fixed order), four blocks' worth of loads
+// in flight per round trip; v[] accumulates.  Spins (bounded) until every word carries this exchange's number.
+template<int NS>
+__device__ __forceinline__ void ll_collect_wave(const CommK &k, const unsigned int n_blocks, double (&v)[3])
+    {
+    const unsigned int lane = threadIdx.x & 63;
+    for (unsigned int b0 = lane; b0 < n_blocks; b0 += 4 * MTD_WAVE)
+        {
+        unsigned long long w[4][NS][2];
+        unsigned long long t0 = 0;
+        for (;;)
+            {
+            bool ok = true;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                {
+                const unsigned int b = b0 + j * MTD_WAVE;
+                if (b < n_blocks)
+#pragma unroll
+                    for (int i = 0; i < NS; ++i)
+                        {
+                        const unsigned long long *p = k.ll + ((size_t)b * NS + i) * 2;
+                        w[j][i][0] = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        w[j][i][1] = __hip_atomic_load(p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        }
+                }
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (b0 + j * MTD_WAVE < n_blocks)
+#pragma unroll
+                    for (int i = 0; i < NS; ++i)
+                        ok = ok && (unsigned int)(w[j][i][0] >> 32) == k.seq && (unsigned int)(w[j][i][1] >> 32) == k.seq;
+            if (ok) break;
+            if (t0 == 0) t0 = wall_clock64();
+            else if (wall_clock64() - t0 > k.timeout_ticks)
+                {
+                atomicAdd(k.err, 1u);
+                break;
+                }
+            __builtin_amdgcn_s_sleep(1);
+            }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (b0 + j * MTD_WAVE < n_blocks)
+#pragma unroll
+                for (int i = 0; i < NS; ++i)
+                    v[i] += __hiloint2double((int)(unsigned int)w[j][i][1], (int)(unsigned int)w[j][i][0]);
+        }
+    }
+
+__device__ __forceinline__ unsigned int dbl_lo(double v) { return (unsigned int)__double2loint(v); }
+__device__ __forceinline__ unsigned int dbl_hi(double v) { return (unsigned int)__double2hiint(v); }
+
+// ONE full wave sends n <= 3 doubles (identical in every lane) to every rank: lane = dst * 2n + word
+__device__ __forceinline__ void comm_send_wave(const CommK &k, const double (&v)[3], const unsigned int n)
+    {
+    const unsigned int lane = threadIdx.x & 63;
+    const unsigned int nw = 2 * n;
+    if (lane < k.world * nw)
+        {
+        const unsigned int dst = lane / nw, w = lane % nw;
+        const double x = (w >> 1) == 0 ? v[0] : ((w >> 1) == 1 ? v[1] : v[2]);
+        comm_send_word(k, dst, w, (w & 1) ? dbl_hi(x) : dbl_lo(x));
+        }
+    }
+
+// ONE full wave receives n <= 3 doubles from every rank and adds them up in rank order (the same bits on every rank);
+// result in every lane.  world * 2n <= 48 lanes poll one word each.
+__device__ __forceinline__ void comm_recv_sum_wave(const CommK &k, double (&total)[3], const unsigned int n)
+    {
+    const unsigned int lane = threadIdx.x & 63;
+    const unsigned int nw = 2 * n;
+    unsigned int half = 0;
+    if (lane < k.world * nw) half = comm_recv_word(k, lane / nw, lane % nw);
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+        {
+        total[i] = 0.0;
+        if (i < (int)n)
+            for (unsigned int r = 0; r < k.world; ++r)
+                {
+                const unsigned int lo = __shfl(half, (int)(r * nw + 2 * i), MTD_WAVE);
+                const unsigned int hi = __shfl(half, (int)(r * nw + 2 * i + 1), MTD_WAVE);
+                total[i] += __hiloint2double((int)hi, (int)lo);
+                }
+        }
+    }
+
+} // namespace mtd

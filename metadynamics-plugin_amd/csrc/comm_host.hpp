@@ -1,0 +1,27 @@
+// comm_host.hpp — host-side handle of the xGMI mailbox (opaque `mtd_comm` of mtd_abi.h)
+#pragma once
+
+#include "comm_device.hpp"
+
+namespace mtd
+{
+constexpr unsigned int COMM_LL_BLOCKS = 1024;   // >= LAM_MAX_BLOCKS: block sums of one launch
+constexpr unsigned int COMM_LL_DOUBLES = 3;     // per block (CHAIN_MAX_CV)
+}
+
+struct mtd_comm
+    {
+    mtd::CommK k;               // seq is filled per exchange
+    void *local;                // this rank's mailbox (uncached device memory)
+    size_t bytes;
+    unsigned int max_doubles;
+    unsigned int seq;           // number of the last exchange started (0: none yet)
+    int connected;
+    };
+
+namespace mtd
+{
+// start exchange seq+1 / describe the exchange started last (for the kernel that receives it)
+int comm_next(mtd_comm *c, CommK &k);
+int comm_current(const mtd_comm *c, CommK &k);
+}

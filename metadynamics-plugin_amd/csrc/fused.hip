@@ -45,6 +45,7 @@ extern "C" int mtd_debug_read_stamps(unsigned long long *host)
 
 #include "lamellar_host.hpp"
 #include "metad_host.hpp"
+#include "comm_host.hpp"
 
 #include <cstdlib>
 #include <cstring>
@@ -59,10 +60,12 @@ constexpr int FCV_UNROLL = 4;
 constexpr int FF_THREADS = 256;
 constexpr int FF_UNROLL = 2;
 
-template<typename S4, int NCV, bool FAST>
+// COMM (particle-sharded step): the last CV block to finish adds up this rank's block partial sums (fixed order) and
+// stores the NCV totals into every rank's mailbox over xGMI (comm_device.hpp); launch B polls its local mailbox.
+template<typename S4, int NCV, bool FAST, bool COMM>
 __global__ __launch_bounds__(FCV_THREADS) void k_fused_cv(const LamKArgs a, const S4 *__restrict__ postype, const unsigned int N,
-                                                          double *__restrict__ partials, const MetadCfg c,
-                                                          const unsigned int n_apply_blocks)
+                                                          double *partials, const MetadCfg c,
+                                                          const unsigned int n_apply_blocks, const CommK ck)
     {
     __shared__ float s_coeff[MTD_MAX_CV * MTD_MAX_TYPES];
     __shared__ double s_wave[(FCV_THREADS / MTD_WAVE) * NCV];
@@ -96,6 +99,25 @@ __global__ __launch_bounds__(FCV_THREADS) void k_fused_cv(const LamKArgs a, cons
     MTD_STAMP(5, block_id == 0 && threadIdx.x == 0);
     lam_cv_block_reduce<NCV>(acc, s_wave, partials, block_id);
     MTD_STAMP(6, block_id == 0 && threadIdx.x == 0);
+    if (COMM)
+        {
+        // every block also posts its sums for the collector (CV block 0 of this launch) in the mailbox's wire format —
+        // value halves tagged with the exchange number, written through to memory: no fence (an agent-scope fence writes
+        // back / invalidates the XCD's whole L2), no atomic ticket, and only the collector waits
+        constexpr int NS = NCV < 3 ? NCV : 3;
+        if (threadIdx.x < NS)
+            ll_store(ck.ll + ((size_t)block_id * NS + threadIdx.x) * 2, ck.seq, partials[block_id * NCV + threadIdx.x]);
+        if (block_id != 0 || threadIdx.x >= MTD_WAVE) return;
+        double v[3] = { 0.0, 0.0, 0.0 };
+        ll_collect_wave<NS>(ck, n_blocks, v);
+        MTD_STAMP(7, threadIdx.x == 0);
+        double tot[3] = { 0.0, 0.0, 0.0 };
+#pragma unroll
+        for (int i = 0; i < NS; ++i) tot[i] = wave_sum(v[i]);
+        MTD_STAMP(8, threadIdx.x == 0);
+        comm_send_wave(ck, tot, NS);                            // this rank's totals into every rank's mailbox over xGMI
+        MTD_STAMP(9, threadIdx.x == 0);
+        }
     }
 
 // Fast form (n_cv <= 3): wave 0 of every block runs the scalar chain with shuffles only while waves 1-3
@@ -111,10 +133,10 @@ template<> struct ff_groups<float4, 2> { static constexpr int value = 2; };
 template<> struct ff_groups<double4, 1> { static constexpr int value = 2; };
 template<> struct ff_groups<double4, 2> { static constexpr int value = 2; };
 
-template<typename S4, int NCV, bool FAST, int GROUPS>
+template<typename S4, int NCV, bool FAST, int GROUPS, bool COMM>
 __global__ __launch_bounds__(FF_THREADS, 4) void k_fused_force(const LamKArgs a, const S4 *__restrict__ postype, const ForcePtrs out,
                                                             const unsigned int N, const double two_over_n, const MetadCfg c,
-                                                            const int deposit, const unsigned int n_grid_blocks)
+                                                            const int deposit, const unsigned int n_grid_blocks, const CommK ck)
     {
     __shared__ ChainResult s_chain;
     __shared__ float s_wcoef[MTD_MAX_CV * MTD_MAX_TYPES];
@@ -141,7 +163,7 @@ __global__ __launch_bounds__(FF_THREADS, 4) void k_fused_force(const LamKArgs a,
     MTD_STAMP(25, blockIdx.x == n_grid_blocks && threadIdx.x == 0);
     if (wave == 0)
         {
-        const ChainResult r = chain_wave(c, deposit != 0, true);
+        const ChainResult r = chain_wave(c, deposit != 0, true, COMM ? &ck : nullptr);
         MTD_STAMP(17, blockIdx.x == 0 && threadIdx.x == 0);
         MTD_STAMP(26, blockIdx.x == n_grid_blocks && threadIdx.x == 0);
         if (lane == 0)
@@ -226,7 +248,7 @@ __global__ __launch_bounds__(FF_THREADS, 4) void k_fused_force(const LamKArgs a,
     if (blockIdx.x == 0 && wave == 0)
         {
         double w_now = 1.0;
-        if (!deposit) w_now = chain_wave(c, false, false).w;     // w(s) from the (final) weight grid
+        if (!deposit) w_now = chain_wave(c, false, false, COMM ? &ck : nullptr).w;     // w(s) from the (final) weight grid
         if (lane < (int)c.n_cv)
             {
             c.st->cv[lane] = lane == 0 ? s_chain.cv[0] : (lane == 1 ? s_chain.cv[1] : s_chain.cv[2]);
@@ -338,18 +360,32 @@ __global__ __launch_bounds__(FF_THREADS) void k_fused_force_general(const LamKAr
 
 template<typename S4, bool FAST>
 int launch_fused_cv(const LamKArgs &k, unsigned int N, const void *d_postype, double *d_partials, unsigned int cv_blocks,
-                    const MetadCfg &cfg, unsigned int n_apply, hipStream_t s)
+                    const MetadCfg &cfg, unsigned int n_apply, const CommK *ck, hipStream_t s)
     {
     const S4 *p = (const S4 *)d_postype;
     const unsigned int grid = cv_blocks + n_apply;
+    if (ck)
+        {
+        switch (k.n_cv)
+            {
+            case 1: k_fused_cv<S4, 1, FAST, true><<<grid, FCV_THREADS, 0, s>>>(k, p, N, d_partials, cfg, n_apply, *ck); break;
+            case 2: k_fused_cv<S4, 2, FAST, true><<<grid, FCV_THREADS, 0, s>>>(k, p, N, d_partials, cfg, n_apply, *ck); break;
+            case 3: k_fused_cv<S4, 3, FAST, true><<<grid, FCV_THREADS, 0, s>>>(k, p, N, d_partials, cfg, n_apply, *ck); break;
+            default: return MTD_ERR_UNSUPPORTED;
+            }
+        MTD_LAUNCH_CHECK();
+        return MTD_SUCCESS;
+        }
+    CommK none;
+    std::memset(&none, 0, sizeof(none));
     switch (k.n_cv)
         {
-        case 1: k_fused_cv<S4, 1, FAST><<<grid, FCV_THREADS, 0, s>>>(k, p, N, d_partials, cfg, n_apply); break;
-        case 2: k_fused_cv<S4, 2, FAST><<<grid, FCV_THREADS, 0, s>>>(k, p, N, d_partials, cfg, n_apply); break;
-        case 3: k_fused_cv<S4, 3, FAST><<<grid, FCV_THREADS, 0, s>>>(k, p, N, d_partials, cfg, n_apply); break;
-        case 4: k_fused_cv<S4, 4, FAST><<<grid, FCV_THREADS, 0, s>>>(k, p, N, d_partials, cfg, n_apply); break;
-        case 5: k_fused_cv<S4, 5, FAST><<<grid, FCV_THREADS, 0, s>>>(k, p, N, d_partials, cfg, n_apply); break;
-        case 6: k_fused_cv<S4, 6, FAST><<<grid, FCV_THREADS, 0, s>>>(k, p, N, d_partials, cfg, n_apply); break;
+        case 1: k_fused_cv<S4, 1, FAST, false><<<grid, FCV_THREADS, 0, s>>>(k, p, N, d_partials, cfg, n_apply, none); break;
+        case 2: k_fused_cv<S4, 2, FAST, false><<<grid, FCV_THREADS, 0, s>>>(k, p, N, d_partials, cfg, n_apply, none); break;
+        case 3: k_fused_cv<S4, 3, FAST, false><<<grid, FCV_THREADS, 0, s>>>(k, p, N, d_partials, cfg, n_apply, none); break;
+        case 4: k_fused_cv<S4, 4, FAST, false><<<grid, FCV_THREADS, 0, s>>>(k, p, N, d_partials, cfg, n_apply, none); break;
+        case 5: k_fused_cv<S4, 5, FAST, false><<<grid, FCV_THREADS, 0, s>>>(k, p, N, d_partials, cfg, n_apply, none); break;
+        case 6: k_fused_cv<S4, 6, FAST, false><<<grid, FCV_THREADS, 0, s>>>(k, p, N, d_partials, cfg, n_apply, none); break;
         default: return MTD_ERR_UNSUPPORTED;
         }
     MTD_LAUNCH_CHECK();
@@ -376,12 +412,21 @@ int mtd_fused_cv_pass(mtd_metad *m, const mtd_lamellar_set *set, unsigned int n_
     *n_partials = blocks;
     const unsigned int n_apply = m->pending_apply ? (m->cfg.len + FCV_THREADS - 1) / FCV_THREADS : 0;
     const bool fast = lam_fast_trig() != 0;
+    CommK ckv;
+    const CommK *ck = nullptr;
+    if (m->comm)
+        {
+        if (set->n_cv > (unsigned int)CHAIN_MAX_CV || set->n_cv != m->cfg.n_cv) return MTD_ERR_UNSUPPORTED;
+        rc = comm_next(m->comm, ckv);                           // this launch sends exchange seq, launch B receives it
+        if (rc) return rc;
+        ck = &ckv;
+        }
     if (dtype == MTD_F32)
-        rc = fast ? launch_fused_cv<float4, true>(k, n_particles, d_postype, d_partials, blocks, m->cfg, n_apply, s)
-                  : launch_fused_cv<float4, false>(k, n_particles, d_postype, d_partials, blocks, m->cfg, n_apply, s);
+        rc = fast ? launch_fused_cv<float4, true>(k, n_particles, d_postype, d_partials, blocks, m->cfg, n_apply, ck, s)
+                  : launch_fused_cv<float4, false>(k, n_particles, d_postype, d_partials, blocks, m->cfg, n_apply, ck, s);
     else
-        rc = fast ? launch_fused_cv<double4, true>(k, n_particles, d_postype, d_partials, blocks, m->cfg, n_apply, s)
-                  : launch_fused_cv<double4, false>(k, n_particles, d_postype, d_partials, blocks, m->cfg, n_apply, s);
+        rc = fast ? launch_fused_cv<double4, true>(k, n_particles, d_postype, d_partials, blocks, m->cfg, n_apply, ck, s)
+                  : launch_fused_cv<double4, false>(k, n_particles, d_postype, d_partials, blocks, m->cfg, n_apply, ck, s);
     if (rc) return rc;
     m->pending_apply = 0;
     return MTD_SUCCESS;
@@ -413,6 +458,14 @@ int mtd_fused_force_pass(mtd_metad *m, const mtd_lamellar_set *set, unsigned int
     const double two_over_n = 2.0 / (double)n_global;
     const bool fast = lam_fast_trig() != 0;
     static const bool force_general = std::getenv("MTD_FUSED_GENERAL") != nullptr;
+    CommK ck;
+    std::memset(&ck, 0, sizeof(ck));
+    if (m->comm)
+        {
+        if (set->n_cv > (unsigned int)CHAIN_MAX_CV || force_general) return MTD_ERR_UNSUPPORTED;
+        rc = comm_current(m->comm, ck);                         // the exchange the last mtd_fused_cv_pass sent
+        if (rc) return rc;
+        }
     if (set->n_cv <= (unsigned int)CHAIN_MAX_CV && !force_general)
         {
         const unsigned int groups = (set->n_cv <= 2) ? 2 : 1;
@@ -420,7 +473,8 @@ int mtd_fused_force_pass(mtd_metad *m, const mtd_lamellar_set *set, unsigned int
         if (fblocks == 0 && n_grid == 0) fblocks = 1;               // still one block to publish the scalars
         const unsigned int grid = n_grid + fblocks;
 #define MTD_LAUNCH_FF(S4, NCV, FASTV) \
-        k_fused_force<S4, NCV, FASTV, ff_groups<S4, NCV>::value><<<grid, FF_THREADS, 0, s>>>(k, (const S4 *)d_postype, out, n_particles, two_over_n, m->cfg, dep, n_grid)
+        do { if (m->comm) k_fused_force<S4, NCV, FASTV, ff_groups<S4, NCV>::value, true><<<grid, FF_THREADS, 0, s>>>(k, (const S4 *)d_postype, out, n_particles, two_over_n, m->cfg, dep, n_grid, ck); \
+             else k_fused_force<S4, NCV, FASTV, ff_groups<S4, NCV>::value, false><<<grid, FF_THREADS, 0, s>>>(k, (const S4 *)d_postype, out, n_particles, two_over_n, m->cfg, dep, n_grid, ck); } while (0)
 #define MTD_LAUNCH_FF_NCV(S4, FASTV) \
         switch (set->n_cv) { case 1: MTD_LAUNCH_FF(S4, 1, FASTV); break; case 2: MTD_LAUNCH_FF(S4, 2, FASTV); break; default: MTD_LAUNCH_FF(S4, 3, FASTV); break; }
         if (dtype == MTD_F32)
@@ -459,6 +513,15 @@ int mtd_fused_force_pass(mtd_metad *m, const mtd_lamellar_set *set, unsigned int
     return MTD_SUCCESS;
     }
 
+int mtd_metad_set_comm(mtd_metad *m, mtd_comm *comm)
+    {
+    if (!m) return MTD_ERR_INVALID_ARGUMENT;
+    if (comm && (!comm->connected || m->cfg.n_cv > (unsigned int)CHAIN_MAX_CV || comm->max_doubles < m->cfg.n_cv))
+        return comm && !comm->connected ? MTD_ERR_INVALID_ARGUMENT : MTD_ERR_UNSUPPORTED;
+    m->comm = comm;
+    return MTD_SUCCESS;
+    }
+
 } // extern "C"
 
 namespace mtd
@@ -480,11 +543,13 @@ int fused_grid_step(mtd_metad *m, unsigned int timestep, hipStream_t s)
     const int dep = (m->add_bias && (timestep % m->stride == 0)) ? 1 : 0;
     const unsigned int n_grid = dep ? m->cfg.n_gblocks : 0;
     const unsigned int grid = n_grid ? n_grid : 1;                  // still one block to publish the scalars
+    CommK ck;
+    std::memset(&ck, 0, sizeof(ck));
     switch (m->cfg.n_cv)
         {
-        case 1: k_fused_force<float4, 1, true, 1><<<grid, FF_THREADS, 0, s>>>(k, nullptr, out, 0, 0.0, m->cfg, dep, n_grid); break;
-        case 2: k_fused_force<float4, 2, true, 1><<<grid, FF_THREADS, 0, s>>>(k, nullptr, out, 0, 0.0, m->cfg, dep, n_grid); break;
-        default: k_fused_force<float4, 3, true, 1><<<grid, FF_THREADS, 0, s>>>(k, nullptr, out, 0, 0.0, m->cfg, dep, n_grid); break;
+        case 1: k_fused_force<float4, 1, true, 1, false><<<grid, FF_THREADS, 0, s>>>(k, nullptr, out, 0, 0.0, m->cfg, dep, n_grid, ck); break;
+        case 2: k_fused_force<float4, 2, true, 1, false><<<grid, FF_THREADS, 0, s>>>(k, nullptr, out, 0, 0.0, m->cfg, dep, n_grid, ck); break;
+        default: k_fused_force<float4, 3, true, 1, false><<<grid, FF_THREADS, 0, s>>>(k, nullptr, out, 0, 0.0, m->cfg, dep, n_grid, ck); break;
         }
     MTD_LAUNCH_CHECK();
     m->pending_apply = dep;

@@ -300,6 +300,7 @@ int mtd_metad_create(mtd_metad **out, unsigned int n_cv, const double *sigma, co
     m->stride = stride;
     m->add_bias = add_bias ? 1 : 0;
     m->pending_apply = 0;
+    m->comm = nullptr;
 
     const size_t G = c.len;
     const size_t bytes_d = 6 * G * sizeof(double);

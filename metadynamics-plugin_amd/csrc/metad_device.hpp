@@ -6,6 +6,7 @@
 #pragma once
 
 #include "mtd_device.hpp"
+#include "comm_device.hpp"
 
 #ifndef MTD_STAMP
 #define MTD_STAMP(slot, cond) do { } while (0)
@@ -353,7 +354,10 @@ struct ChainResult
 
 constexpr int CHAIN_MAX_CV = 3;
 
-__device__ __forceinline__ ChainResult chain_wave(const MetadCfg &c, const bool deposit, const bool closed_form)
+// rx != nullptr: particle-sharded step — the sums over ranks come out of the xGMI mailbox (comm_device.hpp) instead
+// of the registered partial sums
+__device__ __forceinline__ ChainResult chain_wave(const MetadCfg &c, const bool deposit, const bool closed_form,
+                                                  const CommK *rx = nullptr)
     {
     const int lane = threadIdx.x & 63;
     const unsigned int n = c.n_cv;
@@ -368,6 +372,12 @@ __device__ __forceinline__ ChainResult chain_wave(const MetadCfg &c, const bool 
     for (int i = 0; i < CHAIN_MAX_CV; ++i)
         if (i < (int)n && c.src[i].partials) n_part_max = max(n_part_max, c.src[i].n_partials);
     double v[CHAIN_MAX_CV] = { 0.0, 0.0, 0.0 };
+    double rx_total[3] = { 0.0, 0.0, 0.0 };
+    if (rx)
+        {
+        comm_recv_sum_wave(*rx, rx_total, n);
+        n_part_max = 0;
+        }
     for (unsigned int b0 = lane; b0 < n_part_max; b0 += 8 * MTD_WAVE)
         {
 #pragma unroll
@@ -390,8 +400,8 @@ __device__ __forceinline__ ChainResult chain_wave(const MetadCfg &c, const bool 
         r.bias[i] = 0.0;
         if (i < (int)n)
             {
-            const double t = wave_sum(v[i]);
-            r.cv[i] = c.src[i].partials ? c.src[i].shift + c.src[i].scale * t : c.src[i].shift;
+            const double t = rx ? rx_total[i] : wave_sum(v[i]);
+            r.cv[i] = (c.src[i].partials || rx) ? c.src[i].shift + c.src[i].scale * t : c.src[i].shift;
             }
         }
 

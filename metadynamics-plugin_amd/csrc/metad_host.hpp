@@ -12,6 +12,8 @@ struct mtd_metad
     // fused path (fused.hip): the second reweighting pass + accumulate of the last deposit is deferred
     // into the next CV launch; pending_apply != 0 means the grid arrays are one k_apply behind.
     int pending_apply;
+    // particle-sharded fused step: the per-rank CV totals travel through this xGMI mailbox (comm.hip); not owned
+    struct mtd_comm *comm;
     };
 
 namespace mtd

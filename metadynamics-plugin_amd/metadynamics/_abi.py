@@ -128,6 +128,15 @@ _SIGNATURES = {
     "mtd_fused_cv_pass": (C.c_int, [_vp, C.POINTER(LamellarSet), C.c_uint, _vp, C.c_int, C.POINTER(Box), _vp, _up, _vp]),
     "mtd_fused_force_pass": (C.c_int, [_vp, C.POINTER(LamellarSet), C.c_uint, _vp, C.POINTER(_vp), C.c_int, C.c_uint,
                                         C.POINTER(Box), C.c_uint, _vp]),
+    "mtd_comm_create": (C.c_int, [C.POINTER(_vp), C.c_uint, C.c_uint, C.c_uint]),
+    "mtd_comm_handle": (C.c_int, [_vp, _vp]),
+    "mtd_comm_connect": (C.c_int, [_vp, _vp]),
+    "mtd_comm_allreduce_small": (C.c_int, [_vp, _vp, C.c_uint, _vp]),
+    "mtd_comm_status": (C.c_int, [_vp, _up, _vp]),
+    "mtd_comm_world": (C.c_uint, [_vp]),
+    "mtd_comm_rank": (C.c_uint, [_vp]),
+    "mtd_comm_destroy": (C.c_int, [_vp]),
+    "mtd_metad_set_comm": (C.c_int, [_vp, _vp]),
     "mtd_mesh_create": (C.c_int, [C.POINTER(_vp), C.c_uint, C.c_uint, C.c_uint, _dp, C.c_uint, C.c_uint]),
     "mtd_mesh_destroy": (C.c_int, [_vp]),
     "mtd_mesh_set_bug_compat": (C.c_int, [_vp, C.c_int]),

@@ -26,19 +26,31 @@ class ShardedBiasStep:
                                 bias forces of the local particles
     """
 
-    def __init__(self, backend, dist=None, group=None):
+    def __init__(self, backend, dist=None, group=None, mailbox=None, mailbox_max=64):
         self.backend = backend
         self.dist = dist
         self.group = group
+        # xGMI mailbox (metadynamics.xgmi.Mailbox) for the small exchange buffers of a CV set (lamellar sums, Q_lm sums,
+        # energies: a few doubles each); buffers above mailbox_max doubles (the replicated mesh) stay on the collective
+        self.small = mailbox
+        self.small_max = int(mailbox_max)
 
     def step(self, timestep):
+        if getattr(self.backend, "mailbox", None) is not None:
+            # xGMI mailbox attached (metadynamics.xgmi): launch A's last block sends this rank's sums to every rank,
+            # launch B's scalar chain polls the local mailbox — two launches, no collective call
+            self.backend.step_single(timestep)
+            return
         sums = self.backend.cv_pass()
         if self.dist is not None:
             # Q3 of SURVEY §2.3: the reference reduces only half of its Scalar2 buffer; every sum is reduced here.
             # A CV set hands over one buffer per collective variable (n_cv doubles for lamellar sums, the real mesh,
             # the Q_lm sums, one energy): one all-reduce each, in the order of the CVs.
             for buf in (sums if isinstance(sums, (list, tuple)) else [sums]):
-                self.dist.all_reduce(buf, group=self.group)
+                if self.small is not None and buf.numel() <= self.small_max and str(buf.dtype).endswith("float64"):
+                    self.small.all_reduce(buf)
+                else:
+                    self.dist.all_reduce(buf, group=self.group)
         self.backend.force_pass(sums, timestep)
 
 
@@ -326,6 +338,15 @@ class HipLamellarBackend:
         self.d_bias = lib.mtd_metad_bias_device(self.h)
         self.n_part = C.c_uint()
         self._sources = None
+        self.mailbox = None
+
+    def attach_mailbox(self, box):
+        """route the per-step exchange of the fused path through the xGMI mailbox ``box`` (metadynamics.xgmi.Mailbox);
+        ``None`` detaches.  Every rank must attach (or not) alike."""
+        if box is not None and not self.fused:
+            raise ValueError("the mailbox exchange belongs to the fused path")
+        self._abi.check(self.lib.mtd_metad_set_comm(self.h, box.handle if box is not None else None))
+        self.mailbox = box
 
     def close(self):
         if self.h:

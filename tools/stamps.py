@@ -10,6 +10,13 @@ import bench
 from metadynamics import _abi
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1000000
 eng = bench.Engine(n, n, 0, seed=12345, stride=1, fast_trig=1)
+box = None
+if len(sys.argv) > 2 and sys.argv[2] == "mailbox":          # one-rank xGMI mailbox: the sharded step's send / receive code
+    from metadynamics import xgmi
+    h = C.c_void_p()
+    _abi.check(_abi.load().mtd_comm_create(C.byref(h), 0, 1, 8))
+    box = xgmi.Mailbox(h, 0, 1)
+    eng.be.attach_mailbox(box)
 for _ in range(50):
     eng.step()
 torch.cuda.synchronize()
@@ -25,3 +32,5 @@ print("k_fused_force grid block0 : entry->chain %s  ->sync %s  ->cells %s  ->blo
 print("k_fused_force force block : entry->tables %s  wave0 chain %s | wave1: tables->unscaled %s ->sync %s ->stored %s | grid entry -> force entry %s" % (rel(24, 25), rel(25, 26), rel(25, 27), rel(27, 28), rel(28, 29), rel(16, 24)))
 print("A entry -> next... B end(grid blk) %s ; B force store end %s (both from B grid-block entry)" % (rel(16, 20), rel(16, 29)))
 print("chain (grid block0): entry->cv sums %s  ->geometry %s  ->pairs+grid loads %s  ->V_old,scal %s  ->closed form %s  ->res,bias %s  ->bin(end) %s" % (rel(16, 40), rel(40, 41), rel(41, 42), rel(42, 43), rel(43, 44), rel(44, 45), rel(45, 17)))
+if box is not None:
+    print("mailbox: cv block0 entry -> last ticket drawn %s  ->totals %s  ->sent %s | last ticket -> B grid-block entry %s" % (rel(3, 7), rel(7, 8), rel(8, 9), rel(7, 16)))
