@@ -10,7 +10,8 @@ Inputs are resident in HBM before the timed region; nothing synchronises with th
 
     python bench.py --gpus N --steps K --warmup W
 N > 1: launched by torch.distributed.run, one rank per GPU; particles are sharded (10^6 per rank,
-weak scaling), the per-CV partial sums are all-reduced over RCCL each step, the bias grid is
+weak scaling), the per-CV sums of a step travel through the xGMI mailbox (mtd_comm_*: direct stores between
+the GPUs, still two launches per step; RCCL all-reduce if the mailbox cannot be set up), the bias grid is
 replicated (every rank deposits the same hill, no grid collective).
 Rank 0 prints ONE JSON line.
 """
@@ -254,6 +255,7 @@ def main():
         elapsed = time.perf_counter() - t0
         st = host.state()
     else:
+        barrier()                          # ranks enter the first exchange together (the mailbox waits are bounded)
         for _ in range(args.warmup):
             eng.step()
         barrier()

@@ -232,7 +232,7 @@ int mtd_fused_force_pass(mtd_metad *m, const mtd_lamellar_set *set, unsigned int
  * critical path: every rank's kernels store their values straight into the peers' mailboxes over xGMI
  * (hipIpc-mapped uncached device memory) and poll their own.  Large buffers (replicated mesh, packed
  * walker deltas) stay on RCCL.  Every wait is bounded: a peer that never arrives is a counted timeout
- * (MTD_COMM_TIMEOUT_MS, default 2000), not a hang.
+ * (MTD_COMM_TIMEOUT_MS, default 5000), not a hang.
  * ============================================================================================== */
 
 #define MTD_COMM_MAX_RANKS 8     /* the GPUs of one node */

@@ -47,9 +47,9 @@ __global__ __launch_bounds__(AR_THREADS) void k_comm_allreduce(const CommK k, do
 unsigned long long env_timeout_ticks()
     {
     const char *e = std::getenv("MTD_COMM_TIMEOUT_MS");
-    double ms = 2000.0;
+    double ms = 5000.0;
     if (e && *e) ms = std::atof(e);
-    if (!(ms > 0.0)) ms = 2000.0;
+    if (!(ms > 0.0)) ms = 5000.0;
     return (unsigned long long)(ms * 1.0e5);            // wall_clock64: 100 MHz
     }
 
