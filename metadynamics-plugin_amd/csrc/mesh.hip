@@ -30,7 +30,9 @@
 // power of two up to 1024 (radix-2 stages); other sizes return MTD_ERR_UNSUPPORTED.
 #include "mtd_device.hpp"
 
+#include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -79,6 +81,60 @@ __device__ __forceinline__ double tsc_deriv(double x)                 // :470-48
     else if (xsq <= 9.0 / 4.0)
         ret = -fac * x / xabs;
     return ret;
+    }
+
+// The three TSC weights (and derivatives) of one axis for the stencil offsets -1, 0, +1, i.e. tsc(s + 1), tsc(s), tsc(s - 1).
+// In-box particles have |s| <= 1/2 and take the closed forms — no sqrt, no branches, no fp64 division (the general forms
+// cost ~90 fp64 instructions per weight/derivative pair and made the force pass compute bound); anything else (a particle
+// outside the box: clamped cell, large shift) takes the general forms.  The closed derivative keeps Q9: |x| rounded to
+// float in fac and in the quotient x / |x|, the latter as 1 + (|x| - float|x|) / float|x| with a float reciprocal
+// (the correction is ~6e-8, so its own relative error of 1e-7 is invisible in double).
+__device__ __forceinline__ bool tsc_inbox(const double s) { return fabs(s) <= 0.5000001; }
+
+__device__ __forceinline__ void tsc3(const double s, double (&w)[3])
+    {
+    if (tsc_inbox(s))
+        {
+        const double tm = 0.5 - s, tp = 0.5 + s;
+        w[0] = 0.5 * tm * tm;
+        w[1] = 0.75 - s * s;
+        w[2] = 0.5 * tp * tp;
+        }
+    else
+        {
+        w[0] = tsc(s + 1.0); w[1] = tsc(s); w[2] = tsc(s - 1.0);
+        }
+    }
+
+__device__ __forceinline__ double tsc_deriv_outer(const double xabs)      // |x| in [1/2, 3/2]: -fac * |x| / float|x|
+    {
+    const float xf = (float)xabs;
+    const double xa = (double)xf;
+    const double ratio = 1.0 + (xabs - xa) * (double)__frcp_rn(xf);
+    return -(1.5 - xa) * ratio;
+    }
+
+__device__ __forceinline__ void tsc3_deriv(const double s, double (&w)[3], double (&d)[3])
+    {
+    if (tsc_inbox(s))
+        {
+        const double tm = 0.5 - s, tp = 0.5 + s;
+        w[0] = 0.5 * tm * tm;
+        w[1] = 0.75 - s * s;
+        w[2] = 0.5 * tp * tp;
+        d[0] = tsc_deriv_outer(1.0 + s);           // x = s + 1 > 0
+        d[1] = -2.0 * s;
+        d[2] = -tsc_deriv_outer(1.0 - s);          // x = s - 1 < 0
+        }
+    else
+        {
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+            {
+            w[i] = tsc(s - (i - 1));
+            d[i] = tsc_deriv(s - (i - 1));
+            }
+        }
     }
 
 // BoxDim::makeFraction / makeCoordinates / minImage (HOOMD-blue v2 semantics)
@@ -427,6 +483,289 @@ __global__ __launch_bounds__(GT_THREADS) void k_mesh_gather(const MeshGeom g, co
                 }
             }
     rho[(x0 + lx) + g.nx * ((y0 + ly) + g.ny * (z0 + lz))] = acc;
+    }
+
+// ---- 1b-5b. tile path of the assignment and of the force pass ------------------------------------------------------
+// The cell-level pipeline above pays for a sort down to single cells: one returning global atomic, two scattered record
+// stores and a per-cell gather loop per particle (bin 42 + scan 15 + place 40 + sortfix 18 + gather 78 us at 10^6 particles
+// on 128^3).  Here the particles are only grouped by TILE of 16x16x8 cells and the TSC weights are summed in LDS:
+//   1b k_tile_count    a block owns a contiguous chunk of particles: tile of every particle, its arrival slot in the
+//                      block's LDS histogram (LDS atomic), the histogram written tile-major [tile][block]; sum of mode^2
+//   2b scan            exclusive scan of the [tile][block] counts = where each block's particles of each tile go
+//   3b k_tile_place    particle id -> start[tile][block] + slot (4-byte scattered store; no record is built)
+//   4b k_tile_scatter  a block owns a tile: the tile + one halo layer live in LDS as 64-bit FIXED-POINT sums, every particle
+//                      of the tile (position gathered through its id) adds its 27 weights with LDS atomics; integer sums
+//                      do not depend on the order of the adds, so the mesh is bitwise reproducible without any sorting;
+//                      the LDS tile is written to a per-tile buffer
+//   5b k_tile_combine  every mesh cell adds the entries that stand for it in its own tile's buffer and in the halo layers
+//                      of the neighbouring tiles (integers, then one conversion to double)
+//   9b k_tile_forces   a block owns a tile: Re(inv) of the tile + halo staged in LDS, 27 LDS reads per particle
+// Fixed point: an entry is sum(a * W W W) * 2^k in int64 with 2^k * N * max|a| < 2^62 (k = 42 at 10^6 particles, |a| = 1:
+// resolution 2e-13, against 1e-6 asked of the CV).  Meshes with more than TP_MAX_TILES tiles (> 256^3) keep the cell path.
+constexpr int TP_X = 16, TP_Y = 16, TP_Z = 8;
+constexpr unsigned int TP_MAX_TILES = 8192;                         // LDS histogram of k_tile_count: 32 KB
+constexpr int TP_HMAX = (TP_X + 2) * (TP_Y + 2) * (TP_Z + 2);       // 3240 entries, 25.9 KB
+constexpr int TP_THREADS = 256;      // six blocks per CU (26 KB of LDS each): every tile of a 128^3 mesh resident at once
+
+struct TileGeom
+    {
+    unsigned int tx, ty, tz;                    // tile dimensions (clamped to the mesh); edge tiles may be narrower
+    unsigned int ntx, nty, ntz, n_tiles;
+    unsigned int hx, hy, hz, hcells;            // tile + halo: pitch of the LDS image and of the per-tile buffer
+    unsigned int n_blocks, chunk;               // count blocks and particles per count block
+    double scale, inv_scale;                    // fixed point 2^k and 2^-k
+    };
+
+constexpr int TC_THREADS = 1024;       // one block per CU at 10^6 particles: 16 waves hide the load -> locate -> LDS atomic chain
+
+template<typename S4>
+__global__ __launch_bounds__(TC_THREADS) void k_tile_count(const MeshGeom g, const TileGeom tg, const S4 *__restrict__ postype, const unsigned int N,
+                                                    const double *__restrict__ mode, unsigned int *__restrict__ tile_of,
+                                                    unsigned int *__restrict__ slot_of, unsigned int *__restrict__ hist,
+                                                    double *__restrict__ modesq_partials)
+    {
+    extern __shared__ unsigned int s_hist[];
+    __shared__ double s_red[16];
+    for (unsigned int t = threadIdx.x; t < tg.n_tiles; t += blockDim.x) s_hist[t] = 0;
+    __syncthreads();
+    const unsigned int i0 = blockIdx.x * tg.chunk;
+    const unsigned int i1 = min(N, i0 + tg.chunk);
+    double msq = 0.0;
+    for (unsigned int i = i0 + threadIdx.x; i < i1; i += blockDim.x)
+        {
+        const Particle p = scalar4_traits<S4>::load(postype, i);
+        int ix, iy, iz;
+        double sx, sy, sz;
+        locate(g, p, ix, iy, iz, sx, sy, sz);
+        const unsigned int t = (unsigned int)ix / tg.tx + tg.ntx * ((unsigned int)iy / tg.ty + tg.nty * ((unsigned int)iz / tg.tz));
+        tile_of[i] = t;
+        slot_of[i] = atomicAdd(&s_hist[t], 1u);
+        const double a = mode[p.type];
+        msq += a * a;
+        }
+    __syncthreads();
+    for (unsigned int t = threadIdx.x; t < tg.n_tiles; t += blockDim.x) hist[(size_t)t * tg.n_blocks + blockIdx.x] = s_hist[t];
+    msq = block_sum(msq, s_red);
+    if (threadIdx.x == 0) modesq_partials[blockIdx.x] = msq;
+    }
+
+__global__ __launch_bounds__(256) void k_tile_place(const TileGeom tg, const unsigned int N, const unsigned int *__restrict__ tile_of,
+                                                    const unsigned int *__restrict__ slot_of, const unsigned int *__restrict__ start,
+                                                    unsigned int *__restrict__ ids)
+    {
+    for (unsigned int i = blockIdx.x * blockDim.x + threadIdx.x; i < N; i += gridDim.x * blockDim.x)
+        ids[start[(size_t)tile_of[i] * tg.n_blocks + i / tg.chunk] + slot_of[i]] = i;
+    }
+
+template<typename S4>
+__global__ __launch_bounds__(TP_THREADS) void k_tile_scatter(const MeshGeom g, const TileGeom tg, const S4 *__restrict__ postype,
+                                                             const double *__restrict__ mode, const unsigned int *__restrict__ start,
+                                                             const unsigned int *__restrict__ ids, long long *__restrict__ tilebuf,
+                                                             double4 *__restrict__ packed, uint2 *__restrict__ idbase)
+    {
+    __shared__ unsigned long long s_t[TP_HMAX];
+    const unsigned int t = blockIdx.x;
+    const unsigned int tix = t % tg.ntx, tiy = (t / tg.ntx) % tg.nty, tiz = t / (tg.ntx * tg.nty);
+    const int x0 = tix * tg.tx, y0 = tiy * tg.ty, z0 = tiz * tg.tz;
+    const unsigned int q0 = start[(size_t)t * tg.n_blocks], q1 = start[(size_t)(t + 1) * tg.n_blocks];
+    // the first particle is requested before the LDS image is cleared
+    unsigned int q = q0 + threadIdx.x;
+    unsigned int id = 0;
+    Particle p;
+    if (q < q1)
+        {
+        id = ids[q];
+        p = scalar4_traits<S4>::load(postype, id);
+        }
+    for (unsigned int e = threadIdx.x; e < tg.hcells; e += TP_THREADS) s_t[e] = 0ull;
+    __syncthreads();
+    while (q < q1)
+        {
+        const Particle cur = p;
+        const unsigned int cur_id = id;
+        const unsigned int qn = q + TP_THREADS;
+        if (qn < q1)
+            {
+            id = ids[qn];
+            p = scalar4_traits<S4>::load(postype, id);
+            }
+        int ix, iy, iz;
+        double sx, sy, sz;
+        locate(g, cur, ix, iy, iz, sx, sy, sz);
+        const double a0 = mode[cur.type];
+        const double a = a0 * tg.scale;
+        double wx[3], wy[3], wz[3];
+        tsc3(sx, wx);
+        tsc3(sy, wy);
+        tsc3(sz, wz);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) wz[i] *= a;
+        const unsigned int base = (unsigned int)(ix - x0) + tg.hx * ((unsigned int)(iy - y0) + tg.hy * (unsigned int)(iz - z0));
+        // the force pass of this snapshot walks the same tile order: in-cell shift, mode, id and the stencil's corner in
+        // the tile image, stored in place (coalesced) so that it neither gathers nor locates again
+        packed[q] = make_double4(sx, sy, sz, a0);
+        idbase[q] = make_uint2(cur_id, base);
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+                {
+                const double wyz = wy[j] * wz[k];
+                const unsigned int row = base + tg.hx * (j + tg.hy * k);
+#pragma unroll
+                for (int i = 0; i < 3; ++i)
+                    {
+                    // round to nearest integer through the mantissa (|value| < 2^51 by the choice of the scale): the 64-bit
+                    // convert instruction sequence is ten times longer
+                    const double shifted = wx[i] * wyz + 6755399441055744.0;                 // 1.5 * 2^52
+                    atomicAdd(&s_t[row + i], (unsigned long long)(__double_as_longlong(shifted) - 0x4338000000000000ll));
+                    }
+                }
+        q = qn;
+        }
+    __syncthreads();
+    for (unsigned int e = threadIdx.x; e < tg.hcells; e += TP_THREADS) tilebuf[(size_t)t * tg.hcells + e] = (long long)s_t[e];
+    }
+
+// the (tile, local index) pairs along one axis that stand for mesh coordinate c: its own tile, the right halo of the tile to
+// the left if c is the first cell of its tile, the left halo of the tile to the right if it is the last one
+__device__ __forceinline__ int tile_axis_sources(const unsigned int c, const unsigned int n, const unsigned int tw, const unsigned int nt,
+                                                 unsigned int (&tile)[3], unsigned int (&loc)[3])
+    {
+    const unsigned int t0 = c / tw;
+    const unsigned int first = t0 * tw;
+    const unsigned int width = min(tw, n - first);
+    int k = 0;
+    tile[k] = t0; loc[k] = c - first + 1; ++k;
+    if (c == first)
+        {
+        const unsigned int tl = t0 == 0 ? nt - 1 : t0 - 1;
+        tile[k] = tl; loc[k] = min(tw, n - tl * tw) + 1; ++k;
+        }
+    if (c == first + width - 1)
+        {
+        tile[k] = t0 == nt - 1 ? 0 : t0 + 1; loc[k] = 0; ++k;
+        }
+    return k;
+    }
+
+__global__ __launch_bounds__(256) void k_tile_combine(const MeshGeom g, const TileGeom tg, const long long *__restrict__ tilebuf,
+                                                      double *__restrict__ rho)
+    {
+    const unsigned int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= g.n_cells) return;
+    const unsigned int gz = c / (g.nx * g.ny), gy = (c - gz * g.nx * g.ny) / g.nx, gx = c % g.nx;
+    unsigned int txs[3], lxs[3], tys[3], lys[3], tzs[3], lzs[3];
+    const int nxs = tile_axis_sources(gx, g.nx, tg.tx, tg.ntx, txs, lxs);
+    const int nys = tile_axis_sources(gy, g.ny, tg.ty, tg.nty, tys, lys);
+    const int nzs = tile_axis_sources(gz, g.nz, tg.tz, tg.ntz, tzs, lzs);
+    long long sum = 0;
+    for (int k = 0; k < nzs; ++k)
+        for (int j = 0; j < nys; ++j)
+            for (int i = 0; i < nxs; ++i)
+                {
+                const size_t t = txs[i] + tg.ntx * (tys[j] + (size_t)tg.nty * tzs[k]);
+                sum += tilebuf[t * tg.hcells + lxs[i] + tg.hx * (lys[j] + tg.hy * lzs[k])];
+                }
+    rho[c] = (double)sum * tg.inv_scale;
+    }
+
+constexpr int TF_THREADS = 256;        // four blocks per CU (128 VGPRs): one stages its tile while the others sum
+
+template<typename S4>
+__global__ __launch_bounds__(TF_THREADS) void k_tile_forces(const MeshGeom g, const TileGeom tg, const unsigned int *__restrict__ start,
+                                                            const uint2 *__restrict__ idbase, const double4 *__restrict__ packed,
+                                                            const double *__restrict__ inv, S4 *__restrict__ force,
+                                                            const double *__restrict__ d_bias, const double bias_host,
+                                                            const double two_over_n)
+    {
+    typedef typename scalar4_traits<S4>::scalar scalar;
+    __shared__ double s_inv[TP_HMAX];
+    const unsigned int t = blockIdx.x;
+    const unsigned int tix = t % tg.ntx, tiy = (t / tg.ntx) % tg.nty, tiz = t / (tg.ntx * tg.nty);
+    const int x0 = tix * tg.tx, y0 = tiy * tg.ty, z0 = tiz * tg.tz;
+    const unsigned int q0 = start[(size_t)t * tg.n_blocks], q1 = start[(size_t)(t + 1) * tg.n_blocks];
+    if (q0 == q1) return;
+    unsigned int q = q0 + threadIdx.x;
+    double4 pk = make_double4(0.0, 0.0, 0.0, 0.0);
+    uint2 ib = make_uint2(0u, 0u);
+    if (q < q1)
+        {
+        pk = packed[q];
+        ib = idbase[q];
+        }
+    // Re(inv) of the tile + halo, row by row (32 lanes per row of <= 18 entries: no divisions in the loop)
+    const unsigned int wxn = min(tg.tx, g.nx - x0) + 2, wyn = min(tg.ty, g.ny - y0) + 2, wzn = min(tg.tz, g.nz - z0) + 2;
+    const unsigned int lx = threadIdx.x & 31;
+    int gx = x0 + (int)lx - 1;
+    gx = gx < 0 ? gx + (int)g.nx : (gx >= (int)g.nx ? gx - (int)g.nx : gx);
+    // all loads of a thread are issued before the first LDS store (a load -> store loop pays one memory round trip per row)
+    constexpr int TF_ROWS = ((TP_Y + 2) * (TP_Z + 2) + TF_THREADS / 32 - 1) / (TF_THREADS / 32);
+    double v[TF_ROWS];
+    const unsigned int n_rows = wyn * wzn;
+#pragma unroll
+    for (int r = 0; r < TF_ROWS; ++r)
+        {
+        const unsigned int row = (threadIdx.x >> 5) + r * (TF_THREADS / 32);
+        v[r] = 0.0;
+        if (row < n_rows && lx < wxn)
+            {
+            const unsigned int lz = row / wyn, ly = row - lz * wyn;
+            int gy = y0 + (int)ly - 1, gz = z0 + (int)lz - 1;
+            gy = gy < 0 ? gy + (int)g.ny : (gy >= (int)g.ny ? gy - (int)g.ny : gy);
+            gz = gz < 0 ? gz + (int)g.nz : (gz >= (int)g.nz ? gz - (int)g.nz : gz);
+            v[r] = inv[gx + g.nx * (gy + g.ny * gz)];
+            }
+        }
+#pragma unroll
+    for (int r = 0; r < TF_ROWS; ++r)
+        {
+        const unsigned int row = (threadIdx.x >> 5) + r * (TF_THREADS / 32);
+        if (row < n_rows && lx < wxn)
+            {
+            const unsigned int lz = row / wyn, ly = row - lz * wyn;
+            s_inv[lx + tg.hx * (ly + tg.hy * lz)] = v[r];
+            }
+        }
+    __syncthreads();
+    const double bias = d_bias ? *d_bias : bias_host;
+    const double s = two_over_n * bias;                                // :861
+    while (q < q1)
+        {
+        const double4 cur = pk;
+        const uint2 cib = ib;
+        const unsigned int qn = q + TF_THREADS;
+        if (qn < q1)
+            {
+            pk = packed[qn];
+            ib = idbase[qn];
+            }
+        const double a = cur.w, sx = cur.x, sy = cur.y, sz = cur.z;
+        double wxv[3], wyv[3], wzv[3], dxv[3], dyv[3], dzv[3];
+        tsc3_deriv(sx, wxv, dxv);
+        tsc3_deriv(sy, wyv, dyv);
+        tsc3_deriv(sz, wzv, dzv);
+        double g1 = 0.0, g2 = 0.0, g3 = 0.0;   // sums multiplying n_x b1, n_y b2, n_z b3
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+                {
+                const unsigned int row = cib.y + tg.hx * (j + tg.hy * k);
+                const double r0 = s_inv[row], r1 = s_inv[row + 1], r2 = s_inv[row + 2];
+                const double aw = wxv[0] * r0 + wxv[1] * r1 + wxv[2] * r2;       // row sums with W and with W'
+                const double ad = dxv[0] * r0 + dxv[1] * r1 + dxv[2] * r2;
+                g1 += ad * (wyv[j] * wzv[k]);
+                g2 += aw * (dyv[j] * wzv[k]);
+                g3 += aw * (wyv[j] * dzv[k]);
+                }
+        const double c1 = -(double)g.nx * a * g1, c2 = -(double)g.ny * a * g2, c3 = -(double)g.nz * a * g3;
+        const double fx = (c1 * g.binv[0][0] + c2 * g.binv[1][0] + c3 * g.binv[2][0]) * s;
+        const double fy = (c1 * g.binv[0][1] + c2 * g.binv[1][1] + c3 * g.binv[2][1]) * s;
+        const double fz = (c1 * g.binv[0][2] + c2 * g.binv[1][2] + c3 * g.binv[2][2]) * s;
+        force[cib.x] = scalar4_traits<S4>::make((scalar)fx, (scalar)fy, (scalar)fz, (scalar)0);
+        q = qn;
+        }
     }
 
 // ---- 6/8. DFT of lines staged in LDS ---------------------------------------------------------------
@@ -1051,6 +1390,13 @@ struct mtd_mesh
     double k_min, k_max, delta_k;
     int use_table;
     unsigned int n_cv_partials, n_count_blocks;
+    // tile path of the assignment / force pass (k_tile_*): tile geometry, per-tile fixed-point buffers, ids grouped by tile
+    int tile_path;
+    TileGeom tg;               // n_blocks, chunk, scale: as set by the last mtd_mesh_assign
+    unsigned int tile_blocks_max;
+    long long *d_tilebuf;
+    unsigned int *d_ids;
+    double amax;               // max |mode coefficient| (fixed-point scale)
     };
 
 namespace
@@ -1141,17 +1487,34 @@ int mtd_mesh_create(mtd_mesh **out, unsigned int nx, unsigned int ny, unsigned i
     }
     const size_t MH = (size_t)m->hxp * ny * nz;
     m->n_cv_partials = fft_z_pass(m).n_blocks;                 // one partial sum per block of the fused z pass
-    const unsigned int n_tiles = (m->M + SCAN_TILE - 1) / SCAN_TILE;
+    // tile path (k_tile_*): tiles of 16x16x8 cells clamped to the mesh; MTD_MESH_ASSIGN=cells keeps the cell-level pipeline
+    {
+    TileGeom &tg = m->tg;
+    tg.tx = nx < (unsigned int)TP_X ? nx : TP_X; tg.ty = ny < (unsigned int)TP_Y ? ny : TP_Y; tg.tz = nz < (unsigned int)TP_Z ? nz : TP_Z;
+    tg.ntx = (nx + tg.tx - 1) / tg.tx; tg.nty = (ny + tg.ty - 1) / tg.ty; tg.ntz = (nz + tg.tz - 1) / tg.tz;
+    const unsigned long long nt = (unsigned long long)tg.ntx * tg.nty * tg.ntz;
+    tg.hx = tg.tx + 2; tg.hy = tg.ty + 2; tg.hz = tg.tz + 2; tg.hcells = tg.hx * tg.hy * tg.hz;
+    const char *env = std::getenv("MTD_MESH_ASSIGN");
+    m->tile_path = nt <= TP_MAX_TILES && !(env && std::strcmp(env, "cells") == 0);
+    tg.n_tiles = m->tile_path ? (unsigned int)nt : 0;
+    unsigned int nb = (max_particles + 4095) / 4096;
+    m->tile_blocks_max = nb < 1 ? 1 : (nb > 1024 ? 1024 : nb);
+    m->amax = 0.0;
+    for (unsigned int t = 0; t < n_types; ++t) m->amax = std::fmax(m->amax, std::fabs(mode[t]));
+    }
+    const size_t n_scan = std::max<size_t>(m->M, (size_t)m->tg.n_tiles * m->tile_blocks_max);   // entries the scan kernels may see
+    const unsigned int n_tiles = (unsigned int)((n_scan + SCAN_TILE - 1) / SCAN_TILE);
     auto al = [](size_t b) { return (b + 255) / 256 * 256; };
     size_t off = 0;
     auto take = [&](size_t b) { size_t o = off; off += al(b); return o; };
     const size_t o_mode = take(sizeof(double) * n_types), o_rho = take(sizeof(double) * (M + 1)), o_msqp = take(sizeof(double) * m->n_count_blocks), o_cvp = take(sizeof(double) * m->n_cv_partials), o_f = take(sizeof(double2) * MH),
                  o_g = take(sizeof(double2) * MH), o_tw0 = take(sizeof(double2) * nx), o_tw1 = take(sizeof(double2) * ny),
                  o_tw2 = take(sizeof(double2) * nz), o_packed = take(sizeof(double4) * N), o_cell = take(sizeof(unsigned int) * N),
-                 o_count = take(sizeof(unsigned int) * (M + 1)), o_start = take(sizeof(unsigned int) * (M + 1)),
+                 o_count = take(sizeof(unsigned int) * (n_scan + 1)), o_start = take(sizeof(unsigned int) * (n_scan + 1)),
                  o_ids = take(sizeof(uint2) * N), o_tiles = take(sizeof(unsigned int) * n_tiles),
                  o_inv = take(sizeof(double) * M), o_slot = take(sizeof(unsigned int) * N),
-                 o_itab = take(sizeof(double) * (nx + ny + nz));
+                 o_itab = take(sizeof(double) * (nx + ny + nz)),
+                 o_tilebuf = take(sizeof(long long) * (size_t)m->tg.n_tiles * m->tg.hcells), o_ids2 = take(sizeof(unsigned int) * N);
     hipError_t e = hipMalloc(&m->slab, off);
     if (e != hipSuccess)
         {
@@ -1169,6 +1532,8 @@ int mtd_mesh_create(mtd_mesh **out, unsigned int nx, unsigned int ny, unsigned i
     m->d_inv = (double *)(p + o_inv);
     m->d_slot_of = (unsigned int *)(p + o_slot);
     m->d_itab = (double *)(p + o_itab);
+    m->d_tilebuf = (long long *)(p + o_tilebuf);
+    m->d_ids = (unsigned int *)(p + o_ids2);
     e = hipMemset(m->slab, 0, off);
     if (e == hipSuccess) e = hipMemcpy(m->d_mode, mode, sizeof(double) * n_types, hipMemcpyHostToDevice);
     // twiddles exp(-2 pi i j / n), j < n (the radix-2 stages use the first half), in double on the host
@@ -1235,6 +1600,51 @@ int mtd_mesh_assign(mtd_mesh *m, unsigned int n_particles, const void *d_postype
     const unsigned int M = m->M, N = n_particles;
     const unsigned int cell_blocks = (M + 255) / 256;
     const unsigned int n_tiles = (M + SCAN_TILE - 1) / SCAN_TILE;
+
+    if (m->tile_path)
+        {
+        TileGeom &tg = m->tg;
+        unsigned int nb = (N + 4095) / 4096;
+        nb = nb < 1 ? 1 : (nb > m->tile_blocks_max ? m->tile_blocks_max : nb);
+        tg.n_blocks = nb;
+        tg.chunk = N ? (N + nb - 1) / nb : 1;
+        // fixed point: 2^k * N * max|a| < 2^62 even if every particle sat in one cell
+        int k = 40;
+        if (m->amax > 0.0)
+            {
+            k = (int)std::floor(62.0 - std::log2((double)(N ? N : 1) * m->amax)) - 1;
+            const int k_one = 50 - (int)std::ceil(std::log2(m->amax));        // one deposit stays below 2^51 (mantissa rounding)
+            k = k > k_one ? k_one : k;
+            k = k > 60 ? 60 : (k < -900 ? -900 : k);
+            }
+        tg.scale = std::ldexp(1.0, k);
+        tg.inv_scale = std::ldexp(1.0, -k);
+        const size_t lds = sizeof(unsigned int) * tg.n_tiles;
+        if (dtype == MTD_F32)
+            k_tile_count<float4><<<nb, TC_THREADS, lds, s>>>(g, tg, (const float4 *)d_postype, N, m->d_mode, m->d_cell_of, m->d_slot_of, m->d_count, m->d_modesq_partials);
+        else
+            k_tile_count<double4><<<nb, TC_THREADS, lds, s>>>(g, tg, (const double4 *)d_postype, N, m->d_mode, m->d_cell_of, m->d_slot_of, m->d_count, m->d_modesq_partials);
+        MTD_LAUNCH_CHECK();
+        const unsigned int n = tg.n_tiles * nb;
+        const unsigned int n_scan_tiles = (n + SCAN_TILE - 1) / SCAN_TILE;
+        k_scan_tiles<<<n_scan_tiles + 1, 256, 0, s>>>(m->d_count, m->d_start, m->d_tile_sums, n, m->d_modesq_partials, nb, m->d_mode_sq);
+        MTD_LAUNCH_CHECK();
+        k_scan_finish<<<n_scan_tiles, 256, 0, s>>>(m->d_start, m->d_tile_sums, m->d_count, n, N);
+        MTD_LAUNCH_CHECK();
+        unsigned int pb = (N + 255) / 256;
+        pb = pb < 1 ? 1 : (pb > 4096 ? 4096 : pb);
+        k_tile_place<<<pb, 256, 0, s>>>(tg, N, m->d_cell_of, m->d_slot_of, m->d_start, m->d_ids);
+        MTD_LAUNCH_CHECK();
+        if (dtype == MTD_F32)
+            k_tile_scatter<float4><<<tg.n_tiles, TP_THREADS, 0, s>>>(g, tg, (const float4 *)d_postype, m->d_mode, m->d_start, m->d_ids, m->d_tilebuf, m->d_packed, m->d_idcell);
+        else
+            k_tile_scatter<double4><<<tg.n_tiles, TP_THREADS, 0, s>>>(g, tg, (const double4 *)d_postype, m->d_mode, m->d_start, m->d_ids, m->d_tilebuf, m->d_packed, m->d_idcell);
+        MTD_LAUNCH_CHECK();
+        k_tile_combine<<<cell_blocks, 256, 0, s>>>(g, tg, m->d_tilebuf, m->d_rho);
+        MTD_LAUNCH_CHECK();
+        m->n_last = N;
+        return MTD_SUCCESS;
+        }
 
     // the counters are zero on entry: cleared at creation and by k_scan_finish of the previous call
     if (dtype == MTD_F32)
@@ -1327,7 +1737,15 @@ int mtd_mesh_forces(mtd_mesh *m, unsigned int n_particles, const void *d_postype
     const double two_over_n = 2.0 / (double)n_global;
     // the force pass walks the cell-sorted list built by the last mtd_mesh_compute_cv of the same snapshot
     if (n_particles != m->n_last) return MTD_ERR_INVALID_ARGUMENT;
-    (void)d_postype;
+    if (m->tile_path)
+        {
+        if (dtype == MTD_F32)
+            k_tile_forces<float4><<<m->tg.n_tiles, TF_THREADS, 0, s>>>(g, m->tg, m->d_start, m->d_idcell, m->d_packed, m->d_inv, (float4 *)d_force, d_bias, bias_host, two_over_n);
+        else
+            k_tile_forces<double4><<<m->tg.n_tiles, TF_THREADS, 0, s>>>(g, m->tg, m->d_start, m->d_idcell, m->d_packed, m->d_inv, (double4 *)d_force, d_bias, bias_host, two_over_n);
+        MTD_LAUNCH_CHECK();
+        return MTD_SUCCESS;
+        }
     if (dtype == MTD_F32)
         k_mesh_forces<float4><<<blocks, 256, 0, s>>>(g, n_particles, m->d_idcell, m->d_packed, m->d_inv, (float4 *)d_force, d_bias, bias_host, two_over_n);
     else
