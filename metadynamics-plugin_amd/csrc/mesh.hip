@@ -805,6 +805,113 @@ __device__ __forceinline__ unsigned int lds_slot(const unsigned int p, const uns
     return log2n ? (__brev(p) >> (32 - log2n)) : p;
     }
 
+// Power-of-two lines, LDS layout [p][tile] with tile = 2^log2tile lines.  Two radix-2 stages per sweep over LDS (radix-4
+// butterflies in registers: half the LDS traffic and half the barriers of a stage-by-stage loop), all index arithmetic
+// in shifts and masks (tile, n and the stage lengths are powers of two; as run-time divisors they cost more than the
+// butterflies).  twiddle[k] = exp(-2 pi i k / n).
+__device__ __forceinline__ double2 cmul(const double2 a, const double2 w) { return make_double2(a.x * w.x - a.y * w.y, a.x * w.y + a.y * w.x); }
+__device__ __forceinline__ double2 cadd(const double2 a, const double2 b) { return make_double2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ double2 csub(const double2 a, const double2 b) { return make_double2(a.x - b.x, a.y - b.y); }
+
+// decimation in time: bit-reversed order in, natural order out; forward (inverse = 0) or inverse sign
+__device__ __forceinline__ void fft_dit_pow2(double2 *s, const double2 *__restrict__ twiddle, const unsigned int log2n,
+                                             const unsigned int log2tile, const int inverse)
+    {
+    const unsigned int n = 1u << log2n, tile = 1u << log2tile, tmask = tile - 1;
+    unsigned int log2len = 1;                                    // next stage: len = 2^log2len
+    if (log2n & 1)
+        {
+        // single radix-2 stage len = 2 (twiddle 1)
+        for (unsigned int idx = threadIdx.x; idx < (n >> 1) << log2tile; idx += FFT_THREADS)
+            {
+            const unsigned int t = idx & tmask, bf = idx >> log2tile;
+            const unsigned int i0 = bf << 1;
+            const double2 u = s[(i0 << log2tile) + t], v = s[((i0 + 1) << log2tile) + t];
+            s[(i0 << log2tile) + t] = cadd(u, v);
+            s[((i0 + 1) << log2tile) + t] = csub(u, v);
+            }
+        __syncthreads();
+        log2len = 2;
+        }
+    for (; log2len < log2n + 1; log2len += 2)
+        {
+        // stages len = 2^log2len and 2 len in one sweep: elements a, b = a + len/2, c = a + len, d = c + len/2
+        const unsigned int log2half = log2len - 1, half = 1u << log2half;
+        for (unsigned int idx = threadIdx.x; idx < (n >> 2) << log2tile; idx += FFT_THREADS)
+            {
+            const unsigned int t = idx & tmask, bf = idx >> log2tile;          // radix-4 butterfly 0 .. n/4 - 1
+            const unsigned int grp = bf >> log2half, j = bf & (half - 1);
+            const unsigned int ia = (grp << (log2len + 1)) + j;
+            double2 w1 = twiddle[j << (log2n - log2len)];                        // exp(-2 pi i j / len)
+            double2 w2 = twiddle[j << (log2n - log2len - 1)];                    // exp(-2 pi i j / 2 len)
+            if (inverse)
+                {
+                w1.y = -w1.y;
+                w2.y = -w2.y;
+                }
+            double2 *pa = s + (ia << log2tile) + t;
+            const unsigned int sh = half << log2tile;
+            const double2 a = pa[0], b = cmul(pa[sh], w1), c = pa[2 * sh], d = cmul(pa[3 * sh], w1);
+            const double2 a1 = cadd(a, b), b1 = csub(a, b), c1 = cmul(cadd(c, d), w2), d1 = cmul(csub(c, d), w2);
+            // second stage: (a1, c1) with w2 and (b1, d1) with w2 * exp(-+ i pi / 2) = -+ i w2
+            const double2 d1r = inverse ? make_double2(-d1.y, d1.x) : make_double2(d1.y, -d1.x);
+            pa[0] = cadd(a1, c1);
+            pa[2 * sh] = csub(a1, c1);
+            pa[sh] = cadd(b1, d1r);
+            pa[3 * sh] = csub(b1, d1r);
+            }
+        __syncthreads();
+        }
+    }
+
+// decimation in frequency, inverse sign: natural order in, bit-reversed order out
+__device__ __forceinline__ void fft_dif_pow2_inverse(double2 *s, const double2 *__restrict__ twiddle, const unsigned int log2n,
+                                                     const unsigned int log2tile)
+    {
+    const unsigned int n = 1u << log2n, tile = 1u << log2tile, tmask = tile - 1;
+    int log2len = (int)log2n;
+    for (; log2len >= 2; log2len -= 2)
+        {
+        // stages len = 2^log2len and len / 2 in one sweep: elements a, b = a + len/4, c = a + len/2, d = a + 3 len/4
+        const unsigned int log2q = log2len - 2, q = 1u << log2q;
+        for (unsigned int idx = threadIdx.x; idx < (n >> 2) << log2tile; idx += FFT_THREADS)
+            {
+            const unsigned int t = idx & tmask, bf = idx >> log2tile;
+            const unsigned int grp = bf >> log2q, j = bf & (q - 1);
+            const unsigned int ia = (grp << log2len) + j;
+            double2 wa = twiddle[j << (log2n - log2len)];                        // conj -> exp(+2 pi i j / len)
+            double2 w2 = twiddle[j << (log2n - log2len + 1)];                    // conj -> exp(+2 pi i j / (len/2))
+            wa.y = -wa.y;
+            w2.y = -w2.y;
+            double2 *pa = s + (ia << log2tile) + t;
+            const unsigned int sh = q << log2tile;
+            const double2 a = pa[0], b = pa[sh], c = pa[2 * sh], d = pa[3 * sh];
+            const double2 a1 = cadd(a, c), c1 = cmul(csub(a, c), wa);
+            const double2 bd = csub(b, d);
+            const double2 b1 = cadd(b, d), d1 = cmul(make_double2(-bd.y, bd.x), wa);         // (b - d) * i wa
+            pa[0] = cadd(a1, b1);
+            pa[sh] = cmul(csub(a1, b1), w2);
+            pa[2 * sh] = cadd(c1, d1);
+            pa[3 * sh] = cmul(csub(c1, d1), w2);
+            }
+        __syncthreads();
+        }
+    if (log2len == 1)
+        {
+        for (unsigned int idx = threadIdx.x; idx < (n >> 1) << log2tile; idx += FFT_THREADS)
+            {
+            const unsigned int t = idx & tmask, bf = idx >> log2tile;
+            const unsigned int i0 = bf << 1;
+            const double2 u = s[(i0 << log2tile) + t], v = s[((i0 + 1) << log2tile) + t];
+            s[(i0 << log2tile) + t] = cadd(u, v);
+            s[((i0 + 1) << log2tile) + t] = csub(u, v);
+            }
+        __syncthreads();
+        }
+    }
+
+__device__ __forceinline__ unsigned int ilog2_dev(const unsigned int v) { return 31u - (unsigned int)__clz((int)v); }
+
 template<bool REAL_INPUT, bool REAL_OUTPUT>
 __global__ __launch_bounds__(FFT_THREADS) void k_fft_lines(const double *__restrict__ real_in, double2 *__restrict__ data,
                                                            double *__restrict__ real_out,
@@ -821,6 +928,7 @@ __global__ __launch_bounds__(FFT_THREADS) void k_fft_lines(const double *__restr
     const unsigned int tin = blockIdx.x % tiles_per_row;
     const size_t base = (size_t)row * row_stride + (size_t)tin * tile * line_stride;
     const unsigned int total = n * tile;
+    const unsigned int log2tile = ilog2_dev(tile);               // tile is a power of two (fft_tile_for)
 
     // load with bit-reversed position (decimation in time)
     for (unsigned int idx = threadIdx.x; idx < total; idx += FFT_THREADS)
@@ -828,13 +936,13 @@ __global__ __launch_bounds__(FFT_THREADS) void k_fft_lines(const double *__restr
         unsigned int t, p;
         if (p_fastest)
             {
-            t = idx / n;
-            p = idx % n;
+            t = log2n ? idx >> log2n : idx / n;
+            p = log2n ? idx & (n - 1) : idx % n;
             }
         else
             {
-            p = idx / tile;
-            t = idx % tile;
+            p = idx >> log2tile;
+            t = idx & (tile - 1);
             }
         const size_t a = base + (size_t)t * line_stride + (size_t)p * elem_stride;
         double2 v;
@@ -851,39 +959,20 @@ __global__ __launch_bounds__(FFT_THREADS) void k_fft_lines(const double *__restr
         dft_direct(s, s + total, twiddle, n, tile, inverse);
         s += total;                                              // the result buffer
         }
-    const unsigned int half_total = (n / 2) * tile;
-    for (unsigned int len = 2, stage = 1; log2n && len <= n; len <<= 1, ++stage)
-        {
-        const unsigned int half = len >> 1;
-        const unsigned int tw_step = n / len;
-        for (unsigned int idx = threadIdx.x; idx < half_total; idx += FFT_THREADS)
-            {
-            const unsigned int t = idx % tile;
-            const unsigned int bf = idx / tile;              // butterfly index 0 .. n/2-1
-            const unsigned int grp = bf / half, j = bf % half;
-            const unsigned int i0 = grp * len + j, i1 = i0 + half;
-            double2 w = twiddle[j * tw_step];                // exp(-2 pi i j / len)
-            if (inverse) w.y = -w.y;
-            const double2 u = s[i0 * tile + t], v = s[i1 * tile + t];
-            const double2 tv = make_double2(v.x * w.x - v.y * w.y, v.x * w.y + v.y * w.x);
-            s[i0 * tile + t] = make_double2(u.x + tv.x, u.y + tv.y);
-            s[i1 * tile + t] = make_double2(u.x - tv.x, u.y - tv.y);
-            }
-        __syncthreads();
-        }
+    if (log2n) fft_dit_pow2(s, twiddle, log2n, log2tile, inverse);
 
     for (unsigned int idx = threadIdx.x; idx < total; idx += FFT_THREADS)
         {
         unsigned int t, p;
         if (p_fastest)
             {
-            t = idx / n;
-            p = idx % n;
+            t = log2n ? idx >> log2n : idx / n;
+            p = log2n ? idx & (n - 1) : idx % n;
             }
         else
             {
-            p = idx / tile;
-            t = idx % tile;
+            p = idx >> log2tile;
+            t = idx & (tile - 1);
             }
         const size_t a = base + (size_t)t * line_stride + (size_t)p * elem_stride;
         if (REAL_OUTPUT)
@@ -918,38 +1007,13 @@ __device__ __forceinline__ double tsc_fourier(double x)              // :487-511
 // fused z pass, the inverse passes — touches ~56 % of the full-spectrum bytes.  The real part of the inverse transform that
 // interpolateForces reads (:851-857) is the inverse of the Hermitian part of G, which the spectral step forms directly.
 // LDS layout [p][tile] as in k_fft_lines; `tile` adjacent x lines per block.
-__device__ __forceinline__ void fft_stages_dit(double2 *s, const double2 *__restrict__ twiddle, const unsigned int n,
-                                               const unsigned int tile, const int inverse)
-    {
-    const unsigned int half_total = (n / 2) * tile;
-    for (unsigned int len = 2; len <= n; len <<= 1)
-        {
-        const unsigned int half = len >> 1;
-        const unsigned int tw_step = n / len;
-        for (unsigned int idx = threadIdx.x; idx < half_total; idx += FFT_THREADS)
-            {
-            const unsigned int t = idx % tile;
-            const unsigned int bf = idx / tile;
-            const unsigned int grp = bf / half, j = bf % half;
-            const unsigned int i0 = grp * len + j, i1 = i0 + half;
-            double2 w = twiddle[j * tw_step];                // exp(-2 pi i j / len)
-            if (inverse) w.y = -w.y;
-            const double2 u = s[i0 * tile + t], v = s[i1 * tile + t];
-            const double2 tv = make_double2(v.x * w.x - v.y * w.y, v.x * w.y + v.y * w.x);
-            s[i0 * tile + t] = make_double2(u.x + tv.x, u.y + tv.y);
-            s[i1 * tile + t] = make_double2(u.x - tv.x, u.y - tv.y);
-            }
-        __syncthreads();
-        }
-    }
-
 // radix-2 stages in place, or the direct transform into the second buffer; returns the buffer that holds the result
 __device__ __forceinline__ double2 *lds_transform(double2 *s, const double2 *__restrict__ twiddle, const unsigned int n,
                                                   const unsigned int log2n, const unsigned int tile, const int inverse)
     {
     if (log2n)
         {
-        fft_stages_dit(s, twiddle, n, tile, inverse);
+        fft_dit_pow2(s, twiddle, log2n, ilog2_dev(tile), inverse);
         return s;
         }
     dft_direct(s, s + n * tile, twiddle, n, tile, inverse);
@@ -1071,7 +1135,7 @@ __global__ __launch_bounds__(FFT_THREADS) void k_fft_z_spectral(const MeshGeom g
 
     for (unsigned int idx = threadIdx.x; idx < total; idx += FFT_THREADS)
         {
-        const unsigned int p = idx / tile, t = idx % tile;
+        const unsigned int p = idx >> ilog2_dev(tile), t = idx & (tile - 1);
         s[lds_slot(p, log2n) * tile + t] = fmesh[base + t + (size_t)p * plane];
         }
     __syncthreads();
@@ -1081,25 +1145,8 @@ __global__ __launch_bounds__(FFT_THREADS) void k_fft_z_spectral(const MeshGeom g
         dft_direct(s, s + total, twiddle, n, tile, 0);               // forward, natural order, into the second buffer
         s += total;
         }
-    const unsigned int half_total = (n / 2) * tile;
-    for (unsigned int len = 2; log2n && len <= n; len <<= 1)             // forward, decimation in time
-        {
-        const unsigned int half = len >> 1;
-        const unsigned int tw_step = n / len;
-        for (unsigned int idx = threadIdx.x; idx < half_total; idx += FFT_THREADS)
-            {
-            const unsigned int t = idx % tile;
-            const unsigned int bf = idx / tile;
-            const unsigned int grp = bf / half, j = bf % half;
-            const unsigned int i0 = grp * len + j, i1 = i0 + half;
-            const double2 w = twiddle[j * tw_step];                      // exp(-2 pi i j / len)
-            const double2 u = s[i0 * tile + t], v = s[i1 * tile + t];
-            const double2 tv = make_double2(v.x * w.x - v.y * w.y, v.x * w.y + v.y * w.x);
-            s[i0 * tile + t] = make_double2(u.x + tv.x, u.y + tv.y);
-            s[i1 * tile + t] = make_double2(u.x - tv.x, u.y - tv.y);
-            }
-        __syncthreads();
-        }
+    const unsigned int log2tile = ilog2_dev(tile);
+    if (log2n) fft_dit_pow2(s, twiddle, log2n, log2tile, 0);          // forward, decimation in time
 
     // spectral step in place: updateMeshes :697-712 + computeCV :896-905 on the stored half of the spectrum.
     // f(-k) = conj f(k), so the cell -k (not stored for 0 < k_x < nx/2) has the same |f|^2 and its own interpolation factor
@@ -1109,7 +1156,7 @@ __global__ __launch_bounds__(FFT_THREADS) void k_fft_z_spectral(const MeshGeom g
     const double msq = *mode_sq;
     for (unsigned int idx = threadIdx.x; idx < total; idx += FFT_THREADS)
         {
-        const unsigned int p = idx / tile, t = idx % tile;             // p = k_z index
+        const unsigned int p = idx >> log2tile, t = idx & (tile - 1);  // p = k_z index
         const unsigned int wx = x_first + t;
         if (wx > nxh)                                                  // padding column of the half-spectrum rows
             {
@@ -1147,28 +1194,10 @@ __global__ __launch_bounds__(FFT_THREADS) void k_fft_z_spectral(const MeshGeom g
         dft_direct(s, s_first, twiddle, n, tile, 1);                 // inverse, natural order, back into the first buffer
         s = s_first;
         }
-    for (unsigned int len = n; log2n && len >= 2; len >>= 1)             // inverse, decimation in frequency
-        {
-        const unsigned int half = len >> 1;
-        const unsigned int tw_step = n / len;
-        for (unsigned int idx = threadIdx.x; idx < half_total; idx += FFT_THREADS)
-            {
-            const unsigned int t = idx % tile;
-            const unsigned int bf = idx / tile;
-            const unsigned int grp = bf / half, j = bf % half;
-            const unsigned int i0 = grp * len + j, i1 = i0 + half;
-            double2 w = twiddle[j * tw_step];
-            w.y = -w.y;                                                  // exp(+2 pi i j / len)
-            const double2 u = s[i0 * tile + t], v = s[i1 * tile + t];
-            const double2 d = make_double2(u.x - v.x, u.y - v.y);
-            s[i0 * tile + t] = make_double2(u.x + v.x, u.y + v.y);
-            s[i1 * tile + t] = make_double2(d.x * w.x - d.y * w.y, d.x * w.y + d.y * w.x);
-            }
-        __syncthreads();
-        }
+    if (log2n) fft_dif_pow2_inverse(s, twiddle, log2n, log2tile);        // inverse, decimation in frequency
     for (unsigned int idx = threadIdx.x; idx < total; idx += FFT_THREADS)
         {
-        const unsigned int q = idx / tile, t = idx % tile;             // LDS slot q holds position z = bitrev(q) (radix-2 path)
+        const unsigned int q = idx >> log2tile, t = idx & (tile - 1);  // LDS slot q holds position z = bitrev(q) (radix-2 path)
         const unsigned int z = lds_slot(q, log2n);
         gmesh[base + t + (size_t)z * plane] = s[q * tile + t];
         }
