@@ -627,47 +627,34 @@ __global__ __launch_bounds__(TP_THREADS) void k_tile_scatter(const MeshGeom g, c
     for (unsigned int e = threadIdx.x; e < tg.hcells; e += TP_THREADS) tilebuf[(size_t)t * tg.hcells + e] = (long long)s_t[e];
     }
 
-// the (tile, local index) pairs along one axis that stand for mesh coordinate c: its own tile, the right halo of the tile to
-// the left if c is the first cell of its tile, the left halo of the tile to the right if it is the last one
-__device__ __forceinline__ int tile_axis_sources(const unsigned int c, const unsigned int n, const unsigned int tw, const unsigned int nt,
-                                                 unsigned int (&tile)[3], unsigned int (&loc)[3])
-    {
-    const unsigned int t0 = c / tw;
-    const unsigned int first = t0 * tw;
-    const unsigned int width = min(tw, n - first);
-    int k = 0;
-    tile[k] = t0; loc[k] = c - first + 1; ++k;
-    if (c == first)
-        {
-        const unsigned int tl = t0 == 0 ? nt - 1 : t0 - 1;
-        tile[k] = tl; loc[k] = min(tw, n - tl * tw) + 1; ++k;
-        }
-    if (c == first + width - 1)
-        {
-        tile[k] = t0 == nt - 1 ? 0 : t0 + 1; loc[k] = 0; ++k;
-        }
-    return k;
-    }
-
+// Which entries of the per-tile buffers stand for a mesh cell: along one axis coordinate c is held by its own tile, by the
+// right halo of the tile to the left if c is the first cell of its tile and by the left halo of the tile to the right if it
+// is the last one.  The offset of an entry is a sum of one term per axis, so a table of nx + ny + nz rows
+// {offset 0, offset 1, offset 2, count} (built once per mesh) replaces the divisions: a block owns one mesh row, its y and
+// z terms are uniform, most cells have one source per axis.
 __global__ __launch_bounds__(256) void k_tile_combine(const MeshGeom g, const TileGeom tg, const long long *__restrict__ tilebuf,
-                                                      double *__restrict__ rho)
+                                                      const uint4 *__restrict__ tsrc, double *__restrict__ rho)
     {
-    const unsigned int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= g.n_cells) return;
-    const unsigned int gz = c / (g.nx * g.ny), gy = (c - gz * g.nx * g.ny) / g.nx, gx = c % g.nx;
-    unsigned int txs[3], lxs[3], tys[3], lys[3], tzs[3], lzs[3];
-    const int nxs = tile_axis_sources(gx, g.nx, tg.tx, tg.ntx, txs, lxs);
-    const int nys = tile_axis_sources(gy, g.ny, tg.ty, tg.nty, tys, lys);
-    const int nzs = tile_axis_sources(gz, g.nz, tg.tz, tg.ntz, tzs, lzs);
-    long long sum = 0;
-    for (int k = 0; k < nzs; ++k)
-        for (int j = 0; j < nys; ++j)
-            for (int i = 0; i < nxs; ++i)
+    const unsigned int gy = blockIdx.y, gz = blockIdx.z;
+    const uint4 ay = tsrc[g.nx + gy], az = tsrc[g.nx + g.ny + gz];
+    const size_t row = (size_t)g.nx * (gy + (size_t)g.ny * gz);
+    for (unsigned int gx = blockIdx.x * blockDim.x + threadIdx.x; gx < g.nx; gx += gridDim.x * blockDim.x)
+        {
+        const uint4 ax = tsrc[gx];
+        long long sum = 0;
+        for (unsigned int k = 0; k < az.w; ++k)
+            {
+            const unsigned int oz = k == 0 ? az.x : (k == 1 ? az.y : az.z);
+            for (unsigned int j = 0; j < ay.w; ++j)
                 {
-                const size_t t = txs[i] + tg.ntx * (tys[j] + (size_t)tg.nty * tzs[k]);
-                sum += tilebuf[t * tg.hcells + lxs[i] + tg.hx * (lys[j] + tg.hy * lzs[k])];
+                const size_t base = (size_t)oz + (j == 0 ? ay.x : (j == 1 ? ay.y : ay.z));
+                sum += tilebuf[base + ax.x];
+                if (ax.w > 1) sum += tilebuf[base + ax.y];
+                if (ax.w > 2) sum += tilebuf[base + ax.z];
                 }
-    rho[c] = (double)sum * tg.inv_scale;
+            }
+        rho[row + gx] = (double)sum * tg.inv_scale;
+        }
     }
 
 constexpr int TF_THREADS = 256;        // four blocks per CU (128 VGPRs): one stages its tile while the others sum
@@ -1424,6 +1411,7 @@ struct mtd_mesh
     TileGeom tg;               // n_blocks, chunk, scale: as set by the last mtd_mesh_assign
     unsigned int tile_blocks_max;
     long long *d_tilebuf;
+    uint4 *d_tsrc;             // per-axis table of the tile-buffer offsets that stand for a mesh coordinate (k_tile_combine)
     unsigned int *d_ids;
     double amax;               // max |mode coefficient| (fixed-point scale)
     };
@@ -1543,7 +1531,8 @@ int mtd_mesh_create(mtd_mesh **out, unsigned int nx, unsigned int ny, unsigned i
                  o_ids = take(sizeof(uint2) * N), o_tiles = take(sizeof(unsigned int) * n_tiles),
                  o_inv = take(sizeof(double) * M), o_slot = take(sizeof(unsigned int) * N),
                  o_itab = take(sizeof(double) * (nx + ny + nz)),
-                 o_tilebuf = take(sizeof(long long) * (size_t)m->tg.n_tiles * m->tg.hcells), o_ids2 = take(sizeof(unsigned int) * N);
+                 o_tilebuf = take(sizeof(long long) * (size_t)m->tg.n_tiles * m->tg.hcells), o_ids2 = take(sizeof(unsigned int) * N),
+                 o_tsrc = take(sizeof(uint4) * (nx + ny + nz));
     hipError_t e = hipMalloc(&m->slab, off);
     if (e != hipSuccess)
         {
@@ -1563,7 +1552,35 @@ int mtd_mesh_create(mtd_mesh **out, unsigned int nx, unsigned int ny, unsigned i
     m->d_itab = (double *)(p + o_itab);
     m->d_tilebuf = (long long *)(p + o_tilebuf);
     m->d_ids = (unsigned int *)(p + o_ids2);
+    m->d_tsrc = (uint4 *)(p + o_tsrc);
     e = hipMemset(m->slab, 0, off);
+    if (e == hipSuccess && m->tile_path)
+        {
+        // entry offset = tile * hcells + lx + hx (ly + hy lz) with tile = tx + ntx (ty + nty tz): one term per axis
+        std::vector<unsigned int> tab(4 * (size_t)(nx + ny + nz), 0u);
+        const TileGeom &tg = m->tg;
+        const unsigned int dims[3] = {nx, ny, nz}, tws[3] = {tg.tx, tg.ty, tg.tz}, nts[3] = {tg.ntx, tg.nty, tg.ntz};
+        const unsigned long long tile_mul[3] = {1ull * tg.hcells, 1ull * tg.ntx * tg.hcells, 1ull * tg.ntx * tg.nty * tg.hcells};
+        const unsigned long long loc_mul[3] = {1ull, tg.hx, 1ull * tg.hx * tg.hy};
+        size_t o = 0;
+        for (int a = 0; a < 3; ++a)
+            for (unsigned int c = 0; c < dims[a]; ++c, ++o)
+                {
+                const unsigned int n = dims[a], tw = tws[a], nt = nts[a];
+                const unsigned int t0 = c / tw, first = t0 * tw, width = std::min(tw, n - first);
+                unsigned int k = 0;
+                auto put = [&](unsigned int tile, unsigned int loc) { tab[4 * o + k++] = (unsigned int)(tile * tile_mul[a] + loc * loc_mul[a]); };
+                put(t0, c - first + 1);
+                if (c == first)
+                    {
+                    const unsigned int tl = t0 == 0 ? nt - 1 : t0 - 1;
+                    put(tl, std::min(tw, n - tl * tw) + 1);
+                    }
+                if (c == first + width - 1) put(t0 == nt - 1 ? 0 : t0 + 1, 0);
+                tab[4 * o + 3] = k;
+                }
+        e = hipMemcpy(m->d_tsrc, tab.data(), sizeof(unsigned int) * tab.size(), hipMemcpyHostToDevice);
+        }
     if (e == hipSuccess) e = hipMemcpy(m->d_mode, mode, sizeof(double) * n_types, hipMemcpyHostToDevice);
     // twiddles exp(-2 pi i j / n), j < n (the radix-2 stages use the first half), in double on the host
     const unsigned int dims[3] = {nx, ny, nz};
@@ -1669,7 +1686,10 @@ int mtd_mesh_assign(mtd_mesh *m, unsigned int n_particles, const void *d_postype
         else
             k_tile_scatter<double4><<<tg.n_tiles, TP_THREADS, 0, s>>>(g, tg, (const double4 *)d_postype, m->d_mode, m->d_start, m->d_ids, m->d_tilebuf, m->d_packed, m->d_idcell);
         MTD_LAUNCH_CHECK();
-        k_tile_combine<<<cell_blocks, 256, 0, s>>>(g, tg, m->d_tilebuf, m->d_rho);
+        {
+        const unsigned int cthreads = m->nx >= 256 ? 256 : (m->nx > 64 ? 128 : 64);
+        k_tile_combine<<<dim3((m->nx + cthreads - 1) / cthreads, m->ny, m->nz), cthreads, 0, s>>>(g, tg, m->d_tilebuf, m->d_tsrc, m->d_rho);
+        }
         MTD_LAUNCH_CHECK();
         m->n_last = N;
         return MTD_SUCCESS;
