@@ -8,6 +8,9 @@
 // final-reduce launches (:510-541, :771-885), texture-bound force gather (:566-754).
 //
 // MI355X design: single rank, no ghost cells (the multi-GPU plan replicates the mesh).
+// Assignment and force pass run by TILES (steps 1b-5b, 9b further down: particles grouped by 16x16x8 tile, weights summed
+// in LDS as 64-bit fixed point, Re(inv) read from an LDS image); the cell-level steps 1-5 and 9 listed here remain for
+// meshes with more than 8192 tiles and behind MTD_MESH_ASSIGN=cells.
 //   1 k_mesh_bin        cell of every particle and its arrival slot in that cell (ONE returning atomic per particle),
 //                       block sums of mode^2
 //   2 scan (2 kernels)  exclusive scan of the counts -> cell starts; the counters are cleared for the next call
