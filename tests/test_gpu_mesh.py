@@ -59,11 +59,35 @@ class GpuMesh:
         return (out[0::2] + 1j * out[1::2]).reshape(nz, ny, nx)
 
 
+@pytest.fixture(params=["tiles", "cells"])
+def assign_path(request, monkeypatch):
+    """both assignment / force pipelines of mesh.hip: by tiles (default) and the cell-level one (meshes > 256^3)"""
+    monkeypatch.setenv("MTD_MESH_ASSIGN", request.param)
+    return request.param
+
+
+def test_mesh_bitwise_independent_of_particle_order(abi):
+    """tile path: the weights are summed as 64-bit fixed point, so the mesh does not depend on the order of the adds"""
+    N, L = 40011, 12.0
+    pos, types = util.snapshot_random(N, L, seed=3, dtype=np.float64)
+    box = abi.Box.make(L)
+    perm = np.random.default_rng(0).permutation(N)
+    rho = []
+    for order in (np.arange(N), perm):
+        m = GpuMesh(abi, (32, 16, 24), [1.0, -0.7], N)
+        d = torch.from_numpy(util.pack_postype(pos[order], types[order], np.float64)).cuda()
+        m.cv(d, abi.MTD_F64, box, N)
+        rho.append(m.array(0).copy())
+        m.close()
+    assert np.array_equal(rho[0], rho[1])
+    assert np.abs(rho[0]).max() > 0
+
+
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
 @pytest.mark.parametrize("dims,tilt", [((8, 8, 8), {}), ((16, 8, 32), dict(xy=0.2, xz=-0.1, yz=0.15)), ((32, 32, 32), {}),
                                        # sizes that are not powers of two (direct transforms, partial gather tiles, odd lengths)
                                        ((12, 20, 6), dict(xy=0.1, xz=0.05, yz=-0.2)), ((5, 7, 9), {}), ((48, 16, 36), {})])
-def test_mesh_cv_and_forces(abi, ref, dtype, dims, tilt):
+def test_mesh_cv_and_forces(abi, ref, dtype, dims, tilt, assign_path):
     N = 6007
     Ls = (9.0, 7.5, 11.0)
     rng = np.random.default_rng(11)
@@ -103,7 +127,7 @@ def test_mesh_cv_and_forces(abi, ref, dtype, dims, tilt):
         g.close()
 
 
-def test_mesh_edge_cases(abi, ref):
+def test_mesh_edge_cases(abi, ref, assign_path):
     """crowded cells (many particles per cell: per-cell sort), particles exactly on the box boundary (ix == nx -> 0,
     :556-561), N_global != N, empty system"""
     lib = abi.load()
