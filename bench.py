@@ -51,8 +51,8 @@ def parse():
     ap.add_argument("--path", choices=["fused", "generic"], default="fused",
                     help="fused: two launches per step (headline); generic: separate C-ABI calls per stage")
     ap.add_argument("--driver", choices=["host", "abi"], default=None,
-                    help="host: metadynamics.integrate API, C++ run loop (default at N=1); abi: C-ABI calls from Python "
-                         "(default for N>1, where torch.distributed carries the all-reduce)")
+                    help="host: metadynamics.integrate API, C++ run loop (default; at N>1 with the xGMI mailbox as its "
+                         "communicator); abi: C-ABI calls from Python (N>1 fallback when the all-reduce has to go through RCCL)")
     ap.add_argument("--dtype", choices=["f32", "f64"], default="f32",
                     help="Scalar of the particle arrays (HOOMD single / double precision build); headline: f32 as in BASELINE.json")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -129,11 +129,14 @@ class HostEngine:
     """The same workload through the reference-shaped API: metadynamics.cv / metadynamics.integrate over the C++
     host classes; the step loop is System::run in C++ (what HOOMD's run loop does)."""
 
-    def __init__(self, n, seed, stride, fast_trig, path, dtype=np.float32):
+    def __init__(self, pos, types, L, n_global, stride, fast_trig, path, dtype=np.float32, mailbox=None):
+        """pos / types: this rank's particles (the whole snapshot at N = 1); mailbox: metadynamics.xgmi.Mailbox of a
+        particle-sharded run — it plays the role of HOOMD's MPI communicator in the execution configuration"""
         from metadynamics import context, cv, integrate
-        pos, types = util.snapshot_random(n, BOX_L, seed=seed, dtype=np.float32)
-        self.pos_np, self.types_np, self.L = pos, types, BOX_L
-        self.ctx = context.initialize(pos, types, ["A", "B"], BOX_L, dtype=dtype)
+        self.pos_np, self.types_np, self.L = pos, types, L
+        self.ctx = context.initialize(pos, types, ["A", "B"], L, dtype=dtype, n_global=n_global)
+        if mailbox is not None:
+            context.exec_conf.setMailbox(mailbox.handle.value)
         self.meta = integrate.mode_metadynamics(dt=0.005, stride=stride, mode="well_tempered", W=W, deltaT=DELTA_T, T=T)
         self.cvs = []
         for i, vecs in enumerate((util.CV1_VECTORS, util.CV2_VECTORS)):
@@ -231,9 +234,7 @@ def main():
 
     n_local = args.particles
     n_global = n_local * world
-    driver = args.driver or ("host" if world == 1 else "abi")
-    if driver == "host" and world > 1:
-        raise SystemExit("--driver host is single-GPU; N>1 uses the C-ABI backend with torch.distributed")
+    driver = args.driver or "host"
 
     def barrier():
         torch.cuda.synchronize()
@@ -245,8 +246,13 @@ def main():
     # the event-bracketed pass over the dominant kernel always goes through the C-ABI backend (same kernels)
     eng = Engine(n_local, n_global, rank, seed=12345 if world == 1 else 12346, stride=args.stride,
                  fast_trig=args.fast_trig, dist=dist, path=args.path, dtype=np_dtype)
+    if driver == "host" and dist is not None and eng.be.mailbox is None:
+        driver = "abi"                     # no mailbox on this node: the C-ABI backend with the RCCL all-reduce
     if driver == "host":
-        host = HostEngine(n_local, 12345, args.stride, args.fast_trig, args.path, dtype=np_dtype)
+        # sharded: the C++ host classes take the mailbox as their communicator (fused lamellar step)
+        barrier()                          # ranks enter the first exchange (prepRun's deposit) together
+        host = HostEngine(eng.pos_np, eng.types_np, eng.L, n_global, args.stride, args.fast_trig, args.path, dtype=np_dtype,
+                          mailbox=eng.be.mailbox)
         host.run(max(args.warmup - 1, 0))
         barrier()
         t0 = time.perf_counter()
@@ -264,11 +270,11 @@ def main():
             eng.step()
         barrier()
         elapsed = time.perf_counter() - t0
-        if dist is not None:
-            tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            elapsed = float(tt.item())
         st = eng.state()
+    if dist is not None:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
     mailbox_timeouts = None
     if eng.be.mailbox is not None:
         tt = torch.tensor([eng.be.mailbox.timeouts()], dtype=torch.int64, device="cuda" if dist.get_backend() == "nccl" else "cpu")

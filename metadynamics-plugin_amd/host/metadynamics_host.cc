@@ -735,6 +735,15 @@ void IntegratorMetaDynamics::setupGrid()
                               m_add_bias ? 1 : 0);
     if (rc == MTD_ERR_INVALID_ARGUMENT) throw std::runtime_error("Error creating collective variable.");
     mtd_check(rc, "mtd_metad_create");
+    // domain decomposition (the reference: MPI_Allreduce of the CV sums, root computes the bias, MPI_Bcast, :346-351, :571-575):
+    // here every rank keeps the replicated grid and the CV sums of the fused step travel through the xGMI mailbox
+    if (m_exec_conf->getMailbox())
+        {
+        if (!fusedLamellarPossible())
+            throw std::runtime_error("metadynamics: a domain-decomposed run through the host classes needs a set of at most three "
+                                     "lamellar collective variables (fused step); other sets: metadynamics.sharded.HipCvSetBackend");
+        mtd_check(mtd_metad_set_comm(m_engine, m_exec_conf->getMailbox()), "mtd_metad_set_comm");
+        }
     }
 
 // :121-217
@@ -869,6 +878,9 @@ void IntegratorMetaDynamics::updateBiasPotential(unsigned int timestep)
         fusedLamellarStep(timestep);
     else
         {
+        if (m_exec_conf->getMailbox())
+            throw std::runtime_error("metadynamics: this set of collective variables cannot take the fused step, which is the only "
+                                     "domain-decomposed path of the host classes");
         m_used_fused = false;
         // collect values of collective variables (:321-327) — they stay on the device
         for (unsigned int i = 0; i < m_variables.size(); ++i) m_variables[i].m_cv->enqueueCurrentValue(timestep, m_engine, i);

@@ -4,6 +4,7 @@
 // the classes in metadynamics_host.h only rely on the members declared here.
 #pragma once
 
+#include <cstdint>
 #include <hip/hip_runtime.h>
 
 #include <array>
@@ -118,8 +119,17 @@ class ExecutionConfiguration
         hipStream_t getStream() const { return m_stream; }
         void sync() const { hip_check(hipStreamSynchronize(m_stream), "hipStreamSynchronize"); }
 
+        //! Domain decomposition: the role of HOOMD's MPI communicator (ExecutionConfiguration::getMPICommunicator) for this
+        //! plugin's small per-step sums is played by the xGMI mailbox (mtd_comm, one rank per GPU of the node); the handle
+        //! is created and connected by the launcher (metadynamics.xgmi.connect) and only borrowed here
+        void setMailbox(uintptr_t comm) { m_comm = reinterpret_cast<mtd_comm *>(comm); }
+        mtd_comm *getMailbox() const { return m_comm; }
+        unsigned int getNRanks() const { return m_comm ? mtd_comm_world(m_comm) : 1; }
+        unsigned int getRank() const { return m_comm ? mtd_comm_rank(m_comm) : 0; }
+
     private:
         hipStream_t m_stream;
+        mtd_comm *m_comm = nullptr;
     };
 
 //! Particle arrays in HOOMD layout; Scalar is chosen per system (dtype), the arrays live in HBM

@@ -109,6 +109,9 @@ PYBIND11_MODULE(_metadynamics, m)
     py::class_<ExecutionConfiguration, std::shared_ptr<ExecutionConfiguration>>(m, "ExecutionConfiguration")
         .def(py::init<>())
         .def("isCUDAEnabled", &ExecutionConfiguration::isCUDAEnabled)
+        .def("setMailbox", &ExecutionConfiguration::setMailbox)
+        .def("getNRanks", &ExecutionConfiguration::getNRanks)
+        .def("getRank", &ExecutionConfiguration::getRank)
         .def("sync", &ExecutionConfiguration::sync);
 
     py::class_<ParticleData, std::shared_ptr<ParticleData>>(m, "ParticleData")

@@ -117,3 +117,51 @@ def test_mailbox_between_processes(world):
     assert r["set_errs"]["cv"] < 1e-6 and r["set_errs"]["bias"] < 1e-5
     assert r["set_energy_cv"][0] == pytest.approx(r["set_energy_cv"][1], rel=1e-12)
     assert r["set_force_err"] < 1e-5
+
+
+def test_host_classes_take_the_mailbox_as_communicator(abi):
+    """metadynamics.cv / integrate over the C++ host classes with a (one-rank) mailbox in the execution configuration:
+    same step as without; a CV set that cannot take the fused step is refused in a domain-decomposed run"""
+    import ctypes as C
+    from metadynamics import context, cv, integrate, xgmi
+    lib = abi.load()
+    N, L = 30000, 30.0
+    pos, types = util.snapshot_random(N, L, seed=21, modulated=True, dtype=np.float32)
+
+    def run(box, umbrella=False):
+        context.initialize(pos, types, ["A", "B"], L, dtype=np.float32, n_global=N)
+        if box is not None:
+            context.exec_conf.setMailbox(box.handle.value)
+            assert context.exec_conf.getNRanks() == 1 and context.exec_conf.getRank() == 0
+        meta = integrate.mode_metadynamics(dt=0.005, stride=1, mode="well_tempered", W=1.0, deltaT=7.0, T=1.0)
+        cvs = []
+        for i, vecs in enumerate((util.CV1_VECTORS, util.CV2_VECTORS)):
+            c = cv.lamellar(sigma=0.02, mode=dict(A=1.0, B=-1.0), lattice_vectors=vecs, name="c%d" % i)
+            c.set_grid(-1.0, 1.0, 48)
+            cvs.append(c)
+        if umbrella:
+            cvs[0].set_params(umbrella="harmonic", kappa=1.0, cv0=0.0)
+        context.run(5)
+        t = context.current.system.getCurrentTimeStep()
+        integ = meta.cpp_integrator
+        out = dict(cv=[c.cpp_force.getCurrentValue(t) for c in cvs], V=integ.getLogValue("bias", t), w=integ.getLogValue("weight", t),
+                   n=integ.getNumGaussians(), fused=integ.usedFusedPath(), f=cvs[0].cpp_force.getForces().copy())
+        context.current = None
+        return out
+
+    plain = run(None)
+    h = C.c_void_p()
+    abi.check(lib.mtd_comm_create(C.byref(h), 0, 1, 8))
+    box = xgmi.Mailbox(h, 0, 1)
+    try:
+        dd = run(box)
+        assert dd["fused"] and plain["fused"] and dd["n"] == plain["n"]
+        assert np.allclose(dd["cv"], plain["cv"], rtol=1e-13, atol=0)
+        assert dd["V"] == pytest.approx(plain["V"], rel=1e-10) and dd["w"] == pytest.approx(plain["w"], rel=1e-10)
+        assert np.abs(dd["f"] - plain["f"]).max() <= 1e-6 * np.abs(plain["f"]).max()
+        assert box.timeouts() == 0
+        with pytest.raises(RuntimeError):
+            run(box, umbrella=True)
+    finally:
+        context.current = None
+        box.close()
