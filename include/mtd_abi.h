@@ -225,6 +225,13 @@ int mtd_fused_force_pass(mtd_metad *m, const mtd_lamellar_set *set, unsigned int
                          void *const *d_force, int dtype, unsigned int n_global, const mtd_box *global_box,
                          unsigned int timestep, mtd_stream_t stream);
 
+/* Measurement aid (bench.py): the next n_launches launches of mtd_fused_force_pass record their own begin and end through the
+ * start / stop events of hipExtLaunchKernelGGL — the dispatch's time stamps, i.e. the duration a kernel trace reports for the
+ * launch, without a profiler attached.  mtd_profile_force_end SYNCHRONISES, returns the durations (microseconds) of the
+ * launches made since _begin and releases the events. */
+int mtd_profile_force_begin(unsigned int n_launches);
+int mtd_profile_force_end(double *durations_us, unsigned int capacity, unsigned int *n_out);
+
 /* ================================================================================================
  * xGMI mailbox: all-reduce (sum) of a few doubles between the GPUs of one node, one process per GPU
  * replaces the host-staged MPI_Allreduce of the per-step CV sums (LamellarOrderParameterGPU.cc:69-77,

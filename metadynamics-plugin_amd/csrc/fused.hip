@@ -25,6 +25,7 @@
 // get_array, which flush it), so the grid arrays are "one apply behind" between B and the next A.
 // Forces never wait for it: dV/ds_c only needs grid_old + dV on <= (2 n_cv + 1) 2^n_cv cells.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 // Diagnostic build only (-DMTD_STAMPS, tools/stamps.sh): s_memrealtime (100 MHz) stamps of one grid block and
 // one particle block per kernel, written to a buffer of their own; the product build has no stamps.
@@ -49,6 +50,7 @@ extern "C" int mtd_debug_read_stamps(unsigned long long *host)
 
 #include <cstdlib>
 #include <cstring>
+#include <vector>
 
 namespace
 {
@@ -358,6 +360,24 @@ __global__ __launch_bounds__(FF_THREADS) void k_fused_force_general(const LamKAr
     lam_force_pass<S4, FAST, FF_UNROLL>(a, postype, out, N, block_id * FF_THREADS + threadIdx.x, n_blocks * FF_THREADS, s_wcoef, s_mt);
     }
 
+// ---- measurement aid: per-launch durations of launch B from the dispatch's own time stamps -----------------------------
+struct ForceProfile
+    {
+    std::vector<hipEvent_t> ev;      // start / stop pairs
+    size_t used = 0;
+    };
+ForceProfile g_force_profile;
+
+bool force_profile_next(hipEvent_t &start, hipEvent_t &stop)
+    {
+    ForceProfile &p = g_force_profile;
+    if (p.used + 2 > p.ev.size()) return false;
+    start = p.ev[p.used];
+    stop = p.ev[p.used + 1];
+    p.used += 2;
+    return true;
+    }
+
 template<typename S4, bool FAST>
 int launch_fused_cv(const LamKArgs &k, unsigned int N, const void *d_postype, double *d_partials, unsigned int cv_blocks,
                     const MetadCfg &cfg, unsigned int n_apply, const CommK *ck, hipStream_t s)
@@ -472,9 +492,17 @@ int mtd_fused_force_pass(mtd_metad *m, const mtd_lamellar_set *set, unsigned int
         unsigned int fblocks = (n_particles + FF_STREAM_THREADS * FF_U * groups - 1) / (FF_STREAM_THREADS * FF_U * groups);
         if (fblocks == 0 && n_grid == 0) fblocks = 1;               // still one block to publish the scalars
         const unsigned int grid = n_grid + fblocks;
+        // measurement aid (mtd_profile_force_begin): the launch records its own begin and end through the start / stop events of
+        // hipExtLaunchKernelGGL — the dispatch's time stamps, what a kernel trace reports for it
+        hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+        const bool timed = force_profile_next(ev_start, ev_stop);
+#define MTD_LAUNCH_FF_K(KERNEL) \
+        do { if (timed) hipExtLaunchKernelGGL(KERNEL, dim3(grid), dim3(FF_THREADS), 0, s, ev_start, ev_stop, 0, k, (const S4T *)d_postype, out, n_particles, two_over_n, m->cfg, dep, n_grid, ck); \
+             else KERNEL<<<grid, FF_THREADS, 0, s>>>(k, (const S4T *)d_postype, out, n_particles, two_over_n, m->cfg, dep, n_grid, ck); } while (0)
 #define MTD_LAUNCH_FF(S4, NCV, FASTV) \
-        do { if (m->comm) k_fused_force<S4, NCV, FASTV, ff_groups<S4, NCV>::value, true><<<grid, FF_THREADS, 0, s>>>(k, (const S4 *)d_postype, out, n_particles, two_over_n, m->cfg, dep, n_grid, ck); \
-             else k_fused_force<S4, NCV, FASTV, ff_groups<S4, NCV>::value, false><<<grid, FF_THREADS, 0, s>>>(k, (const S4 *)d_postype, out, n_particles, two_over_n, m->cfg, dep, n_grid, ck); } while (0)
+        do { typedef S4 S4T; \
+             if (m->comm) MTD_LAUNCH_FF_K((k_fused_force<S4, NCV, FASTV, ff_groups<S4, NCV>::value, true>)); \
+             else MTD_LAUNCH_FF_K((k_fused_force<S4, NCV, FASTV, ff_groups<S4, NCV>::value, false>)); } while (0)
 #define MTD_LAUNCH_FF_NCV(S4, FASTV) \
         switch (set->n_cv) { case 1: MTD_LAUNCH_FF(S4, 1, FASTV); break; case 2: MTD_LAUNCH_FF(S4, 2, FASTV); break; default: MTD_LAUNCH_FF(S4, 3, FASTV); break; }
         if (dtype == MTD_F32)
@@ -487,6 +515,7 @@ int mtd_fused_force_pass(mtd_metad *m, const mtd_lamellar_set *set, unsigned int
             }
 #undef MTD_LAUNCH_FF_NCV
 #undef MTD_LAUNCH_FF
+#undef MTD_LAUNCH_FF_K
         }
     else
         {
@@ -510,6 +539,40 @@ int mtd_fused_force_pass(mtd_metad *m, const mtd_lamellar_set *set, unsigned int
         }
     MTD_LAUNCH_CHECK();
     m->pending_apply = dep;
+    return MTD_SUCCESS;
+    }
+
+int mtd_profile_force_begin(unsigned int n_launches)
+    {
+    ForceProfile &p = g_force_profile;
+    for (hipEvent_t e : p.ev) (void)hipEventDestroy(e);
+    p.ev.clear();
+    p.used = 0;
+    for (unsigned int i = 0; i < 2 * n_launches; ++i)
+        {
+        hipEvent_t e = nullptr;
+        MTD_HIP_TRY(hipEventCreate(&e));
+        p.ev.push_back(e);
+        }
+    return MTD_SUCCESS;
+    }
+
+int mtd_profile_force_end(double *durations_us, unsigned int capacity, unsigned int *n_out)
+    {
+    ForceProfile &p = g_force_profile;
+    if (!durations_us || !n_out) return MTD_ERR_INVALID_ARGUMENT;
+    MTD_HIP_TRY(hipDeviceSynchronize());
+    unsigned int n = 0;
+    for (size_t i = 0; i + 1 < p.used && n < capacity; i += 2)
+        {
+        float ms = 0.0f;
+        MTD_HIP_TRY(hipEventElapsedTime(&ms, p.ev[i], p.ev[i + 1]));
+        durations_us[n++] = 1.0e3 * (double)ms;
+        }
+    *n_out = n;
+    for (hipEvent_t e : p.ev) (void)hipEventDestroy(e);
+    p.ev.clear();
+    p.used = 0;
     return MTD_SUCCESS;
     }
 
