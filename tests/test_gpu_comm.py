@@ -49,7 +49,8 @@ def _run_world(world, n_global, steps=6, timeout=300):
     return json.loads(line)
 
 
-def test_mailbox_single_rank_matches_plain_fused_step(abi):
+@pytest.mark.parametrize("n_cv,dtype", [(2, np.float32), (1, np.float64), (3, np.float32), (3, np.float64)])
+def test_mailbox_single_rank_matches_plain_fused_step(abi, n_cv, dtype):
     """world = 1: the send / receive code of the fused kernels with the rank talking to itself"""
     import ctypes as C
     from metadynamics import xgmi
@@ -64,10 +65,10 @@ def test_mailbox_single_rank_matches_plain_fused_step(abi):
     assert v.cpu().tolist() == [1.5, -2.0, 3.25]
     N, L = 50000, 30.0
     pos, types = util.snapshot_random(N, L, seed=9, modulated=True, dtype=np.float32)
-    grid = dict(sigma=[0.02, 0.02], cv_min=[-1.0, -1.0], cv_max=[1.0, 1.0], num_points=[64, 48])
+    grid = dict(sigma=[0.02, 0.02, 0.03][:n_cv], cv_min=[-1.0] * n_cv, cv_max=[1.0] * n_cv, num_points=[64, 48, 20][:n_cv])
     kw = dict(W=1.0, T_shift=7.0, T=1.0, stride=2, mode="well_tempered")
-    cvs = [(util.CV1_VECTORS, util.MODE_AB), (util.CV2_VECTORS, util.MODE_AB)]
-    d = torch.from_numpy(util.pack_postype(pos, types, np.float32)).cuda()
+    cvs = [(util.CV1_VECTORS, util.MODE_AB), (util.CV2_VECTORS, util.MODE_AB), ([(0, 0, 3), (1, 2, 0)], [0.5, -1.5])][:n_cv]
+    d = torch.from_numpy(util.pack_postype(pos.astype(dtype), types, dtype)).cuda()
     a = HipLamellarBackend(cvs, d, N, L, grid, fast_trig=False, **kw)
     b = HipLamellarBackend(cvs, d, N, L, grid, fast_trig=False, **kw)
     b.attach_mailbox(box)
@@ -79,7 +80,7 @@ def test_mailbox_single_rank_matches_plain_fused_step(abi):
         assert np.allclose(sb["bias"], sa["bias"], rtol=1e-9, atol=1e-12 * max(abs(x) for x in sa["bias"]))
         assert sb["V"] == pytest.approx(sa["V"], rel=1e-10) and sb["w"] == pytest.approx(sa["w"], rel=1e-10)
         assert sb["num_gaussians"] == sa["num_gaussians"]
-    for c in range(2):
+    for c in range(n_cv):
         fa, fb = a.forces[c].cpu().numpy(), b.forces[c].cpu().numpy()
         assert np.abs(fa - fb).max() <= 1e-6 * np.abs(fa).max()
     assert box.timeouts() == 0
@@ -100,7 +101,7 @@ def test_mailbox_rejects_bad_arguments(abi):
     abi.check(lib.mtd_comm_destroy(h))
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 4])
 def test_mailbox_between_processes(world):
     r = _run_world(world, 60000)
     assert r["connected"], "the mailbox could not be set up between processes on this box"
