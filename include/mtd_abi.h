@@ -258,6 +258,14 @@ int mtd_comm_connect(mtd_comm *c, const void *handles);
 int mtd_comm_allreduce_small(mtd_comm *c, double *d_values, unsigned int n, mtd_stream_t stream);
 /* number of timed-out waits so far; SYNCHRONISES the stream */
 int mtd_comm_status(mtd_comm *c, unsigned int *timeouts, mtd_stream_t stream);
+/* Bulk buffers readable by every rank (the slab-decomposed mesh pulls its peers' slabs straight out of them over xGMI):
+ * mtd_comm_share allocates `bytes` of uncached device memory on this rank (peers' reads and this GPU's writes must not
+ * sit in a non-coherent L2) and returns its address, its slot number and its IPC handle; after the caller's control plane
+ * has gathered the handles of that slot from all ranks, mtd_comm_open maps them: peers[r] is rank r's buffer as seen from
+ * this process (peers[rank] = the local address).  At most MTD_COMM_MAX_SHARED buffers; released by mtd_comm_destroy. */
+#define MTD_COMM_MAX_SHARED 8
+int mtd_comm_share(mtd_comm *c, size_t bytes, void **d_local, unsigned int *slot, void *out_handle);
+int mtd_comm_open(mtd_comm *c, unsigned int slot, const void *handles, void **peers);
 unsigned int mtd_comm_world(const mtd_comm *c);
 unsigned int mtd_comm_rank(const mtd_comm *c);
 int mtd_comm_destroy(mtd_comm *c);
@@ -326,6 +334,21 @@ int mtd_mesh_virial(mtd_mesh *m, const mtd_box *box, unsigned int n_global, doub
  * 3 Re(inv_fourier_mesh) double[M] (the imaginary part is never used, OrderParameterMesh.cc:851-857); 7 sum of mode^2 */
 int mtd_mesh_get_array(mtd_mesh *m, int which, void *host_out, mtd_stream_t stream);
 
+
+/* Slab decomposition of the mesh over the ranks of an xGMI mailbox (replaces the ghost-cell exchange and the
+ * distributed FFT of OrderParameterMesh.cc:263-316, 659-746 — dfftlib over MPI — for meshes whose replicated transform no
+ * longer pays).  Rank r owns the z planes [r nz/W, (r+1) nz/W) for the x and y passes and the y rows [r ny/W, (r+1) ny/W)
+ * for the z pass; the transposes between them are remote loads out of four buffers every rank exports
+ * (mtd_comm_share, sizes from mtd_mesh_slab_bytes: local assignment, transformed slab, pencils of G, slab of Re(inv)).
+ * nz and ny must be multiples of the number of ranks.  mtd_mesh_slab_compute_cv runs the whole forward / spectral / inverse
+ * sequence with four mailbox exchanges as barriers (one carries sum mode^2, one the CV sum) and leaves the complete Re(inv)
+ * on every rank for mtd_mesh_forces; *d_cv_sum is a device double, the CV is half of it.  The normalised Fourier mesh
+ * (log quantities, virial) is not kept in slab runs. */
+int mtd_mesh_slab_bytes(const mtd_mesh *m, unsigned int world, size_t *bytes /* [4] */);
+int mtd_mesh_slab_attach(mtd_mesh *m, mtd_comm *comm, void *const *rho_peers, void *const *f_peers, void *const *g_peers,
+                         void *const *inv_peers);
+int mtd_mesh_slab_compute_cv(mtd_mesh *m, unsigned int n_particles, const void *d_postype, int dtype, const mtd_box *box,
+                             unsigned int n_global, const double **d_cv_sum, mtd_stream_t stream);
 /* ================================================================================================
  * Steinhardt Q_l (cv.steinhardt) — the reference has only a host implementation (SteinhardtQl.cc); these entry points
  * are what a GPU class of it would call.  Neighbour list in HOOMD's layout (NeighborList::getHeadList / getNNeighArray /

@@ -164,6 +164,65 @@ int mtd_comm_connect(mtd_comm *c, const void *handles)
     return MTD_SUCCESS;
     }
 
+int mtd_comm_share(mtd_comm *c, size_t bytes, void **d_local, unsigned int *slot, void *out_handle)
+    {
+    if (!c || !d_local || !slot || !out_handle || bytes == 0) return MTD_ERR_INVALID_ARGUMENT;
+    if (c->n_shared >= MTD_COMM_MAX_SHARED) return MTD_ERR_UNSUPPORTED;
+    void *p = nullptr;
+    hipError_t e = hipExtMallocWithFlags(&p, bytes, hipDeviceMallocUncached);
+    if (e != hipSuccess)
+        {
+        (void)hipGetLastError();
+        e = hipExtMallocWithFlags(&p, bytes, hipDeviceMallocFinegrained);
+        }
+    if (e != hipSuccess)
+        {
+        (void)hipGetLastError();
+        return (int)e;
+        }
+    e = hipMemset(p, 0, bytes);
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    hipIpcMemHandle_t h;
+    std::memset(&h, 0, sizeof(h));
+    if (e == hipSuccess && c->k.world > 1) e = hipIpcGetMemHandle(&h, p);
+    if (e != hipSuccess)
+        {
+        (void)hipGetLastError();
+        (void)hipFree(p);
+        return (int)e;
+        }
+    const unsigned int s = c->n_shared++;
+    c->shared_local[s] = p;
+    c->shared_peer[s][c->k.rank] = p;
+    std::memcpy(out_handle, &h, sizeof(h));
+    *d_local = p;
+    *slot = s;
+    return MTD_SUCCESS;
+    }
+
+int mtd_comm_open(mtd_comm *c, unsigned int slot, const void *handles, void **peers)
+    {
+    if (!c || slot >= c->n_shared || !peers || (c->k.world > 1 && !handles)) return MTD_ERR_INVALID_ARGUMENT;
+    for (unsigned int r = 0; r < c->k.world; ++r)
+        {
+        if (r != c->k.rank && !c->shared_peer[slot][r])
+            {
+            hipIpcMemHandle_t h;
+            std::memcpy(&h, (const char *)handles + (size_t)r * MTD_COMM_HANDLE_BYTES, sizeof(h));
+            void *p = nullptr;
+            hipError_t e = hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess);
+            if (e != hipSuccess)
+                {
+                (void)hipGetLastError();
+                return (int)e;
+                }
+            c->shared_peer[slot][r] = p;
+            }
+        peers[r] = c->shared_peer[slot][r];
+        }
+    return MTD_SUCCESS;
+    }
+
 int mtd_comm_allreduce_small(mtd_comm *c, double *d_values, unsigned int n, mtd_stream_t stream)
     {
     if (!c || !d_values || n == 0 || n > c->max_doubles) return MTD_ERR_INVALID_ARGUMENT;
@@ -195,6 +254,12 @@ int mtd_comm_destroy(mtd_comm *c)
     (void)hipDeviceSynchronize();
     for (unsigned int r = 0; r < c->k.world; ++r)
         if (r != c->k.rank && c->k.box[r]) (void)hipIpcCloseMemHandle(c->k.box[r]);
+    for (unsigned int s = 0; s < c->n_shared; ++s)
+        {
+        for (unsigned int r = 0; r < c->k.world; ++r)
+            if (r != c->k.rank && c->shared_peer[s][r]) (void)hipIpcCloseMemHandle(c->shared_peer[s][r]);
+        if (c->shared_local[s]) (void)hipFree(c->shared_local[s]);
+        }
     if (c->k.err) (void)hipFree(c->k.err);
     if (c->local) (void)hipFree(c->local);
     delete c;

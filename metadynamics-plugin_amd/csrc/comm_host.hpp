@@ -17,6 +17,10 @@ struct mtd_comm
     unsigned int max_doubles;
     unsigned int seq;           // number of the last exchange started (0: none yet)
     int connected;
+    // bulk buffers shared with the peers (mtd_comm_share / mtd_comm_open: the slab-decomposed mesh): released with the comm
+    void *shared_local[MTD_COMM_MAX_SHARED];
+    void *shared_peer[MTD_COMM_MAX_SHARED][MTD_COMM_MAX_RANKS];
+    unsigned int n_shared;
     };
 
 namespace mtd

@@ -32,6 +32,7 @@
 // 1e-6 on it.  Mesh sizes: 4 ... 256 per axis (any, direct transform in LDS for lengths that are not powers of two), or a
 // power of two up to 1024 (radix-2 stages); other sizes return MTD_ERR_UNSUPPORTED.
 #include "mtd_device.hpp"
+#include "comm_host.hpp"
 
 #include <algorithm>
 #include <cmath>
@@ -1106,18 +1107,29 @@ __global__ void k_interp_tables(const unsigned int nx, const unsigned int ny, co
     itab[i] = tsc_fourier(kH);
     }
 
+// Slab decomposition (SlabArgs::world > 1): the z lines of this rank's y rows [y0, y0 + ny_loc) are read
+// straight out of the peers' exported slabs (element z lives on rank z / nz_loc: the all-to-all of a distributed FFT as
+// remote loads of `tile`-wide segments, no transpose buffer), G leaves in pencil layout [z][y_loc][x] for the peers to pull.
+struct SlabArgs
+    {
+    const double2 *f[MTD_COMM_MAX_RANKS];      // exported slabs after the x and y passes, [z_loc][y][hxp]
+    unsigned int world, nz_loc, ny_loc, y0;
+    };
+
+template<bool DIST>
 __global__ __launch_bounds__(FFT_THREADS) void k_fft_z_spectral(const MeshGeom g, double2 *__restrict__ fmesh, double2 *__restrict__ gmesh,
                                                                 const double2 *__restrict__ twiddle, const unsigned int log2n,
                                                                 const unsigned int tile, const unsigned int tiles_per_row,
                                                                 const double *__restrict__ mode_sq, const double n_global,
-                                                                const double *__restrict__ itab, double *__restrict__ cv_partials)
+                                                                const double *__restrict__ itab, double *__restrict__ cv_partials,
+                                                                const SlabArgs sl)
     {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ double s_red[16];
     double2 *s = (double2 *)smem;
     const unsigned int n = g.nz;
     const unsigned int plane = g.hxp * g.ny;                             // half-spectrum arrays: rows of pitch hxp
-    const unsigned int wy = blockIdx.x / tiles_per_row;                  // row = y index
+    const unsigned int wy = (DIST ? sl.y0 : 0u) + blockIdx.x / tiles_per_row;   // row = y index (global)
     const unsigned int x_first = (blockIdx.x % tiles_per_row) * tile;
     const size_t base = (size_t)wy * g.hxp + x_first;
     const unsigned int total = n * tile;
@@ -1126,7 +1138,13 @@ __global__ __launch_bounds__(FFT_THREADS) void k_fft_z_spectral(const MeshGeom g
     for (unsigned int idx = threadIdx.x; idx < total; idx += FFT_THREADS)
         {
         const unsigned int p = idx >> ilog2_dev(tile), t = idx & (tile - 1);
-        s[lds_slot(p, log2n) * tile + t] = fmesh[base + t + (size_t)p * plane];
+        if (DIST)
+            {
+            const unsigned int q = p / sl.nz_loc, zl = p - q * sl.nz_loc;
+            s[lds_slot(p, log2n) * tile + t] = sl.f[q][base + t + (size_t)zl * plane];
+            }
+        else
+            s[lds_slot(p, log2n) * tile + t] = fmesh[base + t + (size_t)p * plane];
         }
     __syncthreads();
     double2 *const s_first = s;
@@ -1151,7 +1169,7 @@ __global__ __launch_bounds__(FFT_THREADS) void k_fft_z_spectral(const MeshGeom g
         if (wx > nxh)                                                  // padding column of the half-spectrum rows
             {
             s[p * tile + t] = make_double2(0.0, 0.0);
-            fmesh[base + t + (size_t)p * plane] = make_double2(0.0, 0.0);
+            if (!DIST) fmesh[base + t + (size_t)p * plane] = make_double2(0.0, 0.0);
             continue;
             }
         const double I = itab[wx] * itab[g.nx + wy] * itab[g.nx + g.ny + p];
@@ -1165,7 +1183,7 @@ __global__ __launch_bounds__(FFT_THREADS) void k_fft_z_spectral(const MeshGeom g
         double2 G = make_double2(f.x * val, f.y * val);
         G.x -= f.x * diagonal_term;
         G.y -= f.y * diagonal_term;
-        fmesh[base + t + (size_t)p * plane] = f;
+        if (!DIST) fmesh[base + t + (size_t)p * plane] = f;       // (slab runs keep no normalised f: log quantities need one rank)
         s[p * tile + t] = G;
         if (wx != 0 || wy != 0 || p != 0)                              // exclude the DC bin (:889-894)
             {
@@ -1189,10 +1207,61 @@ __global__ __launch_bounds__(FFT_THREADS) void k_fft_z_spectral(const MeshGeom g
         {
         const unsigned int q = idx >> log2tile, t = idx & (tile - 1);  // LDS slot q holds position z = bitrev(q) (radix-2 path)
         const unsigned int z = lds_slot(q, log2n);
-        gmesh[base + t + (size_t)z * plane] = s[q * tile + t];
+        if (DIST)
+            gmesh[((size_t)z * sl.ny_loc + (wy - sl.y0)) * g.hxp + x_first + t] = s[q * tile + t];
+        else
+            gmesh[base + t + (size_t)z * plane] = s[q * tile + t];
         }
     term = block_sum(term, s_red);
     if (threadIdx.x == 0) cv_partials[blockIdx.x] = term;
+    }
+
+// ---- slab decomposition: the pulls between the local transform passes --------------------------------------------
+struct PeerPtrs { const void *p[MTD_COMM_MAX_RANKS]; };
+
+// this rank's slab of the mesh = sum over ranks (rank order) of their local assignments
+__global__ __launch_bounds__(256) void k_slab_pull_rho(const PeerPtrs peers, const unsigned int world, const size_t first, const size_t n,
+                                                       double *__restrict__ out)
+    {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        {
+        double v = 0.0;
+        for (unsigned int q = 0; q < world; ++q) v += ((const double *)peers.p[q])[first + i];
+        out[i] = v;
+        }
+    }
+
+// this rank's z slab of G, all y rows: row y comes out of the pencil block of rank y / ny_loc
+__global__ __launch_bounds__(256) void k_slab_pull_g(const PeerPtrs peers, const unsigned int z0, const unsigned int nz_loc,
+                                                     const unsigned int ny, const unsigned int ny_loc, const unsigned int hxp,
+                                                     double2 *__restrict__ out)
+    {
+    const size_t n = (size_t)nz_loc * ny * hxp;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        {
+        const unsigned int x = (unsigned int)(i % hxp);
+        const size_t row = i / hxp;
+        const unsigned int y = (unsigned int)(row % ny), zl = (unsigned int)(row / ny);
+        const unsigned int q = y / ny_loc;
+        out[i] = ((const double2 *)peers.p[q])[((size_t)(z0 + zl) * ny_loc + (y - q * ny_loc)) * hxp + x];
+        }
+    }
+
+// the whole Re(inv) from the slabs of all ranks
+__global__ __launch_bounds__(256) void k_slab_pull_inv(const PeerPtrs peers, const unsigned int world, const size_t slab_cells,
+                                                       double *__restrict__ out)
+    {
+    const size_t n = slab_cells * world;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        {
+        const unsigned int q = (unsigned int)(i / slab_cells);
+        out[i] = ((const double *)peers.p[q])[i - (size_t)q * slab_cells];
+        }
+    }
+
+__global__ void k_copy_doubles(const double *__restrict__ in, double *__restrict__ out, const size_t n)
+    {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) out[i] = in[i];
     }
 
 // ---- 9. forces --------------------------------------------------------------------------------------
@@ -1417,6 +1486,12 @@ struct mtd_mesh
     uint4 *d_tsrc;             // per-axis table of the tile-buffer offsets that stand for a mesh coordinate (k_tile_combine)
     unsigned int *d_ids;
     double amax;               // max |mode coefficient| (fixed-point scale)
+    // slab decomposition over the ranks of a mailbox (mtd_mesh_slab_attach): exported buffers of every rank as mapped here
+    struct mtd_comm *slab_comm;
+    unsigned int slab_world, slab_rank;
+    const void *slab_rho[MTD_COMM_MAX_RANKS], *slab_f[MTD_COMM_MAX_RANKS], *slab_g[MTD_COMM_MAX_RANKS], *slab_inv[MTD_COMM_MAX_RANKS];
+    double *d_slab_rho;        // this rank's reduced slab (device memory of its own)
+    double *d_slab_sum;        // [0] CV integrand of this rank's pencils -> sum over ranks, [1] barrier token
     };
 
 namespace
@@ -1620,6 +1695,8 @@ int mtd_mesh_create(mtd_mesh **out, unsigned int nx, unsigned int ny, unsigned i
 int mtd_mesh_destroy(mtd_mesh *m)
     {
     if (!m) return MTD_SUCCESS;
+    if (m->d_slab_rho) (void)hipFree(m->d_slab_rho);
+    if (m->d_slab_sum) (void)hipFree(m->d_slab_sum);
     if (m->d_table) (void)hipFree(m->d_table);
     if (m->d_log_scratch) (void)hipFree(m->d_log_scratch);
     hipError_t e = hipFree(m->slab);
@@ -1637,7 +1714,14 @@ int mtd_mesh_set_bug_compat(mtd_mesh *m, int on)
     return MTD_SUCCESS;
     }
 
+static int mesh_assign_local(mtd_mesh *m, unsigned int n_particles, const void *d_postype, int dtype, const mtd_box *box, mtd_stream_t stream);
+
 int mtd_mesh_assign(mtd_mesh *m, unsigned int n_particles, const void *d_postype, int dtype, const mtd_box *box, mtd_stream_t stream)
+    {
+    return mesh_assign_local(m, n_particles, d_postype, dtype, box, stream);
+    }
+
+static int mesh_assign_local(mtd_mesh *m, unsigned int n_particles, const void *d_postype, int dtype, const mtd_box *box, mtd_stream_t stream)
     {
     if (!m || (n_particles && !d_postype)) return MTD_ERR_INVALID_ARGUMENT;
     if (dtype != MTD_F32 && dtype != MTD_F64) return MTD_ERR_INVALID_ARGUMENT;
@@ -1753,8 +1837,10 @@ int mtd_mesh_spectral(mtd_mesh *m, const mtd_box *box, unsigned int n_global, co
     rc = launch_fft_y(m, m->d_f, 0, s);
     if (rc) return rc;
     const FftPass pz = fft_z_pass(m);
-    k_fft_z_spectral<<<pz.n_blocks, FFT_THREADS, fft_lds_bytes(pz.n, pz.tile), s>>>(
-        g, m->d_f, m->d_g, pz.tw, ilog2(pz.n), pz.tile, pz.tiles_per_row, m->d_mode_sq, (double)n_global, m->d_itab, m->d_cv_partials);
+    SlabArgs none;
+    std::memset(&none, 0, sizeof(none));
+    k_fft_z_spectral<false><<<pz.n_blocks, FFT_THREADS, fft_lds_bytes(pz.n, pz.tile), s>>>(
+        g, m->d_f, m->d_g, pz.tw, ilog2(pz.n), pz.tile, pz.tiles_per_row, m->d_mode_sq, (double)n_global, m->d_itab, m->d_cv_partials, none);
     MTD_LAUNCH_CHECK();
     rc = launch_fft_y(m, m->d_g, 1, s);
     if (rc) return rc;
@@ -1803,6 +1889,120 @@ int mtd_mesh_forces(mtd_mesh *m, unsigned int n_particles, const void *d_postype
     else
         k_mesh_forces<double4><<<blocks, 256, 0, s>>>(g, n_particles, m->d_idcell, m->d_packed, m->d_inv, (double4 *)d_force, d_bias, bias_host, two_over_n);
     MTD_LAUNCH_CHECK();
+    return MTD_SUCCESS;
+    }
+
+// ---- slab-decomposed mesh (replaces the ghost-cell exchange + dfftlib calls of OrderParameterMesh.cc:263-316, 659-746)
+int mtd_mesh_slab_bytes(const mtd_mesh *m, unsigned int world, size_t *bytes)
+    {
+    if (!m || !bytes || world == 0 || world > MTD_COMM_MAX_RANKS) return MTD_ERR_INVALID_ARGUMENT;
+    if (m->nz % world || m->ny % world) return MTD_ERR_UNSUPPORTED;
+    bytes[0] = sizeof(double) * (size_t)m->M;                                          // local assignment, whole mesh
+    bytes[1] = sizeof(double2) * (size_t)(m->nz / world) * m->ny * m->hxp;             // slab after the x and y passes
+    bytes[2] = sizeof(double2) * (size_t)m->nz * (m->ny / world) * m->hxp;             // pencils after the inverse z pass
+    bytes[3] = sizeof(double) * (size_t)(m->nz / world) * m->ny * m->nx;               // slab of Re(inv)
+    return MTD_SUCCESS;
+    }
+
+int mtd_mesh_slab_attach(mtd_mesh *m, mtd_comm *comm, void *const *rho_peers, void *const *f_peers, void *const *g_peers,
+                         void *const *inv_peers)
+    {
+    if (!m || !comm || !rho_peers || !f_peers || !g_peers || !inv_peers) return MTD_ERR_INVALID_ARGUMENT;
+    const unsigned int world = mtd_comm_world(comm);
+    if (m->nz % world || m->ny % world || !m->tile_path) return MTD_ERR_UNSUPPORTED;
+    m->slab_comm = comm;
+    m->slab_world = world;
+    m->slab_rank = mtd_comm_rank(comm);
+    for (unsigned int r = 0; r < world; ++r)
+        {
+        if (!rho_peers[r] || !f_peers[r] || !g_peers[r] || !inv_peers[r]) return MTD_ERR_INVALID_ARGUMENT;
+        m->slab_rho[r] = rho_peers[r]; m->slab_f[r] = f_peers[r]; m->slab_g[r] = g_peers[r]; m->slab_inv[r] = inv_peers[r];
+        }
+    if (!m->d_slab_rho) MTD_HIP_TRY(hipMalloc((void **)&m->d_slab_rho, sizeof(double) * (size_t)(m->nz / world) * m->ny * m->nx));
+    if (!m->d_slab_sum)
+        {
+        MTD_HIP_TRY(hipMalloc((void **)&m->d_slab_sum, sizeof(double) * 2));
+        MTD_HIP_TRY(hipMemset(m->d_slab_sum, 0, sizeof(double) * 2));
+        }
+    return MTD_SUCCESS;
+    }
+
+// One call per step and rank; four exchanges (bounded waits of the mailbox) separate the phases:
+//   local assignment -> [all ranks assigned] -> pull + sum this rank's slab, x and y transforms -> [all slabs transformed;
+//   carries sum mode^2] -> z lines gathered from all slabs, spectral step, inverse z -> [all pencils done; carries the CV
+//   sum] -> pull this rank's slab of G, inverse y and x -> [all slabs of Re(inv) done] -> pull the whole Re(inv)
+// *d_cv_sum (device) = sum over ranks of the CV integrand (the CV is half of it, as for mtd_mesh_compute_cv's partial sums).
+int mtd_mesh_slab_compute_cv(mtd_mesh *m, unsigned int n_particles, const void *d_postype, int dtype, const mtd_box *box,
+                             unsigned int n_global, const double **d_cv_sum, mtd_stream_t stream)
+    {
+    if (!m || !m->slab_comm || !d_cv_sum || n_global == 0) return MTD_ERR_INVALID_ARGUMENT;
+    MeshGeom g;
+    int rc = fill_geom(g, m, box);
+    if (rc) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    const unsigned int W = m->slab_world, r = m->slab_rank, nzl = m->nz / W, nyl = m->ny / W;
+    const size_t slab_cells = (size_t)nzl * m->ny * m->nx;
+    double *rho_x = (double *)m->slab_rho[r];
+    double2 *f_x = (double2 *)m->slab_f[r], *g_x = (double2 *)m->slab_g[r];
+    double *inv_x = (double *)m->slab_inv[r];
+    PeerPtrs pp;
+    auto peers_of = [&](const void *const *src) { std::memset(&pp, 0, sizeof(pp)); for (unsigned int q = 0; q < W; ++q) pp.p[q] = src[q]; };
+
+    // 1. local assignment of this rank's particles onto the whole mesh, exported
+    rc = mesh_assign_local(m, n_particles, d_postype, dtype, box, stream);
+    if (rc) return rc;
+    k_copy_doubles<<<1024, 256, 0, s>>>(m->d_rho, rho_x, (size_t)m->M);
+    MTD_LAUNCH_CHECK();
+    rc = mtd_comm_allreduce_small(m->slab_comm, m->d_slab_sum + 1, 1, stream);                 // barrier
+    if (rc) return rc;
+    // 2. this rank's slab, x and y transforms in the exported buffer
+    peers_of(m->slab_rho);
+    k_slab_pull_rho<<<1024, 256, 0, s>>>(pp, W, (size_t)r * slab_cells, slab_cells, m->d_slab_rho);
+    MTD_LAUNCH_CHECK();
+    const unsigned int n_lines = m->ny * nzl;
+    unsigned int x_pairs = 16;
+    while (x_pairs > 1 && fft_lds_bytes(m->nx, x_pairs) > 64 * 1024) x_pairs >>= 1;
+    const unsigned int x_tile = 2 * x_pairs, x_blocks = (n_lines + x_tile - 1) / x_tile;
+    const size_t x_lds = fft_lds_bytes(m->nx, x_pairs);
+    k_fft_x_r2c<<<x_blocks, FFT_THREADS, x_lds, s>>>(m->d_slab_rho, f_x, m->d_tw[0], m->nx, ilog2(m->nx), x_tile, m->hxp, n_lines);
+    MTD_LAUNCH_CHECK();
+    FftPass py = fft_y_pass(m);
+    py.n_blocks = py.tiles_per_row * nzl;
+    k_fft_lines<false, false><<<py.n_blocks, FFT_THREADS, fft_lds_bytes(py.n, py.tile), s>>>(
+        nullptr, f_x, nullptr, py.tw, py.n, ilog2(py.n), py.tile, py.elem_stride, py.line_stride, py.tiles_per_row, py.row_stride, 0, py.p_fastest);
+    MTD_LAUNCH_CHECK();
+    rc = mtd_comm_allreduce_small(m->slab_comm, m->d_mode_sq, 1, stream);                       // barrier + global sum mode^2 (:630)
+    if (rc) return rc;
+    // 3. z lines of this rank's y rows from all slabs, spectral step, inverse z: pencils exported
+    const FftPass pz = fft_z_pass(m);
+    SlabArgs sl;
+    std::memset(&sl, 0, sizeof(sl));
+    for (unsigned int q = 0; q < W; ++q) sl.f[q] = (const double2 *)m->slab_f[q];
+    sl.world = W; sl.nz_loc = nzl; sl.ny_loc = nyl; sl.y0 = r * nyl;
+    const unsigned int z_blocks = pz.tiles_per_row * nyl;
+    k_fft_z_spectral<true><<<z_blocks, FFT_THREADS, fft_lds_bytes(pz.n, pz.tile), s>>>(
+        g, nullptr, g_x, pz.tw, ilog2(pz.n), pz.tile, pz.tiles_per_row, m->d_mode_sq, (double)n_global, m->d_itab, m->d_cv_partials, sl);
+    MTD_LAUNCH_CHECK();
+    rc = mtd_reduce_partials(m->d_cv_partials, z_blocks, 1, 1, 1.0, 0.0, m->d_slab_sum, stream);
+    if (rc) return rc;
+    rc = mtd_comm_allreduce_small(m->slab_comm, m->d_slab_sum, 1, stream);                      // barrier + CV sum
+    if (rc) return rc;
+    // 4. this rank's slab of G from the pencils, inverse y and x: slab of Re(inv) exported
+    peers_of(m->slab_g);
+    k_slab_pull_g<<<1024, 256, 0, s>>>(pp, r * nzl, nzl, m->ny, nyl, m->hxp, m->d_g);
+    MTD_LAUNCH_CHECK();
+    k_fft_lines<false, false><<<py.n_blocks, FFT_THREADS, fft_lds_bytes(py.n, py.tile), s>>>(
+        nullptr, m->d_g, nullptr, py.tw, py.n, ilog2(py.n), py.tile, py.elem_stride, py.line_stride, py.tiles_per_row, py.row_stride, 1, py.p_fastest);
+    MTD_LAUNCH_CHECK();
+    k_fft_x_c2r<<<x_blocks, FFT_THREADS, x_lds, s>>>(m->d_g, inv_x, m->d_tw[0], m->nx, ilog2(m->nx), x_tile, m->hxp, n_lines);
+    MTD_LAUNCH_CHECK();
+    rc = mtd_comm_allreduce_small(m->slab_comm, m->d_slab_sum + 1, 1, stream);                 // barrier
+    if (rc) return rc;
+    // 5. the whole Re(inv) for the local force pass
+    peers_of(m->slab_inv);
+    k_slab_pull_inv<<<1024, 256, 0, s>>>(pp, W, slab_cells, m->d_inv);
+    MTD_LAUNCH_CHECK();
+    *d_cv_sum = m->d_slab_sum;
     return MTD_SUCCESS;
     }
 

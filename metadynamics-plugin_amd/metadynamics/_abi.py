@@ -135,6 +135,8 @@ _SIGNATURES = {
     "mtd_comm_connect": (C.c_int, [_vp, _vp]),
     "mtd_comm_allreduce_small": (C.c_int, [_vp, _vp, C.c_uint, _vp]),
     "mtd_comm_status": (C.c_int, [_vp, _up, _vp]),
+    "mtd_comm_share": (C.c_int, [_vp, C.c_size_t, C.POINTER(_vp), _up, _vp]),
+    "mtd_comm_open": (C.c_int, [_vp, C.c_uint, _vp, C.POINTER(_vp)]),
     "mtd_comm_world": (C.c_uint, [_vp]),
     "mtd_comm_rank": (C.c_uint, [_vp]),
     "mtd_comm_destroy": (C.c_int, [_vp]),
@@ -152,6 +154,9 @@ _SIGNATURES = {
     "mtd_mesh_spectral": (C.c_int, [_vp, C.POINTER(Box), C.c_uint, C.POINTER(_vp), _up, _vp]),
     "mtd_mesh_compute_cv": (C.c_int, [_vp, C.c_uint, _vp, C.c_int, C.POINTER(Box), C.c_uint, C.POINTER(_vp), _up, _vp]),
     "mtd_mesh_forces": (C.c_int, [_vp, C.c_uint, _vp, _vp, C.c_int, C.POINTER(Box), C.c_uint, _vp, C.c_double, _vp]),
+    "mtd_mesh_slab_bytes": (C.c_int, [_vp, C.c_uint, C.POINTER(C.c_size_t)]),
+    "mtd_mesh_slab_attach": (C.c_int, [_vp, _vp, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp)]),
+    "mtd_mesh_slab_compute_cv": (C.c_int, [_vp, C.c_uint, _vp, C.c_int, C.POINTER(Box), C.c_uint, C.POINTER(_vp), _vp]),
     "mtd_mesh_get_array": (C.c_int, [_vp, C.c_int, _vp, _vp]),
     "mtd_ql_scratch_doubles": (C.c_size_t, [C.c_uint]),
     "mtd_ql_accumulate_local": (C.c_int, [C.c_uint, _vp, C.c_int, C.POINTER(Box), _vp, _vp, _vp, C.c_int, C.c_double, C.c_double,

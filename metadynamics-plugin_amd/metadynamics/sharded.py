@@ -47,6 +47,8 @@ class ShardedBiasStep:
             # A CV set hands over one buffer per collective variable (n_cv doubles for lamellar sums, the real mesh,
             # the Q_lm sums, one energy): one all-reduce each, in the order of the CVs.
             for buf in (sums if isinstance(sums, (list, tuple)) else [sums]):
+                if buf is None:
+                    continue                    # the part exchanged what it needed itself (MeshSlabPart)
                 if self.small is not None and buf.numel() <= self.small_max and str(buf.dtype).endswith("float64"):
                     self.small.all_reduce(buf)
                 else:
@@ -157,6 +159,33 @@ class MeshPart:
     def forces(self, d_bias):
         self._abi.check(self.lib.mtd_mesh_forces(self.h, self.N, self.d_pos.data_ptr(), self.force.data_ptr(), self.dt,
                                                  C.byref(self.box), self.N_global, d_bias, 0.0, None))
+
+
+class MeshSlabPart(MeshPart):
+    """cv.mesh with the mesh DECOMPOSED over the ranks of an xGMI mailbox instead of replicated: z slabs
+    for the x / y transforms, y rows for the z transform, the transposes as remote loads out of exported buffers
+    (``mtd_mesh_slab_*``).  nz and ny must be multiples of the number of ranks.  The whole forward / spectral / inverse
+    sequence, its four barriers included, runs inside ``local_pass``; there is nothing left for the caller to all-reduce."""
+
+    def __init__(self, nx, ny, nz, mode, d_postype, n_global, box_L, mailbox, dist, bug_compat=True):
+        super().__init__(nx, ny, nz, mode, d_postype, n_global, box_L, bug_compat=bug_compat)
+        self.box_mail = mailbox
+        sizes = (C.c_size_t * 4)()
+        self._abi.check(self.lib.mtd_mesh_slab_bytes(self.h, mailbox.world, sizes))
+        peers = []
+        for k in range(4):
+            _, addr = mailbox.share(dist, sizes[k])
+            peers.append((C.c_void_p * mailbox.world)(*addr))
+        self._abi.check(self.lib.mtd_mesh_slab_attach(self.h, mailbox.handle, peers[0], peers[1], peers[2], peers[3]))
+        self.cv_sum = C.c_void_p()
+
+    def local_pass(self):
+        self._abi.check(self.lib.mtd_mesh_slab_compute_cv(self.h, self.N, self.d_pos.data_ptr(), self.dt, C.byref(self.box),
+                                                          self.N_global, C.byref(self.cv_sum), None))
+        return None
+
+    def finish(self, engine, slot):
+        self._abi.check(self.lib.mtd_metad_set_cv_source(engine, slot, self.cv_sum.value, 1, 1, 0, 0.5, 0.0))
 
 
 class SteinhardtPart:

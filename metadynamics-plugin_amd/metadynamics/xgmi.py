@@ -24,6 +24,27 @@ class Mailbox:
         self._abi.check(self.lib.mtd_comm_allreduce_small(self.handle, tensor.data_ptr(), int(tensor.numel()), None))
         return tensor
 
+    def barrier(self):
+        """all ranks' earlier work on the null stream is complete (and visible in their shared buffers) before anything
+        enqueued after this call runs: a one-double exchange"""
+        if getattr(self, "_token", None) is None:
+            import torch
+            self._token = torch.zeros(1, dtype=torch.float64, device="cuda")
+        self.all_reduce(self._token)
+
+    def share(self, dist, nbytes):
+        """a buffer of ``nbytes`` on every rank that all ranks can read: returns (local address, [address of rank r's
+        buffer as mapped here]); collective over ``dist``"""
+        import torch
+        dev = _control_device(dist)
+        local, slot, h = C.c_void_p(), C.c_uint(), (C.c_ubyte * 64)()
+        self._abi.check(self.lib.mtd_comm_share(self.handle, int(nbytes), C.byref(local), C.byref(slot), h))
+        handles = torch.empty(self.world * 64, dtype=torch.uint8, device=dev)
+        dist.all_gather_into_tensor(handles, torch.frombuffer(bytearray(bytes(h)), dtype=torch.uint8).to(dev))
+        peers = (C.c_void_p * self.world)()
+        self._abi.check(self.lib.mtd_comm_open(self.handle, slot.value, handles.cpu().numpy().tobytes(), peers))
+        return local.value, [peers[r] for r in range(self.world)]
+
     def timeouts(self):
         n = C.c_uint()
         self._abi.check(self.lib.mtd_comm_status(self.handle, C.byref(n), None))

@@ -144,6 +144,60 @@ def main():
         out["set_energy_cv"] = [set_states[-1]["cv"][1], e_tot]
         out["set_force_err"] = float((f_loc.cpu() - f_all.cpu()[sl]).abs().max() / f_all.cpu().abs().max())
         one_set.close()
+    # ---- the mesh CV with the mesh decomposed into slabs over the ranks (mtd_mesh_slab_*), against one rank holding all
+    #      particles and the whole mesh; nz = ny = 24 divides by 2, 3 and 4 (direct transforms), 32 by 2 and 4 (radix-4)
+    slab = {}
+    for dims in [(16, 24, 24)] + ([(32, 32, 32)] if world in (2, 4) else []):
+        mode = [1.0, -0.7]
+        dpos = torch.from_numpy(util.pack_postype(pos[sl].copy(), types[sl].copy(), np.float32)).cuda()
+        part = sharded.MeshSlabPart(dims[0], dims[1], dims[2], mode, dpos, n_global, L, box, dist)
+        lam = sharded.LamellarPart(util.CV1_VECTORS, util.MODE_AB, dpos, n_global, L)
+        one_part = None
+        if rank == 0:
+            d_all = torch.from_numpy(util.pack_postype(pos, types, np.float32)).cuda()
+            one_part = sharded.MeshPart(dims[0], dims[1], dims[2], mode, d_all, n_global, L)
+            one_part.local_pass()
+            probe = sharded.HipCvSetBackend([one_part], dict(sigma=[1.0], cv_min=[-1.0], cv_max=[1.0], num_points=[8]), **KW)
+            probe.force_pass(None, 0)
+            s_one = probe.state()["cv"][0]
+        else:
+            s_one = 0.0
+        t = torch.tensor([s_one], dtype=torch.float64)
+        dist.broadcast(t, 0)
+        s_one = float(t.item())
+        grid3 = dict(sigma=[0.02, 0.05 * abs(s_one)], cv_min=[-1.0, 0.25 * s_one], cv_max=[1.0, 1.75 * s_one], num_points=[40, 30])
+        bs = sharded.HipCvSetBackend([lam, part], grid3, **KW)
+        st_step = ShardedBiasStep(bs, dist, mailbox=box)
+        for t_ in range(3):
+            st_step.step(t_)
+        torch.cuda.synchronize()
+        st_slab = bs.state()
+        # the particles do not move, so every hill lands on the same point and dV/ds there is ~0: the force comparison
+        # takes a bias factor of one instead
+        unit_bias = torch.ones(1, dtype=torch.float64, device="cuda")
+        part.forces(unit_bias.data_ptr())
+        torch.cuda.synchronize()
+        key = "x".join(str(d) for d in dims)
+        slab[key] = dict(timeouts=box.timeouts())
+        if rank == 0:
+            lam1 = sharded.LamellarPart(util.CV1_VECTORS, util.MODE_AB, d_all, n_global, L)
+            one2 = sharded.MeshPart(dims[0], dims[1], dims[2], mode, d_all, n_global, L)
+            b1 = sharded.HipCvSetBackend([lam1, one2], grid3, **KW)
+            for t_ in range(3):
+                b1.force_pass(b1.cv_pass(), t_)
+            one2.forces(unit_bias.data_ptr())
+            torch.cuda.synchronize()
+            st1 = b1.state()
+            f_slab, f_one = part.force.cpu().numpy(), one2.force.cpu().numpy()
+            slab[key].update(cv=[st_slab["cv"][1], st1["cv"][1]],
+                             cv_rel=abs(st_slab["cv"][1] - st1["cv"][1]) / abs(st1["cv"][1]),
+                             force_rel=float(np.abs(f_slab[:, :3] - f_one[sl, :3]).max() / np.abs(f_one[:, :3]).max()),
+                             force_max=float(np.abs(f_one[:, :3]).max()))
+            b1.close()
+            probe.close()
+        dist.barrier()
+        bs.close()
+    out["slab"] = slab
     dist.barrier()
     cs.close()
     be.close()

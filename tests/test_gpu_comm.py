@@ -113,6 +113,12 @@ def test_mailbox_between_processes(world):
     assert r["errs"]["cv"] < 1e-6 and r["errs"]["V"] < 1e-5 and r["errs"]["w"] < 1e-5
     assert r["errs"]["bias"] < 1e-5
     assert r["force_rel_err"] < 1e-5
+    # mesh CV with the mesh decomposed into slabs over the ranks, against the whole mesh on one rank
+    for key, v in r["slab"].items():
+        assert v["timeouts"] == 0, key
+        assert v["cv_rel"] < 1e-9, (key, v)
+        assert v["force_rel"] < 1e-7 and v["force_max"] > 1e-12, (key, v)
+    assert "16x24x24" in r["slab"]
     # generic CV set through the stand-alone mailbox all-reduce
     assert r["timeouts_set"] == 0
     assert r["set_errs"]["cv"] < 1e-6 and r["set_errs"]["bias"] < 1e-5
