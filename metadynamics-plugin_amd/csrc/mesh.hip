@@ -805,8 +805,10 @@ __device__ __forceinline__ double2 cadd(const double2 a, const double2 b) { retu
 __device__ __forceinline__ double2 csub(const double2 a, const double2 b) { return make_double2(a.x - b.x, a.y - b.y); }
 
 // decimation in time: bit-reversed order in, natural order out; forward (inverse = 0) or inverse sign
+// `stride`: elements between consecutive positions of a line in LDS (the tile, or tile + 1 where a kernel also walks the
+// image along the positions — the x passes — and an odd stride keeps those walks off one bank group)
 __device__ __forceinline__ void fft_dit_pow2(double2 *s, const double2 *__restrict__ twiddle, const unsigned int log2n,
-                                             const unsigned int log2tile, const int inverse)
+                                             const unsigned int log2tile, const int inverse, const unsigned int stride)
     {
     const unsigned int n = 1u << log2n, tile = 1u << log2tile, tmask = tile - 1;
     unsigned int log2len = 1;                                    // next stage: len = 2^log2len
@@ -817,9 +819,9 @@ __device__ __forceinline__ void fft_dit_pow2(double2 *s, const double2 *__restri
             {
             const unsigned int t = idx & tmask, bf = idx >> log2tile;
             const unsigned int i0 = bf << 1;
-            const double2 u = s[(i0 << log2tile) + t], v = s[((i0 + 1) << log2tile) + t];
-            s[(i0 << log2tile) + t] = cadd(u, v);
-            s[((i0 + 1) << log2tile) + t] = csub(u, v);
+            const double2 u = s[i0 * stride + t], v = s[(i0 + 1) * stride + t];
+            s[i0 * stride + t] = cadd(u, v);
+            s[(i0 + 1) * stride + t] = csub(u, v);
             }
         __syncthreads();
         log2len = 2;
@@ -840,8 +842,8 @@ __device__ __forceinline__ void fft_dit_pow2(double2 *s, const double2 *__restri
                 w1.y = -w1.y;
                 w2.y = -w2.y;
                 }
-            double2 *pa = s + (ia << log2tile) + t;
-            const unsigned int sh = half << log2tile;
+            double2 *pa = s + ia * stride + t;
+            const unsigned int sh = half * stride;
             const double2 a = pa[0], b = cmul(pa[sh], w1), c = pa[2 * sh], d = cmul(pa[3 * sh], w1);
             const double2 a1 = cadd(a, b), b1 = csub(a, b), c1 = cmul(cadd(c, d), w2), d1 = cmul(csub(c, d), w2);
             // second stage: (a1, c1) with w2 and (b1, d1) with w2 * exp(-+ i pi / 2) = -+ i w2
@@ -950,7 +952,7 @@ __global__ __launch_bounds__(FFT_THREADS) void k_fft_lines(const double *__restr
         dft_direct(s, s + total, twiddle, n, tile, inverse);
         s += total;                                              // the result buffer
         }
-    if (log2n) fft_dit_pow2(s, twiddle, log2n, log2tile, inverse);
+    if (log2n) fft_dit_pow2(s, twiddle, log2n, log2tile, inverse, tile);
 
     for (unsigned int idx = threadIdx.x; idx < total; idx += FFT_THREADS)
         {
@@ -1000,11 +1002,12 @@ __device__ __forceinline__ double tsc_fourier(double x)              // :487-511
 // LDS layout [p][tile] as in k_fft_lines; `tile` adjacent x lines per block.
 // radix-2 stages in place, or the direct transform into the second buffer; returns the buffer that holds the result
 __device__ __forceinline__ double2 *lds_transform(double2 *s, const double2 *__restrict__ twiddle, const unsigned int n,
-                                                  const unsigned int log2n, const unsigned int tile, const int inverse)
+                                                  const unsigned int log2n, const unsigned int tile, const int inverse,
+                                                  const unsigned int stride)
     {
     if (log2n)
         {
-        fft_dit_pow2(s, twiddle, log2n, ilog2_dev(tile), inverse);
+        fft_dit_pow2(s, twiddle, log2n, ilog2_dev(tile), inverse, stride);
         return s;
         }
     dft_direct(s, s + n * tile, twiddle, n, tile, inverse);
@@ -1023,19 +1026,23 @@ __global__ __launch_bounds__(FFT_THREADS) void k_fft_x_r2c(const double *__restr
     double2 *s = (double2 *)smem;
     const size_t line0 = (size_t)blockIdx.x * tile;
     const unsigned int pairs = tile / 2;
+    // both loops below walk the LDS image along the positions (consecutive lanes = consecutive p or k, as the coalesced
+    // global access wants): with a row of `pairs` 16-byte slots = 256 B every lane would hit the same banks, so the
+    // power-of-two path pads the row by one slot (fft_x_stride)
+    const unsigned int ps = log2n ? pairs + 1 : pairs;
     for (unsigned int idx = threadIdx.x; idx < n * pairs; idx += FFT_THREADS)
         {
-        const unsigned int u = idx / n, p = idx % n;
+        const unsigned int u = log2n ? idx >> log2n : idx / n, p = log2n ? idx & (n - 1) : idx % n;
         const size_t la = line0 + 2 * u, lb = la + 1;                // lines past the end (odd line counts) are zero
-        s[lds_slot(p, log2n) * pairs + u] = make_double2(la < n_lines ? real_in[la * n + p] : 0.0, lb < n_lines ? real_in[lb * n + p] : 0.0);
+        s[lds_slot(p, log2n) * ps + u] = make_double2(la < n_lines ? real_in[la * n + p] : 0.0, lb < n_lines ? real_in[lb * n + p] : 0.0);
         }
     __syncthreads();
-    s = lds_transform(s, twiddle, n, log2n, pairs, 0);
+    s = lds_transform(s, twiddle, n, log2n, pairs, 0, ps);
     const unsigned int hx = n / 2 + 1;
     for (unsigned int idx = threadIdx.x; idx < hx * pairs; idx += FFT_THREADS)
         {
         const unsigned int u = idx / hx, k = idx % hx;
-        const double2 zk = s[k * pairs + u], zm = s[((n - k) % n) * pairs + u];
+        const double2 zk = s[k * ps + u], zm = s[((n - k) % n) * ps + u];
         if (line0 + 2 * u < n_lines) half_out[(line0 + 2 * u) * hxp + k] = make_double2(0.5 * (zk.x + zm.x), 0.5 * (zk.y - zm.y));
         if (line0 + 2 * u + 1 < n_lines) half_out[(line0 + 2 * u + 1) * hxp + k] = make_double2(0.5 * (zk.y + zm.y), -0.5 * (zk.x - zm.x));
         }
@@ -1052,6 +1059,7 @@ __global__ __launch_bounds__(FFT_THREADS) void k_fft_x_c2r(const double2 *__rest
     double2 *s = (double2 *)smem;
     const size_t line0 = (size_t)blockIdx.x * tile;
     const unsigned int pairs = tile / 2;
+    const unsigned int ps = log2n ? pairs + 1 : pairs;                // padded rows: see k_fft_x_r2c
     const unsigned int hx = n / 2 + 1;
     for (unsigned int idx = threadIdx.x; idx < hx * pairs; idx += FFT_THREADS)
         {
@@ -1059,16 +1067,16 @@ __global__ __launch_bounds__(FFT_THREADS) void k_fft_x_c2r(const double2 *__rest
         const double2 zero = make_double2(0.0, 0.0);
         const double2 A = line0 + 2 * u < n_lines ? half_in[(line0 + 2 * u) * hxp + k] : zero;
         const double2 B = line0 + 2 * u + 1 < n_lines ? half_in[(line0 + 2 * u + 1) * hxp + k] : zero;
-        s[lds_slot(k, log2n) * pairs + u] = make_double2(A.x - B.y, A.y + B.x);                 // A + i B
+        s[lds_slot(k, log2n) * ps + u] = make_double2(A.x - B.y, A.y + B.x);                    // A + i B
         if (k != 0 && 2 * k != n)                                                                 // conj A + i conj B at n - k
-            s[lds_slot(n - k, log2n) * pairs + u] = make_double2(A.x + B.y, -A.y + B.x);
+            s[lds_slot(n - k, log2n) * ps + u] = make_double2(A.x + B.y, -A.y + B.x);
         }
     __syncthreads();
-    s = lds_transform(s, twiddle, n, log2n, pairs, 1);
+    s = lds_transform(s, twiddle, n, log2n, pairs, 1, ps);
     for (unsigned int idx = threadIdx.x; idx < n * pairs; idx += FFT_THREADS)
         {
-        const unsigned int u = idx / n, p = idx % n;
-        const double2 z = s[p * pairs + u];
+        const unsigned int u = log2n ? idx >> log2n : idx / n, p = log2n ? idx & (n - 1) : idx % n;
+        const double2 z = s[p * ps + u];
         if (line0 + 2 * u < n_lines) real_out[(line0 + 2 * u) * n + p] = z.x;
         if (line0 + 2 * u + 1 < n_lines) real_out[(line0 + 2 * u + 1) * n + p] = z.y;
         }
@@ -1154,7 +1162,7 @@ __global__ __launch_bounds__(FFT_THREADS) void k_fft_z_spectral(const MeshGeom g
         s += total;
         }
     const unsigned int log2tile = ilog2_dev(tile);
-    if (log2n) fft_dit_pow2(s, twiddle, log2n, log2tile, 0);          // forward, decimation in time
+    if (log2n) fft_dit_pow2(s, twiddle, log2n, log2tile, 0, tile);    // forward, decimation in time
 
     // spectral step in place: updateMeshes :697-712 + computeCV :896-905 on the stored half of the spectrum.
     // f(-k) = conj f(k), so the cell -k (not stored for 0 < k_x < nx/2) has the same |f|^2 and its own interpolation factor
@@ -1457,6 +1465,8 @@ unsigned int ilog2(unsigned int n)
 
 // dynamic LDS of a line pass: one buffer of n * tile elements, two for the direct transform
 size_t fft_lds_bytes(unsigned int n, unsigned int tile) { return (size_t)n * tile * sizeof(double2) * (is_pow2(n) ? 1 : 2); }
+// x passes: rows padded by one slot on the power-of-two path (k_fft_x_r2c)
+size_t fft_x_lds_bytes(unsigned int n, unsigned int pairs) { return is_pow2(n) ? (size_t)n * (pairs + 1) * sizeof(double2) : fft_lds_bytes(n, pairs); }
 
 } // namespace
 
@@ -1829,9 +1839,9 @@ int mtd_mesh_spectral(mtd_mesh *m, const mtd_box *box, unsigned int n_global, co
     // x passes: two real lines per complex transform, `x_tile` real lines per block (the last block may run short)
     const unsigned int n_lines = m->ny * m->nz;
     unsigned int x_pairs = 16;
-    while (x_pairs > 1 && fft_lds_bytes(m->nx, x_pairs) > 64 * 1024) x_pairs >>= 1;
+    while (x_pairs > 1 && fft_x_lds_bytes(m->nx, x_pairs) > 64 * 1024) x_pairs >>= 1;
     const unsigned int x_tile = 2 * x_pairs, x_blocks = (n_lines + x_tile - 1) / x_tile;
-    const size_t x_lds = fft_lds_bytes(m->nx, x_pairs);
+    const size_t x_lds = fft_x_lds_bytes(m->nx, x_pairs);
     k_fft_x_r2c<<<x_blocks, FFT_THREADS, x_lds, s>>>(m->d_rho, m->d_f, m->d_tw[0], m->nx, ilog2(m->nx), x_tile, m->hxp, n_lines);
     MTD_LAUNCH_CHECK();
     rc = launch_fft_y(m, m->d_f, 0, s);
@@ -1961,9 +1971,9 @@ int mtd_mesh_slab_compute_cv(mtd_mesh *m, unsigned int n_particles, const void *
     MTD_LAUNCH_CHECK();
     const unsigned int n_lines = m->ny * nzl;
     unsigned int x_pairs = 16;
-    while (x_pairs > 1 && fft_lds_bytes(m->nx, x_pairs) > 64 * 1024) x_pairs >>= 1;
+    while (x_pairs > 1 && fft_x_lds_bytes(m->nx, x_pairs) > 64 * 1024) x_pairs >>= 1;
     const unsigned int x_tile = 2 * x_pairs, x_blocks = (n_lines + x_tile - 1) / x_tile;
-    const size_t x_lds = fft_lds_bytes(m->nx, x_pairs);
+    const size_t x_lds = fft_x_lds_bytes(m->nx, x_pairs);
     k_fft_x_r2c<<<x_blocks, FFT_THREADS, x_lds, s>>>(m->d_slab_rho, f_x, m->d_tw[0], m->nx, ilog2(m->nx), x_tile, m->hxp, n_lines);
     MTD_LAUNCH_CHECK();
     FftPass py = fft_y_pass(m);
