@@ -80,3 +80,46 @@ def test_boxdim_host_maths(mod, ref):
     assert p.dtype == np.float32 and p.view(np.int32)[0, 3] == 5
     p = mod.pack_postype(np.array([[1.0, 2.0, 3.0]]), np.array([7], dtype=np.int32), mod.MTD_F64)
     assert p.dtype == np.float64 and p.view(np.int32)[0, 6] == 7       # low word of w
+
+
+def test_sharded_step_routes_buffers_between_mailbox_and_collective():
+    """ShardedBiasStep: float64 buffers up to mailbox_max elements go through the xGMI mailbox, larger ones (the replicated
+    mesh) and other dtypes through the process group, None (a part that exchanged for itself: MeshSlabPart) is skipped;
+    a backend with a mailbox attached runs its own two-launch step"""
+    torch = pytest.importorskip("torch")
+    from metadynamics.sharded import ShardedBiasStep
+
+    class Rec:
+        def __init__(self):
+            self.calls = []
+
+        def all_reduce(self, buf, group=None):
+            self.calls.append(int(buf.numel()))
+
+    class Backend:
+        mailbox = None
+
+        def __init__(self, bufs):
+            self.bufs, self.done = bufs, []
+
+        def cv_pass(self):
+            return self.bufs
+
+        def force_pass(self, sums, t):
+            self.done.append(t)
+
+        def step_single(self, t):
+            self.done.append(("single", t))
+
+    bufs = [torch.zeros(2, dtype=torch.float64), None, torch.zeros(5000, dtype=torch.float64), torch.zeros(3, dtype=torch.int32)]
+    box, pg = Rec(), Rec()
+    be = Backend(bufs)
+    ShardedBiasStep(be, pg, mailbox=box, mailbox_max=64).step(7)
+    assert box.calls == [2] and pg.calls == [5000, 3] and be.done == [7]
+    pg2 = Rec()
+    ShardedBiasStep(Backend(bufs[:1]), pg2).step(0)
+    assert pg2.calls == [2]                                # no mailbox: everything through the collective
+    be3 = Backend(bufs)
+    be3.mailbox = object()
+    ShardedBiasStep(be3, pg).step(3)
+    assert be3.done == [("single", 3)]
