@@ -225,6 +225,14 @@ int mtd_fused_force_pass(mtd_metad *m, const mtd_lamellar_set *set, unsigned int
                          void *const *d_force, int dtype, unsigned int n_global, const mtd_box *global_box,
                          unsigned int timestep, mtd_stream_t stream);
 
+/* The same launch for a MIXED set of collective variables: `set` holds the lamellar CVs among the grid's variables,
+ * slots[c] is the grid variable behind CV c of the set (any order, each < the grid's n_cv); the other variables' values
+ * arrive through their registered sources as in mtd_metad_update_bias, which this call replaces for the step, and their
+ * force kernels read mtd_metad_bias_device afterwards.  slots == NULL: identity (set->n_cv must equal the grid's). */
+int mtd_fused_force_pass_slots(mtd_metad *m, const mtd_lamellar_set *set, const unsigned int *slots, unsigned int n_particles,
+                               const void *d_postype, void *const *d_force, int dtype, unsigned int n_global,
+                               const mtd_box *global_box, unsigned int timestep, mtd_stream_t stream);
+
 /* Measurement aid (bench.py): the next n_launches launches of mtd_fused_force_pass record their own begin and end through the
  * start / stop events of hipExtLaunchKernelGGL — the dispatch's time stamps, i.e. the duration a kernel trace reports for the
  * launch, without a profiler attached.  mtd_profile_force_end SYNCHRONISES, returns the durations (microseconds) of the

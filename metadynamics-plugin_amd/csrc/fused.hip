@@ -179,7 +179,8 @@ __global__ __launch_bounds__(FF_THREADS, 4) void k_fused_force(const LamKArgs a,
             for (unsigned int i = lane; i < NCV * MTD_MAX_TYPES; i += MTD_WAVE)
                 {
                 const unsigned int cv = i / MTD_MAX_TYPES;
-                const double b = cv == 0 ? r.bias[0] : (cv == 1 ? r.bias[1] : r.bias[2]);
+                const unsigned int gs = cv < a.n_cv ? a.slot[cv] : 0u;                 // the grid's variable behind CV cv of the set
+                const double b = gs == 0 ? r.bias[0] : (gs == 1 ? r.bias[1] : r.bias[2]);
                 s_wcoef[i] = (cv < a.n_cv) ? (float)((double)a.coeff[cv][i % MTD_MAX_TYPES] * b * two_over_n) : 0.0f;
                 }
         }
@@ -353,7 +354,7 @@ __global__ __launch_bounds__(FF_THREADS) void k_fused_force_general(const LamKAr
     for (unsigned int i = threadIdx.x; i < MTD_MAX_CV * MTD_MAX_TYPES; i += blockDim.x)
         {
         const unsigned int cv = i / MTD_MAX_TYPES;
-        const double b = cv < a.n_cv ? sh.bias[cv] : 0.0;
+        const double b = cv < a.n_cv ? sh.bias[a.slot[cv]] : 0.0;
         s_wcoef[i] = (float)((double)a.coeff[cv][i % MTD_MAX_TYPES] * b * two_over_n);
         }
     __syncthreads();
@@ -456,13 +457,32 @@ int mtd_fused_force_pass(mtd_metad *m, const mtd_lamellar_set *set, unsigned int
                          void *const *d_force, int dtype, unsigned int n_global, const mtd_box *global_box,
                          unsigned int timestep, mtd_stream_t stream)
     {
+    if (!m || !set) return MTD_ERR_INVALID_ARGUMENT;
+    if (set->n_cv != m->cfg.n_cv) return MTD_ERR_UNSUPPORTED;   // CV c of the set is CV c of the grid
+    return mtd_fused_force_pass_slots(m, set, nullptr, n_particles, d_postype, d_force, dtype, n_global, global_box, timestep, stream);
+    }
+
+int mtd_fused_force_pass_slots(mtd_metad *m, const mtd_lamellar_set *set, const unsigned int *slots, unsigned int n_particles,
+                               const void *d_postype, void *const *d_force, int dtype, unsigned int n_global,
+                               const mtd_box *global_box, unsigned int timestep, mtd_stream_t stream)
+    {
     if (!m) return MTD_ERR_INVALID_ARGUMENT;
     LamKArgs k;
     int rc = fill_kargs(k, set, global_box);
     if (rc) return rc;
     if (!d_force || n_global == 0 || (n_particles && !d_postype)) return MTD_ERR_INVALID_ARGUMENT;
     if (dtype != MTD_F32 && dtype != MTD_F64) return MTD_ERR_INVALID_ARGUMENT;
-    if (set->n_cv != m->cfg.n_cv) return MTD_ERR_UNSUPPORTED;   // CV c of the set is CV c of the grid
+    if (set->n_cv > m->cfg.n_cv) return MTD_ERR_UNSUPPORTED;
+    if (!slots && set->n_cv != m->cfg.n_cv) return MTD_ERR_INVALID_ARGUMENT;
+    if (slots)
+        {
+        if (m->comm) return MTD_ERR_UNSUPPORTED;                // the mailbox carries the sums of a pure lamellar set only
+        for (unsigned int c = 0; c < set->n_cv; ++c)
+            {
+            if (slots[c] >= m->cfg.n_cv) return MTD_ERR_INVALID_ARGUMENT;
+            k.slot[c] = (unsigned char)slots[c];
+            }
+        }
     hipStream_t s = (hipStream_t)stream;
     rc = metad_flush(m, s);                                     // a deposit may only be pending across ONE cv pass
     if (rc) return rc;
@@ -482,11 +502,11 @@ int mtd_fused_force_pass(mtd_metad *m, const mtd_lamellar_set *set, unsigned int
     std::memset(&ck, 0, sizeof(ck));
     if (m->comm)
         {
-        if (set->n_cv > (unsigned int)CHAIN_MAX_CV || force_general) return MTD_ERR_UNSUPPORTED;
+        if (m->cfg.n_cv > (unsigned int)CHAIN_MAX_CV || force_general) return MTD_ERR_UNSUPPORTED;
         rc = comm_current(m->comm, ck);                         // the exchange the last mtd_fused_cv_pass sent
         if (rc) return rc;
         }
-    if (set->n_cv <= (unsigned int)CHAIN_MAX_CV && !force_general)
+    if (m->cfg.n_cv <= (unsigned int)CHAIN_MAX_CV && !force_general)
         {
         const unsigned int groups = (set->n_cv <= 2) ? 2 : 1;
         unsigned int fblocks = (n_particles + FF_STREAM_THREADS * FF_U * groups - 1) / (FF_STREAM_THREADS * FF_U * groups);

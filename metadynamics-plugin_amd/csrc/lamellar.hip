@@ -246,6 +246,7 @@ int fill_kargs(LamKArgs &k, const mtd_lamellar_set *set, const mtd_box *box)
     k.n_modes = set->n_modes;
     k.n_types = set->n_types;
     for (unsigned int c = 0; c <= set->n_cv; ++c) k.first[c] = set->first[c];
+    for (unsigned int c = 0; c < MTD_MAX_CV; ++c) k.slot[c] = (unsigned char)c;
     const double two_pi = 2.0 * M_PI;
     for (unsigned int m = 0; m < set->n_modes; ++m)
         for (int d = 0; d < 3; ++d)

@@ -19,7 +19,8 @@ struct LamKArgs
     double B[3][3];                           // reciprocal rows without 2*pi
     unsigned int n_cv, n_modes, n_types, _pad;
     unsigned int first[MTD_MAX_CV + 1];
-    unsigned int _pad2[3];
+    unsigned char slot[MTD_MAX_CV];           // CV c of the set is collective variable slot[c] of the bias grid (fused force pass)
+    unsigned int _pad2;
     float4 h[MTD_MAX_MODES];                  // Miller indices (h, k, l, fold): fold = 1 when the mode 2(h,k,l) of the same CV is
                                               // folded into this one by the CV pass, else 0
     unsigned char corder[MTD_MAX_MODES];      // CV pass: the modes of CV c it visits are corder[first[c] .. first[c] + nact[c])

@@ -861,6 +861,55 @@ void IntegratorMetaDynamics::fusedLamellarStep(unsigned int timestep)
     m_used_fused = true;
     }
 
+// A mixed set (e.g. lamellar + mesh): the grid-engine launch of the step (the fused force kernel without particles inside
+// mtd_metad_update_bias) also carries the force blocks of the set's lamellar CVs — one launch instead of the grid launch plus
+// a lamellar force kernel per CV.  The CV values have been enqueued (registered sources) by the caller.  Returns false when
+// the set has no eligible lamellar CV (the caller then runs mtd_metad_update_bias).
+bool IntegratorMetaDynamics::mixedLamellarStep(unsigned int timestep)
+    {
+    if (!m_allow_fused || m_adaptive || m_variables.size() > 3) return false;     // the one-wave chain handles <= 3 variables
+    std::vector<unsigned int> slots;
+    unsigned int n_modes = 0;
+    for (unsigned int i = 0; i < m_variables.size(); ++i)
+        {
+        auto lam = std::dynamic_pointer_cast<LamellarOrderParameterGPU>(m_variables[i].m_cv);
+        if (lam && !lam->hasUmbrella())
+            {
+            slots.push_back(i);
+            n_modes += (unsigned int)lam->getLatticeVectors().size();
+            }
+        }
+    if (slots.empty() || n_modes > MTD_MAX_MODES) return false;
+    std::memset(&m_fused_set, 0, sizeof(m_fused_set));
+    m_fused_set.n_cv = (unsigned int)slots.size();
+    m_fused_set.n_types = m_pdata->getNTypes();
+    m_fused_force_ptrs.assign(slots.size(), nullptr);
+    unsigned int k = 0;
+    for (unsigned int c = 0; c < slots.size(); ++c)
+        {
+        auto lam = std::static_pointer_cast<LamellarOrderParameterGPU>(m_variables[slots[c]].m_cv);
+        m_fused_set.first[c] = k;
+        for (const auto &v : lam->getLatticeVectors())
+            {
+            m_fused_set.hkl[k][0] = v.x;
+            m_fused_set.hkl[k][1] = v.y;
+            m_fused_set.hkl[k][2] = v.z;
+            ++k;
+            }
+        for (unsigned int t = 0; t < m_fused_set.n_types; ++t) m_fused_set.coeff[c][t] = lam->getMode()[t];
+        m_fused_force_ptrs[c] = lam->getForceArray().data();
+        }
+    m_fused_set.first[slots.size()] = k;
+    m_fused_set.n_modes = k;
+    const mtd_box box = m_pdata->getGlobalBox().toMtd();
+    mtd_check(mtd_fused_force_pass_slots(m_engine, &m_fused_set, slots.data(), m_pdata->getN(), m_pdata->positionsPtr(),
+                                         m_fused_force_ptrs.data(), m_pdata->getDtype(), m_pdata->getNGlobal(), &box, timestep,
+                                         m_exec_conf->getStream()),
+              "mtd_fused_force_pass_slots");
+    for (unsigned int i : slots) m_variables[i].m_cv->markComputed(timestep);
+    return true;
+    }
+
 // :314-588, grid branch
 void IntegratorMetaDynamics::updateBiasPotential(unsigned int timestep)
     {
@@ -884,7 +933,8 @@ void IntegratorMetaDynamics::updateBiasPotential(unsigned int timestep)
         m_used_fused = false;
         // collect values of collective variables (:321-327) — they stay on the device
         for (unsigned int i = 0; i < m_variables.size(); ++i) m_variables[i].m_cv->enqueueCurrentValue(timestep, m_engine, i);
-        mtd_check(mtd_metad_update_bias(m_engine, timestep, s), "mtd_metad_update_bias");
+        if (!mixedLamellarStep(timestep))
+            mtd_check(mtd_metad_update_bias(m_engine, timestep, s), "mtd_metad_update_bias");
         // update current bias potential derivative for every collective variable (:578-584)
         const double *d_bias = mtd_metad_bias_device(m_engine);
         for (unsigned int i = 0; i < m_variables.size(); ++i) m_variables[i].m_cv->setBiasFactorDevice(d_bias + i);

@@ -352,6 +352,7 @@ class IntegratorMetaDynamics
         void writeGrid(const std::string &filename, unsigned int timestep);   // :831-926
         bool fusedLamellarPossible() const;
         void fusedLamellarStep(unsigned int timestep);
+        bool mixedLamellarStep(unsigned int timestep);
 
         std::shared_ptr<SystemDefinition> m_sysdef;
         std::shared_ptr<ParticleData> m_pdata;

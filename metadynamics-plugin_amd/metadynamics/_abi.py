@@ -141,6 +141,8 @@ _SIGNATURES = {
     "mtd_comm_rank": (C.c_uint, [_vp]),
     "mtd_comm_destroy": (C.c_int, [_vp]),
     "mtd_metad_set_comm": (C.c_int, [_vp, _vp]),
+    "mtd_fused_force_pass_slots": (C.c_int, [_vp, C.POINTER(LamellarSet), _up, C.c_uint, _vp, C.POINTER(_vp), C.c_int, C.c_uint,
+                                              C.POINTER(Box), C.c_uint, _vp]),
     "mtd_mesh_create": (C.c_int, [C.POINTER(_vp), C.c_uint, C.c_uint, C.c_uint, _dp, C.c_uint, C.c_uint]),
     "mtd_mesh_destroy": (C.c_int, [_vp]),
     "mtd_mesh_set_bug_compat": (C.c_int, [_vp, C.c_int]),
