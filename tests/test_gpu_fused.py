@@ -142,3 +142,62 @@ def test_fused_sharded_n_global(abi, ref):
         assert np.abs(F[:, :3] - F_ref[:, :3]).max() <= 1e-5 * np.abs(F_ref[:, :3]).max()
     finally:
         g.close()
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_fused_force_pass_with_slot_map(abi, dtype):
+    """mtd_fused_force_pass_slots: a 3-variable grid whose variable 0 is a host-provided scalar and whose variables 2 and 1
+    (in that order) are the two lamellar CVs of the set — against mtd_metad_update_bias + mtd_lamellar_forces on an
+    identical engine"""
+    import ctypes as C
+    lib = abi.load()
+    N, L = 30011, 24.0
+    traj, types = make_traj(N, L, 4, dtype)
+    box = abi.Box.make(L)
+    dt = abi.MTD_F32 if dtype == np.float32 else abi.MTD_F64
+    tdt = torch.float32 if dtype == np.float32 else torch.float64
+    lset = abi.LamellarSet.make(CVS)
+    slots = (C.c_uint * 2)(2, 1)
+    dbl = lambda v: (C.c_double * len(v))(*[float(x) for x in v])
+
+    def engine():
+        h = C.c_void_p()
+        abi.check(lib.mtd_metad_create(C.byref(h), 3, dbl([0.3, 0.03, 0.04]), dbl([-2.0, -1.0, -1.0]), dbl([2.0, 1.0, 1.0]),
+                                       (C.c_uint * 3)(12, 20, 16), 1.0, 7.0, 1.0, 1, 1, 1))
+        return h
+
+    ha, hb = engine(), engine()
+    scratch = torch.zeros(lib.mtd_lamellar_scratch_doubles(N), dtype=torch.float64, device="cuda")
+    fa = [torch.zeros((N, 4), dtype=tdt, device="cuda") for _ in range(2)]
+    fb = [torch.zeros((N, 4), dtype=tdt, device="cuda") for _ in range(2)]
+    pa, pb = (C.c_void_p * 2)(*[f.data_ptr() for f in fa]), (C.c_void_p * 2)(*[f.data_ptr() for f in fb])
+    for t, pos in enumerate(traj):
+        d_pos = torch.from_numpy(util.pack_postype(pos, types, dtype)).cuda()
+        n_part = C.c_uint()
+        abi.check(lib.mtd_lamellar_cv_partials(C.byref(lset), N, d_pos.data_ptr(), dt, C.byref(box), scratch.data_ptr(), C.byref(n_part), None))
+        for h in (ha, hb):
+            abi.check(lib.mtd_metad_set_cv_value(h, 0, 0.1 * t - 0.15))
+            abi.check(lib.mtd_metad_set_cv_source(h, 2, scratch.data_ptr(), n_part.value, 2, 0, 1.0 / N, 0.0))   # set CV 0 -> variable 2
+            abi.check(lib.mtd_metad_set_cv_source(h, 1, scratch.data_ptr(), n_part.value, 2, 1, 1.0 / N, 0.0))   # set CV 1 -> variable 1
+        abi.check(lib.mtd_fused_force_pass_slots(ha, C.byref(lset), slots, N, d_pos.data_ptr(), pa, dt, N, C.byref(box), t, None))
+        abi.check(lib.mtd_metad_update_bias(hb, t, None))
+        d_bias = lib.mtd_metad_bias_device(hb)
+        for c, slot in enumerate((2, 1)):
+            one = abi.LamellarSet.make([CVS[c]])
+            abi.check(lib.mtd_lamellar_forces(C.byref(one), N, d_pos.data_ptr(), (C.c_void_p * 1)(fb[c].data_ptr()), dt, N,
+                                              d_bias + 8 * slot, C.byref(box), None))
+        torch.cuda.synchronize()
+        for c in range(2):
+            A, B = fa[c].cpu().numpy().astype(np.float64), fb[c].cpu().numpy().astype(np.float64)
+            assert np.abs(B).max() > 0
+            assert np.abs(A - B).max() <= 2e-6 * np.abs(B).max()
+    cv_a, cv_b = (C.c_double * 3)(), (C.c_double * 3)()
+    ba, bb = (C.c_double * 3)(), (C.c_double * 3)()
+    Va, Vb = C.c_double(), C.c_double()
+    abi.check(lib.mtd_metad_get_state(ha, cv_a, ba, C.byref(Va), None, None, None, None))
+    abi.check(lib.mtd_metad_get_state(hb, cv_b, bb, C.byref(Vb), None, None, None, None))
+    assert list(cv_a) == list(cv_b)
+    assert np.allclose(list(ba), list(bb), rtol=1e-9, atol=1e-12) and Va.value == pytest.approx(Vb.value, rel=1e-12)
+    assert lib.mtd_fused_force_pass_slots(ha, C.byref(lset), (C.c_uint * 2)(3, 1), N, d_pos.data_ptr(), pa, dt, N, C.byref(box), 9, None) == -1
+    for h in (ha, hb):
+        abi.check(lib.mtd_metad_destroy(h))
