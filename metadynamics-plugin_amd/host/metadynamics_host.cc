@@ -2,6 +2,7 @@
 // /root/reference/metadynamics/.
 #include "metadynamics_host.h"
 
+#include <algorithm>
 #include <sys/stat.h>
 
 #include <cstdio>
@@ -861,14 +862,15 @@ void IntegratorMetaDynamics::fusedLamellarStep(unsigned int timestep)
     m_used_fused = true;
     }
 
-// A mixed set (e.g. lamellar + mesh): the grid-engine launch of the step (the fused force kernel without particles inside
-// mtd_metad_update_bias) also carries the force blocks of the set's lamellar CVs — one launch instead of the grid launch plus
-// a lamellar force kernel per CV.  The CV values have been enqueued (registered sources) by the caller.  Returns false when
-// the set has no eligible lamellar CV (the caller then runs mtd_metad_update_bias).
-bool IntegratorMetaDynamics::mixedLamellarStep(unsigned int timestep)
+// A mixed set (e.g. lamellar + mesh): its lamellar CVs (those without an umbrella) are served by the two fused launches of
+// the pure lamellar step — launch A sums all of them in one pass over the positions and carries the deferred grid pass,
+// and the grid-engine launch of the step (the fused force kernel, which mtd_metad_update_bias runs without particles)
+// also carries their force blocks: no k_apply launch, no CV and force kernel per lamellar CV.  `slots`: their indices
+// among the grid's variables.
+std::vector<unsigned int> IntegratorMetaDynamics::mixedLamellarSlots() const
     {
-    if (!m_allow_fused || m_adaptive || m_variables.size() > 3) return false;     // the one-wave chain handles <= 3 variables
     std::vector<unsigned int> slots;
+    if (!m_allow_fused || m_adaptive || m_variables.size() > 3) return slots;     // the one-wave chain handles <= 3 variables
     unsigned int n_modes = 0;
     for (unsigned int i = 0; i < m_variables.size(); ++i)
         {
@@ -879,7 +881,12 @@ bool IntegratorMetaDynamics::mixedLamellarStep(unsigned int timestep)
             n_modes += (unsigned int)lam->getLatticeVectors().size();
             }
         }
-    if (slots.empty() || n_modes > MTD_MAX_MODES) return false;
+    if (n_modes > MTD_MAX_MODES) slots.clear();
+    return slots;
+    }
+
+void IntegratorMetaDynamics::mixedLamellarCvPass(const std::vector<unsigned int> &slots)
+    {
     std::memset(&m_fused_set, 0, sizeof(m_fused_set));
     m_fused_set.n_cv = (unsigned int)slots.size();
     m_fused_set.n_types = m_pdata->getNTypes();
@@ -901,13 +908,26 @@ bool IntegratorMetaDynamics::mixedLamellarStep(unsigned int timestep)
         }
     m_fused_set.first[slots.size()] = k;
     m_fused_set.n_modes = k;
+    if (m_fused_partials.bytes() == 0) m_fused_partials.resize(sizeof(double) * mtd_lamellar_scratch_doubles(m_pdata->getN()));
+    const mtd_box box = m_pdata->getGlobalBox().toMtd();
+    unsigned int n_partials = 0;
+    mtd_check(mtd_fused_cv_pass(m_engine, &m_fused_set, m_pdata->getN(), m_pdata->positionsPtr(), m_pdata->getDtype(), &box,
+                                (double *)m_fused_partials.data(), &n_partials, m_exec_conf->getStream()),
+              "mtd_fused_cv_pass");
+    for (unsigned int c = 0; c < slots.size(); ++c)
+        mtd_check(mtd_metad_set_cv_source(m_engine, slots[c], (const double *)m_fused_partials.data(), n_partials,
+                                          (unsigned int)slots.size(), c, 1.0 / (double)m_pdata->getNGlobal(), 0.0),
+                  "mtd_metad_set_cv_source");
+    }
+
+void IntegratorMetaDynamics::mixedLamellarForcePass(const std::vector<unsigned int> &slots, unsigned int timestep)
+    {
     const mtd_box box = m_pdata->getGlobalBox().toMtd();
     mtd_check(mtd_fused_force_pass_slots(m_engine, &m_fused_set, slots.data(), m_pdata->getN(), m_pdata->positionsPtr(),
                                          m_fused_force_ptrs.data(), m_pdata->getDtype(), m_pdata->getNGlobal(), &box, timestep,
                                          m_exec_conf->getStream()),
               "mtd_fused_force_pass_slots");
     for (unsigned int i : slots) m_variables[i].m_cv->markComputed(timestep);
-    return true;
     }
 
 // :314-588, grid branch
@@ -932,8 +952,14 @@ void IntegratorMetaDynamics::updateBiasPotential(unsigned int timestep)
                                      "domain-decomposed path of the host classes");
         m_used_fused = false;
         // collect values of collective variables (:321-327) — they stay on the device
-        for (unsigned int i = 0; i < m_variables.size(); ++i) m_variables[i].m_cv->enqueueCurrentValue(timestep, m_engine, i);
-        if (!mixedLamellarStep(timestep))
+        const std::vector<unsigned int> lam_slots = mixedLamellarSlots();
+        if (!lam_slots.empty()) mixedLamellarCvPass(lam_slots);
+        for (unsigned int i = 0; i < m_variables.size(); ++i)
+            if (std::find(lam_slots.begin(), lam_slots.end(), i) == lam_slots.end())
+                m_variables[i].m_cv->enqueueCurrentValue(timestep, m_engine, i);
+        if (!lam_slots.empty())
+            mixedLamellarForcePass(lam_slots, timestep);
+        else
             mtd_check(mtd_metad_update_bias(m_engine, timestep, s), "mtd_metad_update_bias");
         // update current bias potential derivative for every collective variable (:578-584)
         const double *d_bias = mtd_metad_bias_device(m_engine);

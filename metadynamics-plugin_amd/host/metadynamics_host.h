@@ -352,7 +352,9 @@ class IntegratorMetaDynamics
         void writeGrid(const std::string &filename, unsigned int timestep);   // :831-926
         bool fusedLamellarPossible() const;
         void fusedLamellarStep(unsigned int timestep);
-        bool mixedLamellarStep(unsigned int timestep);
+        std::vector<unsigned int> mixedLamellarSlots() const;
+        void mixedLamellarCvPass(const std::vector<unsigned int> &slots);
+        void mixedLamellarForcePass(const std::vector<unsigned int> &slots, unsigned int timestep);
 
         std::shared_ptr<SystemDefinition> m_sysdef;
         std::shared_ptr<ParticleData> m_pdata;
