@@ -100,9 +100,10 @@ def connect(dist, max_doubles=64, self_test=True):
     if ok and self_test:
         ok = agree(_self_test(box, torch))
     if not ok:
+        # every rank leaves the same way (the barrier is collective: ranks whose mailbox never came up take part too)
+        torch.cuda.synchronize()
+        dist.barrier()
         if box is not None:
-            torch.cuda.synchronize()
-            dist.barrier()
             box.close()
         return None
     return box
