@@ -27,12 +27,13 @@ def _free_port():
     return port
 
 
-def _run_world(world, n_global, steps=6, timeout=300):
+def _run_world(world, n_global, steps=6, timeout=300, extra_env=None):
     port = _free_port()
     procs = []
     for r in range(world):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                    HSA_ENABLE_IPC_MODE_LEGACY="0", MTD_COMM_TIMEOUT_MS="3000")
+        env.update(extra_env or {})
         procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "_comm_worker.py"), str(n_global), str(steps)],
                                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
     outs = []
@@ -172,3 +173,9 @@ def test_host_classes_take_the_mailbox_as_communicator(abi):
     finally:
         context.current = None
         box.close()
+
+
+def test_mailbox_setup_failure_is_agreed_by_all_ranks():
+    """one rank cannot map its peers: every rank gets None back from xgmi.connect (and keeps the collective path)"""
+    r = _run_world(2, 1000, extra_env={"MTD_XGMI_TEST_FAIL_RANK": "1"})
+    assert r["connected"] is False
