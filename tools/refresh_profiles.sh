@@ -18,6 +18,10 @@ timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/c3 
 cp $(find $O/c3 -name "*kernel_stats.csv" | head -1) $O/config3_mesh_kernel_stats.csv
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/c5 -o ql -- python3 tools/bench_ql.py 60 > $O/config5.log 2>&1
 cp $(find $O/c5 -name "*kernel_stats.csv" | head -1) $O/config5_steinhardt_kernel_stats.csv
+# the particle-sharded code path with one rank (mailbox to itself) and with two ranks sharing this GPU (rehearsal: software path only)
+MTD_BENCH_FORCE_DIST=1 timeout -k 10 300 python3 bench.py --no-cpu-baseline > $O/mailbox_1rank.log 2>&1; grep '^{"metric"' $O/mailbox_1rank.log | tail -1 > $O/bench_mailbox_1rank.json
+MTD_XGMI_MAILBOX=0 MTD_BENCH_FORCE_DIST=1 timeout -k 10 300 python3 bench.py --no-cpu-baseline > $O/rccl_1rank.log 2>&1; grep '^{"metric"' $O/rccl_1rank.log | tail -1 > $O/bench_rccl_1rank.json
+MTD_BENCH_REHEARSAL=1 timeout -k 10 300 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29561 bench.py --gpus 2 --particles 500000 > $O/rehearsal2.log 2>&1; grep '^{"metric"' $O/rehearsal2.log | tail -1 > $O/bench_rehearsal_2ranks_one_gpu.json
 set +x
 rm -rf $O/kt $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE $O/c3 $O/c5
 ls -la $O; cat $O/pmc_summary.json | head -20; grep "config" $O/config3.log $O/config5.log
