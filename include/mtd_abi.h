@@ -278,8 +278,9 @@ unsigned int mtd_comm_world(const mtd_comm *c);
 unsigned int mtd_comm_rank(const mtd_comm *c);
 int mtd_comm_destroy(mtd_comm *c);
 
-/* Particle-sharded fused step: with a comm attached, mtd_fused_cv_pass's last block to finish adds up the block
- * partial sums of this rank and sends the n_cv totals to every rank, and mtd_fused_force_pass's scalar chain takes
+/* Particle-sharded fused step: with a comm attached, every CV block of mtd_fused_cv_pass also posts its sums for a collector
+ * (the first CV block), which adds them up in a fixed order and sends the n_cv totals to every rank, and
+ * mtd_fused_force_pass's scalar chain takes
  * s_c = scale_c * (sum over ranks) + shift_c from the mailbox instead of the registered partial sums (scale / shift
  * as registered with mtd_metad_set_cv_source): still two launches per step, no collective call.  n_cv <= 3.
  * comm == NULL detaches. */

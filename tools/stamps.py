@@ -33,4 +33,4 @@ print("k_fused_force force block : entry->tables %s  wave0 chain %s | wave1: tab
 print("A entry -> next... B end(grid blk) %s ; B force store end %s (both from B grid-block entry)" % (rel(16, 20), rel(16, 29)))
 print("chain (grid block0): entry->cv sums %s  ->geometry %s  ->pairs+grid loads %s  ->V_old,scal %s  ->closed form %s  ->res,bias %s  ->bin(end) %s" % (rel(16, 40), rel(40, 41), rel(41, 42), rel(42, 43), rel(43, 44), rel(44, 45), rel(45, 17)))
 if box is not None:
-    print("mailbox: cv block0 entry -> last ticket drawn %s  ->totals %s  ->sent %s | last ticket -> B grid-block entry %s" % (rel(3, 7), rel(7, 8), rel(8, 9), rel(7, 16)))
+    print("mailbox: cv block0 entry -> all block sums collected %s  ->totals %s  ->sent %s | collected -> B grid-block entry %s" % (rel(3, 7), rel(7, 8), rel(8, 9), rel(7, 16)))
