@@ -155,7 +155,8 @@ class HostEngine:
     def state(self):
         t = self.ctx.system.getCurrentTimeStep()
         integ = self.meta.cpp_integrator
-        return dict(cv=[c.cpp_force.getCurrentValue(t) for c in self.cvs], V=integ.getLogValue("bias", t),
+        # the values the bias was evaluated at (global sums of a sharded run), as the grid engine holds them
+        return dict(cv=list(integ.getCurrentValues()), V=integ.getLogValue("bias", t),
                     w=integ.getLogValue("weight", t), num_gaussians=integ.getNumGaussians(), fused=integ.usedFusedPath())
 
 
