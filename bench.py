@@ -404,7 +404,7 @@ def main():
             out["config"]["exchange"] = eng.exchange
             if mailbox_timeouts is not None:
                 out["config"]["mailbox_timeouts"] = mailbox_timeouts
-        if not args.no_cpu_baseline and world == 1 and st.get("num_gaussians") and args.stride == 1:
+        if not args.no_cpu_baseline and st.get("num_gaussians") and args.stride == 1:      # any N: the grid is replicated
             out["self_check"] = self_check(st, args.stride)
         if not args.no_cpu_baseline and world == 1:
             pos, types = eng.pos_np, eng.types_np
