@@ -68,8 +68,11 @@ class Engine:
         self.dist = dist
         L = BOX_L * (n_global / N_PER_GPU) ** (1.0 / 3.0)  # constant density (config 4: L = 200 at 8e6)
         pos, types = util.snapshot_random(n_global, L, seed=seed, dtype=np.float32)
+        self.full = None
         if dist is not None:
             # every rank draws the same global snapshot and keeps its contiguous slice (lamellar CVs need no locality)
+            if rank == 0:
+                self.full = (pos, types)           # rank 0 checks the global CV values against the oracle afterwards
             sl = slice(rank * n_local, (rank + 1) * n_local)
             pos, types = pos[sl].copy(), types[sl].copy()
         self.pos_np, self.types_np, self.L = pos, types, L
@@ -406,6 +409,17 @@ def main():
                 out["config"]["mailbox_timeouts"] = mailbox_timeouts
         if not args.no_cpu_baseline and st.get("num_gaussians") and args.stride == 1:      # any N: the grid is replicated
             out["self_check"] = self_check(st, args.stride)
+        if not args.no_cpu_baseline and eng.full is not None:
+            # sharded run: the CV values the ranks agreed on against the oracle on the whole snapshot (checker, untimed).
+            # On a random snapshot the sums cancel to O(sqrt(N)): the tolerance of the parity tests is 1e-6 n_wave / sqrt(N)
+            sys.path.insert(0, os.path.join(ROOT, "oracle"))
+            import mtd_ref
+            fpos, ftypes = eng.full
+            opt = util.oracle_postype(fpos, ftypes)
+            rbox = mtd_ref.Box.make(eng.L)
+            ref_cv = [mtd_ref.lamellar_cv(v, opt, util.MODE_AB, rbox) for v in (util.CV1_VECTORS, util.CV2_VECTORS)]
+            out["cv_check"] = {"cv_oracle": ref_cv, "abs_err": [abs(a - b) for a, b in zip(st["cv"], ref_cv)],
+                               "tolerance": 1e-6 * 8 / np.sqrt(n_global)}
         if not args.no_cpu_baseline and world == 1:
             pos, types = eng.pos_np, eng.types_np
             v, dt = cpu_baseline(pos, types, eng.L, args.cpu_steps)
