@@ -361,7 +361,11 @@ int mtd_mesh_slab_compute_cv(mtd_mesh *m, unsigned int n_particles, const void *
 /* ================================================================================================
  * Steinhardt Q_l (cv.steinhardt) — the reference has only a host implementation (SteinhardtQl.cc); these entry points
  * are what a GPU class of it would call.  Neighbour list in HOOMD's layout (NeighborList::getHeadList / getNNeighArray /
- * getNListArray, device uint32 arrays); half_nlist = storage mode half (third-law path, SteinhardtQl.cc:80, 173-179, 328-333)
+ * getNListArray, device uint32 arrays); half_nlist: 0 = storage mode full, 1 = storage mode half (third-law path,
+ * SteinhardtQl.cc:80, 173-179, 328-333), 2 = a full list that is symmetric ((i, j) listed <=> (j, i) listed, as HOOMD builds
+ * them) and indexes no ghost particle: the CV pass then visits every pair once, from its lower index — Y_lm(-d) = (-1)^l
+ * Y_lm(d), so the reference's two visits add up to twice the even degrees and cancel in the odd ones, the scaling of :173-179;
+ * the force pass treats 2 like 0.  Not for mtd_ql_accumulate_local with ghost particles.
  * ============================================================================================== */
 
 /* device doubles the two calls share (block partial sums, Q_lm tables, Q_l, CV value) */

@@ -197,6 +197,7 @@ template<int PPB, int CAP> struct ChunkShared
     unsigned int wave_total[PPB / MTD_WAVE];
     double px[PPB], py[PPB], pz[PPB];              // the central particles' own positions
     double dx[CAP], dy[CAP], dz[CAP];              // min-imaged separations r_i - r_j; excluded pairs carry an infinite dx
+    unsigned int kept[QL_THREADS / MTD_WAVE];      // CV pass: pairs each wave kept of its share of the batch (compacted segments)
     };
 
 template<typename S4, int LMAX, typename CS>
@@ -280,6 +281,54 @@ __device__ __forceinline__ void chunk_gather(const QlArgs<LMAX> &a, const S4 *__
     __syncthreads();
     }
 
+// CV pass: the same gather, but only the pairs that take part are stored, densely: every wave appends the pairs it keeps
+// of its share of the batch (entries w*64 + lane + k*256) to its own segment [w * CAP/4, ...) of the LDS arrays, in entry
+// order (ballot + popcount: deterministic), and publishes the count.  Pairs beyond the cut-off (a neighbour list is built
+// with a buffer) or of another type no longer idle a lane of the arithmetic phase.  SYM (symmetric full list without ghost
+// particles: (i, j) listed <=> (j, i) listed): the pair is visited once, from its lower index — Y_lm(-d) = (-1)^l Y_lm(d),
+// so the two visits of the reference add up to twice the even degrees and cancel in the odd ones, which is exactly the
+// scaling the finalize step applies to half lists (SteinhardtQl.cc:173-179).
+template<typename S4, int LMAX, bool SYM, typename CS>
+__device__ __forceinline__ void chunk_gather_compact(const QlArgs<LMAX> &a, const S4 *__restrict__ postype,
+                                                     const unsigned int *__restrict__ nlist, const unsigned int chunk,
+                                                     const unsigned int base, const unsigned int n, CS &cs)
+    {
+    constexpr unsigned int SEG = CS::cap / (QL_THREADS / MTD_WAVE);
+    const unsigned int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    unsigned int cnt = 0;                                                        // wave-uniform
+#pragma unroll
+    for (unsigned int k = 0; k < CS::cap / QL_THREADS; ++k)
+        {
+        const unsigned int t = k * QL_THREADS + threadIdx.x;
+        bool keep = false;
+        double dx = 0.0, dy = 0.0, dz = 0.0;
+        if (t < n)
+            {
+            const unsigned int e = base + t;
+            const unsigned int p = chunk_owner(cs, e);
+            const unsigned int j = nlist[cs.start[p] + (e - cs.off[p])];
+            if (!(SYM && j < chunk * CS::ppb + p))
+                {
+                const Particle pj = scalar4_traits<S4>::load(postype, j);
+                dx = cs.px[p] - pj.x; dy = cs.py[p] - pj.y; dz = cs.pz[p] - pj.z;
+                min_image(a, dx, dy, dz);
+                keep = (unsigned int)pj.type == a.type && (dx * dx + dy * dy + dz * dz <= a.rcutsq);   // :126, :141
+                }
+            }
+        const unsigned long long mask = __ballot(keep);
+        if (keep)
+            {
+            const unsigned int slot = wave * SEG + cnt + (unsigned int)__popcll(mask & ((1ull << lane) - 1ull));
+            cs.dx[slot] = dx;
+            cs.dy[slot] = dy;
+            cs.dz[slot] = dz;
+            }
+        cnt += (unsigned int)__popcll(mask);
+        }
+    if (lane == 0) cs.kept[wave] = cnt;
+    __syncthreads();
+    }
+
 // ---- CV accumulation -------------------------------------------------------------------------------
 // The 28 complex accumulators (lmax = 6) alone are 112 VGPRs: with everything else that is two waves per SIMD, and the fp64
 // dependency chains of the recurrence are then exposed.  So the orders m are split between two ROLES (even / odd waves of
@@ -294,11 +343,16 @@ template<int LMAX, int ROLE>
 __device__ __forceinline__ void ql_accumulate_pairs(const QlArgs<LMAX> &a, const AccChunk &cs, const unsigned int n,
                                                     const unsigned int first, cplx (&Q)[LMAX + 1][LMAX + 1])
     {
-    for (unsigned int t = first; t < n; t += QL_THREADS / 2)
+    // the kept pairs of the batch sit in one segment per gathering wave (chunk_gather_compact): flat index -> segment
+    constexpr unsigned int SEG = AccChunk::cap / (QL_THREADS / MTD_WAVE);
+    const unsigned int c0 = cs.kept[0], c1 = c0 + cs.kept[1], c2 = c1 + cs.kept[2], kept = c2 + cs.kept[3];
+    (void)n;
+    for (unsigned int fi = first; fi < kept; fi += QL_THREADS / 2)
         {
+        const unsigned int seg = (fi >= c0) + (fi >= c1) + (fi >= c2);
+        const unsigned int t = seg * SEG + fi - (seg == 0 ? 0u : (seg == 1 ? c0 : (seg == 2 ? c1 : c2)));
         const double dx = cs.dx[t], dy = cs.dy[t], dz = cs.dz[t];
         const double rsq = dx * dx + dy * dy + dz * dz;
-        if (!(rsq <= a.rcutsq)) continue;
         const PairGeom g = pair_geom(dx, dy, dz, rsq);
         double f, fprime_divr;
         smoothing(a, rsq, g.inv_r, f, fprime_divr);
@@ -348,7 +402,7 @@ __device__ __forceinline__ void ql_wave_reduce(const cplx (&Q)[LMAX + 1][LMAX + 
 
 // the whole chunk loop of one role, with its own accumulators: the two instantiations sit in the two arms of a wave-uniform
 // branch, so their registers overlap (one shared Q array would keep all 28 entries live in both)
-template<typename S4, int LMAX, int ROLE>
+template<typename S4, int LMAX, int ROLE, bool SYM>
 __device__ __forceinline__ void ql_accumulate_role(const QlArgs<LMAX> &a, const S4 *__restrict__ postype,
                                                    const unsigned int *__restrict__ head_list, const unsigned int *__restrict__ n_neigh,
                                                    const unsigned int *__restrict__ nlist, AccChunk &cs, double *s_row)
@@ -370,7 +424,7 @@ __device__ __forceinline__ void ql_accumulate_role(const QlArgs<LMAX> &a, const 
             {
             const unsigned int n = min(total - base, (unsigned int)QL_CAP);
             if (base) __syncthreads();                                         // previous batch consumed
-            chunk_gather<S4, LMAX>(a, postype, nlist, base, n, cs, nullptr);
+            chunk_gather_compact<S4, LMAX, SYM>(a, postype, nlist, chunk, base, n, cs);
             ql_accumulate_pairs<LMAX, ROLE>(a, cs, n, first, Q);
             }
         }
@@ -379,7 +433,7 @@ __device__ __forceinline__ void ql_accumulate_role(const QlArgs<LMAX> &a, const 
     ql_wave_reduce<LMAX, ROLE>(Q, s_row);
     }
 
-template<typename S4, int LMAX>
+template<typename S4, int LMAX, bool SYM>
 __global__ __launch_bounds__(QL_THREADS, (LMAX <= 6 ? 4 : 2)) void k_ql_accumulate(const QlArgs<LMAX> a, const S4 *__restrict__ postype,
                                                                  const unsigned int *__restrict__ head_list,
                                                                  const unsigned int *__restrict__ n_neigh,
@@ -392,9 +446,9 @@ __global__ __launch_bounds__(QL_THREADS, (LMAX <= 6 ? 4 : 2)) void k_ql_accumula
     for (unsigned int q = threadIdx.x; q < (QL_THREADS / MTD_WAVE) * 2 * NLM; q += QL_THREADS) (&s_wave[0][0])[q] = 0.0;
     // both arms run the same sequence of block barriers (the chunk loop depends on blockIdx and N only)
     if (wave & 1)
-        ql_accumulate_role<S4, LMAX, 1>(a, postype, head_list, n_neigh, nlist, cs, s_wave[wave]);
+        ql_accumulate_role<S4, LMAX, 1, SYM>(a, postype, head_list, n_neigh, nlist, cs, s_wave[wave]);
     else
-        ql_accumulate_role<S4, LMAX, 0>(a, postype, head_list, n_neigh, nlist, cs, s_wave[wave]);
+        ql_accumulate_role<S4, LMAX, 0, SYM>(a, postype, head_list, n_neigh, nlist, cs, s_wave[wave]);
     __syncthreads();
     const unsigned int n_out = (a.lmax + 1) * (a.lmax + 2);     // 2 * n_lm of the RUNTIME lmax (same (l,m) order)
     for (unsigned int q = threadIdx.x; q < n_out; q += blockDim.x)
@@ -659,8 +713,10 @@ int accumulate_impl(unsigned int N, const void *d_postype, int dtype, const mtd_
                     unsigned int type, const double *ql_ref, unsigned int n_global, double *d_partials, unsigned int *n_partials,
                     double *d_qprime, double *d_qlm, double *d_ql, double *d_value, bool accumulate, bool finalize, hipStream_t s)
     {
+    // half: 0 full list, 1 half list, 2 full list that is symmetric and indexes no ghost particle — the CV pass then visits
+    // every pair once and the finalize step scales like for a half list (chunk_gather_compact)
     QlArgs<LMAX> a;
-    int rc = fill_args<LMAX>(a, N, box, rcut, ron, lmax, type, ql_ref, n_global, half);
+    int rc = fill_args<LMAX>(a, N, box, rcut, ron, lmax, type, ql_ref, n_global, half != 0);
     if (rc) return rc;
     if (!accumulate)
         {
@@ -671,9 +727,19 @@ int accumulate_impl(unsigned int N, const void *d_postype, int dtype, const mtd_
     const unsigned int blocks = ql_blocks(N, QL_ACC_PPB, 1024);
     const unsigned int n_out = (lmax + 1) * (lmax + 2);
     if (dtype == MTD_F32)
-        k_ql_accumulate<float4, LMAX><<<blocks, QL_THREADS, 0, s>>>(a, (const float4 *)d_postype, d_head, d_nneigh, d_nlist, d_partials);
+        {
+        if (half == 2)
+            k_ql_accumulate<float4, LMAX, true><<<blocks, QL_THREADS, 0, s>>>(a, (const float4 *)d_postype, d_head, d_nneigh, d_nlist, d_partials);
+        else
+            k_ql_accumulate<float4, LMAX, false><<<blocks, QL_THREADS, 0, s>>>(a, (const float4 *)d_postype, d_head, d_nneigh, d_nlist, d_partials);
+        }
     else
-        k_ql_accumulate<double4, LMAX><<<blocks, QL_THREADS, 0, s>>>(a, (const double4 *)d_postype, d_head, d_nneigh, d_nlist, d_partials);
+        {
+        if (half == 2)
+            k_ql_accumulate<double4, LMAX, true><<<blocks, QL_THREADS, 0, s>>>(a, (const double4 *)d_postype, d_head, d_nneigh, d_nlist, d_partials);
+        else
+            k_ql_accumulate<double4, LMAX, false><<<blocks, QL_THREADS, 0, s>>>(a, (const double4 *)d_postype, d_head, d_nneigh, d_nlist, d_partials);
+        }
     MTD_LAUNCH_CHECK();
     *n_partials = blocks;
     rc = mtd_reduce_partials(d_partials, blocks, n_out, n_out, 1.0, 0.0, d_qprime, (mtd_stream_t)s);
@@ -690,6 +756,7 @@ int forces_impl(unsigned int N, const void *d_postype, void *d_force, int dtype,
                 unsigned int type, const double *ql_ref, unsigned int n_global, const double *d_qlm, const double *d_bias,
                 double bias_host, hipStream_t s)
     {
+    half = half == 1 ? 1 : 0;                                                // a symmetric full list (2) is a full list here
     QlArgs<LMAX> a;
     int rc = fill_args<LMAX>(a, N, box, rcut, ron, lmax, type, ql_ref, n_global, half);
     if (rc) return rc;

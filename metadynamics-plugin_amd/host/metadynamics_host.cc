@@ -443,7 +443,7 @@ void SteinhardtQl::computeCV(unsigned int timestep)
     const mtd_box box = m_pdata->getBox().toMtd();
     mtd_check(mtd_ql_accumulate(m_pdata->getN(), m_pdata->positionsPtr(), m_pdata->getDtype(), &box,
                                 (const unsigned int *)m_nlist->getHeadList().data(), (const unsigned int *)m_nlist->getNNeighArray().data(),
-                                (const unsigned int *)m_nlist->getNListArray().data(), m_nlist->getStorageMode() == NeighborList::half,
+                                (const unsigned int *)m_nlist->getNListArray().data(), m_nlist->getStorageMode() == NeighborList::half ? 1 : (m_nlist->isSymmetricFull() ? 2 : 0),
                                 m_rcut, m_ron, m_lmax, m_type, m_Ql_ref.data(), m_pdata->getNGlobal(), (double *)m_scratch.data(),
                                 &m_d_value, &m_d_Ql, &m_d_Qlm, m_exec_conf->getStream()),
               "mtd_ql_accumulate");
@@ -474,7 +474,7 @@ void SteinhardtQl::computeBiasForces(unsigned int timestep)
     const mtd_box box = m_pdata->getBox().toMtd();
     mtd_check(mtd_ql_forces(m_pdata->getN(), m_pdata->positionsPtr(), m_force.data(), m_pdata->getDtype(), &box,
                             (const unsigned int *)m_nlist->getHeadList().data(), (const unsigned int *)m_nlist->getNNeighArray().data(),
-                            (const unsigned int *)m_nlist->getNListArray().data(), m_nlist->getStorageMode() == NeighborList::half,
+                            (const unsigned int *)m_nlist->getNListArray().data(), m_nlist->getStorageMode() == NeighborList::half ? 1 : (m_nlist->isSymmetricFull() ? 2 : 0),
                             m_rcut, m_ron, m_lmax, m_type, m_Ql_ref.data(), m_pdata->getNGlobal(), (const double *)m_scratch.data(),
                             m_bias_device, m_bias, m_exec_conf->getStream()),
               "mtd_ql_forces");

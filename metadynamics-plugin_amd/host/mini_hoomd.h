@@ -314,7 +314,21 @@ class NeighborList
             if (n) m_nneigh.upload(n_neigh, sizeof(unsigned int) * n);
             if (n_list) m_nlist.upload(nlist, sizeof(unsigned int) * n_list);
             m_has = true;
+            // a full list of HOOMD is symmetric by construction ((i, j) listed <=> (j, i) listed) and, on one rank, indexes
+            // local particles only; the stand-in checks what it is handed, since SteinhardtQl's CV pass then visits every pair once
+            m_symmetric = true;
+            for (size_t i = 0; i < n && m_symmetric; ++i)
+                for (unsigned int k = 0; k < n_neigh[i] && m_symmetric; ++k)
+                    {
+                    const unsigned int j = nlist[head[i] + k];
+                    bool back = false;
+                    if (j < n)
+                        for (unsigned int q = 0; q < n_neigh[j] && !back; ++q) back = nlist[head[j] + q] == i;
+                    m_symmetric = back;
+                    }
             }
+        //! full list, (i, j) listed <=> (j, i) listed, no ghost particles
+        bool isSymmetricFull() const { return m_mode == full && m_has && m_symmetric; }
         //! HOOMD rebuilds the list here when particles moved too far; the stand-in only checks that one was supplied
         void compute(unsigned int timestep)
             {
@@ -330,6 +344,7 @@ class NeighborList
         storageMode m_mode;
         unsigned int m_last;
         bool m_has;
+        bool m_symmetric = false;
         DeviceBuffer m_head, m_nneigh, m_nlist;
     };
 

@@ -114,3 +114,50 @@ def test_ql_config5_size(abi, ref):
     assert 0.5 * 144 * 0.57452 ** 2 < Ql[6] < 144 * 0.57452 ** 2
     # size-independent property: the force field sums to ~zero only for the pair-symmetric part; check finiteness + scale
     assert np.isfinite(g[3]).all() and np.abs(g[3]).max() > 0
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_ql_symmetric_full_list_visits_each_pair_once(abi, ref, dtype):
+    """half_nlist = 2: a symmetric full list without ghosts — the CV pass visits each pair from its lower index and scales
+    like a half list; the reference's result for the FULL list is reproduced (odd degrees cancel exactly instead of to
+    rounding), the force pass is the full-list one"""
+    pos, L = noisy_fcc(6, seed=3)
+    pos = pos.astype(dtype)
+    N = len(pos)
+    types = (np.random.default_rng(2).random(N) < 0.15).astype(np.int32)      # two types: only type 0 takes part
+    nl = util.build_nlist(pos.astype(np.float64), L, 1.55)                    # list with a buffer beyond r_cut
+    Ql_ref = [0.3, 0.2, 0.1, 0.4, 1.0, 0.6, 1.0]
+    lib = abi.load()
+    box = abi.Box.make(L)
+    dt = abi.MTD_F32 if dtype == np.float32 else abi.MTD_F64
+    d_pos = torch.from_numpy(util.pack_postype(pos, types, dtype)).cuda()
+    d_head, d_nn, d_nl = (torch.from_numpy(x.astype(np.int32)).cuda() for x in nl)
+    out = {}
+    for mode in (0, 2):
+        scratch = torch.zeros(lib.mtd_ql_scratch_doubles(6), dtype=torch.float64, device="cuda")
+        p_val, p_ql, p_qlm = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        abi.check(lib.mtd_ql_accumulate(N, abi.ptr(d_pos), dt, C.byref(box), abi.ptr(d_head), abi.ptr(d_nn), abi.ptr(d_nl), mode,
+                                        1.4, 1.2, 6, 0, util.dbl_array(Ql_ref), N, abi.ptr(scratch),
+                                        C.byref(p_val), C.byref(p_ql), C.byref(p_qlm), None))
+        force = torch.zeros((N, 4), dtype=d_pos.dtype, device="cuda")
+        d_bias = torch.tensor([0.7], dtype=torch.float64, device="cuda")
+        abi.check(lib.mtd_ql_forces(N, abi.ptr(d_pos), abi.ptr(force), dt, C.byref(box), abi.ptr(d_head), abi.ptr(d_nn), abi.ptr(d_nl),
+                                    mode, 1.4, 1.2, 6, 0, util.dbl_array(Ql_ref), N, abi.ptr(scratch), abi.ptr(d_bias), 0.0, None))
+        torch.cuda.synchronize()
+        s = scratch.cpu().numpy()
+        off = lambda p: (p.value - scratch.data_ptr()) // 8
+        q = s[off(p_qlm):off(p_qlm) + 2 * 49]
+        out[mode] = (s[off(p_val)], s[off(p_ql):off(p_ql) + 7].copy(), q[0::2] + 1j * q[1::2], force.cpu().numpy().astype(np.float64))
+    r = run_ref(ref, pos.astype(np.float64), types, L, nl, 1.4, 1.2, 6, 0, Ql_ref, bias=0.7)
+    qs = np.abs(r[2]).max()
+    for mode in (0, 2):
+        val, Ql, Qlm, F = out[mode]
+        assert np.abs(Qlm - r[2]).max() <= 1e-11 * qs
+        assert val == pytest.approx(r[0], rel=1e-10)
+        assert np.allclose(Ql, r[1], rtol=1e-10, atol=1e-13 * np.abs(r[1]).max())
+    # odd degrees: exact zeros in the once-per-pair pass
+    odd = [l * l + p for l in (1, 3, 5) for p in range(2 * l + 1)]
+    assert np.all(out[2][2][odd] == 0.0)
+    fs = np.abs(r[3][:, :3]).max()
+    tol = 1e-9 if dtype == np.float64 else 2e-7
+    assert np.abs(out[2][3][:, :3] - r[3][:, :3]).max() <= tol * fs
