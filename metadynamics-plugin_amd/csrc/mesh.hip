@@ -93,7 +93,10 @@ __device__ __forceinline__ double tsc_deriv(double x)                 // :470-48
 // outside the box: clamped cell, large shift) takes the general forms.  The closed derivative keeps Q9: |x| rounded to
 // float in fac and in the quotient x / |x|, the latter as 1 + (|x| - float|x|) / float|x| with a float reciprocal
 // (the correction is ~6e-8, so its own relative error of 1e-7 is invisible in double).
-__device__ __forceinline__ bool tsc_inbox(const double s) { return fabs(s) <= 0.5000001; }
+// exactly |s| <= 1/2: a hair beyond it the closed forms are off by O(|s| - 1/2) in the derivative — harmless by itself, but
+// the z (or x, y) force sums differences of neighbouring mesh rows, and on a smooth field that cancellation turned 3e-7
+// into 3e-4 of the component for a particle sitting on a cell boundary (found by tools/fuzz_mesh.py)
+__device__ __forceinline__ bool tsc_inbox(const double s) { return fabs(s) <= 0.5; }
 
 __device__ __forceinline__ void tsc3(const double s, double (&w)[3])
     {

@@ -240,3 +240,40 @@ def test_qmax_virial_table(abi, ref, tilt):
     assert np.allclose(vir, v_ref, rtol=1e-9, atol=1e-9 * np.abs(v_ref).max())
     assert lib.mtd_mesh_set_table(m.h, util.dbl_array(K), util.dbl_array(dK), npts, 2.0, 1.0) == -1   # MTD_ERR_INVALID_ARGUMENT
     m.close()
+
+
+def test_mesh_particles_on_cell_boundaries(abi, ref, monkeypatch):
+    """particles sitting exactly on cell faces / corners (in-cell shift = -1/2 up to the rounding of an fp32 position): the
+    force sums differences of neighbouring mesh rows, which magnifies any O(1e-7) liberty in the TSC derivative there a
+    thousandfold (regression: closed forms applied a hair beyond |shift| = 1/2, found by tools/fuzz_mesh.py).  The two
+    pipelines share their shifts and must agree to the rounding of the fp32 force array; against the oracle one particle
+    may sit further out (Q9: the reference rounds |x| to float inside the derivative)."""
+    dims, Ls = (64, 20, 24), (12.3082284, 9.7, 6.6019954)
+    rng = np.random.default_rng(3)
+    N = 20000
+    f = rng.random((N, 3))
+    f[:2000] = np.round(f[:2000] * np.array(dims)) / np.array(dims)          # on cell corners
+    f[2000:4000, 2] = np.round(f[2000:4000, 2] * dims[2]) / dims[2]          # on z faces
+    f[0] = [0.0, 0.0, 0.0]; f[1] = [0.999999999, 0.5, 0.0]; f[2] = [0.5, 0.0, 0.999999999]
+    pos = ((f - 0.5) * np.array(Ls)).astype(np.float32)
+    types = rng.integers(0, 2, N).astype(np.int32)
+    mode = [1.0, -0.6]
+    box, rbox = abi.Box.make(Ls), ref.Box.make(Ls)
+    d_pos = torch.from_numpy(util.pack_postype(pos, types, np.float32)).cuda()
+    opt = util.oracle_postype(pos, types)
+    r = ref.Mesh(*dims, mode)
+    s_ref = r.cv(opt, rbox)
+    F_ref = r.forces(opt, rbox, 0.8)
+    F = {}
+    for path in ("tiles", "cells"):
+        monkeypatch.setenv("MTD_MESH_ASSIGN", path)
+        g = GpuMesh(abi, dims, mode, N)
+        try:
+            assert g.cv(d_pos, abi.MTD_F32, box, N) == pytest.approx(s_ref, rel=1e-9)
+            F[path] = g.forces(d_pos, abi.MTD_F32, box, N, 0.8)
+        finally:
+            g.close()
+    fm = np.abs(F_ref).max()
+    assert np.abs(F["tiles"] - F["cells"]).max() <= 5e-7 * fm
+    per = np.abs(F["tiles"][:, :3] - F_ref[:, :3]).max(axis=1) / fm
+    assert int((per > 5e-7).sum()) <= 1 and per.max() <= 1e-3
