@@ -810,7 +810,8 @@ static int ql_dispatch(unsigned int n_particles, const void *d_postype, int dtyp
                        mtd_stream_t stream)
     {
     if (!d_scratch) return MTD_ERR_INVALID_ARGUMENT;
-    if (accumulate && n_particles && (!d_postype || !d_head_list || !d_n_neigh || !d_nlist)) return MTD_ERR_INVALID_ARGUMENT;
+    // (an empty neighbour list may come with a null d_nlist: it is only dereferenced for particles with n_neigh > 0)
+    if (accumulate && n_particles && (!d_postype || !d_head_list || !d_n_neigh)) return MTD_ERR_INVALID_ARGUMENT;
     if (dtype != MTD_F32 && dtype != MTD_F64) return MTD_ERR_INVALID_ARGUMENT;
     if (lmax > 12) return MTD_ERR_UNSUPPORTED;
     double *partials, *qprime, *qlm, *ql, *value;
@@ -879,7 +880,7 @@ int mtd_ql_forces(unsigned int n_particles, const void *d_postype, void *d_force
                   double rcut, double ron, unsigned int lmax, unsigned int type, const double *Ql_ref, unsigned int n_global,
                   const double *d_scratch, const double *d_bias, double bias_host, mtd_stream_t stream)
     {
-    if (!d_scratch || (n_particles && (!d_postype || !d_force || !d_head_list || !d_n_neigh || !d_nlist))) return MTD_ERR_INVALID_ARGUMENT;
+    if (!d_scratch || (n_particles && (!d_postype || !d_force || !d_head_list || !d_n_neigh))) return MTD_ERR_INVALID_ARGUMENT;
     if (dtype != MTD_F32 && dtype != MTD_F64) return MTD_ERR_INVALID_ARGUMENT;
     if (lmax > 12) return MTD_ERR_UNSUPPORTED;
     if (n_particles == 0) return MTD_SUCCESS;
