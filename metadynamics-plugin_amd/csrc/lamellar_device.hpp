@@ -172,7 +172,11 @@ __device__ __forceinline__ void lam_cv_accumulate(const LamKArgs &a, const S4 *_
                         cs.x = cos2pi<FAST>(t.x);
                         cs.y = cos2pi<FAST>(t.y);
                         sum[q] += cs;
-                        sum[q] += h.w * ((cs * cs) * 2.0f - 1.0f);    // the second harmonic of this mode when folded (w = 1), branch-free
+                        // the second harmonic of this mode when folded (w = 1), branch-free.  The hardware cosine of the FAST
+                        // path truncates: |c| is low by 3.2e-8 on average, which cancels in sums of c but leaves 2 c^2 - 1 low by
+                        // 6.5e-8 on average — a bias of that size times sum_j a_j / N in the CV, whatever N (tools/probe_cos.hip;
+                        // found by tools/fuzz_fused.py on a one-type system).  One float ulp off the constant takes 92 % of it out.
+                        sum[q] += h.w * ((cs * cs) * 2.0f - (FAST ? 0.99999994f : 1.0f));
                         }
                     }
 #pragma unroll
