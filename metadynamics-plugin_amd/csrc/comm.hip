@@ -13,6 +13,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <vector>
 
 namespace
 {
@@ -42,6 +43,45 @@ __global__ __launch_bounds__(AR_THREADS) void k_comm_allreduce(const CommK k, do
             t += __hiloint2double((int)s_half[r * nw + 2 * j + 1], (int)s_half[r * nw + 2 * j]);
         values[j] = t;
         }
+    }
+
+// Uncached device buffers are never handed back to the runtime while the process lives: a buffer that kernels have used
+// through its uncached mapping, freed and then re-issued by hipMalloc as ordinary memory made later kernels of this library
+// fault on it (ROCm 7.2, gfx950: slab-mesh step, mtd_comm_destroy, a new mesh's transform buffers on the same pages —
+// found by tools/fuzz_slab.py).  Released buffers wait in this pool for the next request of at most their size.
+struct PooledBuffer { void *p; size_t bytes; bool in_use; };
+std::vector<PooledBuffer> g_uncached_pool;
+
+hipError_t uncached_acquire(void **out, size_t bytes)
+    {
+    for (PooledBuffer &b : g_uncached_pool)
+        if (!b.in_use && b.bytes >= bytes)
+            {
+            b.in_use = true;
+            *out = b.p;
+            return hipSuccess;
+            }
+    void *p = nullptr;
+    hipError_t e = hipExtMallocWithFlags(&p, bytes, hipDeviceMallocUncached);
+    if (e != hipSuccess)
+        {
+        (void)hipGetLastError();
+        e = hipExtMallocWithFlags(&p, bytes, hipDeviceMallocFinegrained);
+        }
+    if (e != hipSuccess)
+        {
+        (void)hipGetLastError();
+        return e;
+        }
+    g_uncached_pool.push_back({p, bytes, true});
+    *out = p;
+    return hipSuccess;
+    }
+
+void uncached_release(void *p)
+    {
+    for (PooledBuffer &b : g_uncached_pool)
+        if (b.p == p) b.in_use = false;
     }
 
 unsigned long long env_timeout_ticks()
@@ -93,15 +133,9 @@ int mtd_comm_create(mtd_comm **out, unsigned int rank, unsigned int world, unsig
     c->max_doubles = max_doubles;
     c->bytes = sizeof(unsigned long long) * 2 * world * c->k.words_per_rank;
     // uncached device memory: peers' stores and this GPU's polling loads must not sit in a non-coherent L2
-    hipError_t e = hipExtMallocWithFlags(&c->local, c->bytes, hipDeviceMallocUncached);
+    hipError_t e = uncached_acquire(&c->local, c->bytes);
     if (e != hipSuccess)
         {
-        (void)hipGetLastError();
-        e = hipExtMallocWithFlags(&c->local, c->bytes, hipDeviceMallocFinegrained);
-        }
-    if (e != hipSuccess)
-        {
-        (void)hipGetLastError();
         delete c;
         return (int)e;
         }
@@ -114,7 +148,7 @@ int mtd_comm_create(mtd_comm **out, unsigned int rank, unsigned int world, unsig
     if (e != hipSuccess)
         {
         if (aux) (void)hipFree(aux);
-        (void)hipFree(c->local);
+        uncached_release(c->local);
         delete c;
         return (int)e;
         }
@@ -169,17 +203,8 @@ int mtd_comm_share(mtd_comm *c, size_t bytes, void **d_local, unsigned int *slot
     if (!c || !d_local || !slot || !out_handle || bytes == 0) return MTD_ERR_INVALID_ARGUMENT;
     if (c->n_shared >= MTD_COMM_MAX_SHARED) return MTD_ERR_UNSUPPORTED;
     void *p = nullptr;
-    hipError_t e = hipExtMallocWithFlags(&p, bytes, hipDeviceMallocUncached);
-    if (e != hipSuccess)
-        {
-        (void)hipGetLastError();
-        e = hipExtMallocWithFlags(&p, bytes, hipDeviceMallocFinegrained);
-        }
-    if (e != hipSuccess)
-        {
-        (void)hipGetLastError();
-        return (int)e;
-        }
+    hipError_t e = uncached_acquire(&p, bytes);
+    if (e != hipSuccess) return (int)e;
     e = hipMemset(p, 0, bytes);
     if (e == hipSuccess) e = hipDeviceSynchronize();
     hipIpcMemHandle_t h;
@@ -188,7 +213,7 @@ int mtd_comm_share(mtd_comm *c, size_t bytes, void **d_local, unsigned int *slot
     if (e != hipSuccess)
         {
         (void)hipGetLastError();
-        (void)hipFree(p);
+        uncached_release(p);
         return (int)e;
         }
     const unsigned int s = c->n_shared++;
@@ -258,10 +283,10 @@ int mtd_comm_destroy(mtd_comm *c)
         {
         for (unsigned int r = 0; r < c->k.world; ++r)
             if (r != c->k.rank && c->shared_peer[s][r]) (void)hipIpcCloseMemHandle(c->shared_peer[s][r]);
-        if (c->shared_local[s]) (void)hipFree(c->shared_local[s]);
+        if (c->shared_local[s]) uncached_release(c->shared_local[s]);
         }
     if (c->k.err) (void)hipFree(c->k.err);
-    if (c->local) (void)hipFree(c->local);
+    if (c->local) uncached_release(c->local);
     delete c;
     return MTD_SUCCESS;
     }
