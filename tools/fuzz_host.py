@@ -1,0 +1,80 @@
+#!/usr/bin/env python3
+"""Developer tool (GPU box): the reference-shaped API (metadynamics.cv / integrate over the C++ host classes) with the fused
+paths on (pure lamellar sets: two launches; mixed sets: lamellar CVs through launch A + the grid-engine launch) against the
+same run with setFusedPath(False) (every CV its own kernels, mtd_metad_update_bias): random CV sets of 1-3 variables out of
+lamellar / mesh / lamellar-with-umbrella, random grids, strides, modes.  usage: fuzz_host.py [seconds] [seed]"""
+import os, sys, time
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [os.path.join(root, "metadynamics-plugin_amd"), os.path.join(root, "tests")]
+import numpy as np, torch
+import util
+from metadynamics import context, cv, integrate
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+t0, t_print, it, worst = time.time(), time.time(), 0, dict(cv=0.0, V=0.0, force=0.0)
+n_fused = n_mixed = 0
+while time.time() - t0 < budget:
+    it += 1
+    if time.time() - t_print > 30.0:
+        t_print = time.time()
+        print("fuzz_host: %d cases so far" % it, flush=True)
+    N = int(rng.choice([200, 2000, 12000]))
+    L = float(rng.uniform(8.0, 20.0))
+    dtype = np.float32 if rng.random() < 0.5 else np.float64
+    pos, types = util.snapshot_random(N, L, seed=int(rng.integers(1, 10**6)), modulated=True, dtype=np.float64)
+    pos = (np.mod(pos + L / 2, L) - L / 2).astype(dtype)
+    kinds = [str(k) for k in rng.choice(["lam", "lam", "mesh", "lam_umbrella"], size=int(rng.integers(1, 4)))]
+    if kinds.count("mesh") > 1: kinds = ["lam" if (k == "mesh" and i > kinds.index("mesh")) else k for i, k in enumerate(kinds)]
+    spec = []
+    for k in kinds:
+        if k == "mesh":
+            spec.append(("mesh", int(rng.choice([8, 12, 16]))))
+        else:
+            vecs = [tuple(int(x) for x in rng.integers(-3, 4, 3)) for _ in range(int(rng.integers(1, 5)))]
+            if all(v == (0, 0, 0) for v in vecs): vecs[0] = (0, 0, 2)
+            spec.append((k, vecs))
+    stride, mode = int(rng.integers(1, 3)), ("well_tempered" if rng.random() < 0.7 else "standard")
+    steps = int(rng.integers(2, 6))
+    out = {}
+    for fused in (True, False):
+        context.initialize(pos, types, ["A", "B"], L, dtype=dtype)
+        meta = integrate.mode_metadynamics(dt=0.005, stride=stride, mode=mode, W=1.0, deltaT=5.0, T=1.0)
+        cvs = []
+        for i, (k, par) in enumerate(spec):
+            if k == "mesh":
+                c = cv.mesh(nx=par, mode={"A": 1.0, "B": -0.8}, sigma=0.05, name="m%d" % i)
+                c.set_grid(0.0, 3.0, 24)
+            else:
+                c = cv.lamellar(sigma=0.05, mode=dict(A=1.0, B=-1.0), lattice_vectors=par, name="l%d" % i)
+                c.set_grid(-1.5, 1.5, 24)
+                if k == "lam_umbrella":
+                    c.set_params(umbrella="harmonic", kappa=0.7, cv0=0.1)
+            cvs.append(c)
+        meta.cpp_integrator.setFusedPath(fused)
+        context.run(steps)
+        t = context.current.system.getCurrentTimeStep()
+        integ = meta.cpp_integrator
+        out[fused] = dict(cv=list(integ.getCurrentValues()), V=integ.getLogValue("bias", t), n=integ.getNumGaussians(),
+                          F=[c.cpp_force.getForces().astype(np.float64) for c in cvs], used=integ.usedFusedPath())
+        context.current = None
+    a, b = out[True], out[False]
+    if it <= 3 and os.environ.get("FUZZ_HOST_VERBOSE"):
+        print("case", it, spec, "N", N, "steps", steps, "\n fused", a["cv"], a["V"], a["n"], a["used"], float(np.abs(a["F"][0]).max()),
+              "\n plain", b["cv"], b["V"], b["n"], b["used"], float(np.abs(b["F"][0]).max()), flush=True)
+    if a["used"]: n_fused += 1
+    elif any(k == "lam" for k, _ in spec) and len(spec) <= 3: n_mixed += 1
+    assert a["n"] == b["n"]
+    for x, y in zip(a["cv"], b["cv"]):
+        worst["cv"] = max(worst["cv"], abs(x - y) / max(abs(y), 1e-3))
+        assert abs(x - y) <= 2e-6 * max(abs(y), 1e-3), ("cv", spec, a["cv"], b["cv"])
+    if abs(b["V"]) > 1e-12:
+        worst["V"] = max(worst["V"], abs(a["V"] - b["V"]) / abs(b["V"]))
+        assert abs(a["V"] - b["V"]) <= 1e-4 * abs(b["V"]), ("V", spec, a["V"], b["V"])
+    for c, (fa, fb) in enumerate(zip(a["F"], b["F"])):
+        sc = np.abs(fb).max()
+        if sc > 1e-20:
+            worst["force"] = max(worst["force"], np.abs(fa - fb).max() / sc)
+            assert np.abs(fa - fb).max() <= 2e-4 * sc, ("force", c, spec, np.abs(fa - fb).max() / sc)
+print("fuzz_host: %d random CV sets in %.0f s (%d took the two-launch step, %d the mixed-set launches), worst relative deviations fused vs generic %s"
+      % (it, time.time() - t0, n_fused, n_mixed, {k: float("%.2e" % v) for k, v in worst.items()}))
