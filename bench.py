@@ -326,12 +326,15 @@ def main():
         for _ in range(n_ev):
             eng.step()
         e1.record()
+        # launch A alone sends without anybody receiving: no rank may start that while a peer still polls for the last real
+        # exchange (the slots alternate between two buffers: a third send would overwrite what the peer is waiting for)
+        barrier()
         f0, f1 = event_pair()
         f0.record()
         for _ in range(n_ev):
             eng.be.cv_partials()
         f1.record()
-        torch.cuda.synchronize()
+        barrier()
         step_us, a_us = e0.elapsed_time(e1) * 1e3 / n_ev, f0.elapsed_time(f1) * 1e3 / n_ev
         alt["steps_minus_launch_A_alone_us"] = step_us - a_us
         alt["step_us"], alt["launch_A_alone_us"] = step_us, a_us

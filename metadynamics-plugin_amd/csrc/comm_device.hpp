@@ -13,7 +13,9 @@
 // { half, seq }.  A word is valid for exchange number `seq` when its upper half equals seq.  seq is never 0 (the
 // mailbox starts zeroed).  Slots are double-buffered by the parity of seq: a peer can run at most one exchange ahead
 // of a rank that has not yet read (its exchange seq+1 completes only after this rank's send seq+1, which is ordered
-// after this rank's read of seq on the stream), so two buffers suffice.
+// after this rank's read of seq on the stream), so two buffers suffice — PROVIDED every send of a rank is followed by its own
+// receive of the same exchange before it sends again.  A caller that sends without receiving (bench.py times launch A alone)
+// must put a barrier in front of that: its second such send would overwrite what a slower peer is still polling for.
 //
 // Every poll loop is bounded (wall clock, 100 MHz): on a timeout the kernel counts an error and goes on with whatever
 // it read — it never hangs; mtd_comm_status reports the count.
