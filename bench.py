@@ -253,12 +253,16 @@ def main():
     if dist is not None and eng.be.mailbox is not None:
         # the mailbox passed its self test; a short rehearsal of the real step decides whether it carries the timed run: any
         # bounded wait that expired on any rank (a link that does not deliver) sends every rank back to the collective
-        barrier()
-        for _ in range(50):
-            eng.step()
-        barrier()
-        tt = torch.tensor([eng.be.mailbox.timeouts()], dtype=torch.int64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        # (checked after 1, 5 and 50 steps: a dead link costs one step's bounded waits, not fifty)
+        for chunk in (1, 4, 45):
+            barrier()
+            for _ in range(chunk):
+                eng.step()
+            barrier()
+            tt = torch.tensor([eng.be.mailbox.timeouts()], dtype=torch.int64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            if int(tt.item()) > 0:
+                break
         if int(tt.item()) > 0 or os.environ.get("MTD_BENCH_TEST_FALLBACK") == "1":      # (env: exercises this branch in a rehearsal)
             eng.be.attach_mailbox(None)
             eng.exchange = "%s (mailbox gave %d timeouts in rehearsal)" % ("rccl" if dist.get_backend() == "nccl" else dist.get_backend(), int(tt.item()))
