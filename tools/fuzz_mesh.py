@@ -50,10 +50,19 @@ while time.time() - t0 < budget:
         g.close()
     (s1, r1, F1), (s2, r2, F2) = res["tiles"], res["cells"]
     scale = max(np.abs(r2).max(), 1e-300)
+    # the tile path sums in fixed point with one deposit < 2^51: its resolution is 2^-50 of max|mode| over ALL types, which
+    # shows when the few particles present all carry a much smaller mode than an absent type
+    fx = 2.0 ** -47 * max(abs(a) for a in mode)
     worst["rho"] = max(worst["rho"], np.abs(r1 - r2).max() / scale)
     if s2 != 0.0: worst["cv"] = max(worst["cv"], abs(s1 - s2) / abs(s2))
     if N and np.abs(F2).max() > 0: worst["f"] = max(worst["f"], np.abs(F1 - F2).max() / np.abs(F2).max())
-    assert np.abs(r1 - r2).max() <= 1e-11 * scale, ("rho", dims, N, tilt)
+    if np.abs(r1 - r2).max() > 1e-11 * scale + fx:
+        r = mtd_ref.Mesh(dims[0], dims[1], dims[2], mode)
+        r.cv(util.oracle_postype(pos, types), rbox, n_global=n_global)
+        rho_ref = r.array("mesh").real
+        print("DEBUG rho: case", it, "tiles-vs-oracle", np.abs(r1 - rho_ref).max(), "cells-vs-oracle", np.abs(r2 - rho_ref).max(), "scale", scale,
+              "sum tiles", r1.sum(), "sum cells", r2.sum(), "sum oracle", rho_ref.sum(), "frac", f[:4].tolist(), "dtype", dtype)
+    assert np.abs(r1 - r2).max() <= 1e-11 * scale + fx, ("rho", dims, N, tilt)
     assert abs(s1 - s2) <= 1e-9 * max(abs(s2), 1e-300), ("cv", dims, N, tilt, s1, s2)
     ftol = 1e-8 if dtype == np.float64 else 5e-7                      # fp32 force arrays: one rounding
     if N and np.abs(F1 - F2).max() > ftol * max(np.abs(F2).max(), 1e-300):
@@ -73,7 +82,7 @@ while time.time() - t0 < budget:
         rho_ref = r.array("mesh").real
         sc = max(np.abs(rho_ref).max(), 1e-300)
         worst["rho_ref"] = max(worst["rho_ref"], np.abs(r1 - rho_ref).max() / sc)
-        assert np.abs(r1 - rho_ref).max() <= 1e-11 * sc, ("rho vs oracle", dims, N, tilt)
+        assert np.abs(r1 - rho_ref).max() <= 1e-11 * sc + fx, ("rho vs oracle", dims, N, tilt)
         if s_ref != 0.0:
             worst["cv_ref"] = max(worst["cv_ref"], abs(s1 - s_ref) / abs(s_ref))
             assert abs(s1 - s_ref) <= 1e-8 * abs(s_ref), ("cv vs oracle", dims, N, tilt, s1, s_ref)
