@@ -693,34 +693,45 @@ __global__ __launch_bounds__(TF_THREADS) void k_tile_forces(const MeshGeom g, co
     const unsigned int lx = threadIdx.x & 31;
     int gx = x0 + (int)lx - 1;
     gx = gx < 0 ? gx + (int)g.nx : (gx >= (int)g.nx ? gx - (int)g.nx : gx);
-    // all loads of a thread are issued before the first LDS store (a load -> store loop pays one memory round trip per row)
+    // all loads of a thread are issued before the first LDS store (a load -> store loop pays one memory round trip per row).
+    // Row r of a thread is row (tid / 32) + 8 r of the image: (ly, lz) advance by 8 rows with compares instead of a division
+    // per row (the unrolled divisions were more vector instructions than the whole particle loop), the LDS row offset is
+    // computed once and kept.
     constexpr int TF_ROWS = ((TP_Y + 2) * (TP_Z + 2) + TF_THREADS / 32 - 1) / (TF_THREADS / 32);
+    constexpr unsigned int TF_STEP = TF_THREADS / 32;
     double v[TF_ROWS];
+    unsigned int srow[TF_ROWS];                                        // LDS offset of the row, ~0u: nothing to stage
     const unsigned int n_rows = wyn * wzn;
+    {
+    unsigned int row = threadIdx.x >> 5;
+    unsigned int lz = row / wyn, ly = row - lz * wyn;
 #pragma unroll
     for (int r = 0; r < TF_ROWS; ++r)
         {
-        const unsigned int row = (threadIdx.x >> 5) + r * (TF_THREADS / 32);
         v[r] = 0.0;
+        srow[r] = ~0u;
         if (row < n_rows && lx < wxn)
             {
-            const unsigned int lz = row / wyn, ly = row - lz * wyn;
             int gy = y0 + (int)ly - 1, gz = z0 + (int)lz - 1;
             gy = gy < 0 ? gy + (int)g.ny : (gy >= (int)g.ny ? gy - (int)g.ny : gy);
             gz = gz < 0 ? gz + (int)g.nz : (gz >= (int)g.nz ? gz - (int)g.nz : gz);
             v[r] = inv[gx + g.nx * (gy + g.ny * gz)];
+            srow[r] = lx + tg.hx * (ly + tg.hy * lz);
             }
+        row += TF_STEP;
+        ly += TF_STEP;
+#pragma unroll
+        for (int turn = 0; turn < 3; ++turn)                           // wyn >= 3 and 8 rows further: at most three wraps
+            if (ly >= wyn)
+                {
+                ly -= wyn;
+                ++lz;
+                }
         }
+    }
 #pragma unroll
     for (int r = 0; r < TF_ROWS; ++r)
-        {
-        const unsigned int row = (threadIdx.x >> 5) + r * (TF_THREADS / 32);
-        if (row < n_rows && lx < wxn)
-            {
-            const unsigned int lz = row / wyn, ly = row - lz * wyn;
-            s_inv[lx + tg.hx * (ly + tg.hy * lz)] = v[r];
-            }
-        }
+        if (srow[r] != ~0u) s_inv[srow[r]] = v[r];
     __syncthreads();
     const double bias = d_bias ? *d_bias : bias_host;
     const double s = two_over_n * bias;                                // :861

@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """Developer tool: BASELINE.json configs[2] (10^6 particles, cv.mesh on 128^3 + 1 lamellar CV, 256^2 grid) through the
-reference-shaped API; prints us/step.  Run under rocprofv3 --kernel-trace --stats for the per-kernel table."""
+reference-shaped API; prints us/step.  Run under rocprofv3 --kernel-trace --stats for the per-kernel table.
+usage: bench_mesh.py [steps] [sfc]   sfc: particle ids follow a Morton curve over 64^3 cells, as after HOOMD's SFCPack sorter
+(the default, ids uncorrelated with positions, is the worst case for the gathers and scattered stores by id)"""
 import os, sys, time
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [os.path.join(root, "metadynamics-plugin_amd"), os.path.join(root, "tests")]
@@ -12,6 +14,14 @@ steps = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 pos, types = util.snapshot_random(N, L, seed=12345, modulated=True, dtype=np.float32)
 pos = (np.mod(pos.astype(np.float64) + L / 2, L) - L / 2).astype(np.float32)   # an MD engine keeps its particles wrapped into the box
 pos[pos >= L / 2] = -L / 2
+if len(sys.argv) > 2 and sys.argv[2] == "sfc":
+    c = np.minimum(((pos.astype(np.float64) + L / 2) / L * 64).astype(np.int64), 63)
+    key = np.zeros(N, dtype=np.int64)
+    for b in range(6):
+        for d in range(3):
+            key |= ((c[:, d] >> b) & 1) << (3 * b + d)
+    order = np.argsort(key, kind="stable")
+    pos, types = np.ascontiguousarray(pos[order]), np.ascontiguousarray(types[order])
 context.initialize(pos, types, ["A", "B"], L, dtype=np.float32)
 meta = integrate.mode_metadynamics(dt=0.005, stride=1, mode="well_tempered", W=1.0, deltaT=7.0, T=1.0)
 lam = cv.lamellar(sigma=0.02, mode=dict(A=1.0, B=-1.0), lattice_vectors=util.CV1_VECTORS)
@@ -30,4 +40,4 @@ t0 = time.perf_counter()
 context.current.system.run(steps - 1)
 torch.cuda.synchronize()
 dt = time.perf_counter() - t0
-print("config 3: %.1f us/step  (%.3e particle-CV-evals/s, 2 CVs)" % (1e6 * dt / steps, 2 * N * steps / dt))
+print("config 3%s: %.1f us/step  (%.3e particle-CV-evals/s, 2 CVs)" % (" (ids along a space-filling curve)" if len(sys.argv) > 2 and sys.argv[2] == "sfc" else "", 1e6 * dt / steps, 2 * N * steps / dt))
