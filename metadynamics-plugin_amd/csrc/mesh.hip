@@ -750,9 +750,13 @@ __global__ __launch_bounds__(TF_THREADS) void k_tile_forces(const MeshGeom g, co
         tsc3_deriv(sx, wxv, dxv);
         tsc3_deriv(sy, wyv, dyv);
         tsc3_deriv(sz, wzv, dzv);
+        // contracted axis by axis: rows with W and W' (x), then planes (y), then the three sums (z) — 90 multiply-adds
+        // instead of 108 with the weight products formed per row
         double g1 = 0.0, g2 = 0.0, g3 = 0.0;   // sums multiplying n_x b1, n_y b2, n_z b3
 #pragma unroll
         for (int k = 0; k < 3; ++k)
+            {
+            double pd = 0.0, pdy = 0.0, pw = 0.0;                                // plane k: sum_j of W_y ad, W'_y aw, W_y aw
 #pragma unroll
             for (int j = 0; j < 3; ++j)
                 {
@@ -760,10 +764,14 @@ __global__ __launch_bounds__(TF_THREADS) void k_tile_forces(const MeshGeom g, co
                 const double r0 = s_inv[row], r1 = s_inv[row + 1], r2 = s_inv[row + 2];
                 const double aw = wxv[0] * r0 + wxv[1] * r1 + wxv[2] * r2;       // row sums with W and with W'
                 const double ad = dxv[0] * r0 + dxv[1] * r1 + dxv[2] * r2;
-                g1 += ad * (wyv[j] * wzv[k]);
-                g2 += aw * (dyv[j] * wzv[k]);
-                g3 += aw * (wyv[j] * dzv[k]);
+                pd += wyv[j] * ad;
+                pdy += dyv[j] * aw;
+                pw += wyv[j] * aw;
                 }
+            g1 += wzv[k] * pd;
+            g2 += wzv[k] * pdy;
+            g3 += dzv[k] * pw;
+            }
         const double c1 = -(double)g.nx * a * g1, c2 = -(double)g.ny * a * g2, c3 = -(double)g.nz * a * g3;
         const double fx = (c1 * g.binv[0][0] + c2 * g.binv[1][0] + c3 * g.binv[2][0]) * s;
         const double fy = (c1 * g.binv[0][1] + c2 * g.binv[1][1] + c3 * g.binv[2][1]) * s;
