@@ -86,7 +86,9 @@ def test_mesh_bitwise_independent_of_particle_order(abi):
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
 @pytest.mark.parametrize("dims,tilt", [((8, 8, 8), {}), ((16, 8, 32), dict(xy=0.2, xz=-0.1, yz=0.15)), ((32, 32, 32), {}),
                                        # sizes that are not powers of two (direct transforms, partial gather tiles, odd lengths)
-                                       ((12, 20, 6), dict(xy=0.1, xz=0.05, yz=-0.2)), ((5, 7, 9), {}), ((48, 16, 36), {})])
+                                       ((12, 20, 6), dict(xy=0.1, xz=0.05, yz=-0.2)), ((5, 7, 9), {}), ((48, 16, 36), {}),
+                                       # one-cell edge tiles in x and y (the loop form of the combine pass; the others take the row form)
+                                       ((17, 33, 16), {})])
 def test_mesh_cv_and_forces(abi, ref, dtype, dims, tilt, assign_path):
     N = 6007
     Ls = (9.0, 7.5, 11.0)
@@ -121,6 +123,13 @@ def test_mesh_cv_and_forces(abi, ref, dtype, dims, tilt, assign_path):
                 F = g.forces(d_pos, dt, box, N, -2.5, device_bias)
                 F_ref = r.forces(opt, rbox, -2.5)
                 tol = 1e-8 if dtype == np.float64 else 2e-7    # fp32 force array: one rounding on store
+                if dtype == np.float32 and dims == (17, 33, 16):
+                    # Q9 (the reference rounds |x| to float inside the TSC derivative): with float32 positions and this
+                    # box / mesh ratio 1 % of the values sit EXACTLY on a float rounding tie, where the last bit of the shift
+                    # (reciprocal multiply + fused multiply-add here, divisions in the oracle) decides the direction: the
+                    # derivative weight moves by 6e-8 and a force component that is a cancelling sum by up to 6.5e-7 of max|F|
+                    # (14 of 6007 particles; both GPU pipelines agree to 2e-15).  BASELINE asks 1e-5.
+                    tol = 1e-6
                 assert np.abs(F[:, :3] - F_ref[:, :3]).max() <= tol * np.abs(F_ref[:, :3]).max()
                 assert np.all(F[:, 3] == 0.0)
     finally:
