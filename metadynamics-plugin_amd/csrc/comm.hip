@@ -10,8 +10,10 @@
 // Protocol and bounds: comm_device.hpp.
 #include "comm_host.hpp"
 
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <vector>
 
@@ -45,22 +47,39 @@ __global__ __launch_bounds__(AR_THREADS) void k_comm_allreduce(const CommK k, do
         }
     }
 
-// Uncached device buffers are never handed back to the runtime while the process lives: a buffer that kernels have used
-// through its uncached mapping, freed and then re-issued by hipMalloc as ordinary memory made later kernels of this library
-// fault on it (ROCm 7.2, gfx950: slab-mesh step, mtd_comm_destroy, a new mesh's transform buffers on the same pages —
-// found by tools/fuzz_slab.py).  Released buffers wait in this pool for the next request of at most their size.
+// Uncached device buffers are never handed back to the runtime while the process lives.  Measured with a stand-alone
+// program that contains no code of this library (tools/probe_uncached.hip, log in profiles/r2/uncached_reuse_probe.log;
+// ROCm 7.2, gfx950): once a range of device addresses has lived as a hipDeviceMallocUncached allocation and has been freed,
+// an ORDINARY hipMalloc that lands on it is no longer coherent between the L2 and HBM — kernels see what kernels wrote, but a
+// copy engine (hipMemcpy to the host) reads stale HBM under it, and host-to-device copies (twiddle tables, mode
+// coefficients) can be shadowed by stale L2 lines: 77 of 480 regions came back with wrong contents, none before the first
+// uncached life.  That is what round 1's slab fuzzing hit (a later mesh on those addresses read garbage tables and, with
+// garbage particle offsets, faulted) — with this library's own kernels in bounds (the replay tools/diag_slab_fault.py maps
+// every allocation; same wrong results from the stand-alone probe).  The other direction exists as well: PLAIN loads from an
+// uncached buffer can hit stale L2 lines of an earlier ordinary life of its addresses, so every read of an exported buffer
+// goes past the L2 (system-scope loads: comm_device.hpp ld_exported) and nothing is transformed in place in one.
+// Released buffers wait here for the next request of EXACTLY their size (a larger one would hide an out-of-bounds access
+// behind its slack); the pool is bounded by the largest set of buffers alive at one time.
 struct PooledBuffer { void *p; size_t bytes; bool in_use; };
 std::vector<PooledBuffer> g_uncached_pool;
+std::mutex g_uncached_mutex;
+
+// diagnostic switches (tools/diag_slab_fault.py): MTD_COMM_POOL=0 hands released buffers back to the runtime (reproduces the
+// hazard above), MTD_TRACE_ALLOC=1 prints every allocation
+bool pool_off() { const char *e = std::getenv("MTD_COMM_POOL"); return e && e[0] == '0'; }
+bool trace_on() { const char *e = std::getenv("MTD_TRACE_ALLOC"); return e && e[0] == '1'; }
 
 hipError_t uncached_acquire(void **out, size_t bytes)
     {
-    for (PooledBuffer &b : g_uncached_pool)
-        if (!b.in_use && b.bytes >= bytes)
-            {
-            b.in_use = true;
-            *out = b.p;
-            return hipSuccess;
-            }
+    std::lock_guard<std::mutex> lock(g_uncached_mutex);
+    if (!pool_off())
+        for (PooledBuffer &b : g_uncached_pool)
+            if (!b.in_use && b.bytes == bytes)
+                {
+                b.in_use = true;
+                *out = b.p;
+                return hipSuccess;
+                }
     void *p = nullptr;
     hipError_t e = hipExtMallocWithFlags(&p, bytes, hipDeviceMallocUncached);
     if (e != hipSuccess)
@@ -73,13 +92,21 @@ hipError_t uncached_acquire(void **out, size_t bytes)
         (void)hipGetLastError();
         return e;
         }
-    g_uncached_pool.push_back({p, bytes, true});
+    if (trace_on()) fprintf(stderr, "[mtd] uncached alloc %p .. %p (%zu bytes)\n", p, (char *)p + bytes, bytes);
+    if (!pool_off()) g_uncached_pool.push_back({p, bytes, true});
     *out = p;
     return hipSuccess;
     }
 
 void uncached_release(void *p)
     {
+    std::lock_guard<std::mutex> lock(g_uncached_mutex);
+    if (pool_off())
+        {
+        if (trace_on()) fprintf(stderr, "[mtd] uncached free %p\n", p);
+        (void)hipFree(p);
+        return;
+        }
     for (PooledBuffer &b : g_uncached_pool)
         if (b.p == p) b.in_use = false;
     }

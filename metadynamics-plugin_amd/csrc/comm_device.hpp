@@ -132,6 +132,19 @@ __device__ __forceinline__ void ll_collect_wave(const CommK &k, const unsigned i
         }
     }
 
+// Loads from an EXPORTED bulk buffer (mtd_comm_share: uncached device memory, local or a peer's mapping): system-scope loads
+// go past the L2.  A plain load may hit a stale L2 line left by an earlier ordinary life of the buffer's addresses — uncached
+// stores neither update nor invalidate it (measured: tools/probe_uncached.hip, comm.hip).
+__device__ __forceinline__ double ld_exported(const double *p)
+    {
+    return __longlong_as_double((long long)__hip_atomic_load((const unsigned long long *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
+    }
+__device__ __forceinline__ double2 ld_exported(const double2 *p)
+    {
+    const double *q = (const double *)p;
+    return make_double2(ld_exported(q), ld_exported(q + 1));
+    }
+
 __device__ __forceinline__ unsigned int dbl_lo(double v) { return (unsigned int)__double2loint(v); }
 __device__ __forceinline__ unsigned int dbl_hi(double v) { return (unsigned int)__double2hiint(v); }
 

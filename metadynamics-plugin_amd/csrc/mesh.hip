@@ -36,6 +36,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <new>
@@ -50,7 +51,7 @@ struct MeshGeom
     {
     unsigned int nx, ny, nz, n_cells;
     unsigned int hxp;                          // row pitch of the half-spectrum arrays (k_x = 0 .. nx/2 stored, then padding)
-    double lo[3], L[3], Linv[3], xy, xz, yz;   // box (local == global: single rank); Linv = 1 / L
+    double lo[3], L[3], xy, xz, yz;            // box (local == global: single rank)
     double binv[3][3];                    // reciprocal rows without 2 pi (force pass, :761-769)
     };
 
@@ -145,21 +146,31 @@ __device__ __forceinline__ void tsc3_deriv(const double s, double (&w)[3], doubl
         }
     }
 
-// BoxDim::makeFraction / makeCoordinates / minImage (HOOMD-blue v2 semantics)
+// BoxDim::makeFraction / makeCoordinates / minImage (HOOMD-blue v2 semantics).
+// Cell and in-cell shift follow the reference's operation order EXACTLY (:540-573 == :784-812: makeFraction, truncation,
+// makeCoordinates of the cell centre, minImage, makeFraction again) — true divisions, one rounding per operation, no fused
+// multiply-add (the translation unit is compiled with -ffp-contract=fast; the pragma switches it off here and the flag
+// travels with the instructions when these functions are inlined).  The shift feeds assignTSCderiv, which rounds |x| to
+// FLOAT (Q9): a shift that differs from the reference's in its last bit can fall on the other side of a float rounding
+// boundary, the derivative weight jumps by 6e-8 and, through the cancelling row differences of the force, one particle
+// moved by up to 1e-3 of max|F| (round-1 verdict).  With the same operations in the same order the shift is the same
+// double, bit for bit, and every tie resolves as in the reference.
 __device__ __forceinline__ void make_fraction(const MeshGeom &g, double x, double y, double z, double &fx, double &fy, double &fz)
     {
+#pragma clang fp contract(off)
     double dx = x - g.lo[0], dy = y - g.lo[1], dz = z - g.lo[2];
     dx -= (g.xz - g.yz * g.xy) * dz + g.xy * dy;
     dy -= g.yz * dz;
-    fx = dx * g.Linv[0];
-    fy = dy * g.Linv[1];
-    fz = dz * g.Linv[2];
+    fx = dx / g.L[0];
+    fy = dy / g.L[1];
+    fz = dz / g.L[2];
     }
 
 // cell (ix,iy,iz) and in-cell shift (mesh units) of a particle — :540-573 == :784-812
 __device__ __forceinline__ void locate(const MeshGeom &g, const Particle &p, int &ix, int &iy, int &iz, double &sx, double &sy,
                                        double &sz)
     {
+#pragma clang fp contract(off)
     double fx, fy, fz;
     make_fraction(g, p.x, p.y, p.z, fx, fy, fz);
     ix = (int)(fx * (double)g.nx);
@@ -172,27 +183,26 @@ __device__ __forceinline__ void locate(const MeshGeom &g, const Particle &p, int
     ix = min(max(ix, 0), (int)g.nx - 1);
     iy = min(max(iy, 0), (int)g.ny - 1);
     iz = min(max(iz, 0), (int)g.nz - 1);
-    // mesh dimensions are powers of two: the divisions by nx, ny, nz are exact multiplications
-    const double cfx = ((double)ix + 0.5) * (1.0 / g.nx), cfy = ((double)iy + 0.5) * (1.0 / g.ny), cfz = ((double)iz + 0.5) * (1.0 / g.nz);
+    const double cfx = ((double)ix + 0.5) / (double)g.nx, cfy = ((double)iy + 0.5) / (double)g.ny, cfz = ((double)iz + 0.5) / (double)g.nz;
     // makeCoordinates(cell centre)
     const double cx = g.lo[0] + cfx * g.L[0] + cfy * g.xy * g.L[1] + cfz * g.xz * g.L[2];
     const double cy = g.lo[1] + cfy * g.L[1] + cfz * g.yz * g.L[2];
     const double cz = g.lo[2] + cfz * g.L[2];
     double wx = p.x - cx, wy = p.y - cy, wz = p.z - cz;
     // minImage
-    double img = rint(wz * g.Linv[2]);              // HOOMD BoxDim::minImage works with the reciprocal lengths too
+    double img = rint(wz / g.L[2]);
     wz -= g.L[2] * img;
     wy -= g.L[2] * g.yz * img;
     wx -= g.L[2] * g.xz * img;
-    img = rint(wy * g.Linv[1]);
+    img = rint(wy / g.L[1]);
     wy -= g.L[1] * img;
     wx -= g.L[1] * g.xy * img;
-    wx -= g.L[0] * rint(wx * g.Linv[0]);
+    wx -= g.L[0] * rint(wx / g.L[0]);
     double sfx, sfy, sfz;
     make_fraction(g, wx + g.lo[0], wy + g.lo[1], wz + g.lo[2], sfx, sfy, sfz);
-    sx = sfx * g.nx;
-    sy = sfy * g.ny;
-    sz = sfz * g.nz;
+    sx = sfx * (double)g.nx;
+    sy = sfy * (double)g.ny;
+    sz = sfz * (double)g.nz;
     }
 
 __device__ __forceinline__ int wrap(int i, int n)
@@ -1219,7 +1229,7 @@ __global__ __launch_bounds__(FFT_THREADS) void k_fft_z_spectral(const MeshGeom g
         if (DIST)
             {
             const unsigned int q = p / sl.nz_loc, zl = p - q * sl.nz_loc;
-            s[lds_slot(p, log2n) * tile + t] = sl.f[q][base + t + (size_t)zl * plane];
+            s[lds_slot(p, log2n) * tile + t] = ld_exported(sl.f[q] + base + t + (size_t)zl * plane);
             }
         else
             s[lds_slot(p, log2n) * tile + t] = fmesh[base + t + (size_t)p * plane];
@@ -1304,7 +1314,7 @@ __global__ __launch_bounds__(256) void k_slab_pull_rho(const PeerPtrs peers, con
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
         {
         double v = 0.0;
-        for (unsigned int q = 0; q < world; ++q) v += ((const double *)peers.p[q])[first + i];
+        for (unsigned int q = 0; q < world; ++q) v += ld_exported((const double *)peers.p[q] + first + i);
         out[i] = v;
         }
     }
@@ -1321,7 +1331,7 @@ __global__ __launch_bounds__(256) void k_slab_pull_g(const PeerPtrs peers, const
         const size_t row = i / hxp;
         const unsigned int y = (unsigned int)(row % ny), zl = (unsigned int)(row / ny);
         const unsigned int q = y / ny_loc;
-        out[i] = ((const double2 *)peers.p[q])[((size_t)(z0 + zl) * ny_loc + (y - q * ny_loc)) * hxp + x];
+        out[i] = ld_exported((const double2 *)peers.p[q] + ((size_t)(z0 + zl) * ny_loc + (y - q * ny_loc)) * hxp + x);
         }
     }
 
@@ -1333,7 +1343,7 @@ __global__ __launch_bounds__(256) void k_slab_pull_inv(const PeerPtrs peers, con
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
         {
         const unsigned int q = (unsigned int)(i / slab_cells);
-        out[i] = ((const double *)peers.p[q])[i - (size_t)q * slab_cells];
+        out[i] = ld_exported((const double *)peers.p[q] + (i - (size_t)q * slab_cells));
         }
     }
 
@@ -1588,7 +1598,6 @@ int fill_geom(MeshGeom &g, const mtd_mesh *m, const mtd_box *box)
         {
         g.lo[i] = box->lo[i];
         g.L[i] = box->L[i];
-        g.Linv[i] = 1.0 / box->L[i];
         }
     g.xy = box->xy; g.xz = box->xz; g.yz = box->yz;
     reciprocal_rows(*box, g.binv);
@@ -1698,6 +1707,7 @@ int mtd_mesh_create(mtd_mesh **out, unsigned int nx, unsigned int ny, unsigned i
         delete m;
         return (int)e;
         }
+    if (const char *tr = std::getenv("MTD_TRACE_ALLOC")) if (tr[0] == '1') fprintf(stderr, "[mtd] mesh %ux%ux%u slab %p .. %p (%zu bytes)\n", nx, ny, nz, m->slab, (char *)m->slab + off, off);
     char *p = (char *)m->slab;
     m->d_mode = (double *)(p + o_mode); m->d_rho = (double *)(p + o_rho); m->d_modesq_partials = (double *)(p + o_msqp);
     m->d_mode_sq = m->d_rho + M;   // directly behind the real mesh: one exchange buffer of M + 1 doubles
@@ -2041,7 +2051,8 @@ int mtd_mesh_slab_compute_cv(mtd_mesh *m, unsigned int n_particles, const void *
     MTD_LAUNCH_CHECK();
     rc = mtd_comm_allreduce_small(m->slab_comm, m->d_slab_sum + 1, 1, stream);                 // barrier
     if (rc) return rc;
-    // 2. this rank's slab, x and y transforms in the exported buffer
+    // 2. this rank's slab: x and y transforms in memory of its own (nothing is transformed in place in an exported buffer:
+    //    plain loads from one may hit stale L2 lines, comm.hip), the result copied out
     peers_of(m->slab_rho);
     k_slab_pull_rho<<<1024, 256, 0, s>>>(pp, W, (size_t)r * slab_cells, slab_cells, m->d_slab_rho);
     MTD_LAUNCH_CHECK();
@@ -2050,12 +2061,14 @@ int mtd_mesh_slab_compute_cv(mtd_mesh *m, unsigned int n_particles, const void *
     while (x_pairs > 1 && fft_x_lds_bytes(m->nx, x_pairs) > 64 * 1024) x_pairs >>= 1;
     const unsigned int x_tile = 2 * x_pairs, x_blocks = (n_lines + x_tile - 1) / x_tile;
     const size_t x_lds = fft_x_lds_bytes(m->nx, x_pairs);
-    k_fft_x_r2c<<<x_blocks, FFT_THREADS, x_lds, s>>>(m->d_slab_rho, f_x, m->d_tw[0], m->nx, ilog2(m->nx), x_tile, m->hxp, n_lines);
+    k_fft_x_r2c<<<x_blocks, FFT_THREADS, x_lds, s>>>(m->d_slab_rho, m->d_f, m->d_tw[0], m->nx, ilog2(m->nx), x_tile, m->hxp, n_lines);
     MTD_LAUNCH_CHECK();
     FftPass py = fft_y_pass(m);
     py.n_blocks = py.tiles_per_row * nzl;
     k_fft_lines<false, false><<<py.n_blocks, FFT_THREADS, fft_lds_bytes(py.n, py.tile), s>>>(
-        nullptr, f_x, nullptr, py.tw, py.n, ilog2(py.n), py.tile, py.elem_stride, py.line_stride, py.tiles_per_row, py.row_stride, 0, py.p_fastest);
+        nullptr, m->d_f, nullptr, py.tw, py.n, ilog2(py.n), py.tile, py.elem_stride, py.line_stride, py.tiles_per_row, py.row_stride, 0, py.p_fastest);
+    MTD_LAUNCH_CHECK();
+    k_copy_doubles<<<1024, 256, 0, s>>>((const double *)m->d_f, (double *)f_x, 2 * (size_t)nzl * m->ny * m->hxp);
     MTD_LAUNCH_CHECK();
     rc = mtd_comm_allreduce_small(m->slab_comm, m->d_mode_sq, 1, stream);                       // barrier + global sum mode^2 (:630)
     if (rc) return rc;

@@ -8,7 +8,7 @@ import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-for p in (os.path.join(ROOT, "metadynamics-plugin_amd"), os.path.join(ROOT, "tests")):
+for p in (os.path.join(ROOT, "metadynamics-plugin_amd"), os.path.join(ROOT, "tests"), os.path.join(ROOT, "oracle")):
     if p not in sys.path:
         sys.path.insert(0, p)
 
@@ -189,9 +189,17 @@ def main():
             torch.cuda.synchronize()
             st1 = b1.state()
             f_slab, f_one = part.force.cpu().numpy(), one2.force.cpu().numpy()
-            slab[key].update(cv=[st_slab["cv"][1], st1["cv"][1]],
+            # the ORACLE on the whole snapshot (ref_mesh_*: OrderParameterMesh.cc:517-968), bias factor one
+            import mtd_ref
+            rmesh = mtd_ref.Mesh(dims[0], dims[1], dims[2], mode)
+            opt = util.oracle_postype(pos, types)
+            s_orc = rmesh.cv(opt, mtd_ref.Box.make(L))
+            f_orc = rmesh.forces(opt, mtd_ref.Box.make(L), 1.0)
+            slab[key].update(cv=[st_slab["cv"][1], st1["cv"][1], s_orc],
                              cv_rel=abs(st_slab["cv"][1] - st1["cv"][1]) / abs(st1["cv"][1]),
+                             cv_rel_oracle=abs(st_slab["cv"][1] - s_orc) / abs(s_orc),
                              force_rel=float(np.abs(f_slab[:, :3] - f_one[sl, :3]).max() / np.abs(f_one[:, :3]).max()),
+                             force_rel_oracle=float(np.abs(f_slab[:, :3] - f_orc[sl, :3]).max() / np.abs(f_orc[:, :3]).max()),
                              force_max=float(np.abs(f_one[:, :3]).max()))
             b1.close()
             probe.close()

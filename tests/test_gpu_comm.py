@@ -119,6 +119,9 @@ def test_mailbox_between_processes(world):
         assert v["timeouts"] == 0, key
         assert v["cv_rel"] < 1e-9, (key, v)
         assert v["force_rel"] < 1e-7 and v["force_max"] > 1e-12, (key, v)
+        # ... and against the oracle on the whole snapshot (stated tolerances: CV 1e-6, forces 1e-5 of max|F|)
+        assert v["cv_rel_oracle"] < 1e-8, (key, v)
+        assert v["force_rel_oracle"] < 1e-5, (key, v)
     assert "16x24x24" in r["slab"]
     # generic CV set through the stand-alone mailbox all-reduce
     assert r["timeouts_set"] == 0
@@ -179,3 +182,59 @@ def test_mailbox_setup_failure_is_agreed_by_all_ranks():
     """one rank cannot map its peers: every rank gets None back from xgmi.connect (and keeps the collective path)"""
     r = _run_world(2, 1000, extra_env={"MTD_XGMI_TEST_FAIL_RANK": "1"})
     assert r["connected"] is False
+
+
+def test_slab_close_then_whole_mesh_sequence(abi, ref):
+    """Regression for the round-1 memory access fault (gpurun_out/dbg_slab.log): whole mesh -> one-rank slab mesh over exported
+    (uncached) buffers -> slab close -> comm destroy -> next whole mesh, several sizes in a row so that later meshes land on
+    addresses earlier buffers used.  Every CV and the forces are checked against the ORACLE (ref_mesh_*,
+    OrderParameterMesh.cc:517-968), not against the other HIP path.  Cause and fix: comm.hip (uncached pool), DESIGN.md §6."""
+    import ctypes as C
+    from test_gpu_mesh import GpuMesh
+    lib = abi.load()
+    rng = np.random.default_rng(5)
+    N, Ls, mode = 4000, (9.0, 11.0, 7.5), [1.0, -0.6]
+    box, rbox = abi.Box.make(Ls), ref.Box.make(Ls)
+    for it in range(8):
+        dims = [(48, 48, 32), (16, 24, 24), (32, 32, 32), (20, 12, 8)][it % 4]
+        pos = ((rng.random((N, 3)) - 0.5) * np.array(Ls)).astype(np.float32)
+        types = rng.integers(0, 2, N).astype(np.int32)
+        d_pos = torch.from_numpy(util.pack_postype(pos, types, np.float32)).cuda()
+        opt = util.oracle_postype(pos, types)
+        r = ref.Mesh(*dims, mode)
+        s_ref = r.cv(opt, rbox)
+        F_ref = r.forces(opt, rbox, 0.8)
+        fm = np.abs(F_ref[:, :3]).max()
+        whole = GpuMesh(abi, dims, mode, N)
+        s_whole = whole.cv(d_pos, abi.MTD_F32, box, N)
+        F_whole = whole.forces(d_pos, abi.MTD_F32, box, N, 0.8)
+        whole.close()
+        assert s_whole == pytest.approx(s_ref, rel=1e-9), (it, dims)
+        assert np.abs(F_whole[:, :3] - F_ref[:, :3]).max() <= 1e-5 * fm, (it, dims)
+        h = C.c_void_p()
+        abi.check(lib.mtd_comm_create(C.byref(h), 0, 1, 8))
+        slab = GpuMesh(abi, dims, mode, N)
+        sizes = (C.c_size_t * 4)()
+        abi.check(lib.mtd_mesh_slab_bytes(slab.h, 1, sizes))
+        peers = []
+        for k in range(4):
+            local, slot, hd = C.c_void_p(), C.c_uint(), (C.c_ubyte * 64)()
+            abi.check(lib.mtd_comm_share(h, sizes[k], C.byref(local), C.byref(slot), hd))
+            pp = (C.c_void_p * 1)()
+            abi.check(lib.mtd_comm_open(h, slot.value, None, pp))
+            peers.append(pp)
+        abi.check(lib.mtd_mesh_slab_attach(slab.h, h, peers[0], peers[1], peers[2], peers[3]))
+        for rep in range(2):                                             # twice: the exported buffers are re-used between steps
+            cv_sum = C.c_void_p()
+            abi.check(lib.mtd_mesh_slab_compute_cv(slab.h, N, abi.ptr(d_pos), abi.MTD_F32, C.byref(box), N, C.byref(cv_sum), None))
+            out = torch.zeros(1, dtype=torch.float64, device="cuda")
+            abi.check(lib.mtd_reduce_partials(cv_sum.value, 1, 1, 1, 0.5, 0.0, out.data_ptr(), None))
+            torch.cuda.synchronize()
+            assert out.item() == pytest.approx(s_ref, rel=1e-9), (it, dims, rep)
+        F_slab = slab.forces(d_pos, abi.MTD_F32, box, N, 0.8)
+        assert np.abs(F_slab[:, :3] - F_ref[:, :3]).max() <= 1e-5 * fm, (it, dims)
+        n_to = C.c_uint()
+        abi.check(lib.mtd_comm_status(h, C.byref(n_to), None))
+        assert n_to.value == 0
+        slab.close()
+        abi.check(lib.mtd_comm_destroy(h))

@@ -201,3 +201,59 @@ def test_fused_force_pass_with_slot_map(abi, dtype):
     assert lib.mtd_fused_force_pass_slots(ha, C.byref(lset), (C.c_uint * 2)(3, 1), N, d_pos.data_ptr(), pa, dt, N, C.byref(box), 9, None) == -1
     for h in (ha, hb):
         abi.check(lib.mtd_metad_destroy(h))
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("fast", [1, 0])
+def test_fused_full_size_config2(abi, ref, dtype, fast):
+    """The instantiation bench.py times (fused two-launch step; fast_trig = 1 is the bench default) at BASELINE.json
+    configs[1] size — 10^6 particles, 2 lamellar CVs x 8 modes, well-tempered, modulated parity snapshot: CV values to 1e-6
+    (LamellarOrderParameter.cc:42-74), every grid array / V / w after three deposits against the oracle's
+    updateBiasPotential (IntegratorMetaDynamics.cc:314-588), per-particle forces against the oracle's computeBiasForces
+    (LamellarOrderParameter.cc:77-140) on a 100 000-particle slice to 1e-5 of max|F|, and linearity in the bias factor over
+    all 10^6 particles (size-independent property)."""
+    lib = abi.load()
+    N, L = 1_000_000, 100.0
+    pos, types = util.snapshot_random(N, L, seed=12345, modulated=True, dtype=dtype)
+    box, rbox = abi.Box.make(L), ref.Box.make(L)
+    opt = util.oracle_postype(pos, types)
+    kw = dict(sigma=[0.05, 0.01], cv_min=[-1.0, -1.0], cv_max=[1.0, 1.0], num_points=[256, 256], W=1.0, T_shift=7.0,
+              T=1.0, stride=1, mode="well_tempered")
+    s_ref = [ref.lamellar_cv(v, opt, m, rbox) for v, m in CVS]
+    assert abs(s_ref[0]) > 0.05
+    lib.mtd_lamellar_set_fast_trig(fast)
+    g = GpuMetad(abi, **kw)
+    r = ref.Metad(**kw)
+    try:
+        f = Fused(abi, g, N, dtype)
+        d_pos = torch.from_numpy(util.pack_postype(pos, types, dtype)).cuda()
+        F_step = []
+        for t in range(3):
+            f.step(t, d_pos, box)
+            torch.cuda.synchronize()
+            F_step.append([x.cpu().numpy().astype(np.float64) for x in f.forces])
+        st = g.state()
+        assert abs(st["cv"][0] - s_ref[0]) <= 1e-6 * abs(s_ref[0]), (st["cv"][0], s_ref[0])
+        assert abs(st["cv"][1] - s_ref[1]) <= 1e-6 * 8 / np.sqrt(N), (st["cv"][1], s_ref[1])
+        for t in range(3):
+            b = r.update_bias(t, st["cv"])           # static snapshot: the same CV values every step
+        compare(g, r, b, label="fused 10^6 fast=%d" % fast)
+        assert abs(b[0]) > 0 and abs(b[1]) > 0
+        sl = slice(0, 100_000)
+        for c, (v, m) in enumerate(CVS):
+            F_ref = ref.lamellar_forces(v, opt[sl], m, rbox, b[c], n_global=N)
+            scale = np.abs(F_ref[:, :3]).max()
+            F = F_step[2][c]
+            assert np.abs(F[sl, :3] - F_ref[:, :3]).max() <= 1e-5 * scale, (c, fast)
+            assert np.all(F[:, 3] == 0.0)
+        # all 10^6 particles: the force of step 1 is the force of step 2 times the ratio of the bias factors (same positions;
+        # the kernel multiplies the unscaled force by the bias factor at store time)
+        r2 = ref.Metad(**kw)
+        b_hist = [r2.update_bias(t, st["cv"]) for t in range(3)]
+        for c in range(2):
+            ratio = b_hist[1][c] / b_hist[2][c]
+            scale = np.abs(F_step[2][c][:, :3]).max()
+            assert np.abs(F_step[1][c][:, :3] - ratio * F_step[2][c][:, :3]).max() <= 4e-6 * scale * max(1.0, abs(ratio))
+    finally:
+        lib.mtd_lamellar_set_fast_trig(0)
+        g.close()

@@ -97,23 +97,37 @@ def test_ql_two_types_and_shard(abi, ref):
     assert np.all(g[3][types == 1] == 0.0)          # other types carry no force (memset at :236)
 
 
-def test_ql_config5_size(abi, ref):
-    """BASELINE.json configs[4]: 256 000 particles (40^3 fcc cells), lmax = 6, r_cut 1.4, r_on 1.2, Ql_ref [0,0,0,0,1,0,1]"""
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_ql_config5_size(abi, ref, dtype):
+    """BASELINE.json configs[4]: 256 000 particles (40^3 fcc cells), lmax = 6, r_cut 1.4, r_on 1.2, Ql_ref [0,0,0,0,1,0,1]:
+    CV and Q_l against the oracle on the whole system (SteinhardtQl.cc:62-201), forces against the oracle's
+    computeBiasForces (SteinhardtQl.cc:203-339) on the first 30 000 central particles (the oracle takes a subset of the
+    head list and the full position array), stated tolerance 1e-5 of max|F|"""
     pos, L = noisy_fcc(40)
     N = len(pos)
     assert N == 256000
+    pos = pos.astype(dtype)
     types = np.zeros(N, dtype=np.int32)
-    nl = util.build_nlist(pos, L, 1.4)
+    nl = util.build_nlist(pos.astype(np.float64), L, 1.4)
     Ql_ref = [0, 0, 0, 0, 1, 0, 1]
-    g = run_gpu(abi, pos, types, L, nl, 1.4, 1.2, 6, 0, Ql_ref, np.float32)
+    g = run_gpu(abi, pos, types, L, nl, 1.4, 1.2, 6, 0, Ql_ref, dtype)
     box = ref.Box.make(L)
-    pt = util.oracle_postype(pos.astype(np.float32), types)
+    pt = util.oracle_postype(pos, types)
     val, Qlm, Ql = ref.ql_compute_cv(pt, box, *nl, 1.4, 1.2, 6, 0, Ql_ref)
     assert g[0] == pytest.approx(val, rel=1e-6)
+    assert np.allclose(g[1], Ql, rtol=1e-6, atol=1e-9 * np.abs(Ql).max())
+    assert np.abs(g[2] - Qlm).max() <= 1e-9 * np.abs(Qlm).max()
     # noisy fcc keeps most of the ideal order: Q6(code) below but near 144 * 0.57452^2
     assert 0.5 * 144 * 0.57452 ** 2 < Ql[6] < 144 * 0.57452 ** 2
-    # size-independent property: the force field sums to ~zero only for the pair-symmetric part; check finiteness + scale
-    assert np.isfinite(g[3]).all() and np.abs(g[3]).max() > 0
+    n_sl = 30000
+    F_ref = ref.ql_compute_forces(pt, box, nl[0][:n_sl], nl[1][:n_sl], nl[2], 1.4, 1.2, 6, 0, Ql_ref, Qlm, 0.9, n_global=N)[:n_sl]
+    fs = np.abs(F_ref[:, :3]).max()
+    assert fs > 0
+    err = np.abs(g[3][:n_sl, :3] - F_ref[:, :3]).max() / fs
+    assert err <= (1e-6 if dtype == np.float32 else 1e-8), err
+    assert np.isfinite(g[3]).all() and np.all(g[3][:, 3] == 0.0)
+    # size-independent property over all particles: a symmetric full list => the pair forces cancel, sum F = 0
+    assert np.abs(g[3][:, :3].sum(axis=0)).max() <= 1e-4 * fs * np.sqrt(N)
 
 
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
