@@ -39,7 +39,8 @@ enum mtd_status
     MTD_SUCCESS = 0,
     MTD_ERR_INVALID_ARGUMENT = -1, /* the reference throws std::runtime_error for these */
     MTD_ERR_UNSUPPORTED = -2,
-    MTD_ERR_NO_DEVICE = -3
+    MTD_ERR_NO_DEVICE = -3,
+    MTD_ERR_COMM_TIMEOUT = -4      /* a mailbox wait expired: the step is poisoned (NaN), sticky until the mailbox is destroyed */
     };
 
 /* HOOMD BoxDim as a POD (reference: hoomd/BoxDim.h, passed by const-ref to every driver) */
@@ -232,6 +233,26 @@ int mtd_fused_force_pass(mtd_metad *m, const mtd_lamellar_set *set, unsigned int
 int mtd_fused_force_pass_slots(mtd_metad *m, const mtd_lamellar_set *set, const unsigned int *slots, unsigned int n_particles,
                                const void *d_postype, void *const *d_force, int dtype, unsigned int n_global,
                                const mtd_box *global_box, unsigned int timestep, mtd_stream_t stream);
+
+/* The whole step in ONE launch (fused_step.hip): a persistent kernel, one 1024-thread block per compute unit, keeps its
+ * particles in registers between the CV phase and the force phase (the positions are read once) and hands the two grid-wide
+ * sums of a step (CV sums; sum R dV, sum R of the reweighting) from block to block inside the launch in the mailbox's wire
+ * format.  Both reweighting passes run in the launch: the grid arrays are final when it ends (nothing stays pending).
+ * Sharded run (mtd_metad_set_comm): block 0 sends the local sums, every block's chain polls the local mailbox.
+ * Envelope: n_cv <= 3, CV c of the set is CV c of the grid, at most 4096 particles per compute unit, the whole grid of
+ * blocks resident at once, and the form selected (mtd_fused_step_set_mode); otherwise the call runs mtd_fused_cv_pass + mtd_fused_force_pass with
+ * d_scratch (>= mtd_lamellar_scratch_doubles) as the partial-sum buffer.  Every in-launch wait is bounded
+ * (MTD_COMM_TIMEOUT_MS): an expired one poisons the step (NaN) and later calls return MTD_ERR_COMM_TIMEOUT.
+ * Replaces per step: LamellarOrderParameterGPU.cc:34-132 for every CV + IntegratorMetaDynamics.cc:314-588. */
+int mtd_fused_step(mtd_metad *m, const mtd_lamellar_set *set, unsigned int n_particles, const void *d_postype,
+                   void *const *d_force, int dtype, unsigned int n_global, const mtd_box *global_box, double *d_scratch,
+                   unsigned int timestep, mtd_stream_t stream);
+/* launches the last mtd_fused_step of this engine took: 1 (persistent kernel) or 2 (two-launch form); 0 before the first */
+unsigned int mtd_fused_step_launches(const mtd_metad *m);
+/* which form mtd_fused_step takes for this engine: 1 the persistent kernel wherever its envelope allows, 0 always the
+ * two-launch form, -1 (default) the environment (MTD_FUSED_STEP=1 / 0) and without it the two-launch form, which measures
+ * faster at 10^6 particles */
+int mtd_fused_step_set_mode(mtd_metad *m, int mode);
 
 /* Measurement aid (bench.py): the next n_launches launches of mtd_fused_force_pass record their own begin and end through the
  * start / stop events of hipExtLaunchKernelGGL — the dispatch's time stamps, i.e. the duration a kernel trace reports for the

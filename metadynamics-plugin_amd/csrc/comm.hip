@@ -35,11 +35,23 @@ __global__ __launch_bounds__(AR_THREADS) void k_comm_allreduce(const CommK k, do
         const double x = values[w >> 1];
         comm_send_word(k, dst, w, (w & 1) ? dbl_hi(x) : dbl_lo(x));
         }
+    __shared__ int s_failed;
+    if (threadIdx.x == 0) s_failed = 0;
+    __syncthreads();
     for (unsigned int i = threadIdx.x; i < k.world * nw; i += AR_THREADS)
-        s_half[i] = comm_recv_word(k, i / nw, i % nw);
+        {
+        bool ok;
+        s_half[i] = comm_recv_word(k, i / nw, i % nw, ok);
+        if (!ok) s_failed = 1;
+        }
     __syncthreads();
     for (unsigned int j = threadIdx.x; j < n; j += AR_THREADS)
         {
+        if (s_failed)                                   // an expired wait: NaN, never a stale or partial sum
+            {
+            values[j] = __longlong_as_double(0x7ff8000000000000ll);
+            continue;
+            }
         double t = 0.0;
         for (unsigned int r = 0; r < k.world; ++r)
             t += __hiloint2double((int)s_half[r * nw + 2 * j + 1], (int)s_half[r * nw + 2 * j]);
@@ -128,7 +140,10 @@ namespace mtd
 int comm_next(mtd_comm *c, CommK &k)
     {
     if (!c || !c->connected) return MTD_ERR_INVALID_ARGUMENT;
-    c->seq = (c->seq == 0xffffffffu) ? 1u : c->seq + 1u;
+    if (comm_failed(c)) return MTD_ERR_COMM_TIMEOUT;
+    // never 0 (the mailbox starts zeroed), and the parity keeps alternating across the wrap (the slot buffers are
+    // double-buffered by it): 0xffffffff is odd, so 2 follows, not 1
+    c->seq = (c->seq == 0xffffffffu) ? 2u : c->seq + 1u;
     k = c->k;
     k.seq = c->seq;
     return MTD_SUCCESS;
@@ -137,6 +152,7 @@ int comm_next(mtd_comm *c, CommK &k)
 int comm_current(const mtd_comm *c, CommK &k)
     {
     if (!c || !c->connected || c->seq == 0) return MTD_ERR_INVALID_ARGUMENT;
+    if (comm_failed(c)) return MTD_ERR_COMM_TIMEOUT;
     k = c->k;
     k.seq = c->seq;
     return MTD_SUCCESS;
@@ -170,15 +186,25 @@ int mtd_comm_create(mtd_comm **out, unsigned int rank, unsigned int world, unsig
     const size_t aux_bytes = 64 + sizeof(unsigned long long) * COMM_LL_BLOCKS * 2 * COMM_LL_DOUBLES;
     e = hipMalloc(&aux, aux_bytes);
     if (e == hipSuccess) e = hipMemset(aux, 0, aux_bytes);
+    unsigned int *h_err = nullptr, *d_err_host = nullptr;
+    if (e == hipSuccess) e = hipHostMalloc((void **)&h_err, sizeof(unsigned int), hipHostMallocMapped);
+    if (e == hipSuccess)
+        {
+        *h_err = 0;
+        e = hipHostGetDevicePointer((void **)&d_err_host, h_err, 0);
+        }
     if (e == hipSuccess) e = hipMemset(c->local, 0, c->bytes);
     if (e == hipSuccess) e = hipDeviceSynchronize();
     if (e != hipSuccess)
         {
         if (aux) (void)hipFree(aux);
+        if (h_err) (void)hipHostFree(h_err);
         uncached_release(c->local);
         delete c;
         return (int)e;
         }
+    c->h_err = h_err;
+    c->k.err_host = d_err_host;
     c->k.err = (unsigned int *)aux;
     c->k.ll = (unsigned long long *)((char *)aux + 64);
     c->k.box[rank] = (unsigned long long *)c->local;
@@ -313,6 +339,7 @@ int mtd_comm_destroy(mtd_comm *c)
         if (c->shared_local[s]) uncached_release(c->shared_local[s]);
         }
     if (c->k.err) (void)hipFree(c->k.err);
+    if (c->h_err) (void)hipHostFree((void *)c->h_err);
     if (c->local) uncached_release(c->local);
     delete c;
     return MTD_SUCCESS;

@@ -17,8 +17,11 @@
 // receive of the same exchange before it sends again.  A caller that sends without receiving (bench.py times launch A alone)
 // must put a barrier in front of that: its second such send would overwrite what a slower peer is still polling for.
 //
-// Every poll loop is bounded (wall clock, 100 MHz): on a timeout the kernel counts an error and goes on with whatever
-// it read — it never hangs; mtd_comm_status reports the count.
+// Every poll loop is bounded (wall clock, 100 MHz) and an expired wait is FATAL for the communicator, like a failed
+// MPI_Allreduce in the reference (LamellarOrderParameterGPU.cc:69-77 aborts): the waiting kernel counts it, raises the
+// sticky flag in host-visible memory (comm_fail) and hands NaN to its consumer — the fused step then writes NaN bias factors
+// and forces and deposits nothing, the stand-alone all-reduce returns NaN — and every later call that touches the mailbox
+// returns MTD_ERR_COMM_TIMEOUT (comm.hip: comm_next / comm_current).  It never hangs and never goes on with a stale value.
 #pragma once
 
 #include "mtd_device.hpp"
@@ -36,12 +39,20 @@ struct CommK
     unsigned int words_per_rank;                // 2 * max_doubles
     unsigned long long *ll;                     // local: block sums of the sending launch in the same wire format, [block][2 * n]
     unsigned int *err;                          // timeouts seen (local)
+    unsigned int *err_host;                     // sticky failure flag in pinned host memory (read by the host without a sync)
     unsigned long long timeout_ticks;           // wall_clock64 ticks (100 MHz)
     };
 
 __device__ __forceinline__ unsigned long long *comm_slot(const CommK &k, unsigned int owner, unsigned int from)
     {
     return k.box[owner] + ((size_t)(k.seq & 1u) * k.world + from) * k.words_per_rank;
+    }
+
+// an expired wait: counted, and the communicator is dead from here on (the host sees the flag at its next call)
+__device__ __forceinline__ void comm_fail(const CommK &k)
+    {
+    atomicAdd(k.err, 1u);
+    __hip_atomic_store(k.err_host, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 
 // one word of this rank's payload into the mailbox of rank `dst`
@@ -51,9 +62,11 @@ __device__ __forceinline__ void comm_send_word(const CommK &k, unsigned int dst,
     __hip_atomic_store(comm_slot(k, dst, k.rank) + w, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 
-// word `w` of rank `src`'s payload from the LOCAL mailbox; spins until it carries this exchange's number
-__device__ __forceinline__ unsigned int comm_recv_word(const CommK &k, unsigned int src, unsigned int w)
+// word `w` of rank `src`'s payload from the LOCAL mailbox; spins until it carries this exchange's number; ok = false
+// when the wait expired (the returned word is then meaningless)
+__device__ __forceinline__ unsigned int comm_recv_word(const CommK &k, unsigned int src, unsigned int w, bool &ok)
     {
+    ok = true;
     const unsigned long long *p = comm_slot(k, k.rank, src) + w;
     unsigned long long word = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     if ((unsigned int)(word >> 32) != k.seq)
@@ -66,7 +79,8 @@ __device__ __forceinline__ unsigned int comm_recv_word(const CommK &k, unsigned 
             if ((unsigned int)(word >> 32) == k.seq) break;
             if (wall_clock64() - t0 > k.timeout_ticks)
                 {
-                atomicAdd(k.err, 1u);
+                comm_fail(k);
+                ok = false;
                 break;
                 }
             }
@@ -83,15 +97,20 @@ __device__ __forceinline__ void ll_store(unsigned long long *p, unsigned int seq
     }
 
 // Collector side, ONE wave: lane l adds up the NS sums of blocks l, l + 64, ... (fixed order), four blocks' worth of loads
-// in flight per round trip; v[] accumulates.  Spins (bounded) until every word carries this exchange's number.
+// in flight per round trip; v[] accumulates.  Block b's sums sit at k.ll + b * stride_words + offset_words (two words per
+// double).  Spins (bounded) until every word carries this exchange's number.  Returns true (in every lane) when a wait
+// expired: v[] then holds NaN.
 template<int NS>
-__device__ __forceinline__ void ll_collect_wave(const CommK &k, const unsigned int n_blocks, double (&v)[3])
+__device__ __forceinline__ bool ll_collect_strided(const CommK &k, const unsigned int n_blocks, const unsigned int stride_words,
+                                                   const unsigned int offset_words, double (&v)[3])
     {
     const unsigned int lane = threadIdx.x & 63;
+    bool any_expired = false;
     for (unsigned int b0 = lane; b0 < n_blocks; b0 += 4 * MTD_WAVE)
         {
         unsigned long long w[4][NS][2];
         unsigned long long t0 = 0;
+        bool expired = false;
         for (;;)
             {
             bool ok = true;
@@ -103,7 +122,7 @@ __device__ __forceinline__ void ll_collect_wave(const CommK &k, const unsigned i
 #pragma unroll
                     for (int i = 0; i < NS; ++i)
                         {
-                        const unsigned long long *p = k.ll + ((size_t)b * NS + i) * 2;
+                        const unsigned long long *p = k.ll + (size_t)b * stride_words + offset_words + 2 * i;
                         w[j][i][0] = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         w[j][i][1] = __hip_atomic_load(p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         }
@@ -118,10 +137,16 @@ __device__ __forceinline__ void ll_collect_wave(const CommK &k, const unsigned i
             if (t0 == 0) t0 = wall_clock64();
             else if (wall_clock64() - t0 > k.timeout_ticks)
                 {
-                atomicAdd(k.err, 1u);
+                comm_fail(k);
+                expired = true;
                 break;
                 }
             __builtin_amdgcn_s_sleep(1);
+            }
+        if (expired)
+            {
+            any_expired = true;
+            break;
             }
 #pragma unroll
         for (int j = 0; j < 4; ++j)
@@ -130,6 +155,96 @@ __device__ __forceinline__ void ll_collect_wave(const CommK &k, const unsigned i
                 for (int i = 0; i < NS; ++i)
                     v[i] += __hiloint2double((int)(unsigned int)w[j][i][1], (int)(unsigned int)w[j][i][0]);
         }
+    any_expired = __any(any_expired);
+    if (any_expired)
+        {
+#pragma unroll
+        for (int i = 0; i < NS; ++i) v[i] = __longlong_as_double(0x7ff8000000000000ll);     // NaN: poisons the totals
+        }
+    return any_expired;
+    }
+
+// The same for sums stored by COLUMNS: word w of block b at k.ll[w * pitch + b] (value i = words first_word + 2 i and + 2 i + 1).
+// Consecutive lanes read consecutive 8-byte words, so a wave-wide load touches 8 cache lines instead of 64 — this is the
+// layout of the all-to-all hand-offs of the one-launch step, where EVERY block reads every block's sums.
+__device__ __forceinline__ void ll_store_column(unsigned long long *ll, const unsigned int pitch, const unsigned int word, const unsigned int b,
+                                                const unsigned int seq, const double v)
+    {
+    __hip_atomic_store(ll + (size_t)word * pitch + b, ((unsigned long long)seq << 32) | (unsigned int)__double2loint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(ll + (size_t)(word + 1) * pitch + b, ((unsigned long long)seq << 32) | (unsigned int)__double2hiint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+
+// Every block of a launch polls here at the same time: a retry waits ~0.3 us (s_sleep 10) so that the readers do not
+// keep the few memory channels behind these lines busy while the writers' stores are still on their way.
+template<int NS>
+__device__ __forceinline__ bool ll_collect_columns(const CommK &k, const unsigned int n_blocks, const unsigned int pitch,
+                                                   const unsigned int first_word, double (&v)[3])
+    {
+    const unsigned int lane = threadIdx.x & 63;
+    bool any_expired = false;
+    for (unsigned int b0 = lane; b0 < n_blocks; b0 += 4 * MTD_WAVE)
+        {
+        unsigned long long w[4][NS][2];
+        unsigned long long t0 = 0;
+        bool expired = false;
+        for (;;)
+            {
+            bool ok = true;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                {
+                const unsigned int b = b0 + j * MTD_WAVE;
+                if (b < n_blocks)
+#pragma unroll
+                    for (int i = 0; i < NS; ++i)
+                        {
+                        const unsigned long long *p = k.ll + (size_t)(first_word + 2 * i) * pitch + b;
+                        w[j][i][0] = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        w[j][i][1] = __hip_atomic_load(p + pitch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        }
+                }
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (b0 + j * MTD_WAVE < n_blocks)
+#pragma unroll
+                    for (int i = 0; i < NS; ++i)
+                        ok = ok && (unsigned int)(w[j][i][0] >> 32) == k.seq && (unsigned int)(w[j][i][1] >> 32) == k.seq;
+            if (ok) break;
+            if (t0 == 0) t0 = wall_clock64();
+            else if (wall_clock64() - t0 > k.timeout_ticks)
+                {
+                comm_fail(k);
+                expired = true;
+                break;
+                }
+            __builtin_amdgcn_s_sleep(10);
+            }
+        if (expired)
+            {
+            any_expired = true;
+            break;
+            }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (b0 + j * MTD_WAVE < n_blocks)
+#pragma unroll
+                for (int i = 0; i < NS; ++i)
+                    v[i] += __hiloint2double((int)(unsigned int)w[j][i][1], (int)(unsigned int)w[j][i][0]);
+        }
+    any_expired = __any(any_expired);
+    if (any_expired)
+        {
+#pragma unroll
+        for (int i = 0; i < NS; ++i) v[i] = __longlong_as_double(0x7ff8000000000000ll);     // NaN: poisons the totals
+        }
+    return any_expired;
+    }
+
+// the sums of one launch stored densely, [block][NS] (sharded CV pass of the two-launch step)
+template<int NS>
+__device__ __forceinline__ bool ll_collect_wave(const CommK &k, const unsigned int n_blocks, double (&v)[3])
+    {
+    return ll_collect_strided<NS>(k, n_blocks, 2 * NS, 0, v);
     }
 
 // Loads from an EXPORTED bulk buffer (mtd_comm_share: uncached device memory, local or a peer's mapping): system-scope loads
@@ -168,11 +283,13 @@ __device__ __forceinline__ void comm_recv_sum_wave(const CommK &k, double (&tota
     const unsigned int lane = threadIdx.x & 63;
     const unsigned int nw = 2 * n;
     unsigned int half = 0;
-    if (lane < k.world * nw) half = comm_recv_word(k, lane / nw, lane % nw);
+    bool ok = true;
+    if (lane < k.world * nw) half = comm_recv_word(k, lane / nw, lane % nw, ok);
+    const bool failed = __any(!ok);                                  // wave-uniform: any expired wait poisons every total
 #pragma unroll
     for (int i = 0; i < 3; ++i)
         {
-        total[i] = 0.0;
+        total[i] = failed ? __longlong_as_double(0x7ff8000000000000ll) : 0.0;
         if (i < (int)n)
             for (unsigned int r = 0; r < k.world; ++r)
                 {

@@ -13,6 +13,7 @@ struct mtd_comm
     {
     mtd::CommK k;               // seq is filled per exchange
     void *local;                // this rank's mailbox (uncached device memory)
+    volatile unsigned int *h_err;   // sticky failure flag (pinned host memory, mapped into the device: CommK::err_host)
     size_t bytes;
     unsigned int max_doubles;
     unsigned int seq;           // number of the last exchange started (0: none yet)
@@ -28,4 +29,6 @@ namespace mtd
 // start exchange seq+1 / describe the exchange started last (for the kernel that receives it)
 int comm_next(mtd_comm *c, CommK &k);
 int comm_current(const mtd_comm *c, CommK &k);
+// a wait of this communicator has expired (sticky): every entry point that would use it returns MTD_ERR_COMM_TIMEOUT
+inline bool comm_failed(const mtd_comm *c) { return c && c->h_err && *c->h_err != 0; }
 }

@@ -50,6 +50,8 @@ extern "C" int mtd_debug_read_stamps(unsigned long long *host)
 
 #include <cstdlib>
 #include <cstring>
+#include <map>
+#include <mutex>
 #include <vector>
 
 namespace
@@ -173,7 +175,7 @@ __global__ __launch_bounds__(FF_THREADS, 4) void k_fused_force(const LamKArgs a,
             s_chain.cv[0] = r.cv[0]; s_chain.cv[1] = r.cv[1]; s_chain.cv[2] = r.cv[2];
             s_chain.bias[0] = r.bias[0]; s_chain.bias[1] = r.bias[1]; s_chain.bias[2] = r.bias[2];
             s_chain.scal = r.scal; s_chain.V = r.V; s_chain.w = r.w;
-            s_chain.bin = r.bin; s_chain.on_grid = r.on_grid; s_chain.oob = r.oob;
+            s_chain.bin = r.bin; s_chain.on_grid = r.on_grid; s_chain.oob = r.oob; s_chain.failed = r.failed;
             }
         if (!grid_block)
             for (unsigned int i = lane; i < NCV * MTD_MAX_TYPES; i += MTD_WAVE)
@@ -200,7 +202,7 @@ __global__ __launch_bounds__(FF_THREADS, 4) void k_fused_force(const LamKArgs a,
         //      updateSigmaGrid (:1122-1155), first loop of updateReweightedEstimator (:1070-1075)
         const unsigned int g = blockIdx.x * FF_THREADS + threadIdx.x;
         double s1 = 0.0, s2 = 0.0;
-        if (g < c.len)
+        if (g < c.len && !s_chain.failed)
             {
             const double dV = (c.W * s_chain.scal) * exp(-gauss_exponent3(c, g, s_chain.cv[0], s_chain.cv[1], s_chain.cv[2]));
             c.grid_delta[g] = dV;
@@ -260,13 +262,14 @@ __global__ __launch_bounds__(FF_THREADS, 4) void k_fused_force(const LamKArgs a,
         if (lane == 0)
             {
             c.st->V = s_chain.V;
+            if (COMM) c.st->failed = (unsigned int)s_chain.failed;       // the deferred pass of a poisoned deposit is skipped
             c.st->bin = s_chain.bin;
             c.st->on_grid = (unsigned int)s_chain.on_grid;
             if (deposit)
                 c.st->scal = s_chain.scal;
             else
                 {
-                c.st->w = w_now;
+                c.st->w = s_chain.failed ? s_chain.V : w_now;            // (V is NaN then)
                 if (s_chain.on_grid) c.hist_delta[s_chain.bin] += 1;
                 }
             if (s_chain.oob) c.st->n_oob += (deposit && c.mode == MTD_MODE_WELL_TEMPERED) ? 2 : 1;
@@ -379,6 +382,29 @@ bool force_profile_next(hipEvent_t &start, hipEvent_t &stop)
     return true;
     }
 
+// Blocks of `kernel` the device holds at one time (occupancy x compute units), cached per kernel.  A launch in which a
+// block WAITS for other blocks of the same launch (the collector of the sharded CV pass) is only issued when the whole grid
+// is resident at once: then the wait is one memory round trip after the slowest block, never a wait for blocks that have not
+// started.  (With a single waiting block a larger grid could not deadlock either — every other block runs to completion
+// unconditionally and frees its slot — but its wait would span whole generations of blocks; refused rather than slow.)
+unsigned int resident_capacity(const void *kernel, int threads)
+    {
+    static std::mutex mu;
+    static std::map<const void *, unsigned int> cache;
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = cache.find(kernel);
+    if (it != cache.end()) return it->second;
+    int per_cu = 0, dev = 0, n_cu = 0;
+    unsigned int cap = 0;
+    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess &&
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, threads, 0) == hipSuccess)
+        cap = (unsigned int)per_cu * (unsigned int)n_cu;
+    else
+        (void)hipGetLastError();
+    cache[kernel] = cap;
+    return cap;
+    }
+
 template<typename S4, bool FAST>
 int launch_fused_cv(const LamKArgs &k, unsigned int N, const void *d_postype, double *d_partials, unsigned int cv_blocks,
                     const MetadCfg &cfg, unsigned int n_apply, const CommK *ck, hipStream_t s)
@@ -387,6 +413,9 @@ int launch_fused_cv(const LamKArgs &k, unsigned int N, const void *d_postype, do
     const unsigned int grid = cv_blocks + n_apply;
     if (ck)
         {
+        const void *kern = k.n_cv == 1 ? (const void *)k_fused_cv<S4, 1, FAST, true>
+                                       : (k.n_cv == 2 ? (const void *)k_fused_cv<S4, 2, FAST, true> : (const void *)k_fused_cv<S4, 3, FAST, true>);
+        if (grid > resident_capacity(kern, FCV_THREADS)) return MTD_ERR_UNSUPPORTED;
         switch (k.n_cv)
             {
             case 1: k_fused_cv<S4, 1, FAST, true><<<grid, FCV_THREADS, 0, s>>>(k, p, N, d_partials, cfg, n_apply, *ck); break;

@@ -22,6 +22,7 @@
 #include <new>
 
 #include "metad_host.hpp"
+#include "comm_host.hpp"
 
 #include <cstdlib>
 
@@ -117,6 +118,7 @@ __global__ __launch_bounds__(GRID_THREADS) void k_apply(const MetadCfg c)
 __global__ __launch_bounds__(GRID_THREADS) void k_evaluate(const MetadCfg c)
     {
     __shared__ EvalShared sh;
+    if (c.st->failed) return;                  // poisoned step (expired mailbox wait): the NaN state stays as it is
     if (threadIdx.x < c.n_cv) sh.cv[threadIdx.x] = c.st->cv[threadIdx.x];
     __syncthreads();
     evaluate_bias(c, sh, false, false);
@@ -301,6 +303,13 @@ int mtd_metad_create(mtd_metad **out, unsigned int n_cv, const double *sigma, co
     m->add_bias = add_bias ? 1 : 0;
     m->pending_apply = 0;
     m->comm = nullptr;
+    m->d_ll = nullptr;
+    m->d_step_err = nullptr;
+    m->h_step_err = nullptr;
+    m->d_step_err_host = nullptr;
+    m->step_seq = 0;
+    m->last_launches = 0;
+    m->step_mode = -1;
 
     const size_t G = c.len;
     const size_t bytes_d = 6 * G * sizeof(double);
@@ -359,6 +368,7 @@ int mtd_metad_create(mtd_metad **out, unsigned int n_cv, const double *sigma, co
 int mtd_metad_destroy(mtd_metad *m)
     {
     if (!m) return MTD_SUCCESS;
+    mtd::fused_step_release(m);
     hipError_t e = hipFree(m->slab);
     delete m;
     return (int)e;
@@ -518,6 +528,8 @@ int mtd_metad_get_state(mtd_metad *m, double *cv, double *bias, double *bias_pot
     if (weight) *weight = st.w;
     if (num_gaussians) *num_gaussians = st.num_gaussians;
     if (num_out_of_bounds) *num_out_of_bounds = st.n_oob;
+    // a poisoned step (expired mailbox wait): the NaN state above is what the step left; the status says why
+    if (m->comm && mtd::comm_failed(m->comm)) return MTD_ERR_COMM_TIMEOUT;
     return MTD_SUCCESS;
     }
 

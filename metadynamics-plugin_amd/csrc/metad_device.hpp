@@ -39,6 +39,8 @@ struct MetadState
     unsigned int n_oob;
     unsigned int bin;
     unsigned int on_grid;
+    unsigned int failed;   // a mailbox wait expired in the last step (comm_device.hpp): nothing was deposited, the deferred pass is skipped
+    unsigned int _pad;
     };
 
 struct MetadCfg
@@ -305,6 +307,7 @@ __device__ __forceinline__ void evaluate_bias(const MetadCfg &c, EvalShared &sh,
 __device__ __forceinline__ void apply_cells(const MetadCfg &c, const unsigned int cell_begin, const unsigned int cell_end,
                                             const bool first, double *s_red)
     {
+    if (c.st->failed) return;                                                // (block-uniform) the step that would have deposited was poisoned
     double s1 = 0.0, s2 = 0.0;
     for (unsigned int b = threadIdx.x; b < c.n_gblocks; b += blockDim.x)
         {
@@ -350,14 +353,21 @@ struct ChainResult
     double scal, V, w;
     unsigned int bin;
     int on_grid, oob;
+    int failed;            // rx / given only: a bounded wait expired — NaN bias factors, nothing may be deposited
+    // per LANE (lanes < 2^n_cv, the corners of the point s itself), closed form only: multilinear weight, the weight-grid
+    // value before this step's deposit and this deposit's increment at the corner cell — w(s) of the grid AFTER the deferred
+    // reweighting pass follows from them in closed form once <dV> is known (k_fused_step)
+    double c_wt, c_wold, c_dV;
     };
 
 constexpr int CHAIN_MAX_CV = 3;
 
 // rx != nullptr: particle-sharded step — the sums over ranks come out of the xGMI mailbox (comm_device.hpp) instead
-// of the registered partial sums
+// of the registered partial sums.  given != nullptr: the (global) sums are handed in (k_fused_step collected them itself);
+// a NaN among them marks an expired wait.  want_weight: also read the weight grid at the corners of s (closed form).
 __device__ __forceinline__ ChainResult chain_wave(const MetadCfg &c, const bool deposit, const bool closed_form,
-                                                  const CommK *rx = nullptr)
+                                                  const CommK *rx = nullptr, const double *given = nullptr,
+                                                  const bool want_weight = false)
     {
     const int lane = threadIdx.x & 63;
     const unsigned int n = c.n_cv;
@@ -378,6 +388,13 @@ __device__ __forceinline__ ChainResult chain_wave(const MetadCfg &c, const bool 
         comm_recv_sum_wave(*rx, rx_total, n);
         n_part_max = 0;
         }
+    else if (given)
+        {
+#pragma unroll
+        for (int i = 0; i < CHAIN_MAX_CV; ++i) rx_total[i] = i < (int)n ? given[i] : 0.0;
+        n_part_max = 0;
+        }
+    const bool handed = rx != nullptr || given != nullptr;
     for (unsigned int b0 = lane; b0 < n_part_max; b0 += 8 * MTD_WAVE)
         {
 #pragma unroll
@@ -400,8 +417,8 @@ __device__ __forceinline__ ChainResult chain_wave(const MetadCfg &c, const bool 
         r.bias[i] = 0.0;
         if (i < (int)n)
             {
-            const double t = rx ? rx_total[i] : wave_sum(v[i]);
-            r.cv[i] = (c.src[i].partials || rx) ? c.src[i].shift + c.src[i].scale * t : c.src[i].shift;
+            const double t = handed ? rx_total[i] : wave_sum(v[i]);
+            r.cv[i] = (c.src[i].partials || handed) ? c.src[i].shift + c.src[i].scale * t : c.src[i].shift;
             }
         }
 
@@ -423,7 +440,7 @@ __device__ __forceinline__ ChainResult chain_wave(const MetadCfg &c, const bool 
         double val = si;
         if (v == 0) val = si - delta;
         if (v == 2) val = si + delta;
-        g_ok = !(val < cmin || val >= cmax);
+        g_ok = val >= cmin && val < cmax;             // (:677-683; a NaN value is off the grid too)
         int lower = (int)((val - cmin) / delta);
         int upper = lower + 1;
         if (upper >= len)
@@ -479,6 +496,9 @@ __device__ __forceinline__ ChainResult chain_wave(const MetadCfg &c, const bool 
         }
     double val = 0.0;
     if (ok) val = is_weight ? c.weight[cell] : c.grid[cell];
+    r.c_wt = wt;
+    r.c_wold = (want_weight && ok && p == 0) ? c.weight[cell] : 0.0;
+    r.c_dV = 0.0;
 
     MTD_STAMP(42, blockIdx.x == 0 && threadIdx.x == 0 && closed_form);
     // 4. V_old(s): corner terms of point 0 summed in the reference's order (:711-733)
@@ -502,9 +522,11 @@ __device__ __forceinline__ ChainResult chain_wave(const MetadCfg &c, const bool 
                     const double sij = c.sigma_inv[i * n + j];
                     gauss_exp += d[i] * d[j] * (1.0 / 2.0) * (sij * sij);
                     }
-        val += (c.W * r.scal) * exp(-gauss_exp);
+        r.c_dV = (c.W * r.scal) * exp(-gauss_exp);
+        val += r.c_dV;
         term = wt * val;
         }
+    if (!ok) r.c_wt = 0.0;
 
     MTD_STAMP(44, blockIdx.x == 0 && threadIdx.x == 0 && closed_form);
     // 6. every lane: the interpolated value of its own point, corners in order
@@ -558,6 +580,26 @@ __device__ __forceinline__ ChainResult chain_wave(const MetadCfg &c, const bool 
         }
     r.on_grid = on_grid ? 1 : 0;
     r.bin = bin;
+    r.failed = 0;
+    if (handed)
+        {
+        bool bad = false;
+#pragma unroll
+        for (int i = 0; i < CHAIN_MAX_CV; ++i) bad = bad || (i < (int)n && rx_total[i] != rx_total[i]);
+        if (bad)
+            {
+            // poisoned step: NaN CV values, bias factors (=> NaN forces), V and w; no hill, no histogram count
+            const double nan = __longlong_as_double(0x7ff8000000000000ll);
+#pragma unroll
+            for (int i = 0; i < CHAIN_MAX_CV; ++i)
+                if (i < (int)n) r.cv[i] = r.bias[i] = nan;
+            r.V = r.w = nan;
+            r.scal = 0.0;
+            r.on_grid = 0;
+            r.oob = 0;
+            r.failed = 1;
+            }
+        }
     return r;
     }
 

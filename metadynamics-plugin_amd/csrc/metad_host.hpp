@@ -14,6 +14,15 @@ struct mtd_metad
     int pending_apply;
     // particle-sharded fused step: the per-rank CV totals travel through this xGMI mailbox (comm.hip); not owned
     struct mtd_comm *comm;
+    // one-launch step (fused_step.hip): block sums of the launch in the mailbox's wire format (hand-off between the blocks of
+    // ONE launch), its exchange counter, and the sticky failure flag of its bounded waits (pinned host memory)
+    unsigned long long *d_ll;
+    unsigned int *d_step_err;
+    volatile unsigned int *h_step_err;
+    unsigned int *d_step_err_host;
+    unsigned int step_seq;
+    unsigned int last_launches;     // launches the last mtd_fused_step took (1: the persistent kernel, 2: the two-launch form)
+    int step_mode;                  // mtd_fused_step_set_mode: -1 environment / default, 0 two launches, 1 one launch where possible
     };
 
 namespace mtd
@@ -22,4 +31,6 @@ namespace mtd
 int metad_flush(mtd_metad *m, hipStream_t s);
 // fused.hip: deferred apply + one launch for the whole update (n_cv <= 3), MTD_ERR_UNSUPPORTED otherwise
 int fused_grid_step(mtd_metad *m, unsigned int timestep, hipStream_t s);
+// fused_step.hip: release the one-launch step's buffers (mtd_metad_destroy)
+void fused_step_release(mtd_metad *m);
 }

@@ -750,7 +750,8 @@ void IntegratorMetaDynamics::setupGrid()
 // :121-217
 void IntegratorMetaDynamics::prepRun(unsigned int timestep)
     {
-    if (!m_is_initialized && m_filename != "")
+    // the hills file belongs to the root rank of a domain-decomposed run (is_root block, IntegratorMetaDynamics.cc:124-146)
+    if (!m_is_initialized && m_filename != "" && m_exec_conf->getRank() == 0)
         {
         openOutputFile();
         if (!m_is_appending) writeFileHeader();
@@ -842,22 +843,12 @@ void IntegratorMetaDynamics::fusedLamellarStep(unsigned int timestep)
 
     const mtd_box box = m_pdata->getGlobalBox().toMtd();
     hipStream_t s = m_exec_conf->getStream();
-    unsigned int n_partials = 0;
-    mtd_check(mtd_fused_cv_pass(m_engine, &m_fused_set, m_pdata->getN(), m_pdata->positionsPtr(), m_pdata->getDtype(), &box,
-                                (double *)m_fused_partials.data(), &n_partials, s),
-              "mtd_fused_cv_pass");
-    if (n_partials != m_fused_n_partials || !m_used_fused)
-        {
-        for (unsigned int c = 0; c < n_cv; ++c)
-            mtd_check(mtd_metad_set_cv_source(m_engine, c, (const double *)m_fused_partials.data(), n_partials, n_cv, c,
-                                              1.0 / (double)m_pdata->getNGlobal(), 0.0),
-                      "mtd_metad_set_cv_source");
-        m_fused_n_partials = n_partials;
-        }
-    mtd_check(mtd_fused_force_pass(m_engine, &m_fused_set, m_pdata->getN(), m_pdata->positionsPtr(), m_fused_force_ptrs.data(),
-                                   m_pdata->getDtype(), m_pdata->getNGlobal(), &box, timestep, s),
-              "mtd_fused_force_pass");
-    // launch B wrote every CV's force array for `timestep`: computeNetForce's cv->compute(timestep) is a no-op
+    // the whole step through one entry point: the two-launch form (CV pass + deferred grid pass, then chain + grid pass +
+    // forces) or, when selected (mtd_fused_step_set_mode / MTD_FUSED_STEP=1), the one-launch persistent kernel
+    mtd_check(mtd_fused_step(m_engine, &m_fused_set, m_pdata->getN(), m_pdata->positionsPtr(), m_fused_force_ptrs.data(),
+                             m_pdata->getDtype(), m_pdata->getNGlobal(), &box, (double *)m_fused_partials.data(), timestep, s),
+              "mtd_fused_step");
+    // the step wrote every CV's force array for `timestep`: computeNetForce's cv->compute(timestep) is a no-op
     for (auto &it : m_variables) it.m_cv->markComputed(timestep);
     m_used_fused = true;
     }
@@ -938,6 +929,9 @@ void IntegratorMetaDynamics::updateBiasPotential(unsigned int timestep)
 
     if (m_adaptive && (timestep % m_stride == 0))                      // :333-341
         {
+        if (m_exec_conf->getNRanks() > 1)
+            throw std::runtime_error("integrate.mode_metadynamics: adaptive Gaussians are not available in a domain-decomposed run of "
+                                     "this build (the derivative products of computeSigma, :1252-1268, are not summed over ranks)");
         // compute derivatives of collective variables, then the instantaneous estimate of the standard deviation matrix
         for (auto &it : m_variables) it.m_cv->computeDerivatives(timestep);
         computeSigma();
@@ -978,8 +972,11 @@ void IntegratorMetaDynamics::updateBiasPotential(unsigned int timestep)
         for (size_t i = 0; i < cv.size(); ++i)
             {
             m_file << std::setprecision(10) << cv[i] << m_delimiter;
+            // row of h_sigma_inv (:536-541), no delimiter (Q16): diag(1 / sigma) (:177) until computeSigma overwrites it in
+            // adaptive mode (:1271-1290)
             for (size_t j = 0; j < cv.size(); ++j)
-                m_file << std::setprecision(10) << (i == j ? 1.0 / m_variables[i].m_sigma : 0.0);   // row of sigma_inv, no delimiter (Q16)
+                m_file << std::setprecision(10)
+                       << (m_sigma_inv.size() == cv.size() * cv.size() ? m_sigma_inv[i * cv.size() + j] : (i == j ? 1.0 / m_variables[i].m_sigma : 0.0));
             if (i != cv.size() - 1) m_file << m_delimiter;
             }
         m_file << std::endl;
@@ -1047,6 +1044,7 @@ void IntegratorMetaDynamics::dumpGrid(const std::string &filename1, const std::s
 // :831-926 — the on-disk format users post-process
 void IntegratorMetaDynamics::writeGrid(const std::string &filename, unsigned int timestep)
     {
+    if (m_exec_conf->getRank() != 0) return;                          // only on the root processor (:835-839)
     if (!m_use_grid || !m_engine) throw std::runtime_error("Error dumping grid.");   // :841-845
     const unsigned int len = mtd_metad_num_elements(m_engine);
     hipStream_t s = m_exec_conf->getStream();

@@ -128,6 +128,10 @@ _SIGNATURES = {
     "mtd_fused_cv_pass": (C.c_int, [_vp, C.POINTER(LamellarSet), C.c_uint, _vp, C.c_int, C.POINTER(Box), _vp, _up, _vp]),
     "mtd_fused_force_pass": (C.c_int, [_vp, C.POINTER(LamellarSet), C.c_uint, _vp, C.POINTER(_vp), C.c_int, C.c_uint,
                                         C.POINTER(Box), C.c_uint, _vp]),
+    "mtd_fused_step": (C.c_int, [_vp, C.POINTER(LamellarSet), C.c_uint, _vp, C.POINTER(_vp), C.c_int, C.c_uint, C.POINTER(Box), _vp,
+                                  C.c_uint, _vp]),
+    "mtd_fused_step_launches": (C.c_uint, [_vp]),
+    "mtd_fused_step_set_mode": (C.c_int, [_vp, C.c_int]),
     "mtd_profile_force_begin": (C.c_int, [C.c_uint]),
     "mtd_profile_force_end": (C.c_int, [_dp, C.c_uint, _up]),
     "mtd_comm_create": (C.c_int, [C.POINTER(_vp), C.c_uint, C.c_uint, C.c_uint]),

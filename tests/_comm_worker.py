@@ -144,6 +144,33 @@ def main():
         out["set_energy_cv"] = [set_states[-1]["cv"][1], e_tot]
         out["set_force_err"] = float((f_loc.cpu() - f_all.cpu()[sl]).abs().max() / f_all.cpu().abs().max())
         one_set.close()
+    # ---- the C++ host classes with the mailbox as communicator: every rank runs the same System loop; the hills file and the
+    #      grid dump belong to the root rank only (IntegratorMetaDynamics.cc:124-146, 835-839)
+    import tempfile
+    from metadynamics import context, cv as cvmod, integrate
+    tmpdir = [tempfile.mkdtemp(prefix="mtd_dd_") if rank == 0 else None]
+    dist.broadcast_object_list(tmpdir, 0)
+    hills, dump = os.path.join(tmpdir[0], "hills.log"), os.path.join(tmpdir[0], "grid.dat")
+    context.initialize(pos[sl].copy(), types[sl].copy(), ["A", "B"], L, dtype=np.float32, n_global=n_global)
+    context.exec_conf.setMailbox(box.handle.value)
+    meta = integrate.mode_metadynamics(dt=0.005, stride=1, mode="well_tempered", W=1.0, deltaT=7.0, T=1.0, filename=hills)
+    hcvs = []
+    for i, vecs in enumerate((util.CV1_VECTORS, util.CV2_VECTORS)):
+        c = cvmod.lamellar(sigma=0.02, mode=dict(A=1.0, B=-1.0), lattice_vectors=vecs, name="c%d" % i)
+        c.set_grid(-1.0, 1.0, 32)
+        hcvs.append(c)
+    meta.dump_grid(dump, period=2)
+    context.run(4)
+    torch.cuda.synchronize()
+    dist.barrier()
+    if rank == 0:
+        lines = open(hills).read().splitlines()
+        out["host_dd"] = dict(fused=bool(meta.cpp_integrator.usedFusedPath()), hills_lines=len(lines),
+                              hills_ok=all(len(l.split("\t")) == 6 for l in lines[1:]), files=sorted(os.listdir(tmpdir[0])))
+        dumps = [f for f in out["host_dd"]["files"] if f.startswith("grid.dat_")]
+        out["host_dd"]["dump_lines"] = [len(open(os.path.join(tmpdir[0], f)).read().splitlines()) for f in dumps]
+    context.current = None
+    dist.barrier()
     # ---- the mesh CV with the mesh decomposed into slabs over the ranks (mtd_mesh_slab_*), against one rank holding all
     #      particles and the whole mesh; nz = ny = 24 divides by 2, 3 and 4 (direct transforms), 32 by 2 and 4 (radix-4)
     slab = {}

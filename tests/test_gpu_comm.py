@@ -27,14 +27,14 @@ def _free_port():
     return port
 
 
-def _run_world(world, n_global, steps=6, timeout=300, extra_env=None):
+def _run_world(world, n_global, steps=6, timeout=300, extra_env=None, worker="_comm_worker.py"):
     port = _free_port()
     procs = []
     for r in range(world):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                    HSA_ENABLE_IPC_MODE_LEGACY="0", MTD_COMM_TIMEOUT_MS="3000")
         env.update(extra_env or {})
-        procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "_comm_worker.py"), str(n_global), str(steps)],
+        procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, worker), str(n_global), str(steps)],
                                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
     outs = []
     try:
@@ -123,6 +123,11 @@ def test_mailbox_between_processes(world):
         assert v["cv_rel_oracle"] < 1e-8, (key, v)
         assert v["force_rel_oracle"] < 1e-5, (key, v)
     assert "16x24x24" in r["slab"]
+    # host classes, domain decomposed: one hills file (header + prepRun deposit + 4 steps), written by the root rank alone
+    hd = r["host_dd"]
+    assert hd["fused"] and hd["hills_lines"] == 6 and hd["hills_ok"], hd
+    assert "hills.log" in hd["files"] and len(hd["dump_lines"]) >= 1 and len(hd["files"]) == 1 + len(hd["dump_lines"]), hd
+    assert all(n == 4 + 32 * 32 for n in hd["dump_lines"]), hd           # three header lines, the column names, one line per cell
     # generic CV set through the stand-alone mailbox all-reduce
     assert r["timeouts_set"] == 0
     assert r["set_errs"]["cv"] < 1e-6 and r["set_errs"]["bias"] < 1e-5
@@ -238,3 +243,19 @@ def test_slab_close_then_whole_mesh_sequence(abi, ref):
         assert n_to.value == 0
         slab.close()
         abi.check(lib.mtd_comm_destroy(h))
+
+
+def test_mailbox_timeout_is_fatal():
+    """A peer that never sends: the bounded wait expires (MTD_COMM_TIMEOUT_MS = 200) and the step is POISONED, not continued on
+    a stale sum — NaN CV values, bias factors and forces, nothing deposited (the grid keeps the hills it had), the deferred pass
+    skipped; the status is sticky: mtd_metad_get_state and every later call that would use the mailbox return
+    MTD_ERR_COMM_TIMEOUT (-4).  Reference semantics: a failed MPI_Allreduce aborts (LamellarOrderParameterGPU.cc:69-77)."""
+    r = _run_world(2, 0, extra_env={"MTD_COMM_TIMEOUT_MS": "200"}, worker="_comm_timeout_worker.py")
+    assert r["connected"]
+    assert r["rc_launch"] == [0, 0]                     # the failing launches themselves are asynchronous
+    assert r["timeouts"] > 0
+    assert r["cv_nan"] and r["bias_nan"] and r["V_nan"] and r["forces_all_nan"]
+    assert r["rc_state"] == -4 and r["rc_next"] == -4 and r["rc_allreduce"] == -4
+    assert r["rc_grid"] == 0 and r["grid_finite"] and r["grid_max"] > 0       # the good step's hill, nothing else
+    assert r["num_gaussians"] == [1, 1]
+    assert "mailbox" in r["status_string"]

@@ -344,13 +344,14 @@ def test_wrap_through_api(api, ref):
         cv.wrap("not a force")
 
 
-def test_adaptive_gaussians_through_api(api, ref):
+def test_adaptive_gaussians_through_api(api, ref, tmp_path):
     """set_params(adaptive=True, sigma_g): every deposit step the derivative arrays (bias factor 1) give the width
     matrix (IntegratorMetaDynamics.cc:333-341, 1205-1294); a box CV keeps its registered sigma on the diagonal"""
     context, cv, integrate = api
     pos, types, L = util.snapshot_config0b()
     context.initialize(pos, types, ["A", "B"], L, dtype=np.float64)
-    meta = integrate.mode_metadynamics(dt=0.005, stride=2, mode="well_tempered", W=1.0, deltaT=7.0, T=1.0)
+    hills = str(tmp_path / "hills_adaptive.log")
+    meta = integrate.mode_metadynamics(dt=0.005, stride=2, mode="well_tempered", W=1.0, deltaT=7.0, T=1.0, filename=hills)
     lv1, lv2 = [(0, 0, 4)], [(0, 0, 4), (0, 4, 0)]
     lam1 = cv.lamellar(sigma=0.05, mode=dict(A=1.0, B=-1.0), lattice_vectors=lv1, name="a")
     lam2 = cv.lamellar(sigma=0.05, mode=dict(A=1.0, B=-1.0), lattice_vectors=lv2, name="b")
@@ -372,6 +373,12 @@ def test_adaptive_gaussians_through_api(api, ref):
     # the derivative arrays come from the lamellar force kernel (1e-5 force tolerance, fp32 trig): widths agree to ~1e-7
     assert np.allclose(got, inv, rtol=1e-6, atol=1e-6 * np.abs(inv).max())
     assert got[2, 2] == pytest.approx(100.0) and got[0, 2] == 0
+    # the hills file records the width matrix of every deposit: the rows of h_sigma_inv as computeSigma left them
+    # (IntegratorMetaDynamics.cc:536-541), each row written without delimiter (Q16) — not diag(1 / sigma)
+    last = open(hills).read().splitlines()[-1].split("\t")
+    for i in range(3):
+        assert last[3 + 2 * i] == "".join("%.10g" % got[i, j] for j in range(3)), (i, last)
+    assert abs(got[0, 1]) > 0
 
     s = [ref.lamellar_cv(lv1, pt, util.MODE_AB, rbox), ref.lamellar_cv(lv2, pt, util.MODE_AB, rbox), len(pos) / L ** 3]
     g = ref.Metad([0.05, 0.05, 0.01], [-1.0, -1.0, 0.5], [1.0, 1.0, 1.5], [48, 40, 16], W=1.0, T_shift=7.0, T=1.0, stride=2,
