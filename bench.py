@@ -57,6 +57,8 @@ def parse():
                     help="Scalar of the particle arrays (HOOMD single / double precision build); headline: f32 as in BASELINE.json")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=4)
+    ap.add_argument("--no-sub-records", action="store_true", help="skip the config 3 / config 5 sub-records (N = 1)")
+    ap.add_argument("--sub-steps", type=int, default=200, help="steps timed for each sub-record")
     return ap.parse_args()
 
 
@@ -182,6 +184,120 @@ def cpu_baseline(pos, types, L, steps):
     return pos.shape[0] * len(cvs) * steps / dt, dt
 
 
+FP64_VECTOR_PEAK_TFLOPS = 78.6   # MI355X_MICROARCH.md: fp64 vector (non-matrix) peak
+
+
+def _timed_host_steps(context, steps):
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    context.current.system.run(steps - 1)          # run(k) = prepRun (one bias update) + k updates
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / steps
+
+
+def sub_record_config3(steps, fast_trig):
+    """BASELINE.json configs[2] (SURVEY config 3): 10^6 particles, cv.mesh on 128^3 (bug-compatible) + one lamellar CV, 256^2 bias
+    grid, well-tempered, stride 1 — through the reference-shaped API (C++ host classes).  Bound: HBM.  Algorithmic bytes:
+    SURVEY 8d's definition for the reference's fp32 / C2C layout (191 MB) and this build's own count (fp64 meshes, half
+    spectrum: DESIGN.md 4.4).  The mesh kernels are also timed on their own through the C ABI (events on the launch stream)."""
+    from metadynamics import context, cv, integrate
+    N, L = N_PER_GPU, BOX_L
+    pos, types = util.snapshot_random(N, L, seed=12345, modulated=True, dtype=np.float32)
+    pos = (np.mod(pos.astype(np.float64) + L / 2, L) - L / 2).astype(np.float32)       # an MD engine keeps its particles in the box
+    pos[pos >= L / 2] = -L / 2
+    _abi.check(_abi.load().mtd_lamellar_set_fast_trig(int(fast_trig)))
+    context.initialize(pos, types, ["A", "B"], L, dtype=np.float32)
+    integrate.mode_metadynamics(dt=0.005, stride=1, mode="well_tempered", W=W, deltaT=DELTA_T, T=T)
+    lam = cv.lamellar(sigma=0.02, mode=dict(A=1.0, B=-1.0), lattice_vectors=util.CV1_VECTORS)
+    lam.set_grid(-1.0, 1.0, 256)
+    mesh = cv.mesh(nx=128, mode={"A": 1.0, "B": -1.0})
+    mesh.set_grid(0.0, 1.0, 256)
+    context.run(12)
+    per_step = _timed_host_steps(context, steps)
+    s_mesh = mesh.cpp_force.getCurrentValue(context.current.system.getCurrentTimeStep())
+    context.current = None
+    # the mesh CV's own launches through the C ABI
+    lib = _abi.load()
+    h = C.c_void_p()
+    mode = (C.c_double * 2)(1.0, -1.0)
+    _abi.check(lib.mtd_mesh_create(C.byref(h), 128, 128, 128, mode, 2, N))
+    d_pos = torch.from_numpy(util.pack_postype(pos, types, np.float32)).cuda()
+    force = torch.zeros((N, 4), dtype=torch.float32, device="cuda")
+    box = _abi.Box.make(L)
+    parts, n_parts = C.c_void_p(), C.c_uint()
+    bias = torch.ones(1, dtype=torch.float64, device="cuda")
+
+    def cv_call():
+        _abi.check(lib.mtd_mesh_compute_cv(h, N, d_pos.data_ptr(), _abi.MTD_F32, C.byref(box), N, C.byref(parts), C.byref(n_parts), None))
+
+    def force_call():
+        _abi.check(lib.mtd_mesh_forces(h, N, d_pos.data_ptr(), force.data_ptr(), _abi.MTD_F32, C.byref(box), N, bias.data_ptr(), 0.0, None))
+
+    def timed(fn, n=60):
+        for _ in range(5):
+            fn()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(n):
+            fn()
+        b.record()
+        torch.cuda.synchronize()
+        return a.elapsed_time(b) * 1e3 / n
+
+    cv_us, f_us = timed(cv_call), timed(force_call)
+    _abi.check(lib.mtd_mesh_destroy(h))
+    M, hfrac = 128 ** 3, 72.0 / 128.0
+    bytes_survey = 48 * N + 68 * M + (64 - 16) * 1_000_000          # SURVEY 8d: 48 B N + 68 B M, + the lamellar CV sharing the position reads
+    bytes_build = 48 * N + 8 * M + (8 + 16 * hfrac) * M + 32 * hfrac * M + 48 * hfrac * M + 32 * hfrac * M + (16 * hfrac + 8) * M + 48 * N
+    return {"workload": "1xMI355X: 10^6 particles, OrderParameterMesh CV on 128^3 mesh (bug-compatible) + 1 lamellar CV, 256^2 bias grid, well-tempered",
+            "ms_per_step": 1e3 * per_step, "value": 2 * N / per_step, "unit": "particle-CV-evals/s", "steps": steps, "dtype": "f64 meshes, f32 particles",
+            "fast_trig": int(fast_trig), "mesh_cv": s_mesh,
+            "roofline": {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "step_algorithmic_bytes_survey_fp32_c2c": bytes_survey, "step_frac_survey": bytes_survey / per_step / 1e9 / HBM_PEAK_GBS,
+                         "step_algorithmic_bytes_this_build_fp64_r2c": int(bytes_build), "step_frac": bytes_build / per_step / 1e9 / HBM_PEAK_GBS,
+                         "mesh_compute_cv_us": cv_us, "mesh_forces_us": f_us,
+                         "dominant_kernels": "k_tile_scatter, k_tile_forces, k_fft_z_spectral (per-kernel table: profiles/r2/config3_mesh_kernel_stats.csv)",
+                         "timing": "host API: wall clock around System::run, synchronised on both sides; mesh calls: HIP events on the launch stream"}}
+
+
+def sub_record_config5(steps):
+    """BASELINE.json configs[4] (SURVEY config 5): 256 000-particle noisy fcc crystal, cv.steinhardt lmax 6, full neighbour list
+    r_cut 1.4, 512-point grid — through the reference-shaped API.  Bound: fp64 vector ALU (no HBM roofline: ~40 B against
+    ~0.9 kflop per pair); flops per pair from DESIGN.md 4.5 (CV pass ~0.5 kflop, contracted force pass ~0.4 kflop)."""
+    from metadynamics import context, cv, integrate
+    pos, L = util.fcc_lattice(40)
+    pos = pos + np.random.default_rng(777).normal(0, 0.05, pos.shape)
+    N = len(pos)
+    context.initialize(pos, np.zeros(N, dtype=np.int32), ["A"], L, dtype=np.float64)
+    integrate.mode_metadynamics(dt=0.005, stride=1, mode="well_tempered", W=W, deltaT=DELTA_T, T=T)
+    nl = cv.nlist_cell(r_cut=1.4)
+    lists = nl.update()
+    st = cv.steinhardt(r_cut=1.4, r_on=1.2, lmax=6, Ql_ref=[0, 0, 0, 0, 1, 0, 1], nlist=nl, type="A", sigma=1.0)
+    st.set_grid(0.0, 1.0, 512)
+    context.run(6)
+    per_step = _timed_host_steps(context, steps)
+    s = st.cpp_force.getCurrentValue(context.current.system.getCurrentTimeStep())
+    context.current = None
+    pairs = len(lists[2])
+    flops = pairs * (500.0 / 2 + 400.0)       # symmetric full list: the CV pass visits a pair once, the force pass every entry
+    return {"workload": "1xMI355X: 2.56x10^5 particles (noisy fcc), SteinhardtQl l<=6 CV with full neighbour list (%.1f neighbours), 1D 512-bin bias grid" % (pairs / N),
+            "ms_per_step": 1e3 * per_step, "value": N / per_step, "unit": "particle-CV-evals/s", "steps": steps, "dtype": "f64",
+            "pair_entries": pairs, "pair_visits_per_s": 1.5 * pairs / per_step, "steinhardt_cv": s,
+            "roofline": {"bound": "valu_fp64", "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s", "achieved": flops / per_step / 1e12,
+                         "frac": flops / per_step / 1e12 / FP64_VECTOR_PEAK_TFLOPS, "flops_per_step_model": flops,
+                         "dominant_kernels": "k_ql_forces, k_ql_accumulate (per-kernel table: profiles/r2/config5_steinhardt_kernel_stats.csv)",
+                         "timing": "host API: wall clock around System::run, synchronised on both sides"}}
+
+
+def kernel_source_sha():
+    """fingerprint of the sources the fused kernels are built from (the PMC traffic figures under profiles/ carry the same)"""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("fused.hip", "lamellar_device.hpp", "metad_device.hpp", "comm_device.hpp", "mtd_device.hpp"):
+        h.update(open(os.path.join(ROOT, "metadynamics-plugin_amd", "csrc", f), "rb").read())
+    return h.hexdigest()
+
+
 def host_cores():
     """CPU cores this process may actually use: the affinity mask capped by the cgroup CPU quota (a 256-thread host can
     hand a container 16)."""
@@ -241,6 +357,12 @@ def main():
     driver = args.driver or "host"
 
     def barrier():
+        # the queue is drained by polling an event first: a blocking synchronise sleeps and wakes up tens of microseconds after
+        # the last kernel — as much as two steps of a 20-step run; after the poll the synchronise calls return at once
+        ev = torch.cuda.Event()
+        ev.record()
+        while not ev.query():
+            pass
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
@@ -268,46 +390,15 @@ def main():
             eng.exchange = "%s (mailbox gave %d timeouts in rehearsal)" % ("rccl" if dist.get_backend() == "nccl" else dist.get_backend(), int(tt.item()))
     if driver == "host" and dist is not None and eng.be.mailbox is None:
         driver = "abi"                     # no mailbox on this node: the C-ABI backend with the RCCL all-reduce
-    if driver == "host":
-        # sharded: the C++ host classes take the mailbox as their communicator (fused lamellar step)
-        barrier()                          # ranks enter the first exchange (prepRun's deposit) together
-        host = HostEngine(eng.pos_np, eng.types_np, eng.L, n_global, args.stride, args.fast_trig, args.path, dtype=np_dtype,
-                          mailbox=eng.be.mailbox)
-        host.run(max(args.warmup - 1, 0))
-        barrier()
-        t0 = time.perf_counter()
-        host.run(args.steps - 1)        # run(k) = prepRun (one bias update) + k updates: exactly args.steps bias steps
-        barrier()
-        elapsed = time.perf_counter() - t0
-        st = host.state()
-    else:
-        barrier()                          # ranks enter the first exchange together (the mailbox waits are bounded)
-        for _ in range(args.warmup):
-            eng.step()
-        barrier()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            eng.step()
-        barrier()
-        elapsed = time.perf_counter() - t0
-        st = eng.state()
-    if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
-    mailbox_timeouts = None
-    if eng.be.mailbox is not None:
-        tt = torch.tensor([eng.be.mailbox.timeouts()], dtype=torch.int64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        mailbox_timeouts = int(tt.item())
-
+    # (measured BEFORE the timed region: the per-launch figures are then taken on a GPU in the same state as the timed steps
+    # and the timed region starts on clocks that are already up)
     # dominant kernel (launch B, the force pass): per-launch durations over the same loop from HIP events on the launch stream.
     # Fused path: every launch carries its own start / stop events (hipExtLaunchKernelGGL, armed by mtd_profile_force_begin):
     # the begin and end of that dispatch and nothing else — no subtraction.  Two cross-checks are reported beside it: the
     # differential (n whole steps) - (n launches of launch A alone), and a plain event pair around B minus the cost of an
     # empty pair (which subtracts one packet too many: low).  The rocprofv3 kernel trace of the same command is under
     # profiles/ (13.4-13.7 us for this kernel; the in-process figures are 14.6-14.7 us — the roofline is priced with those).
-    for _ in range(20 if driver == "host" else 0):
+    for _ in range(20):
         eng.step()
     n_ev = min(args.steps, 500)
     lib = _abi.load()
@@ -367,6 +458,39 @@ def main():
         alt["event_pair_minus_empty_pair_us"] = float(np.mean(pair[pair <= 3.0 * np.median(pair)]))
     alt["empty_event_pair_us"] = ev_overhead_us
 
+    if driver == "host":
+        # sharded: the C++ host classes take the mailbox as their communicator (fused lamellar step)
+        barrier()                          # ranks enter the first exchange (prepRun's deposit) together
+        host = HostEngine(eng.pos_np, eng.types_np, eng.L, n_global, args.stride, args.fast_trig, args.path, dtype=np_dtype,
+                          mailbox=eng.be.mailbox)
+        host.run(max(args.warmup - 1, 0))
+        barrier()
+        t0 = time.perf_counter()
+        host.run(args.steps - 1)        # run(k) = prepRun (one bias update) + k updates: exactly args.steps bias steps
+        barrier()
+        elapsed = time.perf_counter() - t0
+        st = host.state()
+    else:
+        barrier()                          # ranks enter the first exchange together (the mailbox waits are bounded)
+        for _ in range(args.warmup):
+            eng.step()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            eng.step()
+        barrier()
+        elapsed = time.perf_counter() - t0
+        st = eng.state()
+    if dist is not None:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    mailbox_timeouts = None
+    if eng.be.mailbox is not None:
+        tt = torch.tensor([eng.be.mailbox.timeouts()], dtype=torch.int64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        mailbox_timeouts = int(tt.item())
+
     if rank == 0:
         steps_per_s = args.steps / elapsed
         value = steps_per_s * n_global * 2
@@ -380,10 +504,19 @@ def main():
         achieved = force_bytes / (force_us_mean * 1e-6) / 1e9
         # HBM traffic of the dominant kernel from the PMC passes committed under profiles/ (FETCH_SIZE / WRITE_SIZE
         # in separate rocprofv3 runs, gfx950 x2 correction on FETCH_SIZE); only valid for the default workload
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "r1", "pmc_summary.json")
-        if os.path.exists(pmc) and args.path == "fused" and args.stride == 1 and n_local == N_PER_GPU:
-            traffic = json.load(open(pmc)).get("k_fused_force", {}).get("hbm_bytes_per_launch")
+        # (a profiler cannot be attached from inside the run; the figure is only reported while the kernel's sources are the
+        # ones the counters were collected on — otherwise traffic is null and traffic_stale says so)
+        traffic, traffic_src, traffic_stale = None, None, None
+        pmc = os.path.join(ROOT, "profiles", "r2", "pmc_summary.json")
+        if os.path.exists(pmc) and args.path == "fused" and args.stride == 1 and n_local == N_PER_GPU and args.dtype == "f32":
+            rec = json.load(open(pmc))
+            traffic_stale = rec.get("kernel_source_sha256") != kernel_source_sha()
+            if not traffic_stale:
+                traffic = rec.get("k_fused_force", {}).get("hbm_bytes_per_launch")
+                traffic_src = "profiles/r2/pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command on these kernel sources)"
+        # step level: N (P [CV pass read] + P [force pass read] + n_cv P [force writes]) over the measured step
+        step_bytes = n_local * 4 * scalar4
+        step_frac = step_bytes * world / (elapsed / args.steps) / 1e9 / (HBM_PEAK_GBS * world)
         out = {
             "metric": "particle_cv_evals_per_s",
             "value": value,
@@ -404,7 +537,9 @@ def main():
                        "stride": args.stride, "fast_trig": int(args.fast_trig), "path": args.path, "driver": driver},
             "roofline": {"bound": "hbm", "kernel": "k_fused_force" if args.path == "fused" else "k_lamellar_forces", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "traffic_source": "profiles/r1/pmc_summary.json (rocprofv3 --pmc passes of this command)" if traffic else None,
+                         "traffic_source": traffic_src, "traffic_stale": traffic_stale,
+                         "step_frac": step_frac, "step_algorithmic_bytes": step_bytes,
+                         "step_frac_definition": "N*(P + P + n_cv*P) bytes per step (SURVEY.md 8d: 64 B/particle in f32) / ms_per_step / 8 TB/s, per GPU",
                          "algorithmic_bytes_per_launch": force_bytes, "avg_launch_us": force_us_mean, "median_launch_us": force_us,
                          "timing": timing, "launches_timed": int(keep.sum()), "cross_checks": alt,
                          "stalled_samples_dropped": n_stalls},
@@ -447,6 +582,14 @@ def main():
                 out["cpu_baseline_all_cores"] = {"error": str(e)}
             finally:
                 mtd_ref.use_openmp(False)
+        if world == 1 and not args.no_sub_records and n_local == N_PER_GPU:
+            # the other single-GPU configurations of BASELINE.json, bounded runs (not the headline: reported beside it)
+            try:
+                if driver == "host":
+                    host.context.current = None
+                out["extra"] = {"config3": sub_record_config3(args.sub_steps, args.fast_trig), "config5": sub_record_config5(args.sub_steps)}
+            except Exception as e:                                      # never let a sub-record break the headline line
+                out["extra"] = {"error": repr(e)}
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

@@ -262,6 +262,30 @@ int mtd_profile_force_begin(unsigned int n_launches);
 int mtd_profile_force_end(double *durations_us, unsigned int capacity, unsigned int *n_out);
 
 /* ================================================================================================
+ * RCCL all-reduce of large device buffers (rccl.hip; RCCL is bound at run time, no link-time dependency)
+ * replaces: the multiple-walker exchange IntegratorMetaDynamics.cc:393-409 (four host-staged MPI_Allreduce over
+ * m_partition_comm) and, for a particle-sharded mesh CV, the mesh exchange of OrderParameterMesh.cc:263-316, 659-746.
+ * ============================================================================================== */
+#define MTD_RCCL_ID_BYTES 128
+#define MTD_ELEM_F64 1
+#define MTD_ELEM_U32 2
+typedef struct mtd_rccl mtd_rccl;
+/* rank 0: a fresh unique id (MTD_RCCL_ID_BYTES bytes) for the caller's control plane to hand to every rank */
+int mtd_rccl_unique_id(void *out_id);
+/* collective over the `world` ranks holding the same id; one communicator per process and GPU */
+int mtd_rccl_create(mtd_rccl **out, const void *unique_id, unsigned int rank, unsigned int world);
+/* in-place sum over ranks of `count` elements (MTD_ELEM_F64 doubles or MTD_ELEM_U32 unsigned ints) on `stream` */
+int mtd_comm_allreduce_large(mtd_rccl *r, void *d_buffer, size_t count, int elem, mtd_stream_t stream);
+unsigned int mtd_rccl_world(const mtd_rccl *r);
+unsigned int mtd_rccl_rank(const mtd_rccl *r);
+int mtd_rccl_destroy(mtd_rccl *r);
+/* Multiple walkers in one call (IntegratorMetaDynamics.cc:363-451 with m_multiple_walkers): histogram / Gaussian increments
+ * of this walker (mtd_metad_update_phase_a), sum of {grid_delta, sigma_grid_delta} and {hist_delta, hist_gauss_delta} over
+ * the walkers (two all-reduces: the delta groups are contiguous), reweighting + accumulate + evaluation
+ * (mtd_metad_update_phase_b).  Every walker must call it with the same timestep. */
+int mtd_metad_update_bias_walkers(mtd_metad *m, mtd_rccl *walkers, unsigned int timestep, mtd_stream_t stream);
+
+/* ================================================================================================
  * xGMI mailbox: all-reduce (sum) of a few doubles between the GPUs of one node, one process per GPU
  * replaces the host-staged MPI_Allreduce of the per-step CV sums (LamellarOrderParameterGPU.cc:69-77,
  * SteinhardtQl.cc:183-191, WellTemperedEnsemble.cc:57-63) without a collective-library call on the

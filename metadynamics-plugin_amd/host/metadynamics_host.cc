@@ -803,6 +803,7 @@ void IntegratorMetaDynamics::update(unsigned int timestep)
 bool IntegratorMetaDynamics::fusedLamellarPossible() const
     {
     if (m_adaptive) return false;                                      // the deposit width changes between the two launches
+    if (m_multiple_walkers) return false;                              // the walkers' increments are summed between the grid passes
     if (!m_allow_fused || m_variables.empty() || m_variables.size() > MTD_METAD_MAX_CV) return false;
     unsigned int n_modes = 0;
     for (const auto &it : m_variables)
@@ -861,7 +862,7 @@ void IntegratorMetaDynamics::fusedLamellarStep(unsigned int timestep)
 std::vector<unsigned int> IntegratorMetaDynamics::mixedLamellarSlots() const
     {
     std::vector<unsigned int> slots;
-    if (!m_allow_fused || m_adaptive || m_variables.size() > 3) return slots;     // the one-wave chain handles <= 3 variables
+    if (!m_allow_fused || m_adaptive || m_multiple_walkers || m_variables.size() > 3) return slots;     // the one-wave chain handles <= 3 variables
     unsigned int n_modes = 0;
     for (unsigned int i = 0; i < m_variables.size(); ++i)
         {
@@ -953,6 +954,14 @@ void IntegratorMetaDynamics::updateBiasPotential(unsigned int timestep)
                 m_variables[i].m_cv->enqueueCurrentValue(timestep, m_engine, i);
         if (!lam_slots.empty())
             mixedLamellarForcePass(lam_slots, timestep);
+        else if (m_multiple_walkers)
+            {
+            // sum up the walkers' increments between the two grid passes (:393-409)
+            if (!m_exec_conf->getWalkerCommunicator())
+                throw std::runtime_error("integrate.mode_metadynamics: multiple_walkers needs a communicator between the walkers "
+                                         "(ExecutionConfiguration::setWalkerCommunicator)");
+            mtd_check(mtd_metad_update_bias_walkers(m_engine, m_exec_conf->getWalkerCommunicator(), timestep, s), "mtd_metad_update_bias_walkers");
+            }
         else
             mtd_check(mtd_metad_update_bias(m_engine, timestep, s), "mtd_metad_update_bias");
         // update current bias potential derivative for every collective variable (:578-584)

@@ -126,10 +126,15 @@ class ExecutionConfiguration
         mtd_comm *getMailbox() const { return m_comm; }
         unsigned int getNRanks() const { return m_comm ? mtd_comm_world(m_comm) : 1; }
         unsigned int getRank() const { return m_comm ? mtd_comm_rank(m_comm) : 0; }
+        //! the communicator between WALKERS (one simulation per GPU sharing one bias grid): HOOMD's m_partition_comm
+        //! (IntegratorMetaDynamics.cc:393-409).  An RCCL communicator (mtd_rccl_create), borrowed.
+        void setWalkerCommunicator(uintptr_t rccl) { m_walkers = reinterpret_cast<mtd_rccl *>(rccl); }
+        mtd_rccl *getWalkerCommunicator() const { return m_walkers; }
 
     private:
         hipStream_t m_stream;
         mtd_comm *m_comm = nullptr;
+        mtd_rccl *m_walkers = nullptr;
     };
 
 //! Particle arrays in HOOMD layout; Scalar is chosen per system (dtype), the arrays live in HBM

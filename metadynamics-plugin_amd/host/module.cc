@@ -110,6 +110,7 @@ PYBIND11_MODULE(_metadynamics, m)
         .def(py::init<>())
         .def("isCUDAEnabled", &ExecutionConfiguration::isCUDAEnabled)
         .def("setMailbox", &ExecutionConfiguration::setMailbox)
+        .def("setWalkerCommunicator", &ExecutionConfiguration::setWalkerCommunicator)
         .def("getNRanks", &ExecutionConfiguration::getNRanks)
         .def("getRank", &ExecutionConfiguration::getRank)
         .def("sync", &ExecutionConfiguration::sync);

@@ -145,6 +145,13 @@ _SIGNATURES = {
     "mtd_comm_rank": (C.c_uint, [_vp]),
     "mtd_comm_destroy": (C.c_int, [_vp]),
     "mtd_metad_set_comm": (C.c_int, [_vp, _vp]),
+    "mtd_rccl_unique_id": (C.c_int, [_vp]),
+    "mtd_rccl_create": (C.c_int, [C.POINTER(_vp), _vp, C.c_uint, C.c_uint]),
+    "mtd_comm_allreduce_large": (C.c_int, [_vp, _vp, C.c_size_t, C.c_int, _vp]),
+    "mtd_rccl_world": (C.c_uint, [_vp]),
+    "mtd_rccl_rank": (C.c_uint, [_vp]),
+    "mtd_rccl_destroy": (C.c_int, [_vp]),
+    "mtd_metad_update_bias_walkers": (C.c_int, [_vp, _vp, C.c_uint, _vp]),
     "mtd_fused_force_pass_slots": (C.c_int, [_vp, C.POINTER(LamellarSet), _up, C.c_uint, _vp, C.POINTER(_vp), C.c_int, C.c_uint,
                                               C.POINTER(Box), C.c_uint, _vp]),
     "mtd_mesh_create": (C.c_int, [C.POINTER(_vp), C.c_uint, C.c_uint, C.c_uint, _dp, C.c_uint, C.c_uint]),
@@ -192,13 +199,11 @@ def load():
             raise MtdError("libmtd_hip.so not found at %s — build it with __graft_entry__.build() "
                            "(make -C metadynamics-plugin_amd/csrc); there is no CPU fallback." % LIB_PATH)
         # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64.so (SONAME
-        # libamdhip64.so.7).  Importing torch FIRST makes the dynamic linker satisfy this library's
-        # DT_NEEDED with that already-loaded copy, so torch tensors, streams and RCCL buffers and
-        # our kernels share one runtime; loaded the other way round two runtimes would coexist.
-        try:
-            import torch  # noqa: F401
-        except ImportError:
-            pass
+        # libamdhip64.so.7).  A process that uses torch as well (the test / bench harness) imports it
+        # FIRST: the dynamic linker then satisfies this library's DT_NEEDED with that already-loaded copy,
+        # so torch tensors, streams and RCCL buffers and our kernels share one runtime; loaded the other
+        # way round two runtimes would coexist.
+        # (torch is never imported from here: a process without it loads the HIP runtime libmtd_hip.so links against)
         lib = C.CDLL(LIB_PATH)
         for name, (res, args) in _SIGNATURES.items():
             if not hasattr(lib, name):

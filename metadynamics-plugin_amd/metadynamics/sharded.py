@@ -13,8 +13,44 @@ protocol) — libmtd_hip.so through the C ABI, no CPU fallback; the CPU gloo tes
 
 Per-CV exchange of a particle-sharded step: lamellar — its sum; mesh — the replicated real mesh and
 sum(mode^2) (M + 1 doubles); Steinhardt — the (lmax+1)(lmax+2) Q'_lm sums; potential energy / wrapper — one double.
+
+These classes are LAUNCHER-SIDE orchestration for Python drivers (tests, bench.py): device buffers arrive as tensors and the
+control plane is ``torch.distributed``.  A C++ caller needs none of it — the library exports the same exchanges itself:
+``mtd_comm_allreduce_small`` (xGMI mailbox), ``mtd_comm_allreduce_large`` / ``mtd_rccl_*`` (RCCL, bound at run time) and
+``mtd_metad_update_bias_walkers``; pass ``large=RcclAllReduce(...)`` to route the large buffers through them here as well.
 """
 import ctypes as C
+
+
+class RcclAllReduce:
+    """``mtd_comm_allreduce_large`` over an ``mtd_rccl`` communicator built from an id the process group broadcasts:
+    the large exchanges (replicated mesh, walker deltas) without torch's collective — what a C++ host does"""
+
+    def __init__(self, dist):
+        import torch
+        from . import _abi
+        self._abi, self.lib = _abi, _abi.load()
+        rank, world = dist.get_rank(), dist.get_world_size()
+        uid = (C.c_ubyte * 128)()
+        if rank == 0:
+            _abi.check(self.lib.mtd_rccl_unique_id(uid))
+        t = torch.frombuffer(bytearray(bytes(uid)), dtype=torch.uint8).clone()
+        dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+        t = t.to(dev)
+        dist.broadcast(t, 0)
+        blob = (C.c_ubyte * 128)(*t.cpu().numpy().tolist())
+        self.handle = C.c_void_p()
+        _abi.check(self.lib.mtd_rccl_create(C.byref(self.handle), blob, rank, world))
+
+    def all_reduce(self, tensor):
+        elem = 1 if str(tensor.dtype).endswith("float64") else 2
+        self._abi.check(self.lib.mtd_comm_allreduce_large(self.handle, tensor.data_ptr(), int(tensor.numel()), elem, None))
+        return tensor
+
+    def close(self):
+        if self.handle:
+            self._abi.check(self.lib.mtd_rccl_destroy(self.handle))
+            self.handle = None
 
 
 class ShardedBiasStep:
@@ -26,10 +62,11 @@ class ShardedBiasStep:
                                 bias forces of the local particles
     """
 
-    def __init__(self, backend, dist=None, group=None, mailbox=None, mailbox_max=64):
+    def __init__(self, backend, dist=None, group=None, mailbox=None, mailbox_max=64, large=None):
         self.backend = backend
         self.dist = dist
         self.group = group
+        self.large = large            # RcclAllReduce: the large buffers through the library's own RCCL binding
         # xGMI mailbox (metadynamics.xgmi.Mailbox) for the small exchange buffers of a CV set (lamellar sums, Q_lm sums,
         # energies: a few doubles each); buffers above mailbox_max doubles (the replicated mesh) stay on the collective
         self.small = mailbox
@@ -51,6 +88,8 @@ class ShardedBiasStep:
                     continue                    # the part exchanged what it needed itself (MeshSlabPart)
                 if self.small is not None and buf.numel() <= self.small_max and str(buf.dtype).endswith("float64"):
                     self.small.all_reduce(buf)
+                elif self.large is not None and (str(buf.dtype).endswith("float64") or str(buf.dtype).endswith("int32")):
+                    self.large.all_reduce(buf)
                 else:
                     self.dist.all_reduce(buf, group=self.group)
         self.backend.force_pass(sums, timestep)
@@ -65,17 +104,22 @@ class WalkerBiasStep:
         phase_b(deposited)
     """
 
-    def __init__(self, backend, dist, group=None):
+    def __init__(self, backend, dist, group=None, large=None):
         self.backend = backend
         self.dist = dist
         self.group = group
+        self.large = large            # RcclAllReduce: mtd_comm_allreduce_large instead of the process group's collective
 
     def step(self, timestep):
         dep = self.backend.phase_a(timestep)
         if dep:
             real, count = self.backend.delta_buffers()
-            self.dist.all_reduce(real, group=self.group)
-            self.dist.all_reduce(count, group=self.group)
+            if self.large is not None:
+                self.large.all_reduce(real)
+                self.large.all_reduce(count)
+            else:
+                self.dist.all_reduce(real, group=self.group)
+                self.dist.all_reduce(count, group=self.group)
         self.backend.phase_b(dep)
 
 

@@ -8,6 +8,11 @@ import sys
 
 import pytest
 
+try:  # the harness uses torch for device buffers: it must be loaded BEFORE libmtd_hip.so so that both share one HIP runtime
+    import torch  # noqa: F401
+except ImportError:  # pragma: no cover
+    pass
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (os.path.join(ROOT, "metadynamics-plugin_amd"), os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests"), ROOT):
     if p not in sys.path:

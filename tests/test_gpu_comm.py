@@ -259,3 +259,86 @@ def test_mailbox_timeout_is_fatal():
     assert r["rc_grid"] == 0 and r["grid_finite"] and r["grid_max"] > 0       # the good step's hill, nothing else
     assert r["num_gaussians"] == [1, 1]
     assert "mailbox" in r["status_string"]
+
+
+def test_rccl_allreduce_large_and_walker_update(abi, ref):
+    """mtd_rccl_* / mtd_comm_allreduce_large / mtd_metad_update_bias_walkers (rccl.hip): RCCL bound at run time, communicator from
+    a caller-supplied unique id.  One rank here (RCCL refuses two ranks on one device): the call sequence, both element types,
+    and the walker update (IntegratorMetaDynamics.cc:363-451 with m_multiple_walkers) against the oracle's grid engine — with
+    one walker the sums over walkers are the walker's own increments."""
+    import ctypes as C
+    lib = abi.load()
+    uid = (C.c_ubyte * 128)()
+    abi.check(lib.mtd_rccl_unique_id(uid))
+    r = C.c_void_p()
+    abi.check(lib.mtd_rccl_create(C.byref(r), uid, 0, 1))
+    assert lib.mtd_rccl_world(r) == 1 and lib.mtd_rccl_rank(r) == 0
+    v = torch.arange(100000, dtype=torch.float64, device="cuda") * 0.5
+    u = torch.arange(7777, dtype=torch.int32, device="cuda")
+    abi.check(lib.mtd_comm_allreduce_large(r, v.data_ptr(), v.numel(), 1, None))
+    abi.check(lib.mtd_comm_allreduce_large(r, u.data_ptr(), u.numel(), 2, None))
+    torch.cuda.synchronize()
+    assert torch.equal(v.cpu(), torch.arange(100000, dtype=torch.float64) * 0.5) and torch.equal(u.cpu(), torch.arange(7777, dtype=torch.int32))
+    assert lib.mtd_comm_allreduce_large(r, v.data_ptr(), 10, 7, None) == -1
+    from test_gpu_metad import GpuMetad, compare
+    kw = dict(sigma=[0.05, 0.1], cv_min=[-1.0, 0.0], cv_max=[1.0, 2.0], num_points=[33, 20], W=0.7, T_shift=5.0, T=1.3, stride=2, mode="well_tempered")
+    g = GpuMetad(abi, **kw)
+    o = ref.Metad(**kw)
+    try:
+        rng = np.random.default_rng(3)
+        for t in range(9):
+            vals = [rng.uniform(-0.8, 0.8), rng.uniform(0.2, 1.8)]
+            for c, x in enumerate(vals):
+                abi.check(lib.mtd_metad_set_cv_value(g.h, c, float(x)))
+            abi.check(lib.mtd_metad_update_bias_walkers(g.h, r, t, None))
+            b = o.update_bias(t, vals)
+            compare(g, o, b, label="walker step %d" % t)
+    finally:
+        g.close()
+    abi.check(lib.mtd_rccl_destroy(r))
+
+
+def test_host_multiple_walkers(abi):
+    """integrate.set_params(multiple_walkers=True) through the C++ host classes: without a walker communicator the step
+    refuses (it used to be a silent no-op); with one (a one-walker RCCL communicator) the run equals the plain one"""
+    import ctypes as C
+    from metadynamics import context, cv, integrate
+    lib = abi.load()
+    N, L = 20000, 30.0
+    pos, types = util.snapshot_random(N, L, seed=21, modulated=True, dtype=np.float32)
+
+    def run(walkers, comm):
+        context.initialize(pos, types, ["A", "B"], L, dtype=np.float32)
+        if comm is not None:
+            context.exec_conf.setWalkerCommunicator(comm.value)
+        meta = integrate.mode_metadynamics(dt=0.005, stride=1, mode="well_tempered", W=1.0, deltaT=7.0, T=1.0)
+        cvs = []
+        for i, vecs in enumerate((util.CV1_VECTORS, util.CV2_VECTORS)):
+            c = cv.lamellar(sigma=0.02, mode=dict(A=1.0, B=-1.0), lattice_vectors=vecs, name="c%d" % i)
+            c.set_grid(-1.0, 1.0, 40)
+            cvs.append(c)
+        if walkers:
+            meta.set_params(multiple_walkers=True)
+        try:
+            context.run(4)
+            t = context.current.system.getCurrentTimeStep()
+            integ = meta.cpp_integrator
+            return dict(V=integ.getLogValue("bias", t), w=integ.getLogValue("weight", t), n=integ.getNumGaussians(),
+                        fused=integ.usedFusedPath(), f=cvs[0].cpp_force.getForces().copy())
+        finally:
+            context.current = None
+
+    plain = run(False, None)
+    with pytest.raises(RuntimeError):
+        run(True, None)
+    uid = (C.c_ubyte * 128)()
+    abi.check(lib.mtd_rccl_unique_id(uid))
+    r = C.c_void_p()
+    abi.check(lib.mtd_rccl_create(C.byref(r), uid, 0, 1))
+    try:
+        w = run(True, r)
+        assert plain["fused"] and not w["fused"] and w["n"] == plain["n"]
+        assert w["V"] == pytest.approx(plain["V"], rel=1e-6) and w["w"] == pytest.approx(plain["w"], rel=1e-6)
+        assert np.abs(w["f"] - plain["f"]).max() <= 1e-5 * np.abs(plain["f"]).max()
+    finally:
+        abi.check(lib.mtd_rccl_destroy(r))

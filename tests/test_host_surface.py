@@ -2,9 +2,12 @@
 enums, constructor arity — and the pure host logic that needs no device (box maths, argument validation in Python).
 Nothing here touches the GPU: objects that allocate device memory are not constructed."""
 import inspect
+import os
 
 import numpy as np
 import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.fixture(scope="module")
@@ -123,3 +126,26 @@ def test_sharded_step_routes_buffers_between_mailbox_and_collective():
     be3.mailbox = object()
     ShardedBiasStep(be3, pg).step(3)
     assert be3.done == [("single", 3)]
+
+
+def test_product_package_imports_without_torch():
+    """the product (metadynamics package: ctypes view of the C ABI + pybind11 host module + Python API) does not depend on
+    PyTorch — torch is the test / bench harness's tool for device buffers"""
+    import subprocess
+    import sys
+    code = """
+import sys
+sys.path.insert(0, %r)
+class Block:
+    def find_spec(self, name, path=None, target=None):
+        if name == "torch" or name.startswith("torch."):
+            raise ImportError("torch blocked")
+sys.meta_path.insert(0, Block())
+import metadynamics
+from metadynamics import _abi, cv, integrate, context
+assert _abi.load().mtd_abi_version() >= 1
+assert "torch" not in sys.modules
+print("ok")
+""" % os.path.join(ROOT, "metadynamics-plugin_amd")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and r.stdout.strip() == "ok", r.stderr[-2000:]
