@@ -56,3 +56,23 @@ def test_argument_validation_without_gpu(abi):
     assert bad == -1                                              # cv_min >= cv_max (IntegratorMetaDynamics.cc:800-805)
     assert lib.mtd_metad_create(C.byref(h), 7, util.dbl_array([0.1] * 7), util.dbl_array([0.0] * 7),
                                 util.dbl_array([1.0] * 7), util.uint_array([2] * 7), 1.0, 1.0, 1.0, 1, 0, 1) == -2
+
+
+def test_hoomd_adapter_calls_only_declared_entry_points():
+    """adapter/hoomd cannot be compiled here (no HOOMD tree): at least every mtd_* call it makes must be a
+    declared entry point of include/mtd_abi.h, and the translation unit must be empty without MTD_WITH_HOOMD"""
+    import os
+    import re
+    import subprocess
+    from metadynamics import _abi
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    declared = set(_abi.declared_symbols())
+    for f in ("MtdHoomd.h", "MtdHoomd.cc"):
+        text = open(os.path.join(root, "metadynamics-plugin_amd", "adapter", "hoomd", f)).read()
+        text = re.sub(r"//.*", "", text)
+        used = set(re.findall(r"\b(mtd_[a-z0-9_]+)\s*\(", text)) - {"mtd_dtype"}
+        assert used <= declared, sorted(used - declared)
+        assert "#ifdef MTD_WITH_HOOMD" in text
+    r = subprocess.run(["g++", "-std=c++14", "-fsyntax-only", "-I", os.path.join(root, "include"),
+                        os.path.join(root, "metadynamics-plugin_amd", "adapter", "hoomd", "MtdHoomd.cc")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
