@@ -371,9 +371,11 @@ struct ForceProfile
     size_t used = 0;
     };
 ForceProfile g_force_profile;
+std::mutex g_force_profile_mutex;      // the hook is process-wide: armed by one thread (bench.py), consulted by every launch
 
 bool force_profile_next(hipEvent_t &start, hipEvent_t &stop)
     {
+    std::lock_guard<std::mutex> lock(g_force_profile_mutex);
     ForceProfile &p = g_force_profile;
     if (p.used + 2 > p.ev.size()) return false;
     start = p.ev[p.used];
@@ -593,6 +595,7 @@ int mtd_fused_force_pass_slots(mtd_metad *m, const mtd_lamellar_set *set, const 
 
 int mtd_profile_force_begin(unsigned int n_launches)
     {
+    std::lock_guard<std::mutex> lock(g_force_profile_mutex);
     ForceProfile &p = g_force_profile;
     for (hipEvent_t e : p.ev) (void)hipEventDestroy(e);
     p.ev.clear();
@@ -611,6 +614,7 @@ int mtd_profile_force_end(double *durations_us, unsigned int capacity, unsigned 
     ForceProfile &p = g_force_profile;
     if (!durations_us || !n_out) return MTD_ERR_INVALID_ARGUMENT;
     MTD_HIP_TRY(hipDeviceSynchronize());
+    std::lock_guard<std::mutex> lock(g_force_profile_mutex);
     unsigned int n = 0;
     for (size_t i = 0; i + 1 < p.used && n < capacity; i += 2)
         {

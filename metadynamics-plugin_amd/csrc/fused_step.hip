@@ -76,13 +76,20 @@ constexpr int FS_THREADS = 1024;
 constexpr int FS_WAVES = FS_THREADS / MTD_WAVE;
 constexpr int FS_U = 4;                                   // particles per thread, held in registers across the phases
 constexpr unsigned int FS_MAX_BLOCKS = 256;               // one block per compute unit
-constexpr unsigned int FS_CHUNK = FS_THREADS * FS_U;      // particles per block at most
+// Wave 0 of a block owns NO particles: it prefetches the bias-grid patch, collects the blocks' sums and runs the chain, so that
+// nothing of its own stands between the last block's sums and the bias factors.  Waves 1 .. 15 hold FS_U particles per lane
+// (slots u * FS_MAIN + (wave - 1) * 64 + lane), waves 1 .. 4 one more (slots FS_U * FS_MAIN + (wave - 1) * 64 + lane): the
+// same 4096 per block.
+constexpr unsigned int FS_MAIN = (FS_WAVES - 1) * MTD_WAVE;            // 960 particles per register slot
+constexpr unsigned int FS_EXTRA_WAVES = 4;
+constexpr unsigned int FS_CHUNK = FS_U * FS_MAIN + FS_EXTRA_WAVES * MTD_WAVE;   // particles per block at most: 4096
 constexpr unsigned int FS_LL_WORDS = 2 * (CHAIN_MAX_CV + 2);   // per block: <= 3 CV sums + 2 grid sums, two 8-byte words each; stored by
                                                                // columns, ll[word][block] (comm_device.hpp: ll_collect_columns)
 // Every block reads every block's sums: 245 waves polling the same few KB would queue on the one or two memory channels
 // behind them (measured: the hand-off took 3.3 us instead of one round trip).  So a row of 256 words sits in a 4 KB channel
 // stripe of its own and the whole table exists FS_LL_REPLICAS times — a block posts into every replica (a few dozen 8-byte
 // stores) and reads replica (block mod FS_LL_REPLICAS): the reads spread over 8 x as many channels.
+constexpr int FS_FIRST_PROBE_SLEEP = 12;                       // x 64 clocks ~ 0.35 us
 constexpr unsigned int FS_LL_PITCH = 512;                      // words per row: 4 KB
 constexpr unsigned int FS_LL_REPLICAS = 8;
 constexpr unsigned int FS_LL_REPLICA_WORDS = FS_LL_WORDS * FS_LL_PITCH;
@@ -167,6 +174,61 @@ __device__ __forceinline__ void step_force_unscaled(const LamKArgs &a, const Mod
         }
     }
 
+// the same two passes for ONE more particle per lane (waves 1 .. 4), scalar
+template<int NCV> struct ExtraRegs
+    {
+    float g0, g1, g2;
+    int type;
+    bool ok;
+    float f[NCV][3];
+    };
+
+template<int NCV, bool FAST>
+__device__ __forceinline__ void step_cv_sums_one(const LamKArgs &a, const float *s_coeff, const ModeTables &mt, const ExtraRegs<NCV> &X,
+                                                 float (&acc)[NCV])
+    {
+#pragma unroll
+    for (int c = 0; c < NCV; ++c)
+        if (c < (int)a.n_cv)
+            {
+            float sum = 0.0f;
+            const unsigned int k1 = a.first[c] + a.nact[c];
+#pragma unroll 4
+            for (unsigned int k = a.first[c]; k < k1; ++k)
+                {
+                const float4 h = mt.h[k];
+                const float cs = cos2pi<FAST>(h.x * X.g0 + h.y * X.g1 + h.z * X.g2);
+                sum += cs;
+                sum += h.w * ((cs * cs) * 2.0f - (FAST ? 0.99999994f : 1.0f));
+                }
+            acc[c] += (X.ok ? s_coeff[c * MTD_MAX_TYPES + X.type] : 0.0f) * sum;
+            }
+    }
+
+template<int NCV, bool FAST>
+__device__ __forceinline__ void step_force_unscaled_one(const LamKArgs &a, const ModeTables &mt, ExtraRegs<NCV> &X)
+    {
+#pragma unroll
+    for (int c = 0; c < NCV; ++c)
+        {
+        X.f[c][0] = X.f[c][1] = X.f[c][2] = 0.0f;
+        if (c < (int)a.n_cv)
+            {
+            const unsigned int k1 = a.first[c + 1];
+#pragma unroll 4
+            for (unsigned int k = a.first[c]; k < k1; ++k)
+                {
+                const float4 h = mt.h[k];
+                const float4 q = mt.q[k];
+                const float sn = sin2pi<FAST>(h.x * X.g0 + h.y * X.g1 + h.z * X.g2);
+                X.f[c][0] += q.x * sn;
+                X.f[c][1] += q.y * sn;
+                X.f[c][2] += q.z * sn;
+                }
+            }
+        }
+    }
+
 template<typename S4, int NCV, bool FAST, bool COMM>
 __global__ __launch_bounds__(FS_THREADS, 1) void k_fused_step(const LamKArgs a, const S4 *__restrict__ postype, const ForcePtrs out,
                                                            const unsigned int N, const unsigned int chunk, const double two_over_n,
@@ -193,15 +255,33 @@ __global__ __launch_bounds__(FS_THREADS, 1) void k_fused_step(const LamKArgs a, 
     if (threadIdx.x == 0) MTD_BSTAMP(0);
 
     MTD_STAMP(0, blockIdx.x == 0 && threadIdx.x == 0); MTD_STAMP(16, blockIdx.x == gridDim.x - 1 && threadIdx.x == 0); MTD_STAMP(32, blockIdx.x == 0 && threadIdx.x == 64);
-    // ---- phase 0: the particles are requested before the tables are staged
+    // ---- phase 0: the particles are requested before the tables are staged; wave 0 requests the bias-grid patch instead
     StepRegs<NCV, FS_U> R;
+    ExtraRegs<NCV> X;
     RawGroup<S4, FS_U> raw;
-#pragma unroll
-    for (int u = 0; u < FS_U; ++u)
+    S4 raw_x;
+    const bool has_extra = wave >= 1 && wave <= (int)FS_EXTRA_WAVES;
+    const unsigned int slot0 = (unsigned int)(wave - 1) * MTD_WAVE + lane;           // (waves >= 1)
+    const unsigned int ix = p0 + FS_U * FS_MAIN + slot0;
+    GridPatch patch;
+    X.ok = false;
+    if (wave == 0)
         {
-        const unsigned int i = p0 + u * FS_THREADS + threadIdx.x;
-        R.ok[u] = i < p1;
-        if (N) raw.v[u] = postype[R.ok[u] ? i : N - 1];
+#pragma unroll
+        for (int u = 0; u < FS_U; ++u) R.ok[u] = false;
+        patch = chain_prefetch(c);
+        }
+    else
+        {
+#pragma unroll
+        for (int u = 0; u < FS_U; ++u)
+            {
+            const unsigned int i = p0 + u * FS_MAIN + slot0;
+            R.ok[u] = i < p1;
+            if (N) raw.v[u] = postype[R.ok[u] ? i : N - 1];
+            }
+        X.ok = has_extra && ix < p1;
+        if (N && has_extra) raw_x = postype[X.ok ? ix : N - 1];
         }
     load_coeff(a, s_coeff);
     load_modes_cv(a, s_cvt);
@@ -210,23 +290,40 @@ __global__ __launch_bounds__(FS_THREADS, 1) void k_fused_step(const LamKArgs a, 
 
     MTD_STAMP(1, blockIdx.x == 0 && threadIdx.x == 0); MTD_STAMP(17, blockIdx.x == gridDim.x - 1 && threadIdx.x == 0); MTD_STAMP(33, blockIdx.x == 0 && threadIdx.x == 64);
     // ---- phase 1: per-CV sums
-#pragma unroll
-    for (int u = 0; u < FS_U; ++u)
-        {
-        float x0 = 0.0f, x1 = 0.0f, x2 = 0.0f;
-        R.type[u] = 0;
-        if (N)
-            {
-            const Particle p = scalar4_traits<S4>::unpack(raw.v[u]);
-            project(a, p, x0, x1, x2);
-            R.type[u] = p.type;
-            }
-        R.g0[u / 2][u % 2] = x0;
-        R.g1[u / 2][u % 2] = x1;
-        R.g2[u / 2][u % 2] = x2;
-        }
     float acc[NCV];
-    step_cv_sums<NCV, FAST, FS_U>(a, s_coeff, s_cvt, R, acc);
+#pragma unroll
+    for (int i = 0; i < NCV; ++i) acc[i] = 0.0f;
+    if (wave != 0)
+        {
+#pragma unroll
+        for (int u = 0; u < FS_U; ++u)
+            {
+            float x0 = 0.0f, x1 = 0.0f, x2 = 0.0f;
+            R.type[u] = 0;
+            if (N)
+                {
+                const Particle p = scalar4_traits<S4>::unpack(raw.v[u]);
+                project(a, p, x0, x1, x2);
+                R.type[u] = p.type;
+                }
+            R.g0[u / 2][u % 2] = x0;
+            R.g1[u / 2][u % 2] = x1;
+            R.g2[u / 2][u % 2] = x2;
+            }
+        step_cv_sums<NCV, FAST, FS_U>(a, s_coeff, s_cvt, R, acc);
+        if (has_extra)
+            {
+            X.g0 = X.g1 = X.g2 = 0.0f;
+            X.type = 0;
+            if (N)
+                {
+                const Particle p = scalar4_traits<S4>::unpack(raw_x);
+                project(a, p, X.g0, X.g1, X.g2);
+                X.type = p.type;
+                }
+            step_cv_sums_one<NCV, FAST>(a, s_coeff, s_cvt, X, acc);
+            }
+        }
     MTD_STAMP(2, blockIdx.x == 0 && threadIdx.x == 0); MTD_STAMP(18, blockIdx.x == gridDim.x - 1 && threadIdx.x == 0); MTD_STAMP(34, blockIdx.x == 0 && threadIdx.x == 64);
     // block sum: the positions stream in over ~3 us, so the waves finish this phase that far apart; the early ones wait at the
     // barrier (letting them run ahead into their force arithmetic was measured: the late waves then share their SIMDs with
@@ -255,9 +352,6 @@ __global__ __launch_bounds__(FS_THREADS, 1) void k_fused_step(const LamKArgs a, 
     const bool closed = deposit != 0 || b != 0;
     if (wave == 0)
         {
-        // wave 0 forms its own unscaled forces first: the other blocks' sums are still on their way, and nothing of this
-        // wave stands between the end of the chain and the block's barrier then
-        step_force_unscaled<NCV, FAST, FS_U>(a, s_mt, R);
         __builtin_amdgcn_s_setprio(3);
         double tot[3] = { 0.0, 0.0, 0.0 };
         bool expired = false;
@@ -268,6 +362,9 @@ __global__ __launch_bounds__(FS_THREADS, 1) void k_fused_step(const LamKArgs a, 
             double v[3] = { 0.0, 0.0, 0.0 };
             CommK rk = lk;
             rk.ll = lk.ll + (size_t)(b % FS_LL_REPLICAS) * FS_LL_REPLICA_WORDS;
+            // the blocks finish their sums within ~1 us of each other: the first probe leaves a little after this block's own
+            // post (a probe that misses costs a whole further round trip)
+            __builtin_amdgcn_s_sleep(FS_FIRST_PROBE_SLEEP);
             expired = ll_collect_columns<NS>(rk, nb, FS_LL_PITCH, 0, v);
 #pragma unroll
             for (int i = 0; i < NS; ++i) tot[i] = wave_sum(v[i]);
@@ -278,7 +375,7 @@ __global__ __launch_bounds__(FS_THREADS, 1) void k_fused_step(const LamKArgs a, 
         MTD_STAMP(4, blockIdx.x == 0 && threadIdx.x == 0); MTD_STAMP(20, blockIdx.x == gridDim.x - 1 && threadIdx.x == 0);
         if (lane == 0) MTD_BSTAMP(2);
         if (COMM && b == 0) comm_send_wave(ck, tot, NS);                 // this rank's totals into every rank's mailbox
-        const ChainResult r = chain_wave(c, deposit != 0, closed, COMM ? &ck : nullptr, COMM ? nullptr : tot, b == 0 && deposit != 0);
+        const ChainResult r = chain_wave(c, deposit != 0, closed, COMM ? &ck : nullptr, COMM ? nullptr : tot, b == 0 && deposit != 0, &patch);
         c_wt = r.c_wt; c_wold = r.c_wold; c_dV = r.c_dV;
         MTD_STAMP(5, blockIdx.x == 0 && threadIdx.x == 0); MTD_STAMP(21, blockIdx.x == gridDim.x - 1 && threadIdx.x == 0);
         if (lane == 0) MTD_BSTAMP(3);
@@ -298,7 +395,10 @@ __global__ __launch_bounds__(FS_THREADS, 1) void k_fused_step(const LamKArgs a, 
         __builtin_amdgcn_s_setprio(0);
         }
     else
+        {
         step_force_unscaled<NCV, FAST, FS_U>(a, s_mt, R);
+        if (has_extra) step_force_unscaled_one<NCV, FAST>(a, s_mt, X);
+        }
     MTD_STAMP(6, blockIdx.x == 0 && threadIdx.x == 0); MTD_STAMP(22, blockIdx.x == gridDim.x - 1 && threadIdx.x == 0); MTD_STAMP(38, blockIdx.x == 0 && threadIdx.x == 64);
     __syncthreads();
     MTD_STAMP(7, blockIdx.x == 0 && threadIdx.x == 0); MTD_STAMP(23, blockIdx.x == gridDim.x - 1 && threadIdx.x == 0); MTD_STAMP(39, blockIdx.x == 0 && threadIdx.x == 64);
@@ -320,8 +420,13 @@ __global__ __launch_bounds__(FS_THREADS, 1) void k_fused_step(const LamKArgs a, 
                         {
                         const float w = s_wcoef[cvi * MTD_MAX_TYPES + R.type[u]];
                         nt_store(scalar4_traits<S4>::make((scalar)(R.f[u][cvi][0] * w), (scalar)(R.f[u][cvi][1] * w), (scalar)(R.f[u][cvi][2] * w), (scalar)0),
-                                 &f[p0 + u * FS_THREADS + threadIdx.x]);
+                                 &f[p0 + u * FS_MAIN + slot0]);
                         }
+                if (X.ok)
+                    {
+                    const float w = s_wcoef[cvi * MTD_MAX_TYPES + X.type];
+                    nt_store(scalar4_traits<S4>::make((scalar)(X.f[cvi][0] * w), (scalar)(X.f[cvi][1] * w), (scalar)(X.f[cvi][2] * w), (scalar)0), &f[ix]);
+                    }
                 }
             }
         };

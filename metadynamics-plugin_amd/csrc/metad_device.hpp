@@ -362,12 +362,69 @@ struct ChainResult
 
 constexpr int CHAIN_MAX_CV = 3;
 
+// A patch of 6^n_cv bias-grid cells around a GUESS of the collective variables (the previous step's values), loaded by the
+// chain's wave before the real values exist (k_fused_step: while the particles are still being summed).  The stencil of the
+// finite-difference derivative spans cells l - 1 .. l + 2 per variable (l = the cell of s): the patch l_g - 2 .. l_g + 3
+// covers it whenever s moved by at most one cell since the guess — then the chain's one dependent memory round trip (grid
+// values at cells that depend on s) is a shuffle; otherwise the cells are loaded as before.  Slot o0 + 6 (o1 + 6 o2) sits in
+// lane slot % 64, register slot / 64.
+struct GridPatch
+    {
+    double v[4];
+    int org[CHAIN_MAX_CV];
+    };
+
+__device__ __forceinline__ GridPatch chain_prefetch(const MetadCfg &c)
+    {
+    const int lane = threadIdx.x & 63;
+    const int n = (int)c.n_cv;
+    GridPatch gp;
+    int total = 1;
+#pragma unroll
+    for (int i = 0; i < CHAIN_MAX_CV; ++i)
+        {
+        gp.org[i] = 0;
+        if (i < n)
+            {
+            const double s = c.st->cv[i];                                 // the previous step's value (any value is a valid guess)
+            double q = (s - c.cv_min[i]) / c.delta[i];
+            if (!(q > 0.0)) q = 0.0;
+            if (q > (double)c.lengths[i]) q = (double)c.lengths[i];
+            gp.org[i] = (int)q - 2;
+            total *= 6;
+            }
+        }
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+        {
+        gp.v[r] = 0.0;
+        const int slot = lane + 64 * r;
+        if (slot < total)
+            {
+            int rest = slot;
+            bool in = true;
+            unsigned int cell = 0;
+#pragma unroll
+            for (int i = 0; i < CHAIN_MAX_CV; ++i)
+                if (i < n)
+                    {
+                    const int coord = gp.org[i] + rest % 6;
+                    rest /= 6;
+                    in = in && coord >= 0 && coord < (int)c.lengths[i];
+                    cell += (unsigned int)coord * c.factors[i];
+                    }
+            if (in) gp.v[r] = c.grid[cell];
+            }
+        }
+    return gp;
+    }
+
 // rx != nullptr: particle-sharded step — the sums over ranks come out of the xGMI mailbox (comm_device.hpp) instead
 // of the registered partial sums.  given != nullptr: the (global) sums are handed in (k_fused_step collected them itself);
 // a NaN among them marks an expired wait.  want_weight: also read the weight grid at the corners of s (closed form).
 __device__ __forceinline__ ChainResult chain_wave(const MetadCfg &c, const bool deposit, const bool closed_form,
                                                   const CommK *rx = nullptr, const double *given = nullptr,
-                                                  const bool want_weight = false)
+                                                  const bool want_weight = false, const GridPatch *patch = nullptr)
     {
     const int lane = threadIdx.x & 63;
     const unsigned int n = c.n_cv;
@@ -465,6 +522,8 @@ __device__ __forceinline__ ChainResult chain_wave(const MetadCfg &c, const bool 
     double wt = 1.0;
     unsigned int cell = 0;
     double d[CHAIN_MAX_CV];
+    int pslot = 0, pmul = 1;                 // slot of this lane's cell in the prefetched patch; in_patch: it lies inside
+    bool in_patch = patch != nullptr;
 #pragma unroll
     for (int i = 0; i < CHAIN_MAX_CV; ++i)
         {
@@ -492,10 +551,31 @@ __device__ __forceinline__ ChainResult chain_wave(const MetadCfg &c, const bool 
                 }
             cell += coord * c.factors[i];
             d[i] = (c.cv_min[i] + coord * c.delta[i]) - r.cv[i];     // updateGrid :1023-1026
+            if (patch)
+                {
+                const int o = (int)coord - patch->org[i];
+                in_patch = in_patch && o >= 0 && o < 6;
+                pslot += o * pmul;
+                pmul *= 6;
+                }
             }
         }
     double val = 0.0;
-    if (ok) val = is_weight ? c.weight[cell] : c.grid[cell];
+    if (patch)
+        {
+        // every lane takes part in the shuffles; lanes whose cell lies outside the patch (or that read the weight grid) load
+        const int src = (in_patch && ok) ? pslot : 0;
+        double pv = __shfl(patch->v[0], src & 63, MTD_WAVE);
+        if (n == 3)
+            {
+            const double p1 = __shfl(patch->v[1], src & 63, MTD_WAVE), p2 = __shfl(patch->v[2], src & 63, MTD_WAVE),
+                         p3 = __shfl(patch->v[3], src & 63, MTD_WAVE);
+            const int reg = src >> 6;
+            pv = reg == 0 ? pv : (reg == 1 ? p1 : (reg == 2 ? p2 : p3));
+            }
+        if (ok) val = (in_patch && !is_weight) ? pv : (is_weight ? c.weight[cell] : c.grid[cell]);
+        }
+    else if (ok) val = is_weight ? c.weight[cell] : c.grid[cell];
     r.c_wt = wt;
     r.c_wold = (want_weight && ok && p == 0) ? c.weight[cell] : 0.0;
     r.c_dV = 0.0;

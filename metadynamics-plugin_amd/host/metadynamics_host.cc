@@ -1,6 +1,7 @@
 // metadynamics_host.cc — see metadynamics_host.h.  Reference citations are file:line under
 // /root/reference/metadynamics/.
 #include "metadynamics_host.h"
+#include "prof.h"
 
 #include <algorithm>
 #include <sys/stat.h>
@@ -144,6 +145,7 @@ void LamellarOrderParameterGPU::enqueueCurrentValue(unsigned int timestep, mtd_m
 
 double LamellarOrderParameterGPU::getCurrentValue(unsigned int timestep)
     {
+    ProfRange prof_range("Lamellar");
     enqueuePartials();
     mtd_check(mtd_reduce_partials((const double *)m_partials.data(), m_n_partials, 1, 1, 1.0 / (double)m_pdata->getNGlobal(), 0.0,
                                   (double *)m_cv_dev.data(), m_exec_conf->getStream()),
@@ -156,6 +158,7 @@ double LamellarOrderParameterGPU::getCurrentValue(unsigned int timestep)
 
 void LamellarOrderParameterGPU::computeBiasForces(unsigned int timestep)
     {
+    ProfRange prof_range("Lamellar");
     const mtd_box box = m_pdata->getGlobalBox().toMtd();
     void *f[1] = {m_force.data()};
     if (m_bias_device)
@@ -207,6 +210,7 @@ void WellTemperedEnsemble::enqueueCurrentValue(unsigned int, mtd_metad *engine, 
 
 double WellTemperedEnsemble::getCurrentValue(unsigned int)
     {
+    ProfRange prof_range("Well-Tempered Ensemble");
     enqueuePartials();
     mtd_check(mtd_reduce_partials((const double *)m_partials.data(), m_n_partials, 1, 1, 1.0, m_pdata->getExternalEnergy(),
                                   (double *)m_sum.data(), m_exec_conf->getStream()),
@@ -219,6 +223,7 @@ double WellTemperedEnsemble::getCurrentValue(unsigned int)
 // WellTemperedEnsemble.cc:135-188; the CPU path (the parity target) also scales net_torque.w (Q18)
 void WellTemperedEnsemble::computeBiasForces(unsigned int)
     {
+    ProfRange prof_range("Well-Tempered Ensemble");
     mtd_check(mtd_wte_scale_netforce(m_pdata->getN(), m_pdata->getNetForce().data(), m_pdata->getNetTorqueArray().data(),
                                      m_pdata->getNetVirial().data(), m_pdata->getNetVirialPitch(), m_pdata->getDtype(),
                                      m_bias_device, m_bias, 1, m_exec_conf->getStream()),
@@ -328,6 +333,7 @@ void OrderParameterMeshGPU::computeVirial()
 
 void OrderParameterMeshGPU::enqueueCV(unsigned int timestep)
     {
+    ProfRange prof_range("Mesh");
     if (m_cv_last_updated == timestep && !m_is_first_step) return;   // :927-928
     const mtd_box box = m_pdata->getGlobalBox().toMtd();
     mtd_check(mtd_mesh_compute_cv(m_mesh, m_pdata->getN(), m_pdata->positionsPtr(), m_pdata->getDtype(), &box,
@@ -356,6 +362,7 @@ double OrderParameterMeshGPU::getCurrentValue(unsigned int timestep)
 // OrderParameterMesh.cc:1052-1075
 void OrderParameterMeshGPU::computeBiasForces(unsigned int timestep)
     {
+    ProfRange prof_range("forces");
     if (m_is_first_step || m_cv_last_updated != timestep) enqueueCV(timestep);   // :1055-1056
     const mtd_box box = m_pdata->getGlobalBox().toMtd();
     mtd_check(mtd_mesh_forces(m_mesh, m_pdata->getN(), m_pdata->positionsPtr(), m_force.data(), m_pdata->getDtype(), &box,
@@ -412,6 +419,7 @@ double CollectiveWrapper::getCurrentValue(unsigned int timestep)
 // target) also scales torque.w
 void CollectiveWrapper::computeBiasForces(unsigned int timestep)
     {
+    ProfRange prof_range("Collective wrap");
     m_fc->compute(timestep);                                           // :139
     mtd_check(mtd_wrapper_scale_forces(m_pdata->getN(), m_fc->getForceArray().data(), m_fc->getTorqueArray().data(),
                                        m_fc->getVirialArray().data(), m_fc->getVirialPitch(), m_pdata->getDtype(), m_bias_device,
@@ -438,6 +446,7 @@ SteinhardtQl::SteinhardtQl(std::shared_ptr<SystemDefinition> sysdef, double rcut
 
 void SteinhardtQl::computeCV(unsigned int timestep)
     {
+    ProfRange prof_range("CV");
     if (m_cv_last_updated == timestep && m_have_computed) return;    // :64-65
     m_nlist->compute(timestep);                                      // :68
     const mtd_box box = m_pdata->getBox().toMtd();
@@ -468,6 +477,7 @@ double SteinhardtQl::getCurrentValue(unsigned int timestep)
 
 void SteinhardtQl::computeBiasForces(unsigned int timestep)
     {
+    ProfRange prof_range("Force");
     m_nlist->compute(timestep);                                      // :206
     // the reference relies on the Q_lm of the computeCV the integrator triggered earlier in the step (Q20); make sure one exists
     if (!m_have_computed) computeCV(timestep);
@@ -661,6 +671,7 @@ void IntegratorMetaDynamics::setAddHills(bool add_bias)
 // :1205-1294 — derivative products reduced on the device, n_cv x n_cv sqrt / inverse on the host
 void IntegratorMetaDynamics::computeSigma()
     {
+    ProfRange prof_range("Derivatives");
     const unsigned int ncv = (unsigned int)m_variables.size();
     if (m_sigma_scratch.bytes() == 0) m_sigma_scratch.resize(sizeof(double) * mtd_sigma_scratch_doubles());
     std::vector<const void *> force(ncv, nullptr);
@@ -925,6 +936,7 @@ void IntegratorMetaDynamics::mixedLamellarForcePass(const std::vector<unsigned i
 // :314-588, grid branch
 void IntegratorMetaDynamics::updateBiasPotential(unsigned int timestep)
     {
+    ProfRange prof_range("Metadynamics");
     if (m_variables.empty()) return;                                   // :317-318
     hipStream_t s = m_exec_conf->getStream();
 

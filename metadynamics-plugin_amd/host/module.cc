@@ -281,4 +281,10 @@ PYBIND11_MODULE(_metadynamics, m)
         .def("setIntegrator", &System::setIntegrator)
         .def("run", &System::run, py::call_guard<py::gil_scoped_release>())
         .def("getCurrentTimeStep", &System::getCurrentTimeStep);
+
+    // the reference also exports the host-path class names (module.cc:29-31: export_LamellarOrderParameter,
+    // export_OrderParameterMesh), which cv.py instantiates when the execution configuration has no GPU (cv.py:262-268,
+    // 405-410).  This build has no CPU path: the names resolve to the device classes.
+    m.attr("LamellarOrderParameter") = m.attr("LamellarOrderParameterGPU");
+    m.attr("OrderParameterMesh") = m.attr("OrderParameterMeshGPU");
     }

@@ -21,6 +21,8 @@ def test_module_classes_and_methods(mod):
     for cls in ("CollectiveVariable", "IntegratorMetaDynamics", "LamellarOrderParameterGPU", "OrderParameterMeshGPU",
                 "WellTemperedEnsemble", "CollectiveWrapper", "SteinhardtQl", "AspectRatio", "Density", "std_vector_int3"):
         assert hasattr(mod, cls), cls
+    # host-path names of the reference (module.cc:29-31) resolve to the device classes: this build has no CPU path
+    assert mod.LamellarOrderParameter is mod.LamellarOrderParameterGPU and mod.OrderParameterMesh is mod.OrderParameterMeshGPU
     # IntegratorMetaDynamics.cc:1315-1349
     for meth in ("registerCollectiveVariable", "removeAllVariables", "isInitialized", "setGrid", "dumpGrid", "restartFromGridFile",
                  "setAddHills", "setMode", "setStride", "setAdaptive", "setSigmaG", "resetHistogram", "setMultipleWalkers"):
