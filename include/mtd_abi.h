@@ -282,7 +282,8 @@ int mtd_rccl_destroy(mtd_rccl *r);
 /* Multiple walkers in one call (IntegratorMetaDynamics.cc:363-451 with m_multiple_walkers): histogram / Gaussian increments
  * of this walker (mtd_metad_update_phase_a), sum of {grid_delta, sigma_grid_delta} and {hist_delta, hist_gauss_delta} over
  * the walkers (two all-reduces: the delta groups are contiguous), reweighting + accumulate + evaluation
- * (mtd_metad_update_phase_b).  Every walker must call it with the same timestep. */
+ * (mtd_metad_update_phase_b).  Every walker must call it with the same timestep.  walkers == NULL: one walker (the reference in
+ * a run with a single partition, as test/test_2d.py:29 does). */
 int mtd_metad_update_bias_walkers(mtd_metad *m, mtd_rccl *walkers, unsigned int timestep, mtd_stream_t stream);
 
 /* ================================================================================================
@@ -347,6 +348,11 @@ int mtd_mesh_create(mtd_mesh **out, unsigned int nx, unsigned int ny, unsigned i
 int mtd_mesh_destroy(mtd_mesh *m);
 /* 1 (default): interpolation function with the reference's unsigned integer division; 0: as intended */
 int mtd_mesh_set_bug_compat(mtd_mesh *m, int on);
+/* The normalised Fourier mesh f = FFT(mesh) / N (fourier_mesh of the reference, OrderParameterMesh.cc:697-712) is only read by
+ * mtd_mesh_qmax, mtd_mesh_virial and mtd_mesh_get_array(1): the spectral step writes it when `on` (default 1; 18.9 MB per
+ * step at 128^3 otherwise saved).  Those three calls return MTD_ERR_INVALID_ARGUMENT when the last spectral step kept none:
+ * switch it on and run mtd_mesh_spectral again (the real mesh of the step is still in place). */
+int mtd_mesh_set_keep_fourier(mtd_mesh *m, int on);
 unsigned int mtd_mesh_num_cells(const mtd_mesh *m);
 
 /* getCurrentValue (OrderParameterMesh.cc:925-968): assignParticles -> FFT -> updateMeshes -> iFFT -> computeCV.

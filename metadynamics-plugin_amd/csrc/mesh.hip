@@ -567,27 +567,131 @@ __global__ __launch_bounds__(TC_THREADS) void k_tile_count(const MeshGeom g, con
     if (threadIdx.x == 0) modesq_partials[blockIdx.x] = msq;
     }
 
-__global__ __launch_bounds__(256) void k_tile_place(const TileGeom tg, const unsigned int N, const unsigned int *__restrict__ tile_of,
-                                                    const unsigned int *__restrict__ slot_of, const unsigned int *__restrict__ start,
-                                                    unsigned int *__restrict__ ids)
+// 2b. where the particles of (tile, count block) go = [particles of the tiles in front] + [particles of this tile counted by
+// the blocks in front].  ONE launch forms the second term (a scan along each tile's row of the [tile][block] histogram, a
+// block per tile) and the tiles' totals; the first term — a prefix over <= 8192 totals — is formed by whoever needs it (the
+// place kernel once per block in LDS, the scatter / force kernels for their own tile): a second scan launch cost ~5 us of
+// pure latency in this chain of small kernels.  One extra block adds up sum mode^2 (:622).
+__global__ __launch_bounds__(256) void k_tile_rowscan(const unsigned int *__restrict__ hist, unsigned int *__restrict__ rowscan,
+                                                      unsigned int *__restrict__ tile_total, const unsigned int n_tiles, const unsigned int nb,
+                                                      const double *__restrict__ modesq_partials, const unsigned int n_partials,
+                                                      double *__restrict__ mode_sq)
     {
+    __shared__ unsigned int s_wave[4];
+    if (blockIdx.x >= n_tiles)
+        {
+        __shared__ double s_red[16];
+        double v = 0.0;
+        for (unsigned int b = threadIdx.x; b < n_partials; b += 256) v += modesq_partials[b];
+        v = block_sum(v, s_red);
+        if (threadIdx.x == 0) *mode_sq = v;
+        return;
+        }
+    const size_t row = (size_t)blockIdx.x * nb;
+    const unsigned int base = threadIdx.x * 4;                      // nb <= 1024 (tile_blocks_max)
+    unsigned int v[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = base + j < nb ? hist[row + base + j] : 0u;
+    const unsigned int t = v[0] + v[1] + v[2] + v[3];
+    unsigned int incl = t;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1)
+        {
+        const unsigned int o = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += o;
+        }
+    if (lane == 63) s_wave[wave] = incl;
+    __syncthreads();
+    unsigned int wave_off = 0;
+    for (int w = 0; w < wave; ++w) wave_off += s_wave[w];
+    unsigned int excl = wave_off + incl - t;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        {
+        if (base + j < nb) rowscan[row + base + j] = excl;
+        excl += v[j];
+        }
+    if (threadIdx.x == 255) tile_total[blockIdx.x] = wave_off + incl;
+    }
+
+// first particle slot of tile t (and of tile t + 1): the totals of the tiles in front, added up by the whole block in a
+// fixed order.  s_red: >= 8 unsigned ints of shared memory.  Result valid in every thread.
+__device__ __forceinline__ void tile_range(const unsigned int *__restrict__ tile_total, const unsigned int t, unsigned int &q0,
+                                           unsigned int &q1, unsigned int *s_red)
+    {
+    unsigned int v = 0;
+    for (unsigned int i = threadIdx.x; i < t; i += blockDim.x) v += tile_total[i];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    unsigned int r = 0;
+    for (unsigned int w = 0; w < (blockDim.x >> 6); ++w) r += s_red[w];
+    q0 = r;
+    q1 = r + tile_total[t];
+    }
+
+// 3b. place: particle id -> its tile's segment.  A block keeps the prefix over the tile totals in LDS.
+__global__ __launch_bounds__(256) void k_tile_place(const TileGeom tg, const unsigned int N, const unsigned int *__restrict__ tile_of,
+                                                    const unsigned int *__restrict__ slot_of, const unsigned int *__restrict__ rowscan,
+                                                    const unsigned int *__restrict__ tile_total, unsigned int *__restrict__ ids)
+    {
+    extern __shared__ unsigned int s_first[];                    // [n_tiles]: first slot of every tile
+    __shared__ unsigned int s_wsum[4];
+    // exclusive scan of the tile totals: thread t owns the tiles [t * per, (t + 1) * per)
+    const unsigned int per = (tg.n_tiles + 255) / 256;
+    unsigned int mine = 0;
+    for (unsigned int j = 0; j < per; ++j)
+        {
+        const unsigned int t = threadIdx.x * per + j;
+        if (t < tg.n_tiles) mine += tile_total[t];
+        }
+    unsigned int incl = mine;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1)
+        {
+        const unsigned int o = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += o;
+        }
+    if (lane == 63) s_wsum[wave] = incl;
+    __syncthreads();
+    unsigned int run = incl - mine;
+    for (int w = 0; w < wave; ++w) run += s_wsum[w];
+    for (unsigned int j = 0; j < per; ++j)
+        {
+        const unsigned int t = threadIdx.x * per + j;
+        if (t < tg.n_tiles)
+            {
+            s_first[t] = run;
+            run += tile_total[t];
+            }
+        }
+    __syncthreads();
     // (bound by its scattered 4-byte stores: four particles per thread with batched loads changed nothing, ids along a
     // space-filling curve halve it)
     for (unsigned int i = blockIdx.x * blockDim.x + threadIdx.x; i < N; i += gridDim.x * blockDim.x)
-        ids[start[(size_t)tile_of[i] * tg.n_blocks + i / tg.chunk] + slot_of[i]] = i;
+        {
+        const unsigned int t = tile_of[i];
+        ids[s_first[t] + rowscan[(size_t)t * tg.n_blocks + i / tg.chunk] + slot_of[i]] = i;
+        }
     }
 
 template<typename S4>
 __global__ __launch_bounds__(TP_THREADS) void k_tile_scatter(const MeshGeom g, const TileGeom tg, const S4 *__restrict__ postype,
-                                                             const double *__restrict__ mode, const unsigned int *__restrict__ start,
+                                                             const double *__restrict__ mode, const unsigned int *__restrict__ tile_total,
                                                              const unsigned int *__restrict__ ids, long long *__restrict__ tilebuf,
                                                              double4 *__restrict__ packed, uint2 *__restrict__ idbase)
     {
     __shared__ unsigned long long s_t[TP_HMAX];
+    __shared__ unsigned int s_rng[8];
     const unsigned int t = blockIdx.x;
     const unsigned int tix = t % tg.ntx, tiy = (t / tg.ntx) % tg.nty, tiz = t / (tg.ntx * tg.nty);
     const int x0 = tix * tg.tx, y0 = tiy * tg.ty, z0 = tiz * tg.tz;
-    const unsigned int q0 = start[(size_t)t * tg.n_blocks], q1 = start[(size_t)(t + 1) * tg.n_blocks];
+    unsigned int q0, q1;
+    tile_range(tile_total, t, q0, q1, s_rng);
     // the first particle is requested before the LDS image is cleared
     unsigned int q = q0 + threadIdx.x;
     unsigned int id = 0;
@@ -725,7 +829,7 @@ __global__ __launch_bounds__(256) void k_tile_combine_rows(const MeshGeom g, con
 constexpr int TF_THREADS = 256;        // four blocks per CU (128 VGPRs): one stages its tile while the others sum
 
 template<typename S4>
-__global__ __launch_bounds__(TF_THREADS) void k_tile_forces(const MeshGeom g, const TileGeom tg, const unsigned int *__restrict__ start,
+__global__ __launch_bounds__(TF_THREADS) void k_tile_forces(const MeshGeom g, const TileGeom tg, const unsigned int *__restrict__ tile_total,
                                                             const uint2 *__restrict__ idbase, const double4 *__restrict__ packed,
                                                             const double *__restrict__ inv, S4 *__restrict__ force,
                                                             const double *__restrict__ d_bias, const double bias_host,
@@ -733,10 +837,12 @@ __global__ __launch_bounds__(TF_THREADS) void k_tile_forces(const MeshGeom g, co
     {
     typedef typename scalar4_traits<S4>::scalar scalar;
     __shared__ double s_inv[TP_HMAX];
+    __shared__ unsigned int s_rng[8];
     const unsigned int t = blockIdx.x;
     const unsigned int tix = t % tg.ntx, tiy = (t / tg.ntx) % tg.nty, tiz = t / (tg.ntx * tg.nty);
     const int x0 = tix * tg.tx, y0 = tiy * tg.ty, z0 = tiz * tg.tz;
-    const unsigned int q0 = start[(size_t)t * tg.n_blocks], q1 = start[(size_t)(t + 1) * tg.n_blocks];
+    unsigned int q0, q1;
+    tile_range(tile_total, t, q0, q1, s_rng);
     if (q0 == q1) return;
     unsigned int q = q0 + threadIdx.x;
     double4 pk = make_double4(0.0, 0.0, 0.0, 0.0);
@@ -1210,7 +1316,7 @@ __global__ __launch_bounds__(FFT_THREADS) void k_fft_z_spectral(const MeshGeom g
                                                                 const unsigned int tile, const unsigned int tiles_per_row,
                                                                 const double *__restrict__ mode_sq, const double n_global,
                                                                 const double *__restrict__ itab, double *__restrict__ cv_partials,
-                                                                const SlabArgs sl)
+                                                                const SlabArgs sl, const int keep_f)
     {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ double s_red[16];
@@ -1257,7 +1363,7 @@ __global__ __launch_bounds__(FFT_THREADS) void k_fft_z_spectral(const MeshGeom g
         if (wx > nxh)                                                  // padding column of the half-spectrum rows
             {
             s[p * tile + t] = make_double2(0.0, 0.0);
-            if (!DIST) fmesh[base + t + (size_t)p * plane] = make_double2(0.0, 0.0);
+            if (!DIST && keep_f) fmesh[base + t + (size_t)p * plane] = make_double2(0.0, 0.0);
             continue;
             }
         const double I = itab[wx] * itab[g.nx + wy] * itab[g.nx + g.ny + p];
@@ -1271,7 +1377,9 @@ __global__ __launch_bounds__(FFT_THREADS) void k_fft_z_spectral(const MeshGeom g
         double2 G = make_double2(f.x * val, f.y * val);
         G.x -= f.x * diagonal_term;
         G.y -= f.y * diagonal_term;
-        if (!DIST) fmesh[base + t + (size_t)p * plane] = f;       // (slab runs keep no normalised f: log quantities need one rank)
+        // the normalised Fourier mesh is only read by the log quantities (q_max) and the virial: written when asked for
+        // (mtd_mesh_set_keep_fourier; 18.9 MB per step at 128^3).  Slab runs keep none.
+        if (!DIST && keep_f) fmesh[base + t + (size_t)p * plane] = f;
         s[p * tile + t] = G;
         if (wx != 0 || wy != 0 || p != 0)                              // exclude the DC bin (:889-894)
             {
@@ -1555,11 +1663,14 @@ struct mtd_mesh
     unsigned int nx, ny, nz, M, n_types, max_particles;
     unsigned int hxp;          // row pitch of the half-spectrum arrays d_f, d_g (nx/2 + 1 rounded up)
     int bug_compat;
+    int keep_fourier;          // the fused z pass also writes the normalised Fourier mesh (log quantities, virial, get_array(1))
+    int fourier_valid;         // d_f holds the Fourier mesh of the last spectral step
     void *slab;
     double *d_mode, *d_rho, *d_inv, *d_modesq_partials, *d_mode_sq, *d_cv_partials;
     double2 *d_f, *d_g, *d_tw[3];
     double4 *d_packed;
     unsigned int *d_cell_of, *d_slot_of, *d_count, *d_start, *d_tile_sums;
+    unsigned int *d_tile_total;    // tile path: particles per tile (k_tile_rowscan); d_start then holds the row scans
     uint2 *d_idcell;           // (particle id, cell) of every sorted slot
     unsigned int n_last;   // particle count of the last compute_cv (the sorted list the force pass walks)
     // convolution-kernel table (setTable, :148-189): K is stored and never applied (Q7); K' enters the virial
@@ -1664,6 +1775,7 @@ int mtd_mesh_create(mtd_mesh **out, unsigned int nx, unsigned int ny, unsigned i
     m->n_types = n_types;
     m->max_particles = max_particles;
     m->bug_compat = 1;
+    m->keep_fourier = 1;
     const size_t M = m->M, N = max_particles;
     m->n_count_blocks = 4096;
     {
@@ -1700,7 +1812,7 @@ int mtd_mesh_create(mtd_mesh **out, unsigned int nx, unsigned int ny, unsigned i
                  o_inv = take(sizeof(double) * M), o_slot = take(sizeof(unsigned int) * N),
                  o_itab = take(sizeof(double) * (nx + ny + nz)),
                  o_tilebuf = take(sizeof(long long) * (size_t)m->tg.n_tiles * m->tg.hcells), o_ids2 = take(sizeof(unsigned int) * N),
-                 o_tsrc = take(sizeof(uint4) * (nx + ny + nz));
+                 o_tsrc = take(sizeof(uint4) * (nx + ny + nz)), o_ttot = take(sizeof(unsigned int) * ((size_t)m->tg.n_tiles + 1));
     hipError_t e = hipMalloc(&m->slab, off);
     if (e != hipSuccess)
         {
@@ -1722,6 +1834,7 @@ int mtd_mesh_create(mtd_mesh **out, unsigned int nx, unsigned int ny, unsigned i
     m->d_tilebuf = (long long *)(p + o_tilebuf);
     m->d_ids = (unsigned int *)(p + o_ids2);
     m->d_tsrc = (uint4 *)(p + o_tsrc);
+    m->d_tile_total = (unsigned int *)(p + o_ttot);
     e = hipMemset(m->slab, 0, off);
     if (e == hipSuccess && m->tile_path)
         {
@@ -1797,6 +1910,13 @@ int mtd_mesh_destroy(mtd_mesh *m)
     return (int)e;
     }
 
+int mtd_mesh_set_keep_fourier(mtd_mesh *m, int on)
+    {
+    if (!m) return MTD_ERR_INVALID_ARGUMENT;
+    m->keep_fourier = on ? 1 : 0;
+    return MTD_SUCCESS;
+    }
+
 int mtd_mesh_set_bug_compat(mtd_mesh *m, int on)
     {
     if (!m) return MTD_ERR_INVALID_ARGUMENT;
@@ -1851,20 +1971,16 @@ static int mesh_assign_local(mtd_mesh *m, unsigned int n_particles, const void *
         else
             k_tile_count<double4><<<nb, TC_THREADS, lds, s>>>(g, tg, (const double4 *)d_postype, N, m->d_mode, m->d_cell_of, m->d_slot_of, m->d_count, m->d_modesq_partials);
         MTD_LAUNCH_CHECK();
-        const unsigned int n = tg.n_tiles * nb;
-        const unsigned int n_scan_tiles = (n + SCAN_TILE - 1) / SCAN_TILE;
-        k_scan_tiles<<<n_scan_tiles + 1, 256, 0, s>>>(m->d_count, m->d_start, m->d_tile_sums, n, m->d_modesq_partials, nb, m->d_mode_sq);
+        k_tile_rowscan<<<tg.n_tiles + 1, 256, 0, s>>>(m->d_count, m->d_start, m->d_tile_total, tg.n_tiles, nb, m->d_modesq_partials, nb, m->d_mode_sq);
         MTD_LAUNCH_CHECK();
-        k_scan_finish<<<n_scan_tiles, 256, 0, s>>>(m->d_start, m->d_tile_sums, m->d_count, n, N);
-        MTD_LAUNCH_CHECK();
-        unsigned int pb = (N + 255) / 256;
-        pb = pb < 1 ? 1 : (pb > 4096 ? 4096 : pb);
-        k_tile_place<<<pb, 256, 0, s>>>(tg, N, m->d_cell_of, m->d_slot_of, m->d_start, m->d_ids);
+        unsigned int pb = (N + 1023) / 1024;                        // >= four particles per thread: the LDS prefix of the tile totals is formed once per block
+        pb = pb < 1 ? 1 : (pb > 512 ? 512 : pb);
+        k_tile_place<<<pb, 256, sizeof(unsigned int) * tg.n_tiles, s>>>(tg, N, m->d_cell_of, m->d_slot_of, m->d_start, m->d_tile_total, m->d_ids);
         MTD_LAUNCH_CHECK();
         if (dtype == MTD_F32)
-            k_tile_scatter<float4><<<tg.n_tiles, TP_THREADS, 0, s>>>(g, tg, (const float4 *)d_postype, m->d_mode, m->d_start, m->d_ids, m->d_tilebuf, m->d_packed, m->d_idcell);
+            k_tile_scatter<float4><<<tg.n_tiles, TP_THREADS, 0, s>>>(g, tg, (const float4 *)d_postype, m->d_mode, m->d_tile_total, m->d_ids, m->d_tilebuf, m->d_packed, m->d_idcell);
         else
-            k_tile_scatter<double4><<<tg.n_tiles, TP_THREADS, 0, s>>>(g, tg, (const double4 *)d_postype, m->d_mode, m->d_start, m->d_ids, m->d_tilebuf, m->d_packed, m->d_idcell);
+            k_tile_scatter<double4><<<tg.n_tiles, TP_THREADS, 0, s>>>(g, tg, (const double4 *)d_postype, m->d_mode, m->d_tile_total, m->d_ids, m->d_tilebuf, m->d_packed, m->d_idcell);
         MTD_LAUNCH_CHECK();
         {
         const unsigned int cthreads = m->nx >= 256 ? 256 : (m->nx > 64 ? 128 : 64);
@@ -1936,7 +2052,8 @@ int mtd_mesh_spectral(mtd_mesh *m, const mtd_box *box, unsigned int n_global, co
     SlabArgs none;
     std::memset(&none, 0, sizeof(none));
     k_fft_z_spectral<false><<<pz.n_blocks, FFT_THREADS, fft_lds_bytes(pz.n, pz.tile), s>>>(
-        g, m->d_f, m->d_g, pz.tw, ilog2(pz.n), pz.tile, pz.tiles_per_row, m->d_mode_sq, (double)n_global, m->d_itab, m->d_cv_partials, none);
+        g, m->d_f, m->d_g, pz.tw, ilog2(pz.n), pz.tile, pz.tiles_per_row, m->d_mode_sq, (double)n_global, m->d_itab, m->d_cv_partials, none, m->keep_fourier);
+    m->fourier_valid = m->keep_fourier;
     MTD_LAUNCH_CHECK();
     rc = launch_fft_y(m, m->d_g, 1, s);
     if (rc) return rc;
@@ -1974,9 +2091,9 @@ int mtd_mesh_forces(mtd_mesh *m, unsigned int n_particles, const void *d_postype
     if (m->tile_path)
         {
         if (dtype == MTD_F32)
-            k_tile_forces<float4><<<m->tg.n_tiles, TF_THREADS, 0, s>>>(g, m->tg, m->d_start, m->d_idcell, m->d_packed, m->d_inv, (float4 *)d_force, d_bias, bias_host, two_over_n);
+            k_tile_forces<float4><<<m->tg.n_tiles, TF_THREADS, 0, s>>>(g, m->tg, m->d_tile_total, m->d_idcell, m->d_packed, m->d_inv, (float4 *)d_force, d_bias, bias_host, two_over_n);
         else
-            k_tile_forces<double4><<<m->tg.n_tiles, TF_THREADS, 0, s>>>(g, m->tg, m->d_start, m->d_idcell, m->d_packed, m->d_inv, (double4 *)d_force, d_bias, bias_host, two_over_n);
+            k_tile_forces<double4><<<m->tg.n_tiles, TF_THREADS, 0, s>>>(g, m->tg, m->d_tile_total, m->d_idcell, m->d_packed, m->d_inv, (double4 *)d_force, d_bias, bias_host, two_over_n);
         MTD_LAUNCH_CHECK();
         return MTD_SUCCESS;
         }
@@ -2080,7 +2197,8 @@ int mtd_mesh_slab_compute_cv(mtd_mesh *m, unsigned int n_particles, const void *
     sl.world = W; sl.nz_loc = nzl; sl.ny_loc = nyl; sl.y0 = r * nyl;
     const unsigned int z_blocks = pz.tiles_per_row * nyl;
     k_fft_z_spectral<true><<<z_blocks, FFT_THREADS, fft_lds_bytes(pz.n, pz.tile), s>>>(
-        g, nullptr, g_x, pz.tw, ilog2(pz.n), pz.tile, pz.tiles_per_row, m->d_mode_sq, (double)n_global, m->d_itab, m->d_cv_partials, sl);
+        g, nullptr, g_x, pz.tw, ilog2(pz.n), pz.tile, pz.tiles_per_row, m->d_mode_sq, (double)n_global, m->d_itab, m->d_cv_partials, sl, 0);
+    m->fourier_valid = 0;
     MTD_LAUNCH_CHECK();
     rc = mtd_reduce_partials(m->d_cv_partials, z_blocks, 1, 1, 1.0, 0.0, m->d_slab_sum, stream);
     if (rc) return rc;
@@ -2139,6 +2257,7 @@ static int log_scratch(mtd_mesh *m)
 int mtd_mesh_qmax(mtd_mesh *m, const mtd_box *box, unsigned int n_global, double *out, mtd_stream_t stream)
     {
     if (!m || !out || n_global == 0) return MTD_ERR_INVALID_ARGUMENT;
+    if (!m->fourier_valid) return MTD_ERR_INVALID_ARGUMENT;          // mtd_mesh_set_keep_fourier(1) before the spectral step
     MeshGeom g;
     int rc = fill_geom(g, m, box);
     if (rc) return rc;
@@ -2180,6 +2299,7 @@ int mtd_mesh_qmax(mtd_mesh *m, const mtd_box *box, unsigned int n_global, double
 int mtd_mesh_virial(mtd_mesh *m, const mtd_box *box, unsigned int n_global, double bias, double *virial, mtd_stream_t stream)
     {
     if (!m || !virial || n_global == 0) return MTD_ERR_INVALID_ARGUMENT;
+    if (!m->fourier_valid) return MTD_ERR_INVALID_ARGUMENT;
     MeshGeom g;
     int rc = fill_geom(g, m, box);
     if (rc) return rc;
@@ -2212,6 +2332,7 @@ int mtd_mesh_get_array(mtd_mesh *m, int which, void *host_out, mtd_stream_t stre
         case 0: src = m->d_rho; bytes = sizeof(double) * m->M; break;            // real mesh (assignParticles)
         case 1:                                                                  // fourier_mesh, normalised: full mesh from the stored half
             {
+            if (!m->fourier_valid) return MTD_ERR_INVALID_ARGUMENT;
             const size_t MH = (size_t)m->hxp * m->ny * m->nz;
             std::vector<double2> half(MH);
             MTD_HIP_TRY(hipMemcpyAsync(half.data(), m->d_f, sizeof(double2) * MH, hipMemcpyDeviceToHost, (hipStream_t)stream));

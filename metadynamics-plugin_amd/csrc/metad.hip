@@ -476,11 +476,11 @@ int mtd_metad_update_phase_b(mtd_metad *m, int deposited, mtd_stream_t stream)
 
 int mtd_metad_update_bias_walkers(mtd_metad *m, mtd_rccl *walkers, unsigned int timestep, mtd_stream_t stream)
     {
-    if (!m || !walkers) return MTD_ERR_INVALID_ARGUMENT;
+    if (!m) return MTD_ERR_INVALID_ARGUMENT;
     int deposited = 0;
     int rc = mtd_metad_update_phase_a(m, timestep, &deposited, stream);
     if (rc) return rc;
-    if (deposited)
+    if (deposited && walkers)                                    // walkers == NULL: a single walker, the sum is its own increments
         {
         // sum up increments (:393-409): {grid_delta, sigma_grid_delta} and {hist_delta, hist_gauss_delta} are contiguous
         rc = mtd_comm_allreduce_large(walkers, m->cfg.grid_delta, 2 * (size_t)m->cfg.len, MTD_ELEM_F64, stream);

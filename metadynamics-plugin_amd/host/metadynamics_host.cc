@@ -254,7 +254,24 @@ OrderParameterMeshGPU::OrderParameterMeshGPU(std::shared_ptr<SystemDefinition> s
     if (rc == MTD_ERR_UNSUPPORTED)
         throw std::runtime_error("cv.mesh: mesh points per direction: 4 ... 256, or a power of two up to 1024");
     mtd_check(rc, "mtd_mesh_create");
+    // the normalised Fourier mesh is written only once a log quantity (q_max) or the virial has asked for it
+    mtd_check(mtd_mesh_set_keep_fourier(m_mesh, 0), "mtd_mesh_set_keep_fourier");
+    m_keep_fourier = false;
     m_cv_dev.resize(sizeof(double));
+    }
+
+// q_max / virial read the Fourier mesh: from the first request on every spectral step keeps it; the step at hand is redone
+// from the real mesh, which is still in place (same CV partial sums)
+void OrderParameterMeshGPU::needFourierMesh()
+    {
+    if (m_keep_fourier) return;
+    m_keep_fourier = true;
+    mtd_check(mtd_mesh_set_keep_fourier(m_mesh, 1), "mtd_mesh_set_keep_fourier");
+    if (!m_is_first_step)
+        {
+        const mtd_box box = m_pdata->getGlobalBox().toMtd();
+        mtd_check(mtd_mesh_spectral(m_mesh, &box, m_pdata->getNGlobal(), &m_partials, &m_n_partials, m_exec_conf->getStream()), "mtd_mesh_spectral");
+        }
     }
 
 OrderParameterMeshGPU::~OrderParameterMeshGPU()
@@ -292,6 +309,7 @@ void OrderParameterMeshGPU::setUseTable(bool use_table)
 void OrderParameterMeshGPU::computeQmax(unsigned int timestep)
     {
     enqueueCV(timestep);                                               // compute Fourier grid (:1111)
+    needFourierMesh();
     if (timestep && m_q_max_last_computed == timestep) return;         // :1113
     m_q_max_last_computed = timestep;
     const mtd_box box = m_pdata->getGlobalBox().toMtd();
@@ -325,6 +343,7 @@ void OrderParameterMeshGPU::computeVirial()
         m_exec_conf->sync();
         hip_check(hipMemcpy(&bias, m_bias_device, sizeof(double), hipMemcpyDeviceToHost), "bias read-back");
         }
+    needFourierMesh();
     const mtd_box box = m_pdata->getGlobalBox().toMtd();
     double v[6];
     mtd_check(mtd_mesh_virial(m_mesh, &box, m_pdata->getNGlobal(), bias, v, m_exec_conf->getStream()), "mtd_mesh_virial");
@@ -608,7 +627,7 @@ IntegratorMetaDynamics::IntegratorMetaDynamics(std::shared_ptr<SystemDefinition>
     : m_sysdef(sysdef), m_pdata(sysdef->getParticleData()), m_exec_conf(sysdef->getExecConf()), m_deltaT(deltaT), m_W(W),
       m_T_shift(T_shift), m_stride(stride), m_is_initialized(false), m_filename(filename), m_overwrite(overwrite),
       m_is_appending(false), m_delimiter("\t"), m_use_grid(false), m_add_bias(add_bias), m_grid_period(0), m_cur_file(0),
-      m_sigma_g(1.0), m_adaptive(false), m_temp(T), m_mode(mode), m_multiple_walkers(false), m_engine(nullptr),
+      m_sigma_g(1.0), m_adaptive(false), m_temp(T), m_mode(mode), m_multiple_walkers(false), m_warned_single_walker(false), m_engine(nullptr),
       m_allow_fused(true), m_used_fused(false), m_fused_n_partials(0)
     {
     if (!(T_shift > 0.0) || !(W > 0.0)) throw std::runtime_error("IntegratorMetaDynamics: W and deltaT must be positive");   // asserts :58-59
@@ -969,9 +988,14 @@ void IntegratorMetaDynamics::updateBiasPotential(unsigned int timestep)
         else if (m_multiple_walkers)
             {
             // sum up the walkers' increments between the two grid passes (:393-409)
-            if (!m_exec_conf->getWalkerCommunicator())
-                throw std::runtime_error("integrate.mode_metadynamics: multiple_walkers needs a communicator between the walkers "
-                                         "(ExecutionConfiguration::setWalkerCommunicator)");
+            // without a communicator this process is the only walker (a run with one partition: test/test_2d.py:29 sets the
+            // flag in a serial run) — said once, so that nobody runs independent walkers believing the bias is shared
+            if (!m_exec_conf->getWalkerCommunicator() && !m_warned_single_walker)
+                {
+                std::cerr << "integrate.mode_metadynamics: multiple_walkers is set but no walker communicator "
+                             "(ExecutionConfiguration::setWalkerCommunicator): running as a single walker." << std::endl;
+                m_warned_single_walker = true;
+                }
             mtd_check(mtd_metad_update_bias_walkers(m_engine, m_exec_conf->getWalkerCommunicator(), timestep, s), "mtd_metad_update_bias_walkers");
             }
         else

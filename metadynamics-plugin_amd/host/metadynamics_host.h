@@ -188,6 +188,8 @@ class OrderParameterMeshGPU : public CollectiveVariable
 
     private:
         void enqueueCV(unsigned int timestep);
+        void needFourierMesh();
+        bool m_keep_fourier;
         void computeQmax(unsigned int timestep);                      // :1108-1179
         void computeVirial();                                         // :970-1050
         unsigned int m_q_max_last_computed;
@@ -379,7 +381,7 @@ class IntegratorMetaDynamics
         DeviceBuffer m_sigma_scratch;
         double m_temp;
         Enum m_mode;
-        bool m_multiple_walkers;
+        bool m_multiple_walkers, m_warned_single_walker;
 
         mtd_metad *m_engine;
         bool m_allow_fused, m_used_fused;

@@ -300,7 +300,8 @@ def test_rccl_allreduce_large_and_walker_update(abi, ref):
 
 def test_host_multiple_walkers(abi):
     """integrate.set_params(multiple_walkers=True) through the C++ host classes: without a walker communicator the step
-    refuses (it used to be a silent no-op); with one (a one-walker RCCL communicator) the run equals the plain one"""
+    is the only walker (the reference in a serial run, test/test_2d.py:29; a notice says so — it used to be a silent no-op that
+    kept the fused path); with one (a one-walker RCCL communicator) the increments go through the all-reduce; both equal the plain run"""
     import ctypes as C
     from metadynamics import context, cv, integrate
     lib = abi.load()
@@ -329,8 +330,8 @@ def test_host_multiple_walkers(abi):
             context.current = None
 
     plain = run(False, None)
-    with pytest.raises(RuntimeError):
-        run(True, None)
+    alone = run(True, None)                    # no communicator: a single walker (with a notice), the walker code path
+    assert not alone["fused"] and alone["n"] == plain["n"] and alone["V"] == pytest.approx(plain["V"], rel=1e-6)
     uid = (C.c_ubyte * 128)()
     abi.check(lib.mtd_rccl_unique_id(uid))
     r = C.c_void_p()

@@ -93,14 +93,11 @@ while time.time() - t0 < budget:
                 per = np.abs(F1[:, :3] - F_ref[:, :3]).max(axis=1) / fm
                 tol = 1e-8 if dtype == np.float64 else 5e-7
                 n_bad = int((per > tol).sum())
-                # The reference rounds |x| to float inside the TSC derivative (Q9): a shift within a double ulp of a float
-                # rounding boundary lands on the other float in one of the two implementations, the derivative weight jumps
-                # by 6e-8 and the force of THAT particle by 6e-8 times the conditioning of its row differences (2e-6 ... 8e-4 of
-                # max|F| seen, about once per 10^8 weights).  Not a property of this implementation: the two GPU pipelines
-                # share their shifts and agree to 1e-8 above.  So: at most one such particle per case, counted.
+                # The reference rounds |x| to float inside the TSC derivative (Q9).  The in-cell shift is formed with the
+                # reference's operations in the reference's order (mesh.hip: locate), so it is the same double and the rounding
+                # falls the same way: EVERY particle within the tolerance, no counted exemption (round 1 allowed one per case).
                 if n_bad:
                     q9_events += 1
-                    worst["f_ref_q9"] = max(worst.get("f_ref_q9", 0.0), float(per.max()))
-                assert n_bad <= 1 and per.max() <= 1e-2, ("force vs oracle", dims, N, tilt, dtype, n_bad, per.max())
-                worst["f_ref"] = max(worst["f_ref"], float(np.sort(per)[-2] if (n_bad and len(per) > 1) else per.max()))
+                assert n_bad == 0, ("force vs oracle", dims, N, tilt, dtype, n_bad, per.max())
+                worst["f_ref"] = max(worst["f_ref"], float(per.max()))
 print("fuzz_mesh: %d random cases in %.0f s, worst relative deviations %s, Q9 rounding events %d" % (it, time.time() - t0, {k: float("%.2e" % v) for k, v in worst.items()}, q9_events))
