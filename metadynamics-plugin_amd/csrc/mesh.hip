@@ -33,6 +33,7 @@
 // power of two up to 1024 (radix-2 stages); other sizes return MTD_ERR_UNSUPPORTED.
 #include "mtd_device.hpp"
 #include "comm_host.hpp"
+#include "exact_div.hpp"
 
 #include <algorithm>
 #include <cmath>
@@ -52,6 +53,7 @@ struct MeshGeom
     unsigned int nx, ny, nz, n_cells;
     unsigned int hxp;                          // row pitch of the half-spectrum arrays (k_x = 0 .. nx/2 stored, then padding)
     double lo[3], L[3], xy, xz, yz;            // box (local == global: single rank)
+    ExactDivisor dL[3], dn[3];                 // the box lengths and mesh dimensions as divisors of locate (exact_div.hpp)
     double binv[3][3];                    // reciprocal rows without 2 pi (force pass, :761-769)
     };
 
@@ -149,8 +151,8 @@ __device__ __forceinline__ void tsc3_deriv(const double s, double (&w)[3], doubl
 // BoxDim::makeFraction / makeCoordinates / minImage (HOOMD-blue v2 semantics).
 // Cell and in-cell shift follow the reference's operation order EXACTLY (:540-573 == :784-812: makeFraction, truncation,
 // makeCoordinates of the cell centre, minImage, makeFraction again) — true divisions, one rounding per operation, no fused
-// multiply-add (the translation unit is compiled with -ffp-contract=fast; the pragma switches it off here and the flag
-// travels with the instructions when these functions are inlined).  The shift feeds assignTSCderiv, which rounds |x| to
+// multiply-add (this translation unit is compiled with -ffp-contract=on: csrc/Makefile explains why =fast ignored the pragma
+// below); the divisions by the loop-invariant box lengths and mesh dimensions are exact_div's correctly rounded quotients.  The shift feeds assignTSCderiv, which rounds |x| to
 // FLOAT (Q9): a shift that differs from the reference's in its last bit can fall on the other side of a float rounding
 // boundary, the derivative weight jumps by 6e-8 and, through the cancelling row differences of the force, one particle
 // moved by up to 1e-3 of max|F| (round-1 verdict).  With the same operations in the same order the shift is the same
@@ -161,9 +163,9 @@ __device__ __forceinline__ void make_fraction(const MeshGeom &g, double x, doubl
     double dx = x - g.lo[0], dy = y - g.lo[1], dz = z - g.lo[2];
     dx -= (g.xz - g.yz * g.xy) * dz + g.xy * dy;
     dy -= g.yz * dz;
-    fx = dx / g.L[0];
-    fy = dy / g.L[1];
-    fz = dz / g.L[2];
+    fx = exact_div(dx, g.dL[0]);               // == dx / L, correctly rounded (exact_div.hpp)
+    fy = exact_div(dy, g.dL[1]);
+    fz = exact_div(dz, g.dL[2]);
     }
 
 // cell (ix,iy,iz) and in-cell shift (mesh units) of a particle — :540-573 == :784-812
@@ -183,21 +185,21 @@ __device__ __forceinline__ void locate(const MeshGeom &g, const Particle &p, int
     ix = min(max(ix, 0), (int)g.nx - 1);
     iy = min(max(iy, 0), (int)g.ny - 1);
     iz = min(max(iz, 0), (int)g.nz - 1);
-    const double cfx = ((double)ix + 0.5) / (double)g.nx, cfy = ((double)iy + 0.5) / (double)g.ny, cfz = ((double)iz + 0.5) / (double)g.nz;
+    const double cfx = exact_div((double)ix + 0.5, g.dn[0]), cfy = exact_div((double)iy + 0.5, g.dn[1]), cfz = exact_div((double)iz + 0.5, g.dn[2]);
     // makeCoordinates(cell centre)
     const double cx = g.lo[0] + cfx * g.L[0] + cfy * g.xy * g.L[1] + cfz * g.xz * g.L[2];
     const double cy = g.lo[1] + cfy * g.L[1] + cfz * g.yz * g.L[2];
     const double cz = g.lo[2] + cfz * g.L[2];
     double wx = p.x - cx, wy = p.y - cy, wz = p.z - cz;
     // minImage
-    double img = rint(wz / g.L[2]);
+    double img = rint(exact_div(wz, g.dL[2]));
     wz -= g.L[2] * img;
     wy -= g.L[2] * g.yz * img;
     wx -= g.L[2] * g.xz * img;
-    img = rint(wy / g.L[1]);
+    img = rint(exact_div(wy, g.dL[1]));
     wy -= g.L[1] * img;
     wx -= g.L[1] * g.xy * img;
-    wx -= g.L[0] * rint(wx / g.L[0]);
+    wx -= g.L[0] * rint(exact_div(wx, g.dL[0]));
     double sfx, sfy, sfz;
     make_fraction(g, wx + g.lo[0], wy + g.lo[1], wz + g.lo[2], sfx, sfy, sfz);
     sx = sfx * (double)g.nx;
@@ -1711,6 +1713,8 @@ int fill_geom(MeshGeom &g, const mtd_mesh *m, const mtd_box *box)
         g.L[i] = box->L[i];
         }
     g.xy = box->xy; g.xz = box->xz; g.yz = box->yz;
+    for (int i = 0; i < 3; ++i) g.dL[i] = make_exact_divisor(box->L[i]);
+    g.dn[0] = make_exact_divisor((double)m->nx); g.dn[1] = make_exact_divisor((double)m->ny); g.dn[2] = make_exact_divisor((double)m->nz);
     reciprocal_rows(*box, g.binv);
     return MTD_SUCCESS;
     }
@@ -2040,7 +2044,10 @@ int mtd_mesh_spectral(mtd_mesh *m, const mtd_box *box, unsigned int n_global, co
     hipStream_t s = (hipStream_t)stream;
     // x passes: two real lines per complex transform, `x_tile` real lines per block (the last block may run short)
     const unsigned int n_lines = m->ny * m->nz;
-    unsigned int x_pairs = 16;
+    // 8 pairs = 16 real lines per block: at nx = 128 that is 16.5 KB of LDS and 1024 blocks — four per compute unit, so that
+    // one block loads while another transforms and a third stores (16 pairs: 512 blocks, 12.0 + 12.2 us; 8: 10.4 + 10.9)
+    unsigned int x_pairs = 8;
+    { static const unsigned int forced = [] { const char *e = std::getenv("MTD_FFT_XPAIRS"); return e ? (unsigned int)std::atoi(e) : 0u; }(); if (forced) x_pairs = forced; }
     while (x_pairs > 1 && fft_x_lds_bytes(m->nx, x_pairs) > 64 * 1024) x_pairs >>= 1;
     const unsigned int x_tile = 2 * x_pairs, x_blocks = (n_lines + x_tile - 1) / x_tile;
     const size_t x_lds = fft_x_lds_bytes(m->nx, x_pairs);
@@ -2174,7 +2181,7 @@ int mtd_mesh_slab_compute_cv(mtd_mesh *m, unsigned int n_particles, const void *
     k_slab_pull_rho<<<1024, 256, 0, s>>>(pp, W, (size_t)r * slab_cells, slab_cells, m->d_slab_rho);
     MTD_LAUNCH_CHECK();
     const unsigned int n_lines = m->ny * nzl;
-    unsigned int x_pairs = 16;
+    unsigned int x_pairs = 8;
     while (x_pairs > 1 && fft_x_lds_bytes(m->nx, x_pairs) > 64 * 1024) x_pairs >>= 1;
     const unsigned int x_tile = 2 * x_pairs, x_blocks = (n_lines + x_tile - 1) / x_tile;
     const size_t x_lds = fft_x_lds_bytes(m->nx, x_pairs);

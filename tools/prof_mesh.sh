@@ -2,7 +2,7 @@
 # Developer tool (GPU box): per-kernel table of config 3 (tools/bench_mesh.py) under rocprofv3 -> gpurun_out/config3_kernel_stats.csv
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 rm -rf gpurun_out/prof_mesh
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_mesh -o mesh -- python tools/bench_mesh.py 60 > gpurun_out/prof_mesh.log 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_mesh -o mesh -- python tools/bench_mesh.py 60 ${1:-} > gpurun_out/prof_mesh.log 2>&1
 grep "config 3" gpurun_out/prof_mesh.log
 f=$(find gpurun_out/prof_mesh -name "*kernel_stats.csv" | head -1)
 cp "$f" gpurun_out/config3_kernel_stats.csv
