@@ -262,7 +262,7 @@ __global__ __launch_bounds__(FF_THREADS, 4) void k_fused_force(const LamKArgs a,
         if (lane == 0)
             {
             c.st->V = s_chain.V;
-            if (COMM) c.st->failed = (unsigned int)s_chain.failed;       // the deferred pass of a poisoned deposit is skipped
+            c.st->failed = (unsigned int)s_chain.failed;                 // the deferred pass of a poisoned deposit is skipped (0 without a mailbox)
             c.st->bin = s_chain.bin;
             c.st->on_grid = (unsigned int)s_chain.on_grid;
             if (deposit)

@@ -42,6 +42,7 @@ __global__ __launch_bounds__(GRID_THREADS) void k_prepare(const MetadCfg c, cons
     if (threadIdx.x < c.n_cv) c.st->cv[threadIdx.x] = sh.cv[threadIdx.x];
     if (threadIdx.x == 0)
         {
+        c.st->failed = 0;                                   // a step of its own (a poisoned one is flagged by the fused kernels only)
         c.st->bin = sh.bin;
         c.st->on_grid = (unsigned int)sh.on_grid;
         if (sh.on_grid)
