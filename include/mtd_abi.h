@@ -353,6 +353,11 @@ int mtd_mesh_set_bug_compat(mtd_mesh *m, int on);
  * step at 128^3 otherwise saved).  Those three calls return MTD_ERR_INVALID_ARGUMENT when the last spectral step kept none:
  * switch it on and run mtd_mesh_spectral again (the real mesh of the step is still in place). */
 int mtd_mesh_set_keep_fourier(mtd_mesh *m, int on);
+/* Overlap hook: when `hip_event` (a hipEvent_t, NULL to clear) is set, mtd_mesh_spectral / mtd_mesh_compute_cv record it on
+ * their stream right after the pass that completes the CV partial sums (the fused z pass) — the two inverse passes that
+ * follow only feed the force pass.  A caller makes the launch that consumes the CV (the grid engine) wait for this event on
+ * ANOTHER stream, so that it runs beside the inverse passes (host classes: mixed CV sets). */
+int mtd_mesh_set_cv_event(mtd_mesh *m, void *hip_event);
 unsigned int mtd_mesh_num_cells(const mtd_mesh *m);
 
 /* getCurrentValue (OrderParameterMesh.cc:925-968): assignParticles -> FFT -> updateMeshes -> iFFT -> computeCV.

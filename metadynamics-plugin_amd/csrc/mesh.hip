@@ -1675,6 +1675,7 @@ struct mtd_mesh
     int bug_compat;
     int keep_fourier;          // the fused z pass also writes the normalised Fourier mesh (log quantities, virial, get_array(1))
     int fourier_valid;         // d_f holds the Fourier mesh of the last spectral step
+    hipEvent_t cv_event;       // recorded after the pass that completes the CV partial sums (mtd_mesh_set_cv_event), or null
     void *slab;
     double *d_mode, *d_rho, *d_inv, *d_modesq_partials, *d_mode_sq, *d_cv_partials;
     double2 *d_f, *d_g, *d_tw[3];
@@ -1922,6 +1923,13 @@ int mtd_mesh_destroy(mtd_mesh *m)
     return (int)e;
     }
 
+int mtd_mesh_set_cv_event(mtd_mesh *m, void *hip_event)
+    {
+    if (!m) return MTD_ERR_INVALID_ARGUMENT;
+    m->cv_event = (hipEvent_t)hip_event;
+    return MTD_SUCCESS;
+    }
+
 int mtd_mesh_set_keep_fourier(mtd_mesh *m, int on)
     {
     if (!m) return MTD_ERR_INVALID_ARGUMENT;
@@ -2069,6 +2077,7 @@ int mtd_mesh_spectral(mtd_mesh *m, const mtd_box *box, unsigned int n_global, co
     k_fft_z_spectral<false><<<pz.n_blocks, FFT_THREADS, fft_lds_bytes(pz.n, pz.tile), s>>>(
         g, m->d_f, m->d_g, pz.tw, ilog2(pz.n), pz.tile, pz.tiles_per_row, m->d_mode_sq, (double)n_global, m->d_itab, m->d_cv_partials, none, m->keep_fourier);
     m->fourier_valid = m->keep_fourier;
+    if (m->cv_event) MTD_HIP_TRY(hipEventRecord(m->cv_event, s));          // the CV partial sums are complete from here on
     MTD_LAUNCH_CHECK();
     rc = launch_fft_y(m, m->d_g, 1, s);
     if (rc) return rc;

@@ -907,7 +907,7 @@ std::vector<unsigned int> IntegratorMetaDynamics::mixedLamellarSlots() const
     return slots;
     }
 
-void IntegratorMetaDynamics::mixedLamellarCvPass(const std::vector<unsigned int> &slots)
+void IntegratorMetaDynamics::mixedLamellarCvPass(const std::vector<unsigned int> &slots, hipStream_t stream)
     {
     std::memset(&m_fused_set, 0, sizeof(m_fused_set));
     m_fused_set.n_cv = (unsigned int)slots.size();
@@ -934,7 +934,7 @@ void IntegratorMetaDynamics::mixedLamellarCvPass(const std::vector<unsigned int>
     const mtd_box box = m_pdata->getGlobalBox().toMtd();
     unsigned int n_partials = 0;
     mtd_check(mtd_fused_cv_pass(m_engine, &m_fused_set, m_pdata->getN(), m_pdata->positionsPtr(), m_pdata->getDtype(), &box,
-                                (double *)m_fused_partials.data(), &n_partials, m_exec_conf->getStream()),
+                                (double *)m_fused_partials.data(), &n_partials, stream),
               "mtd_fused_cv_pass");
     for (unsigned int c = 0; c < slots.size(); ++c)
         mtd_check(mtd_metad_set_cv_source(m_engine, slots[c], (const double *)m_fused_partials.data(), n_partials,
@@ -942,12 +942,12 @@ void IntegratorMetaDynamics::mixedLamellarCvPass(const std::vector<unsigned int>
                   "mtd_metad_set_cv_source");
     }
 
-void IntegratorMetaDynamics::mixedLamellarForcePass(const std::vector<unsigned int> &slots, unsigned int timestep)
+void IntegratorMetaDynamics::mixedLamellarForcePass(const std::vector<unsigned int> &slots, unsigned int timestep, hipStream_t stream)
     {
     const mtd_box box = m_pdata->getGlobalBox().toMtd();
     mtd_check(mtd_fused_force_pass_slots(m_engine, &m_fused_set, slots.data(), m_pdata->getN(), m_pdata->positionsPtr(),
                                          m_fused_force_ptrs.data(), m_pdata->getDtype(), m_pdata->getNGlobal(), &box, timestep,
-                                         m_exec_conf->getStream()),
+                                         stream),
               "mtd_fused_force_pass_slots");
     for (unsigned int i : slots) m_variables[i].m_cv->markComputed(timestep);
     }
@@ -979,12 +979,46 @@ void IntegratorMetaDynamics::updateBiasPotential(unsigned int timestep)
         m_used_fused = false;
         // collect values of collective variables (:321-327) — they stay on the device
         const std::vector<unsigned int> lam_slots = mixedLamellarSlots();
-        if (!lam_slots.empty()) mixedLamellarCvPass(lam_slots);
+        // The lamellar CVs' two launches depend on little of what the other CVs do: they go to a SIDE STREAM — launch A (one
+        // pass over the positions + the deferred grid pass) runs beside the other CVs' kernels (the mesh assignment), the
+        // grid-engine launch with the lamellar force blocks waits for the event that says "all CV values are there" and runs
+        // beside what the main stream still has to do for the forces (the mesh's two inverse transforms); the main stream
+        // takes up again after it.  Three events order the streams.  Opt-in (MTD_SIDE_STREAM=1): measured slower, mini_hoomd.h.
+        hipStream_t side = lam_slots.empty() ? nullptr : m_exec_conf->getSideStream();
+        hipStream_t ls = side ? side : s;
+        std::shared_ptr<OrderParameterMeshGPU> hooked;
+        if (side)
+            {
+            hip_check(hipEventRecord(m_exec_conf->getEvent(0), s), "hipEventRecord");              // positions / last step's work
+            hip_check(hipStreamWaitEvent(side, m_exec_conf->getEvent(0), 0), "hipStreamWaitEvent");
+            // exactly one other variable and it is a mesh: its CV sums are complete after the fused z pass, two passes early
+            if (m_variables.size() == lam_slots.size() + 1)
+                for (unsigned int i = 0; i < m_variables.size(); ++i)
+                    if (std::find(lam_slots.begin(), lam_slots.end(), i) == lam_slots.end())
+                        hooked = std::dynamic_pointer_cast<OrderParameterMeshGPU>(m_variables[i].m_cv);
+            if (hooked) hooked->setCvEvent(m_exec_conf->getEvent(1));
+            }
+        if (!lam_slots.empty()) mixedLamellarCvPass(lam_slots, ls);
         for (unsigned int i = 0; i < m_variables.size(); ++i)
             if (std::find(lam_slots.begin(), lam_slots.end(), i) == lam_slots.end())
                 m_variables[i].m_cv->enqueueCurrentValue(timestep, m_engine, i);
+        if (side)
+            {
+            if (hooked)
+                hooked->setCvEvent(nullptr);
+            else
+                hip_check(hipEventRecord(m_exec_conf->getEvent(1), s), "hipEventRecord");          // every other CV's value is enqueued
+            hip_check(hipStreamWaitEvent(side, m_exec_conf->getEvent(1), 0), "hipStreamWaitEvent");
+            }
         if (!lam_slots.empty())
-            mixedLamellarForcePass(lam_slots, timestep);
+            {
+            mixedLamellarForcePass(lam_slots, timestep, ls);
+            if (side)
+                {
+                hip_check(hipEventRecord(m_exec_conf->getEvent(2), side), "hipEventRecord");       // bias factors, grid arrays, lamellar forces
+                hip_check(hipStreamWaitEvent(s, m_exec_conf->getEvent(2), 0), "hipStreamWaitEvent");
+                }
+            }
         else if (m_multiple_walkers)
             {
             // sum up the walkers' increments between the two grid passes (:393-409)

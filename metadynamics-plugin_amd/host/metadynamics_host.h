@@ -178,6 +178,8 @@ class OrderParameterMeshGPU : public CollectiveVariable
         void setUseTable(bool use_table);                             // OrderParameterMesh.h:60-63
         //! this build: false = interpolation function as intended instead of the reference's unsigned division (Q6)
         void setBugCompatible(bool on);
+        //! event recorded when the CV partial sums of the next compute are complete (mtd_mesh_set_cv_event); nullptr clears
+        void setCvEvent(hipEvent_t e) { mtd_mesh_set_cv_event(m_mesh, (void *)e); }
         std::vector<std::string> getProvidedLogQuantities() override
             {
             auto l = CollectiveVariable::getProvidedLogQuantities();
@@ -355,8 +357,8 @@ class IntegratorMetaDynamics
         bool fusedLamellarPossible() const;
         void fusedLamellarStep(unsigned int timestep);
         std::vector<unsigned int> mixedLamellarSlots() const;
-        void mixedLamellarCvPass(const std::vector<unsigned int> &slots);
-        void mixedLamellarForcePass(const std::vector<unsigned int> &slots, unsigned int timestep);
+        void mixedLamellarCvPass(const std::vector<unsigned int> &slots, hipStream_t stream);
+        void mixedLamellarForcePass(const std::vector<unsigned int> &slots, unsigned int timestep, hipStream_t stream);
 
         std::shared_ptr<SystemDefinition> m_sysdef;
         std::shared_ptr<ParticleData> m_pdata;

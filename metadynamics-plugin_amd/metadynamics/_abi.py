@@ -158,6 +158,7 @@ _SIGNATURES = {
     "mtd_mesh_destroy": (C.c_int, [_vp]),
     "mtd_mesh_set_bug_compat": (C.c_int, [_vp, C.c_int]),
     "mtd_mesh_set_keep_fourier": (C.c_int, [_vp, C.c_int]),
+    "mtd_mesh_set_cv_event": (C.c_int, [_vp, _vp]),
     "mtd_mesh_num_cells": (C.c_uint, [_vp]),
     "mtd_mesh_set_table": (C.c_int, [_vp, _dp, _dp, C.c_uint, C.c_double, C.c_double]),
     "mtd_mesh_set_use_table": (C.c_int, [_vp, C.c_int]),
