@@ -343,3 +343,48 @@ def test_host_multiple_walkers(abi):
         assert np.abs(w["f"] - plain["f"]).max() <= 1e-5 * np.abs(plain["f"]).max()
     finally:
         abi.check(lib.mtd_rccl_destroy(r))
+
+
+@pytest.mark.parametrize("n_cv", [1, 2, 3])
+def test_one_launch_step_with_mailbox_single_rank(abi, ref, n_cv):
+    """mtd_fused_step as the persistent kernel with a (one-rank) mailbox attached: block 0 collects the blocks' sums and sends
+    them, every block's chain polls the local mailbox — same step as without the mailbox, and against the oracle"""
+    import ctypes as C
+    from metadynamics import xgmi
+    from test_gpu_fused import Fused, make_traj
+    from test_gpu_metad import GpuMetad, compare
+    lib = abi.load()
+    N, L, steps = 100_003, 30.0, 5
+    cvs = [(util.CV1_VECTORS, util.MODE_AB), (util.CV2_VECTORS, util.MODE_AB), ([(0, 0, 3), (1, 2, 0)], [0.5, -1.5])][:n_cv]
+    traj, types = make_traj(N, L, steps, np.float32)
+    box, rbox = abi.Box.make(L), ref.Box.make(L)
+    kw = dict(sigma=[0.02, 0.01, 0.03][:n_cv], cv_min=[-0.6, -0.3, -0.5][:n_cv], cv_max=[0.4, 0.3, 0.5][:n_cv], num_points=[37, 21, 9][:n_cv],
+              W=1.0, T_shift=7.0, T=1.0, stride=1, mode="well_tempered")
+    h = C.c_void_p()
+    abi.check(lib.mtd_comm_create(C.byref(h), 0, 1, 8))
+    mbox = xgmi.Mailbox(h, 0, 1)
+    g = GpuMetad(abi, **kw)
+    r = ref.Metad(**kw)
+    try:
+        abi.check(lib.mtd_metad_set_comm(g.h, mbox.handle))
+        f = Fused(abi, g, N, np.float32, True, cvs)
+        for t in range(steps):
+            d_pos = torch.from_numpy(util.pack_postype(traj[t], types, np.float32)).cuda()
+            f.step(t, d_pos, box)
+            torch.cuda.synchronize()
+            F = [x.cpu().numpy().astype(np.float64) for x in f.forces]
+            st = g.state()
+            opt = util.oracle_postype(traj[t], types)
+            s_ref = [ref.lamellar_cv(v, opt, m, rbox) for v, m in cvs]
+            for c in range(n_cv):
+                assert abs(st["cv"][c] - s_ref[c]) <= max(1e-6 * abs(s_ref[c]), 1e-6 * 8 / np.sqrt(N)), (t, c)
+            b = r.update_bias(t, st["cv"])
+            compare(g, r, b, label="one launch + mailbox step %d" % t)
+            for c, (v, m) in enumerate(cvs):
+                F_ref = ref.lamellar_forces(v, opt, m, rbox, b[c])
+                assert np.abs(F[c][:, :3] - F_ref[:, :3]).max() <= 1e-5 * np.abs(F_ref[:, :3]).max(), (t, c)
+        assert mbox.timeouts() == 0
+        abi.check(lib.mtd_metad_set_comm(g.h, None))
+    finally:
+        g.close()
+        mbox.close()
