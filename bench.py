@@ -400,7 +400,7 @@ def main():
     # profiles/ (13.4-13.7 us for this kernel; the in-process figures are 14.6-14.7 us — the roofline is priced with those).
     for _ in range(20):
         eng.step()
-    n_ev = min(args.steps, 500)
+    n_ev = 300          # launches measured one by one (their own loops, outside the timed region: events per launch perturb the step)
     lib = _abi.load()
 
     def event_pair():
