@@ -397,6 +397,14 @@ def main():
             eng.exchange = "%s (mailbox gave %d timeouts in rehearsal)" % ("rccl" if dist.get_backend() == "nccl" else dist.get_backend(), int(tt.item()))
     if driver == "host" and dist is not None and eng.be.mailbox is None:
         driver = "abi"                     # no mailbox on this node: the C-ABI backend with the RCCL all-reduce
+    host = None
+    if driver == "host":
+        # every piece of set-up comes first — building the host-API system copies the snapshot again and leaves the GPU idle for
+        # ~0.1 s, after which the first milliseconds of work run on lowered clocks (tools/ramp_probe.py: +6-8 % per step after
+        # 20-200 ms of idling, and W = 5 warm-up steps are 0.1 ms of work)
+        barrier()                          # ranks enter the first exchange (prepRun's deposit) together
+        host = HostEngine(eng.pos_np, eng.types_np, eng.L, n_global, args.stride, args.fast_trig, args.path, dtype=np_dtype,
+                          mailbox=eng.be.mailbox)
     # (measured BEFORE the timed region: the per-launch figures are then taken on a GPU in the same state as the timed steps
     # and the timed region starts on clocks that are already up)
     # dominant kernel (launch B, the force pass): per-launch durations over the same loop from HIP events on the launch stream.
@@ -467,10 +475,8 @@ def main():
 
     if driver == "host":
         # sharded: the C++ host classes take the mailbox as their communicator (fused lamellar step)
-        barrier()                          # ranks enter the first exchange (prepRun's deposit) together
-        host = HostEngine(eng.pos_np, eng.types_np, eng.L, n_global, args.stride, args.fast_trig, args.path, dtype=np_dtype,
-                          mailbox=eng.be.mailbox)
-        host.run(max(args.warmup - 1, 0))
+        barrier()
+        host.run(max(args.warmup - 1, 0))  # run(k) = prepRun (one bias update) + k updates: args.warmup untimed bias steps
         barrier()
         t0 = time.perf_counter()
         host.run(args.steps - 1)        # run(k) = prepRun (one bias update) + k updates: exactly args.steps bias steps
