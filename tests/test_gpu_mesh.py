@@ -325,3 +325,30 @@ def test_mesh_forces_every_particle_in_random_triclinic_boxes(abi, ref):
             assert per.max() <= (5e-7 if dtype == np.float32 else 1e-8), (case, dims, tilt, per.max(), int(per.argmax()))
         finally:
             g.close()
+
+
+def test_mesh_256_cubed_tile_path_against_cell_path(abi, monkeypatch):
+    """the largest mesh the tile path takes (256^3: 8192 tiles, the count kernel's two LDS arrays of 8192 counters need the raised
+    dynamic-LDS limit) against the cell-level pipeline: same mesh sums, CV and forces (no oracle at this size: its DFT is O(n^2)
+    per line)"""
+    dims, L, N = (256, 256, 256), 64.0, 200_000
+    pos, types = util.snapshot_random(N, L, seed=11, modulated=True, dtype=np.float32)
+    pos = (np.mod(pos.astype(np.float64) + L / 2, L) - L / 2).astype(np.float32)
+    pos[pos >= L / 2] = -L / 2
+    box = abi.Box.make(L)
+    d_pos = torch.from_numpy(util.pack_postype(pos, types, np.float32)).cuda()
+    out = {}
+    for path in ("tiles", "cells"):
+        monkeypatch.setenv("MTD_MESH_ASSIGN", path)
+        g = GpuMesh(abi, dims, [1.0, -0.7], N)
+        try:
+            s = g.cv(d_pos, abi.MTD_F32, box, N)
+            F = g.forces(d_pos, abi.MTD_F32, box, N, 0.8)
+            out[path] = (s, g.array(0).copy(), F)
+        finally:
+            g.close()
+    assert out["tiles"][0] == pytest.approx(out["cells"][0], rel=1e-9)
+    scale = np.abs(out["cells"][1]).max()
+    assert np.abs(out["tiles"][1] - out["cells"][1]).max() <= 1e-11 * scale
+    fm = np.abs(out["cells"][2]).max()
+    assert fm > 0 and np.abs(out["tiles"][2] - out["cells"][2]).max() <= 5e-7 * fm
