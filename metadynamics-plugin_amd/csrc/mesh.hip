@@ -21,12 +21,15 @@
 //                       LDS (the Poisson-distributed cell counts make this loop divergent — in LDS that costs ALU slots,
 //                       from global memory it cost 316 us of load latency): no atomics on the mesh, no scratch, every
 //                       mesh cell written exactly once
-//   6 k_fft_x_r2c       unnormalised DFT along x of the real mesh, only k_x = 0 .. nx/2 kept (half spectrum, padded rows);
+//   6 k_fft_xy_forward  x and y passes of a mesh plane in one launch (power-of-two planes that fit the LDS: 128^2 does);
+//                       otherwise, and on the slab path:
+//     k_fft_x_r2c       unnormalised DFT along x of the real mesh, only k_x = 0 .. nx/2 kept (half spectrum, padded rows);
 //     k_fft_lines       along y; lines staged in LDS in [pos][line] layout (adjacent lines per block so strided axes
 //                       still move 128-B segments)
 //   7 k_fft_z_spectral  z lines: forward transform, f = F/N, Hermitian part of G = f(|f|^2 - I^2 sum mode^2 / 2N^2), block
 //                       sums of the CV integrand (stored cell + mirror cell), inverse transform — one staging in LDS
-//   8 k_fft_lines       inverse along y; k_fft_x_c2r inverse along x (other half of the line by symmetry, real part out)
+//   8 k_fft_xy_inverse  inverse along y and x of a plane in one launch; otherwise
+//     k_fft_lines       inverse along y; k_fft_x_c2r inverse along x (other half of the line by symmetry, real part out)
 //   9 k_mesh_forces     per particle: 27 reads of Re(inv) with TSC' x TSC x TSC weights
 // Everything is double precision: the CV is quartic in the Fourier amplitudes, fp32 meshes cannot hold
 // 1e-6 on it.  Mesh sizes: 4 ... 256 per axis (any, direct transform in LDS for lengths that are not powers of two), or a
@@ -1270,6 +1273,366 @@ __global__ __launch_bounds__(FFT_THREADS) void k_fft_x_c2r(const double2 *__rest
         }
     }
 
+// ---- 6ab / 8bc. x and y passes of one mesh plane in ONE launch -------------------------------------------------------
+// A line pass is a load phase, a few sweeps over LDS and a store phase that do not overlap inside a block, and with every
+// block of a launch resident at once they do not overlap between blocks either: each pass costs ≈ 10 us at 128^3 whatever
+// the transform itself takes (≈ 3 us).  The half spectrum of a plane does not fit the LDS next to the x lines it comes
+// from, but half of its k_x columns do: `XY_PARTS` blocks per plane, each transforms ALL x lines of the plane (in batches;
+// the second read of the plane comes out of the L2 of the XCD the two blocks share) and keeps only its own k_x columns,
+// then transforms those columns along y and writes them: the x-transformed plane never exists in HBM.  The inverse
+// direction mirrors it: every block inverts all k_x columns along y (in batches of the same size), keeps its own y rows,
+// and inverts those along x.  The arithmetic of every line is that of k_fft_x_r2c / k_fft_lines / k_fft_x_c2r (same
+// butterflies in the same order), so the slab path, which has to stop between the passes, gives bitwise the same mesh.
+constexpr int XY_THREADS = 512;
+constexpr unsigned int XY_PARTS = 2;
+
+// Diagnostic build only (-DMTD_STAMPS, tools/build_stamps.sh, tools/stamps_xy.py): where the blocks of the two kernels spend
+// their time (s_memrealtime, 10 ns ticks); the product build has no stamps.
+#ifdef MTD_STAMPS
+__device__ unsigned long long g_xy_stamps[2][16][256];
+#define XY_STAMP(dir, row) do { if (threadIdx.x == 0 && blockIdx.x < 256) g_xy_stamps[dir][row][blockIdx.x] = wall_clock64(); } while (0)
+#else
+#define XY_STAMP(dir, row) do { } while (0)
+#endif
+
+// idx -> (idx / d, idx % d) for a run-time d without a division (d >= 1, idx * d < 2^32)
+struct FastDiv
+    {
+    unsigned int d, magic;
+    __device__ __forceinline__ void split(const unsigned int idx, unsigned int &q, unsigned int &r) const
+        {
+        q = d == 1 ? idx : __umulhi(idx, magic);
+        r = idx - q * d;
+        }
+    };
+
+// Block barrier that waits for this wave's LDS traffic only: __syncthreads() also drains the global loads in flight, and
+// the next batch is being prefetched into registers across the sweeps (the compiler waits for those where they are used)
+__device__ __forceinline__ void xy_barrier()
+    {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+
+// The radix-4 butterfly of fft_dit_pow2 on registers (a, b, c, d at ia, ia + half, ia + 2 half, ia + 3 half)
+__device__ __forceinline__ void bfly4(double2 &a, double2 &b, double2 &c, double2 &d, const double2 w1, const double2 w2, const int inverse)
+    {
+    const double2 bw = cmul(b, w1), dw = cmul(d, w1);
+    const double2 a1 = cadd(a, bw), b1 = csub(a, bw), c1 = cmul(cadd(c, dw), w2), d1 = cmul(csub(c, dw), w2);
+    const double2 d1r = inverse ? make_double2(-d1.y, d1.x) : make_double2(d1.y, -d1.x);
+    a = cadd(a1, c1);
+    c = csub(a1, c1);
+    b = cadd(b1, d1r);
+    d = csub(b1, d1r);
+    }
+
+__device__ __forceinline__ double2 xy_tw(const double2 *__restrict__ twiddle, const unsigned int i, const int inverse)
+    {
+    double2 w = twiddle[i];
+    if (inverse) w.y = -w.y;
+    return w;
+    }
+
+// fft_dit_pow2 for any number of lines per tile (`td`) with XY_THREADS threads: the same butterflies in the same order on
+// every element (bitwise the same lines), but consecutive stages are chained in registers — radix-2 + radix-4 on 8 elements,
+// two radix-4 stages on 16 — so that a 128-point line takes two sweeps over LDS and two barriers instead of four.
+__device__ __forceinline__ void fft_dit_xy(double2 *s, const double2 *__restrict__ twiddle, const unsigned int log2n, const FastDiv td,
+                                           const int inverse, const unsigned int stride)
+    {
+    const unsigned int n = 1u << log2n;
+    unsigned int log2len = 1;
+    if (log2n & 1)
+        {
+        // stage len = 2 (twiddle 1) and the radix-4 stage len = 4, 8 on positions 8 bf .. 8 bf + 7  (log2n >= 3)
+        const double2 w1 = xy_tw(twiddle, 1u << (log2n - 2), inverse), w2 = xy_tw(twiddle, 1u << (log2n - 3), inverse);
+        const double2 one1 = xy_tw(twiddle, 0, inverse);
+        for (unsigned int idx = threadIdx.x; idx < (n >> 3) * td.d; idx += XY_THREADS)
+            {
+            unsigned int bf, t;
+            td.split(idx, bf, t);
+            double2 *pa = s + (bf << 3) * stride + t;
+            double2 e[8];
+#pragma unroll
+            for (int m = 0; m < 8; ++m) e[m] = pa[m * stride];
+#pragma unroll
+            for (int m = 0; m < 8; m += 2)
+                {
+                const double2 u = e[m], v = e[m + 1];
+                e[m] = cadd(u, v);
+                e[m + 1] = csub(u, v);
+                }
+            bfly4(e[0], e[2], e[4], e[6], one1, one1, inverse);
+            bfly4(e[1], e[3], e[5], e[7], w1, w2, inverse);
+#pragma unroll
+            for (int m = 0; m < 8; ++m) pa[m * stride] = e[m];
+            }
+        xy_barrier();
+        log2len = 4;
+        }
+    // two radix-4 stages (len = 2^log2len .. 8 len) on positions ib + m half, m < 16
+    for (; log2len + 2 < log2n + 1; log2len += 4)
+        {
+        const unsigned int log2half = log2len - 1, half = 1u << log2half;
+        for (unsigned int idx = threadIdx.x; idx < (n >> 4) * td.d; idx += XY_THREADS)
+            {
+            unsigned int bf, t;
+            td.split(idx, bf, t);
+            const unsigned int grp = bf >> log2half, j = bf & (half - 1);
+            double2 *pa = s + ((grp << (log2len + 3)) + j) * stride + t;
+            const unsigned int sh = half * stride;
+            double2 e[16];
+#pragma unroll
+            for (int m = 0; m < 16; ++m) e[m] = pa[m * sh];
+            {
+            const double2 w1 = xy_tw(twiddle, j << (log2n - log2len), inverse), w2 = xy_tw(twiddle, j << (log2n - log2len - 1), inverse);
+#pragma unroll
+            for (int q = 0; q < 16; q += 4) bfly4(e[q], e[q + 1], e[q + 2], e[q + 3], w1, w2, inverse);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                {
+                const unsigned int j2 = j + r * half;
+                const double2 w1 = xy_tw(twiddle, j2 << (log2n - log2len - 2), inverse), w2 = xy_tw(twiddle, j2 << (log2n - log2len - 3), inverse);
+                bfly4(e[r], e[r + 4], e[r + 8], e[r + 12], w1, w2, inverse);
+                }
+#pragma unroll
+            for (int m = 0; m < 16; ++m) pa[m * sh] = e[m];
+            }
+        xy_barrier();
+        }
+    // a last radix-4 stage on its own
+    for (; log2len < log2n + 1; log2len += 2)
+        {
+        const unsigned int log2half = log2len - 1, half = 1u << log2half;
+        for (unsigned int idx = threadIdx.x; idx < (n >> 2) * td.d; idx += XY_THREADS)
+            {
+            unsigned int bf, t;
+            td.split(idx, bf, t);
+            const unsigned int grp = bf >> log2half, j = bf & (half - 1);
+            double2 *pa = s + ((grp << (log2len + 1)) + j) * stride + t;
+            const unsigned int sh = half * stride;
+            const double2 w1 = xy_tw(twiddle, j << (log2n - log2len), inverse), w2 = xy_tw(twiddle, j << (log2n - log2len - 1), inverse);
+            double2 a = pa[0], b = pa[sh], c = pa[2 * sh], d = pa[3 * sh];
+            bfly4(a, b, c, d, w1, w2, inverse);
+            pa[0] = a;
+            pa[sh] = b;
+            pa[2 * sh] = c;
+            pa[3 * sh] = d;
+            }
+        xy_barrier();
+        }
+    }
+
+struct XYPlan
+    {
+    unsigned int nx, ny, nz, log2nx, log2ny, hx, hxp;
+    unsigned int kc_max;        // k_x columns per part (the last part may hold fewer)
+    unsigned int pb;            // forward: line pairs per x batch; inverse: line pairs of a part (ny / 2 / XY_PARTS)
+    unsigned int xs, ys;        // row strides of the two LDS images (odd)
+    FastDiv d_pb, d_kc[XY_PARTS];
+    int xcd_map;                // nz % 8 == 0: the parts of a plane run on one XCD
+    };
+
+// d_kc[i] without indexing the kernel argument by a run-time value (that copies the struct to scratch)
+__device__ __forceinline__ FastDiv xy_kc(const XYPlan &pl, const unsigned int i)
+    {
+    FastDiv f = pl.d_kc[0];
+#pragma unroll
+    for (unsigned int j = 1; j < XY_PARTS; ++j)
+        if (i == j) f = pl.d_kc[j];
+    return f;
+    }
+
+__device__ __forceinline__ void xy_block(const XYPlan &pl, unsigned int &plane, unsigned int &part)
+    {
+    const unsigned int b = blockIdx.x;
+    if (pl.xcd_map)
+        {
+        // consecutive block ids go to consecutive XCDs: ids b and b + 8 share one
+        const unsigned int group = b / (8 * XY_PARTS), r = b % (8 * XY_PARTS);
+        plane = group * 8 + (r & 7);
+        part = r >> 3;
+        }
+    else
+        {
+        plane = b / XY_PARTS;
+        part = b % XY_PARTS;
+        }
+    }
+
+// twiddle tables of both axes at the end of the LDS image (a sweep then waits for LDS, not for the L2)
+__device__ __forceinline__ void xy_twiddles(double2 *T, const double2 *__restrict__ tw_x, const double2 *__restrict__ tw_y, const XYPlan &pl)
+    {
+    for (unsigned int i = threadIdx.x; i < pl.nx / 2 + pl.ny / 2; i += XY_THREADS)
+        T[i] = i < pl.nx / 2 ? tw_x[i] : tw_y[i - pl.nx / 2];
+    }
+
+constexpr int XY_PREFETCH = 10;     // elements per thread of the next batch held in registers while this one is transformed
+
+__global__ __launch_bounds__(XY_THREADS) void k_fft_xy_forward(const double *__restrict__ real_in, double2 *__restrict__ half_out,
+                                                               const double2 *__restrict__ tw_x, const double2 *__restrict__ tw_y,
+                                                               const XYPlan pl)
+    {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double2 *X = (double2 *)smem, *Y = X + (size_t)pl.nx * pl.xs, *TX = Y + (size_t)pl.ny * pl.ys, *TY = TX + pl.nx / 2;
+    unsigned int plane, part;
+    xy_block(pl, plane, part);
+    const unsigned int k0 = part * pl.kc_max, k1 = min(pl.hx, k0 + pl.kc_max), kc = k1 - k0;
+    const FastDiv dk = xy_kc(pl, part);
+    const unsigned int nx = pl.nx, ny = pl.ny, pb = pl.pb, xs = pl.xs, ys = pl.ys;
+    const size_t line_base = (size_t)plane * ny;
+    const unsigned int n_batches = ny / 2 / pb;
+    double2 pre[XY_PREFETCH];
+    auto fetch = [&](const unsigned int batch)
+        {
+#pragma unroll
+        for (int i = 0; i < XY_PREFETCH; ++i)
+            {
+            const unsigned int idx = min(threadIdx.x + i * XY_THREADS, nx * pb - 1);   // clamped: see xy_fetch_columns
+            const unsigned int u = idx >> pl.log2nx, p = idx & (nx - 1);
+            const size_t la = line_base + 2 * (batch * pb + u);
+            pre[i] = make_double2(real_in[la * nx + p], real_in[(la + 1) * nx + p]);
+            }
+        };
+    XY_STAMP(0, 0);
+    fetch(0);
+    xy_twiddles(TX, tw_x, tw_y, pl);
+    for (unsigned int batch = 0; batch < n_batches; ++batch)
+        {
+        const unsigned int pair0 = batch * pb;
+#pragma unroll
+        for (int i = 0; i < XY_PREFETCH; ++i)
+            {
+            const unsigned int idx = threadIdx.x + i * XY_THREADS;
+            if (idx < nx * pb) X[(idx & (nx - 1)) * xs + (idx >> pl.log2nx)] = pre[i];
+            }
+        xy_barrier();
+        // rows to bit-reversed order, lanes along a row: written straight to their bit-reversed rows, the lanes of a wave
+        // (consecutive positions of one line) would queue eight deep on the same banks
+        for (unsigned int idx = threadIdx.x; idx < nx * pb; idx += XY_THREADS)
+            {
+            unsigned int q, u;
+            pl.d_pb.split(idx, q, u);
+            const unsigned int r = lds_slot(q, pl.log2nx);
+            if (q < r)
+                {
+                const double2 a = X[q * xs + u], b = X[r * xs + u];
+                X[q * xs + u] = b;
+                X[r * xs + u] = a;
+                }
+            }
+        xy_barrier();
+        XY_STAMP(0, 1 + 3 * min(batch, 1u));
+        if (batch + 1 < n_batches) fetch(batch + 1);             // in flight during the sweeps below
+        fft_dit_xy(X, TX, pl.log2nx, pl.d_pb, 0, xs);
+        XY_STAMP(0, 2 + 3 * min(batch, 1u));
+        // the two real lines of a pair, k_x columns of this part only, to their (bit-reversed) y rows of the column image
+        for (unsigned int idx = threadIdx.x; idx < kc * pb; idx += XY_THREADS)
+            {
+            unsigned int u, kl;
+            dk.split(idx, u, kl);
+            const unsigned int k = k0 + kl;
+            const double2 zk = X[k * xs + u], zm = X[((nx - k) & (nx - 1)) * xs + u];
+            const unsigned int ya = 2 * (pair0 + u);
+            Y[lds_slot(ya, pl.log2ny) * ys + kl] = make_double2(0.5 * (zk.x + zm.x), 0.5 * (zk.y - zm.y));
+            Y[lds_slot(ya + 1, pl.log2ny) * ys + kl] = make_double2(0.5 * (zk.y + zm.y), -0.5 * (zk.x - zm.x));
+            }
+        xy_barrier();
+        XY_STAMP(0, 3 + 3 * min(batch, 1u));
+        }
+    fft_dit_xy(Y, TY, pl.log2ny, dk, 0, ys);
+    XY_STAMP(0, 7);
+    for (unsigned int idx = threadIdx.x; idx < kc * ny; idx += XY_THREADS)
+        {
+        unsigned int ky, kl;
+        dk.split(idx, ky, kl);
+        const double2 v = Y[ky * ys + kl];
+        double *o = (double *)(half_out + (line_base + ky) * pl.hxp + k0 + kl);
+        __builtin_nontemporal_store(v.x, o);         // streamed out: nothing left for the write-back at the end of the kernel
+        __builtin_nontemporal_store(v.y, o + 1);
+        }
+    XY_STAMP(0, 8);
+    }
+
+__device__ __forceinline__ void xy_fetch_columns(double2 (&pre)[XY_PREFETCH], const double2 *__restrict__ half_in, const XYPlan &pl,
+                                                 const size_t line_base, const unsigned int cpart)
+    {
+    const unsigned int c0 = cpart * pl.kc_max;
+    const FastDiv dc = xy_kc(pl, cpart);
+#pragma unroll
+    for (int i = 0; i < XY_PREFETCH; ++i)
+        {
+        // (clamped, not predicated: every load is issued before the first is waited for, and pre[] stays in registers)
+        const unsigned int idx = min(threadIdx.x + i * XY_THREADS, dc.d * pl.ny - 1);
+        unsigned int ky, cl;
+        dc.split(idx, ky, cl);
+        const double2 v = half_in[(line_base + ky) * pl.hxp + c0 + cl];
+        pre[i].x = v.x;     // (by component: a 16-byte aggregate copy keeps the array in scratch)
+        pre[i].y = v.y;
+        }
+    }
+
+__global__ __launch_bounds__(XY_THREADS) void k_fft_xy_inverse(const double2 *__restrict__ half_in, double *__restrict__ real_out,
+                                                               const double2 *__restrict__ tw_x, const double2 *__restrict__ tw_y,
+                                                               const XYPlan pl)
+    {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double2 *X = (double2 *)smem, *Y = X + (size_t)pl.nx * pl.xs, *TX = Y + (size_t)pl.ny * pl.ys, *TY = TX + pl.nx / 2;
+    unsigned int plane, part;
+    xy_block(pl, plane, part);
+    const unsigned int nx = pl.nx, ny = pl.ny, pairs = pl.pb, xs = pl.xs, ys = pl.ys;
+    const unsigned int y_base = part * 2 * pairs;                // this block's rows: y_base .. y_base + 2 pairs - 1
+    const size_t line_base = (size_t)plane * ny;
+    double2 pre[XY_PREFETCH];
+    XY_STAMP(1, 0);
+    xy_fetch_columns(pre, half_in, pl, line_base, 0);
+    xy_twiddles(TX, tw_x, tw_y, pl);
+    for (unsigned int cpart = 0; cpart < XY_PARTS; ++cpart)
+        {
+        const unsigned int c0 = cpart * pl.kc_max;
+        const FastDiv dc = xy_kc(pl, cpart);
+        const unsigned int cb = dc.d;
+#pragma unroll
+        for (int i = 0; i < XY_PREFETCH; ++i)
+            {
+            const unsigned int idx = threadIdx.x + i * XY_THREADS;
+            if (idx < cb * ny)
+                {
+                unsigned int ky, cl;
+                dc.split(idx, ky, cl);
+                Y[lds_slot(ky, pl.log2ny) * ys + cl] = make_double2(pre[i].x, pre[i].y);
+                }
+            }
+        xy_barrier();
+        XY_STAMP(1, 1 + 3 * cpart);
+        if (cpart + 1 < XY_PARTS) xy_fetch_columns(pre, half_in, pl, line_base, cpart + 1);   // in flight during the sweeps below
+        fft_dit_xy(Y, TY, pl.log2ny, dc, 1, ys);
+        XY_STAMP(1, 2 + 3 * cpart);
+        // rows of this part: A + i B of a pair of rows at k and its mirror at n - k (k_fft_x_c2r)
+        for (unsigned int idx = threadIdx.x; idx < cb * pairs; idx += XY_THREADS)
+            {
+            unsigned int cl, u;
+            pl.d_pb.split(idx, cl, u);
+            const unsigned int k = c0 + cl, ya = y_base + 2 * u;
+            const double2 A = Y[ya * ys + cl], B = Y[(ya + 1) * ys + cl];
+            X[lds_slot(k, pl.log2nx) * xs + u] = make_double2(A.x - B.y, A.y + B.x);
+            if (k != 0 && 2 * k != nx) X[lds_slot(nx - k, pl.log2nx) * xs + u] = make_double2(A.x + B.y, -A.y + B.x);
+            }
+        xy_barrier();
+        XY_STAMP(1, 3 + 3 * cpart);
+        }
+    fft_dit_xy(X, TX, pl.log2nx, pl.d_pb, 1, xs);
+    XY_STAMP(1, 7);
+    for (unsigned int idx = threadIdx.x; idx < nx * pairs; idx += XY_THREADS)
+        {
+        const unsigned int u = idx >> pl.log2nx, p = idx & (nx - 1);
+        const double2 z = X[p * xs + u];
+        const size_t la = line_base + y_base + 2 * u;
+        __builtin_nontemporal_store(z.x, real_out + la * nx + p);
+        __builtin_nontemporal_store(z.y, real_out + (la + 1) * nx + p);
+        }
+    XY_STAMP(1, 8);
+    }
+
 // ---- 6c+7+8a. z lines: forward transform, spectral step, inverse transform — one pass ----------------------
 // The last forward pass, updateMeshes/computeCV and the first inverse pass all work on complete z lines, so they share one
 // staging of the lines in LDS: the Fourier mesh is written once (f, normalised: the log quantities and the virial read
@@ -1766,7 +2129,53 @@ int launch_fft_y(const mtd_mesh *m, double2 *data, int inverse, hipStream_t s)
     return MTD_SUCCESS;
     }
 
+FastDiv fast_div(unsigned int d)
+    {
+    FastDiv f;
+    f.d = d;
+    f.magic = d > 1 ? (unsigned int)(((1ull << 32) + d - 1) / d) : 0u;
+    return f;
+    }
+
+// plan of the fused x/y passes (k_fft_xy_*), or false when the mesh does not qualify (sizes that are not powers of two,
+// planes whose images do not fit the 160 KB of LDS) and the separate passes run
+constexpr size_t XY_LDS_MAX = 160 * 1024;
+bool xy_plan(const mtd_mesh *m, int inverse, XYPlan &pl, size_t &lds)
+    {
+    if (!is_pow2(m->nx) || !is_pow2(m->ny) || m->nx < 4 || m->ny < 2 * XY_PARTS) return false;
+    std::memset(&pl, 0, sizeof(pl));
+    pl.nx = m->nx; pl.ny = m->ny; pl.nz = m->nz; pl.log2nx = ilog2(m->nx); pl.log2ny = ilog2(m->ny);
+    pl.hx = m->nx / 2 + 1; pl.hxp = m->hxp;
+    pl.kc_max = (pl.hx + XY_PARTS - 1) / XY_PARTS;
+    pl.ys = pl.kc_max | 1u;
+    for (unsigned int part = 0; part < XY_PARTS; ++part)
+        {
+        const unsigned int k0 = part * pl.kc_max, k1 = std::min(pl.hx, k0 + pl.kc_max);
+        if (k1 <= k0) return false;
+        pl.d_kc[part] = fast_div(k1 - k0);
+        }
+    const size_t y_bytes = (size_t)pl.ny * pl.ys * sizeof(double2);
+    unsigned int pb = m->ny / 2 / (inverse ? XY_PARTS : 1);      // forward: the largest batch of line pairs that fits
+    const size_t tw_bytes = (size_t)(pl.nx / 2 + pl.ny / 2) * sizeof(double2);
+    while (!inverse && pb > 1 && ((size_t)pl.nx * (pb + 1) * sizeof(double2) + y_bytes + tw_bytes > XY_LDS_MAX || (size_t)pl.nx * pb > (size_t)XY_PREFETCH * XY_THREADS)) pb >>= 1;
+    pl.pb = pb;
+    pl.xs = pb + 1;
+    pl.d_pb = fast_div(pb);
+    pl.xcd_map = m->nz % 8 == 0;
+    lds = (size_t)pl.nx * pl.xs * sizeof(double2) + y_bytes + (size_t)(pl.nx / 2 + pl.ny / 2) * sizeof(double2);
+    // a batch must fit the registers that prefetch it
+    const size_t per_batch = inverse ? (size_t)pl.kc_max * pl.ny : (size_t)pl.nx * pb;
+    return lds <= XY_LDS_MAX && per_batch <= (size_t)XY_PREFETCH * XY_THREADS;
+    }
+
 } // namespace
+
+#ifdef MTD_STAMPS
+extern "C" int mtd_debug_read_xy_stamps(unsigned long long *host)
+    {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_xy_stamps), sizeof(unsigned long long) * 2 * 16 * 256);
+    }
+#endif
 
 extern "C" {
 
@@ -2067,10 +2476,28 @@ int mtd_mesh_spectral(mtd_mesh *m, const mtd_box *box, unsigned int n_global, co
     while (x_pairs > 1 && fft_x_lds_bytes(m->nx, x_pairs) > 64 * 1024) x_pairs >>= 1;
     const unsigned int x_tile = 2 * x_pairs, x_blocks = (n_lines + x_tile - 1) / x_tile;
     const size_t x_lds = fft_x_lds_bytes(m->nx, x_pairs);
-    k_fft_x_r2c<<<x_blocks, FFT_THREADS, x_lds, s>>>(m->d_rho, m->d_f, m->d_tw[0], m->nx, ilog2(m->nx), x_tile, m->hxp, n_lines);
-    MTD_LAUNCH_CHECK();
-    rc = launch_fft_y(m, m->d_f, 0, s);
-    if (rc) return rc;
+    // x and y of a plane in one launch where the plane fits the LDS (k_fft_xy_*); MTD_FFT_XY=0 keeps the separate passes
+    XYPlan xy_f, xy_i;
+    size_t xy_lds_f = 0, xy_lds_i = 0;
+    static const bool xy_off = [] { const char *e = std::getenv("MTD_FFT_XY"); return e && e[0] == '0'; }();
+    const bool xy = !xy_off && xy_plan(m, 0, xy_f, xy_lds_f) && xy_plan(m, 1, xy_i, xy_lds_i);
+    if (xy)
+        {
+        static const hipError_t attr = [] {
+            hipError_t e = hipFuncSetAttribute((const void *)k_fft_xy_forward, hipFuncAttributeMaxDynamicSharedMemorySize, (int)XY_LDS_MAX);
+            return e != hipSuccess ? e : hipFuncSetAttribute((const void *)k_fft_xy_inverse, hipFuncAttributeMaxDynamicSharedMemorySize, (int)XY_LDS_MAX);
+        }();
+        MTD_HIP_TRY(attr);
+        k_fft_xy_forward<<<m->nz * XY_PARTS, XY_THREADS, xy_lds_f, s>>>(m->d_rho, m->d_f, m->d_tw[0], m->d_tw[1], xy_f);
+        MTD_LAUNCH_CHECK();
+        }
+    else
+        {
+        k_fft_x_r2c<<<x_blocks, FFT_THREADS, x_lds, s>>>(m->d_rho, m->d_f, m->d_tw[0], m->nx, ilog2(m->nx), x_tile, m->hxp, n_lines);
+        MTD_LAUNCH_CHECK();
+        rc = launch_fft_y(m, m->d_f, 0, s);
+        if (rc) return rc;
+        }
     const FftPass pz = fft_z_pass(m);
     SlabArgs none;
     std::memset(&none, 0, sizeof(none));
@@ -2079,10 +2506,18 @@ int mtd_mesh_spectral(mtd_mesh *m, const mtd_box *box, unsigned int n_global, co
     m->fourier_valid = m->keep_fourier;
     if (m->cv_event) MTD_HIP_TRY(hipEventRecord(m->cv_event, s));          // the CV partial sums are complete from here on
     MTD_LAUNCH_CHECK();
-    rc = launch_fft_y(m, m->d_g, 1, s);
-    if (rc) return rc;
-    k_fft_x_c2r<<<x_blocks, FFT_THREADS, x_lds, s>>>(m->d_g, m->d_inv, m->d_tw[0], m->nx, ilog2(m->nx), x_tile, m->hxp, n_lines);   // Re(inv)
-    MTD_LAUNCH_CHECK();
+    if (xy)
+        {
+        k_fft_xy_inverse<<<m->nz * XY_PARTS, XY_THREADS, xy_lds_i, s>>>(m->d_g, m->d_inv, m->d_tw[0], m->d_tw[1], xy_i);   // Re(inv)
+        MTD_LAUNCH_CHECK();
+        }
+    else
+        {
+        rc = launch_fft_y(m, m->d_g, 1, s);
+        if (rc) return rc;
+        k_fft_x_c2r<<<x_blocks, FFT_THREADS, x_lds, s>>>(m->d_g, m->d_inv, m->d_tw[0], m->nx, ilog2(m->nx), x_tile, m->hxp, n_lines);   // Re(inv)
+        MTD_LAUNCH_CHECK();
+        }
     *d_partials = m->d_cv_partials;
     *n_partials = m->n_cv_partials;
     return MTD_SUCCESS;
