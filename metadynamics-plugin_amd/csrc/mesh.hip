@@ -688,7 +688,7 @@ template<typename S4>
 __global__ __launch_bounds__(TP_THREADS) void k_tile_scatter(const MeshGeom g, const TileGeom tg, const S4 *__restrict__ postype,
                                                              const double *__restrict__ mode, const unsigned int *__restrict__ tile_total,
                                                              const unsigned int *__restrict__ ids, long long *__restrict__ tilebuf,
-                                                             double4 *__restrict__ packed, uint2 *__restrict__ idbase)
+                                                             double4 *__restrict__ packed)
     {
     __shared__ unsigned long long s_t[TP_HMAX];
     __shared__ unsigned int s_rng[8];
@@ -732,8 +732,8 @@ __global__ __launch_bounds__(TP_THREADS) void k_tile_scatter(const MeshGeom g, c
         const unsigned int base = (unsigned int)(ix - x0) + tg.hx * ((unsigned int)(iy - y0) + tg.hy * (unsigned int)(iz - z0));
         // the force pass of this snapshot walks the same tile order: in-cell shift, mode, id and the stencil's corner in
         // the tile image, stored in place (coalesced) so that it neither gathers nor locates again
-        packed[q] = make_double4(sx, sy, sz, a0);
-        idbase[q] = make_uint2(cur_id, base);
+        // (32 bytes: the fourth word carries id, type and corner as integers; 40-byte records cost the two passes ~3 us)
+        packed[q] = make_double4(sx, sy, sz, __hiloint2double((int)(base | ((unsigned int)cur.type << 16)), (int)cur_id));
 #pragma unroll
         for (int k = 0; k < 3; ++k)
 #pragma unroll
@@ -835,7 +835,7 @@ constexpr int TF_THREADS = 256;        // four blocks per CU (128 VGPRs): one st
 
 template<typename S4>
 __global__ __launch_bounds__(TF_THREADS) void k_tile_forces(const MeshGeom g, const TileGeom tg, const unsigned int *__restrict__ tile_total,
-                                                            const uint2 *__restrict__ idbase, const double4 *__restrict__ packed,
+                                                            const double *__restrict__ mode, const double4 *__restrict__ packed,
                                                             const double *__restrict__ inv, S4 *__restrict__ force,
                                                             const double *__restrict__ d_bias, const double bias_host,
                                                             const double two_over_n)
@@ -851,12 +851,7 @@ __global__ __launch_bounds__(TF_THREADS) void k_tile_forces(const MeshGeom g, co
     if (q0 == q1) return;
     unsigned int q = q0 + threadIdx.x;
     double4 pk = make_double4(0.0, 0.0, 0.0, 0.0);
-    uint2 ib = make_uint2(0u, 0u);
-    if (q < q1)
-        {
-        pk = packed[q];
-        ib = idbase[q];
-        }
+    if (q < q1) pk = packed[q];
     // Re(inv) of the tile + halo, row by row (32 lanes per row of <= 18 entries: no divisions in the loop)
     const unsigned int wxn = min(tg.tx, g.nx - x0) + 2, wyn = min(tg.ty, g.ny - y0) + 2, wzn = min(tg.tz, g.nz - z0) + 2;
     const unsigned int lx = threadIdx.x & 31;
@@ -907,14 +902,11 @@ __global__ __launch_bounds__(TF_THREADS) void k_tile_forces(const MeshGeom g, co
     while (q < q1)
         {
         const double4 cur = pk;
-        const uint2 cib = ib;
         const unsigned int qn = q + TF_THREADS;
-        if (qn < q1)
-            {
-            pk = packed[qn];
-            ib = idbase[qn];
-            }
-        const double a = cur.w, sx = cur.x, sy = cur.y, sz = cur.z;
+        if (qn < q1) pk = packed[qn];
+        const unsigned int bt = (unsigned int)__double2hiint(cur.w);          // the record of k_tile_scatter
+        const uint2 cib = make_uint2((unsigned int)__double2loint(cur.w), bt & 0xffffu);
+        const double a = mode[bt >> 16], sx = cur.x, sy = cur.y, sz = cur.z;
         double wxv[3], wyv[3], wzv[3], dxv[3], dyv[3], dzv[3];
         tsc3_deriv(sx, wxv, dxv);
         tsc3_deriv(sy, wyv, dyv);
@@ -2214,7 +2206,7 @@ int mtd_mesh_create(mtd_mesh **out, unsigned int nx, unsigned int ny, unsigned i
     const unsigned long long nt = (unsigned long long)tg.ntx * tg.nty * tg.ntz;
     tg.hx = tg.tx + 2; tg.hy = tg.ty + 2; tg.hz = tg.tz + 2; tg.hcells = tg.hx * tg.hy * tg.hz;
     const char *env = std::getenv("MTD_MESH_ASSIGN");
-    m->tile_path = nt <= TP_MAX_TILES && !(env && std::strcmp(env, "cells") == 0);
+    m->tile_path = nt <= TP_MAX_TILES && n_types <= 65536 && !(env && std::strcmp(env, "cells") == 0);   // (16 bits of a record hold the type)
     tg.n_tiles = m->tile_path ? (unsigned int)nt : 0;
     unsigned int nb = (max_particles + 4095) / 4096;
     m->tile_blocks_max = nb < 1 ? 1 : (nb > 1024 ? 1024 : nb);
@@ -2407,9 +2399,9 @@ static int mesh_assign_local(mtd_mesh *m, unsigned int n_particles, const void *
         k_tile_place<<<pb, 256, sizeof(unsigned int) * tg.n_tiles, s>>>(tg, N, m->d_cell_of, m->d_slot_of, m->d_start, m->d_tile_total, m->d_ids);
         MTD_LAUNCH_CHECK();
         if (dtype == MTD_F32)
-            k_tile_scatter<float4><<<tg.n_tiles, TP_THREADS, 0, s>>>(g, tg, (const float4 *)d_postype, m->d_mode, m->d_tile_total, m->d_ids, m->d_tilebuf, m->d_packed, m->d_idcell);
+            k_tile_scatter<float4><<<tg.n_tiles, TP_THREADS, 0, s>>>(g, tg, (const float4 *)d_postype, m->d_mode, m->d_tile_total, m->d_ids, m->d_tilebuf, m->d_packed);
         else
-            k_tile_scatter<double4><<<tg.n_tiles, TP_THREADS, 0, s>>>(g, tg, (const double4 *)d_postype, m->d_mode, m->d_tile_total, m->d_ids, m->d_tilebuf, m->d_packed, m->d_idcell);
+            k_tile_scatter<double4><<<tg.n_tiles, TP_THREADS, 0, s>>>(g, tg, (const double4 *)d_postype, m->d_mode, m->d_tile_total, m->d_ids, m->d_tilebuf, m->d_packed);
         MTD_LAUNCH_CHECK();
         {
         const unsigned int cthreads = m->nx >= 256 ? 256 : (m->nx > 64 ? 128 : 64);
@@ -2550,9 +2542,9 @@ int mtd_mesh_forces(mtd_mesh *m, unsigned int n_particles, const void *d_postype
     if (m->tile_path)
         {
         if (dtype == MTD_F32)
-            k_tile_forces<float4><<<m->tg.n_tiles, TF_THREADS, 0, s>>>(g, m->tg, m->d_tile_total, m->d_idcell, m->d_packed, m->d_inv, (float4 *)d_force, d_bias, bias_host, two_over_n);
+            k_tile_forces<float4><<<m->tg.n_tiles, TF_THREADS, 0, s>>>(g, m->tg, m->d_tile_total, m->d_mode, m->d_packed, m->d_inv, (float4 *)d_force, d_bias, bias_host, two_over_n);
         else
-            k_tile_forces<double4><<<m->tg.n_tiles, TF_THREADS, 0, s>>>(g, m->tg, m->d_tile_total, m->d_idcell, m->d_packed, m->d_inv, (double4 *)d_force, d_bias, bias_host, two_over_n);
+            k_tile_forces<double4><<<m->tg.n_tiles, TF_THREADS, 0, s>>>(g, m->tg, m->d_tile_total, m->d_mode, m->d_packed, m->d_inv, (double4 *)d_force, d_bias, bias_host, two_over_n);
         MTD_LAUNCH_CHECK();
         return MTD_SUCCESS;
         }
