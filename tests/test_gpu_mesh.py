@@ -88,7 +88,11 @@ def test_mesh_bitwise_independent_of_particle_order(abi):
                                        # sizes that are not powers of two (direct transforms, partial gather tiles, odd lengths)
                                        ((12, 20, 6), dict(xy=0.1, xz=0.05, yz=-0.2)), ((5, 7, 9), {}), ((48, 16, 36), {}),
                                        # one-cell edge tiles in x and y (the loop form of the combine pass; the others take the row form)
-                                       ((17, 33, 16), {})])
+                                       ((17, 33, 16), {}),
+                                       # corners of the one-launch x/y transform (k_fft_xy_*): one k_x column in a part, one line
+                                       # pair per batch, the longest lines whose planes still fit the LDS, planes that do not
+                                       ((4, 4, 4), {}), ((256, 8, 4), {}), ((4, 64, 8), dict(xy=-0.15, xz=0.1, yz=0.05)), ((64, 128, 16), {}),
+                                       ((512, 4, 8), {}), ((256, 256, 4), {})])
 def test_mesh_cv_and_forces(abi, ref, dtype, dims, tilt, assign_path):
     N = 6007
     Ls = (9.0, 7.5, 11.0)
