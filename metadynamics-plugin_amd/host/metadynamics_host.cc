@@ -245,9 +245,9 @@ void WellTemperedEnsemble::computeBiasForces(unsigned int)
 
 OrderParameterMeshGPU::OrderParameterMeshGPU(std::shared_ptr<SystemDefinition> sysdef, unsigned int nx, unsigned int ny,
                                              unsigned int nz, std::vector<double> mode, std::vector<int3> zero_modes)
-    : CollectiveVariable(sysdef, "mesh"), m_mesh(nullptr), m_mode(mode), m_zero_modes(zero_modes), m_k_min(0.0), m_k_max(0.0),
-      m_delta_k(0.0), m_use_table(false), m_is_first_step(true), m_partials(nullptr), m_n_partials(0), m_cv_last_updated(0),
-      m_cv(0.0), m_q_max_last_computed(0), m_q_max{0.0, 0.0, 0.0}, m_sq_max(0.0)
+    : CollectiveVariable(sysdef, "mesh"), m_keep_fourier(false), m_q_max_last_computed(0), m_q_max{0.0, 0.0, 0.0}, m_sq_max(0.0),
+      m_mesh(nullptr), m_mode(mode), m_zero_modes(zero_modes), m_k_min(0.0), m_k_max(0.0), m_delta_k(0.0), m_use_table(false),
+      m_is_first_step(true), m_partials(nullptr), m_n_partials(0), m_cv_last_updated(0), m_cv(0.0)
     {
     if (mode.size() != m_pdata->getNTypes()) throw std::runtime_error("Error setting up cv.mesh");   // OrderParameterMesh.cc:44-49
     int rc = mtd_mesh_create(&m_mesh, nx, ny, nz, mode.data(), (unsigned int)mode.size(), m_pdata->getN());
