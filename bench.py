@@ -373,7 +373,7 @@ def main():
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
-        torch.cuda.synchronize()
+            torch.cuda.synchronize()
 
     np_dtype = np.float32 if args.dtype == "f32" else np.float64
     # the event-bracketed pass over the dominant kernel always goes through the C-ABI backend (same kernels)
