@@ -51,6 +51,33 @@ namespace
 
 using namespace mtd;
 
+// Non-temporal stores stream an output array out while the kernel runs; left dirty in the L2s it is written back when the
+// kernel ends, on its tail.  That pays for the transforms' outputs (fused z pass 17.9 -> 15.7 us with its 19 MB, the reader
+// 16.7 -> 17.1) and NOT where the next kernel finds the data in the L2s: the records of the scatter pass (force pass 26.7 ->
+// 35.1 us), the per-tile buffers (combine 10.8 -> 13.7), the count kernel's arrays (place 14.4 -> 19.1), and not for the
+// scattered 16-byte force stores (26.7 -> 42.3).
+typedef double v2d_t __attribute__((ext_vector_type(2)));
+typedef float v4f_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void nt_store(const double2 v, double2 *p)
+    {
+    const v2d_t x = { v.x, v.y };
+    __builtin_nontemporal_store(x, (v2d_t *)p);
+    }
+__device__ __forceinline__ void nt_store(const double4 v, double4 *p)
+    {
+    const v2d_t x = { v.x, v.y }, y = { v.z, v.w };
+    __builtin_nontemporal_store(x, (v2d_t *)p);
+    __builtin_nontemporal_store(y, (v2d_t *)p + 1);
+    }
+__device__ __forceinline__ void nt_store(const float4 v, float4 *p)
+    {
+    const v4f_t x = { v.x, v.y, v.z, v.w };
+    __builtin_nontemporal_store(x, (v4f_t *)p);
+    }
+__device__ __forceinline__ void nt_store(const double v, double *p) { __builtin_nontemporal_store(v, p); }
+__device__ __forceinline__ void nt_store(const long long v, long long *p) { __builtin_nontemporal_store(v, p); }
+__device__ __forceinline__ void nt_store(const unsigned int v, unsigned int *p) { __builtin_nontemporal_store(v, p); }
+
 struct MeshGeom
     {
     unsigned int nx, ny, nz, n_cells;
@@ -1539,8 +1566,8 @@ __global__ __launch_bounds__(XY_THREADS) void k_fft_xy_forward(const double *__r
         dk.split(idx, ky, kl);
         const double2 v = Y[ky * ys + kl];
         double *o = (double *)(half_out + (line_base + ky) * pl.hxp + k0 + kl);
-        __builtin_nontemporal_store(v.x, o);         // streamed out: nothing left for the write-back at the end of the kernel
-        __builtin_nontemporal_store(v.y, o + 1);
+        nt_store(v.x, o);                            // streamed out: nothing left for the write-back at the end of the kernel
+        nt_store(v.y, o + 1);
         }
     XY_STAMP(0, 8);
     }
@@ -1771,7 +1798,9 @@ __global__ __launch_bounds__(FFT_THREADS) void k_fft_z_spectral(const MeshGeom g
         if (DIST)
             gmesh[((size_t)z * sl.ny_loc + (wy - sl.y0)) * g.hxp + x_first + t] = s[q * tile + t];
         else
-            gmesh[base + t + (size_t)z * plane] = s[q * tile + t];
+            {
+            nt_store(s[q * tile + t], gmesh + base + t + (size_t)z * plane);
+            }
         }
     term = block_sum(term, s_red);
     if (threadIdx.x == 0) cv_partials[blockIdx.x] = term;
@@ -2472,14 +2501,16 @@ int mtd_mesh_spectral(mtd_mesh *m, const mtd_box *box, unsigned int n_global, co
     XYPlan xy_f, xy_i;
     size_t xy_lds_f = 0, xy_lds_i = 0;
     static const bool xy_off = [] { const char *e = std::getenv("MTD_FFT_XY"); return e && e[0] == '0'; }();
-    const bool xy = !xy_off && xy_plan(m, 0, xy_f, xy_lds_f) && xy_plan(m, 1, xy_i, xy_lds_i);
+    // (a runtime that refuses the 160 KB of dynamic LDS leaves the separate passes, it does not fail the step)
+    static const bool xy_lds_ok = [] {
+        hipError_t e = hipFuncSetAttribute((const void *)k_fft_xy_forward, hipFuncAttributeMaxDynamicSharedMemorySize, (int)XY_LDS_MAX);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_fft_xy_inverse, hipFuncAttributeMaxDynamicSharedMemorySize, (int)XY_LDS_MAX);
+        if (e != hipSuccess) (void)hipGetLastError();
+        return e == hipSuccess;
+    }();
+    const bool xy = !xy_off && xy_lds_ok && xy_plan(m, 0, xy_f, xy_lds_f) && xy_plan(m, 1, xy_i, xy_lds_i);
     if (xy)
         {
-        static const hipError_t attr = [] {
-            hipError_t e = hipFuncSetAttribute((const void *)k_fft_xy_forward, hipFuncAttributeMaxDynamicSharedMemorySize, (int)XY_LDS_MAX);
-            return e != hipSuccess ? e : hipFuncSetAttribute((const void *)k_fft_xy_inverse, hipFuncAttributeMaxDynamicSharedMemorySize, (int)XY_LDS_MAX);
-        }();
-        MTD_HIP_TRY(attr);
         k_fft_xy_forward<<<m->nz * XY_PARTS, XY_THREADS, xy_lds_f, s>>>(m->d_rho, m->d_f, m->d_tw[0], m->d_tw[1], xy_f);
         MTD_LAUNCH_CHECK();
         }
