@@ -215,23 +215,6 @@ __device__ __forceinline__ void lam_cv_block_reduce(const float (&acc)[NCV], dou
         }
     }
 
-// Force arrays are written once per step and not re-read by this library: non-temporal stores keep
-// 32 MB of dirty lines out of the L2s, whose write-back otherwise lands on the kernel's tail (measured:
-// -1.9 us per step at 10^6 particles, 2 CVs).
-__device__ __forceinline__ void nt_store(const float4 v, float4 *p)
-    {
-    typedef float v4f __attribute__((ext_vector_type(4)));
-    v4f x = { v.x, v.y, v.z, v.w };
-    __builtin_nontemporal_store(x, (v4f *)p);
-    }
-__device__ __forceinline__ void nt_store(const double4 v, double4 *p)
-    {
-    typedef double v2d __attribute__((ext_vector_type(2)));
-    v2d x = { v.x, v.y }, y = { v.z, v.w };
-    __builtin_nontemporal_store(x, (v2d *)p);
-    __builtin_nontemporal_store(y, (v2d *)p + 1);
-    }
-
 // Forces of every fused CV for this thread's particles.  s_wcoef[c*MTD_MAX_TYPES + type] must hold
 // a_c(type) * bias_c * 2 / N_global (LamellarOrderParameter.cc:120-133 folded into one factor).
 template<typename S4, bool FAST, int U>

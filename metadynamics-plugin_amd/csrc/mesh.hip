@@ -51,32 +51,10 @@ namespace
 
 using namespace mtd;
 
-// Non-temporal stores stream an output array out while the kernel runs; left dirty in the L2s it is written back when the
-// kernel ends, on its tail.  That pays for the transforms' outputs (fused z pass 17.9 -> 15.7 us with its 19 MB, the reader
-// 16.7 -> 17.1) and NOT where the next kernel finds the data in the L2s: the records of the scatter pass (force pass 26.7 ->
-// 35.1 us), the per-tile buffers (combine 10.8 -> 13.7), the count kernel's arrays (place 14.4 -> 19.1), and not for the
-// scattered 16-byte force stores (26.7 -> 42.3).
-typedef double v2d_t __attribute__((ext_vector_type(2)));
-typedef float v4f_t __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void nt_store(const double2 v, double2 *p)
-    {
-    const v2d_t x = { v.x, v.y };
-    __builtin_nontemporal_store(x, (v2d_t *)p);
-    }
-__device__ __forceinline__ void nt_store(const double4 v, double4 *p)
-    {
-    const v2d_t x = { v.x, v.y }, y = { v.z, v.w };
-    __builtin_nontemporal_store(x, (v2d_t *)p);
-    __builtin_nontemporal_store(y, (v2d_t *)p + 1);
-    }
-__device__ __forceinline__ void nt_store(const float4 v, float4 *p)
-    {
-    const v4f_t x = { v.x, v.y, v.z, v.w };
-    __builtin_nontemporal_store(x, (v4f_t *)p);
-    }
-__device__ __forceinline__ void nt_store(const double v, double *p) { __builtin_nontemporal_store(v, p); }
-__device__ __forceinline__ void nt_store(const long long v, long long *p) { __builtin_nontemporal_store(v, p); }
-__device__ __forceinline__ void nt_store(const unsigned int v, unsigned int *p) { __builtin_nontemporal_store(v, p); }
+// Non-temporal stores (nt_store, mtd_device.hpp) in this file: they pay for the transforms' outputs (fused z pass 17.9 -> 15.7 us
+// with its 19 MB, the reader 16.7 -> 17.1) and NOT where the next kernel finds the data in the L2s: the records of the scatter
+// pass (force pass 26.7 -> 35.1 us), the per-tile buffers (combine 10.8 -> 13.7), the count kernel's arrays (place 14.4 ->
+// 19.1), and not for the scattered 16-byte force stores (26.7 -> 42.3).
 
 struct MeshGeom
     {

@@ -59,6 +59,31 @@ __device__ __forceinline__ double block_sum(double v, double *s_red)
     return r;
     }
 
+// ---- non-temporal stores ---------------------------------------------------------------------------
+// An array that a kernel writes once and nothing in the L2s is waiting for (force arrays: not re-read by this library) is
+// streamed out while the kernel runs; left dirty in the L2s it is written back when the kernel ends, on its tail (measured:
+// -1.9 us per step for the 32 MB of the headline force pass, 17.9 -> 15.7 us for the mesh's fused z pass).  Output that the
+// NEXT kernel reads is better left where it is (mesh.hip: the L2s are not emptied between the launches of a stream).
+typedef double mtd_v2d __attribute__((ext_vector_type(2)));
+typedef float mtd_v4f __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void nt_store(const float4 v, float4 *p)
+    {
+    const mtd_v4f x = { v.x, v.y, v.z, v.w };
+    __builtin_nontemporal_store(x, (mtd_v4f *)p);
+    }
+__device__ __forceinline__ void nt_store(const double4 v, double4 *p)
+    {
+    const mtd_v2d x = { v.x, v.y }, y = { v.z, v.w };
+    __builtin_nontemporal_store(x, (mtd_v2d *)p);
+    __builtin_nontemporal_store(y, (mtd_v2d *)p + 1);
+    }
+__device__ __forceinline__ void nt_store(const double2 v, double2 *p)
+    {
+    const mtd_v2d x = { v.x, v.y };
+    __builtin_nontemporal_store(x, (mtd_v2d *)p);
+    }
+__device__ __forceinline__ void nt_store(const double v, double *p) { __builtin_nontemporal_store(v, p); }
+
 // ---- particle loads: Scalar4 with the type id bit-cast into w -----------------------------------
 
 struct Particle

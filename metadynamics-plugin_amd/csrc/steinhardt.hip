@@ -666,7 +666,7 @@ __global__ __launch_bounds__(QL_THREADS, (LMAX <= 6 ? 4 : 2)) void k_ql_forces(c
                     atomicAdd(fi + 2, (scalar)Fz);
                     }
                 else
-                    force[i] = scalar4_traits<S4>::make((scalar)Fx, (scalar)Fy, (scalar)Fz, (scalar)0);
+                    nt_store(scalar4_traits<S4>::make((scalar)Fx, (scalar)Fy, (scalar)Fz, (scalar)0), force + i);   // written once, not re-read here
                 }
             }
         }
