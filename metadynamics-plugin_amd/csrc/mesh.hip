@@ -625,28 +625,11 @@ __global__ __launch_bounds__(256) void k_tile_rowscan(const unsigned int *__rest
     if (threadIdx.x == 255) tile_total[blockIdx.x] = wave_off + incl;
     }
 
-// first particle slot of tile t (and of tile t + 1): the totals of the tiles in front, added up by the whole block in a
-// fixed order.  s_red: >= 8 unsigned ints of shared memory.  Result valid in every thread.
-__device__ __forceinline__ void tile_range(const unsigned int *__restrict__ tile_total, const unsigned int t, unsigned int &q0,
-                                           unsigned int &q1, unsigned int *s_red)
-    {
-    unsigned int v = 0;
-    for (unsigned int i = threadIdx.x; i < t; i += blockDim.x) v += tile_total[i];
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-    __syncthreads();
-    if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = v;
-    __syncthreads();
-    unsigned int r = 0;
-    for (unsigned int w = 0; w < (blockDim.x >> 6); ++w) r += s_red[w];
-    q0 = r;
-    q1 = r + tile_total[t];
-    }
-
 // 3b. place: particle id -> its tile's segment.  A block keeps the prefix over the tile totals in LDS.
 __global__ __launch_bounds__(256) void k_tile_place(const TileGeom tg, const unsigned int N, const unsigned int *__restrict__ tile_of,
                                                     const unsigned int *__restrict__ slot_of, const unsigned int *__restrict__ rowscan,
-                                                    const unsigned int *__restrict__ tile_total, unsigned int *__restrict__ ids)
+                                                    const unsigned int *__restrict__ tile_total, unsigned int *__restrict__ ids,
+                                                    unsigned int *__restrict__ tile_first)
     {
     extern __shared__ unsigned int s_first[];                    // [n_tiles]: first slot of every tile
     __shared__ unsigned int s_wsum[4];
@@ -676,6 +659,7 @@ __global__ __launch_bounds__(256) void k_tile_place(const TileGeom tg, const uns
         if (t < tg.n_tiles)
             {
             s_first[t] = run;
+            if (blockIdx.x == 0) tile_first[t] = run;                // for the scatter and force kernels: one load instead of a prefix
             run += tile_total[t];
             }
         }
@@ -692,16 +676,15 @@ __global__ __launch_bounds__(256) void k_tile_place(const TileGeom tg, const uns
 template<typename S4>
 __global__ __launch_bounds__(TP_THREADS) void k_tile_scatter(const MeshGeom g, const TileGeom tg, const S4 *__restrict__ postype,
                                                              const double *__restrict__ mode, const unsigned int *__restrict__ tile_total,
+                                                             const unsigned int *__restrict__ tile_first,
                                                              const unsigned int *__restrict__ ids, long long *__restrict__ tilebuf,
                                                              double4 *__restrict__ packed)
     {
     __shared__ unsigned long long s_t[TP_HMAX];
-    __shared__ unsigned int s_rng[8];
     const unsigned int t = blockIdx.x;
     const unsigned int tix = t % tg.ntx, tiy = (t / tg.ntx) % tg.nty, tiz = t / (tg.ntx * tg.nty);
     const int x0 = tix * tg.tx, y0 = tiy * tg.ty, z0 = tiz * tg.tz;
-    unsigned int q0, q1;
-    tile_range(tile_total, t, q0, q1, s_rng);
+    const unsigned int q0 = tile_first[t], q1 = q0 + tile_total[t];  // (k_tile_place, k_tile_rowscan)
     // the first particle is requested before the LDS image is cleared
     unsigned int q = q0 + threadIdx.x;
     unsigned int id = 0;
@@ -840,6 +823,7 @@ constexpr int TF_THREADS = 256;        // four blocks per CU (128 VGPRs): one st
 
 template<typename S4>
 __global__ __launch_bounds__(TF_THREADS) void k_tile_forces(const MeshGeom g, const TileGeom tg, const unsigned int *__restrict__ tile_total,
+                                                            const unsigned int *__restrict__ tile_first,
                                                             const double *__restrict__ mode, const double4 *__restrict__ packed,
                                                             const double *__restrict__ inv, S4 *__restrict__ force,
                                                             const double *__restrict__ d_bias, const double bias_host,
@@ -847,12 +831,10 @@ __global__ __launch_bounds__(TF_THREADS) void k_tile_forces(const MeshGeom g, co
     {
     typedef typename scalar4_traits<S4>::scalar scalar;
     __shared__ double s_inv[TP_HMAX];
-    __shared__ unsigned int s_rng[8];
     const unsigned int t = blockIdx.x;
     const unsigned int tix = t % tg.ntx, tiy = (t / tg.ntx) % tg.nty, tiz = t / (tg.ntx * tg.nty);
     const int x0 = tix * tg.tx, y0 = tiy * tg.ty, z0 = tiz * tg.tz;
-    unsigned int q0, q1;
-    tile_range(tile_total, t, q0, q1, s_rng);
+    const unsigned int q0 = tile_first[t], q1 = q0 + tile_total[t];
     if (q0 == q1) return;
     unsigned int q = q0 + threadIdx.x;
     double4 pk = make_double4(0.0, 0.0, 0.0, 0.0);
@@ -2044,6 +2026,7 @@ struct mtd_mesh
     double4 *d_packed;
     unsigned int *d_cell_of, *d_slot_of, *d_count, *d_start, *d_tile_sums;
     unsigned int *d_tile_total;    // tile path: particles per tile (k_tile_rowscan); d_start then holds the row scans
+    unsigned int *d_tile_first;    // first slot of every tile in the tile-ordered arrays (k_tile_place)
     uint2 *d_idcell;           // (particle id, cell) of every sorted slot
     unsigned int n_last;   // particle count of the last compute_cv (the sorted list the force pass walks)
     // convolution-kernel table (setTable, :148-189): K is stored and never applied (Q7); K' enters the virial
@@ -2233,7 +2216,7 @@ int mtd_mesh_create(mtd_mesh **out, unsigned int nx, unsigned int ny, unsigned i
                  o_inv = take(sizeof(double) * M), o_slot = take(sizeof(unsigned int) * N),
                  o_itab = take(sizeof(double) * (nx + ny + nz)),
                  o_tilebuf = take(sizeof(long long) * (size_t)m->tg.n_tiles * m->tg.hcells), o_ids2 = take(sizeof(unsigned int) * N),
-                 o_tsrc = take(sizeof(uint4) * (nx + ny + nz)), o_ttot = take(sizeof(unsigned int) * ((size_t)m->tg.n_tiles + 1));
+                 o_tsrc = take(sizeof(uint4) * (nx + ny + nz)), o_ttot = take(sizeof(unsigned int) * 2 * ((size_t)m->tg.n_tiles + 1));
     hipError_t e = hipMalloc(&m->slab, off);
     if (e != hipSuccess)
         {
@@ -2256,6 +2239,7 @@ int mtd_mesh_create(mtd_mesh **out, unsigned int nx, unsigned int ny, unsigned i
     m->d_ids = (unsigned int *)(p + o_ids2);
     m->d_tsrc = (uint4 *)(p + o_tsrc);
     m->d_tile_total = (unsigned int *)(p + o_ttot);
+    m->d_tile_first = m->d_tile_total + m->tg.n_tiles + 1;
     e = hipMemset(m->slab, 0, off);
     if (e == hipSuccess && m->tile_path)
         {
@@ -2403,12 +2387,12 @@ static int mesh_assign_local(mtd_mesh *m, unsigned int n_particles, const void *
         MTD_LAUNCH_CHECK();
         unsigned int pb = (N + 1023) / 1024;                        // >= four particles per thread: the LDS prefix of the tile totals is formed once per block
         pb = pb < 1 ? 1 : (pb > 512 ? 512 : pb);
-        k_tile_place<<<pb, 256, sizeof(unsigned int) * tg.n_tiles, s>>>(tg, N, m->d_cell_of, m->d_slot_of, m->d_start, m->d_tile_total, m->d_ids);
+        k_tile_place<<<pb, 256, sizeof(unsigned int) * tg.n_tiles, s>>>(tg, N, m->d_cell_of, m->d_slot_of, m->d_start, m->d_tile_total, m->d_ids, m->d_tile_first);
         MTD_LAUNCH_CHECK();
         if (dtype == MTD_F32)
-            k_tile_scatter<float4><<<tg.n_tiles, TP_THREADS, 0, s>>>(g, tg, (const float4 *)d_postype, m->d_mode, m->d_tile_total, m->d_ids, m->d_tilebuf, m->d_packed);
+            k_tile_scatter<float4><<<tg.n_tiles, TP_THREADS, 0, s>>>(g, tg, (const float4 *)d_postype, m->d_mode, m->d_tile_total, m->d_tile_first, m->d_ids, m->d_tilebuf, m->d_packed);
         else
-            k_tile_scatter<double4><<<tg.n_tiles, TP_THREADS, 0, s>>>(g, tg, (const double4 *)d_postype, m->d_mode, m->d_tile_total, m->d_ids, m->d_tilebuf, m->d_packed);
+            k_tile_scatter<double4><<<tg.n_tiles, TP_THREADS, 0, s>>>(g, tg, (const double4 *)d_postype, m->d_mode, m->d_tile_total, m->d_tile_first, m->d_ids, m->d_tilebuf, m->d_packed);
         MTD_LAUNCH_CHECK();
         {
         const unsigned int cthreads = m->nx >= 256 ? 256 : (m->nx > 64 ? 128 : 64);
@@ -2551,9 +2535,9 @@ int mtd_mesh_forces(mtd_mesh *m, unsigned int n_particles, const void *d_postype
     if (m->tile_path)
         {
         if (dtype == MTD_F32)
-            k_tile_forces<float4><<<m->tg.n_tiles, TF_THREADS, 0, s>>>(g, m->tg, m->d_tile_total, m->d_mode, m->d_packed, m->d_inv, (float4 *)d_force, d_bias, bias_host, two_over_n);
+            k_tile_forces<float4><<<m->tg.n_tiles, TF_THREADS, 0, s>>>(g, m->tg, m->d_tile_total, m->d_tile_first, m->d_mode, m->d_packed, m->d_inv, (float4 *)d_force, d_bias, bias_host, two_over_n);
         else
-            k_tile_forces<double4><<<m->tg.n_tiles, TF_THREADS, 0, s>>>(g, m->tg, m->d_tile_total, m->d_mode, m->d_packed, m->d_inv, (double4 *)d_force, d_bias, bias_host, two_over_n);
+            k_tile_forces<double4><<<m->tg.n_tiles, TF_THREADS, 0, s>>>(g, m->tg, m->d_tile_total, m->d_tile_first, m->d_mode, m->d_packed, m->d_inv, (double4 *)d_force, d_bias, bias_host, two_over_n);
         MTD_LAUNCH_CHECK();
         return MTD_SUCCESS;
         }
