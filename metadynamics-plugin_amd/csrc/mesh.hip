@@ -544,6 +544,26 @@ struct TileGeom
     double scale, inv_scale;                    // fixed point 2^k and 2^-k
     };
 
+// Diagnostic build only (-DMTD_STAMPS, tools/stamps_tiles.py): per-block time stamps of the scatter and the force pass
+#ifdef MTD_STAMPS
+__device__ unsigned long long g_tile_stamps[2][8][1024];
+#define TILE_STAMP(k, row) do { if (threadIdx.x == 0 && blockIdx.x < 1024) g_tile_stamps[k][row][blockIdx.x] = wall_clock64(); } while (0)
+#else
+#define TILE_STAMP(k, row) do { } while (0)
+#endif
+
+// The mode coefficients of the first TP_MODE_LDS types in LDS: looked up by a type that has just arrived from memory, a global
+// table costs every trip of the particle loops another dependent round trip.
+constexpr unsigned int TP_MODE_LDS = 32;
+__device__ __forceinline__ void stage_modes(double *s_mode, const double *__restrict__ mode, const unsigned int n_types)
+    {
+    if (threadIdx.x < TP_MODE_LDS) s_mode[threadIdx.x] = threadIdx.x < n_types ? mode[threadIdx.x] : 0.0;
+    }
+__device__ __forceinline__ double mode_of(const double *s_mode, const double *__restrict__ mode, const unsigned int type)
+    {
+    return type < TP_MODE_LDS ? s_mode[type] : mode[type];
+    }
+
 constexpr int TC_THREADS = 1024;       // one block per CU at 10^6 particles: 16 waves hide the load -> locate -> LDS atomic chain
 
 template<typename S4>
@@ -678,38 +698,46 @@ __global__ __launch_bounds__(TP_THREADS) void k_tile_scatter(const MeshGeom g, c
                                                              const double *__restrict__ mode, const unsigned int *__restrict__ tile_total,
                                                              const unsigned int *__restrict__ tile_first,
                                                              const unsigned int *__restrict__ ids, long long *__restrict__ tilebuf,
-                                                             double4 *__restrict__ packed)
+                                                             double4 *__restrict__ packed, const unsigned int n_types)
     {
     __shared__ unsigned long long s_t[TP_HMAX];
+    __shared__ double s_mode[TP_MODE_LDS];
     const unsigned int t = blockIdx.x;
     const unsigned int tix = t % tg.ntx, tiy = (t / tg.ntx) % tg.nty, tiz = t / (tg.ntx * tg.nty);
     const int x0 = tix * tg.tx, y0 = tiy * tg.ty, z0 = tiz * tg.tz;
+    TILE_STAMP(0, 0);
     const unsigned int q0 = tile_first[t], q1 = q0 + tile_total[t];  // (k_tile_place, k_tile_rowscan)
-    // the first particle is requested before the LDS image is cleared
+    // Software pipeline over the thread's particles: ids run two particles ahead, positions one, and the position travels RAW
+    // (as loaded) to the iteration that uses it.  Carried as a converted Particle it was waited for right behind its load — the
+    // conversion to double sat there — and every trip paid the id -> position chain of two memory round trips in full.
+    // The loads are unconditional (slots clamped to the tile's last one, which exists: the loop runs only if q < q1): behind a
+    // branch the compiler cannot count them and waits for all of them at the first use of any.
     unsigned int q = q0 + threadIdx.x;
-    unsigned int id = 0;
-    Particle p;
-    if (q < q1)
-        {
-        id = ids[q];
-        p = scalar4_traits<S4>::load(postype, id);
+    const unsigned int q_last = q1 ? q1 - 1 : 0u;
+    unsigned int id = 0, id_next = 0;
+    S4 raw = scalar4_traits<S4>::make(0, 0, 0, 0);
+    if (q0 < q1)                                                     // (uniform over the block; an empty tile — or no particles at
+        {                                                            // all, and then no position array either — loads nothing)
+        id = ids[min(q, q_last)];
+        id_next = ids[min(q + TP_THREADS, q_last)];
+        raw = postype[id];
         }
+    stage_modes(s_mode, mode, n_types);
     for (unsigned int e = threadIdx.x; e < tg.hcells; e += TP_THREADS) s_t[e] = 0ull;
     __syncthreads();
+    TILE_STAMP(0, 1);
     while (q < q1)
         {
-        const Particle cur = p;
+        const Particle cur = scalar4_traits<S4>::unpack(raw);
         const unsigned int cur_id = id;
         const unsigned int qn = q + TP_THREADS;
-        if (qn < q1)
-            {
-            id = ids[qn];
-            p = scalar4_traits<S4>::load(postype, id);
-            }
+        raw = postype[id_next];
+        id = id_next;
+        id_next = ids[min(qn + TP_THREADS, q_last)];
         int ix, iy, iz;
         double sx, sy, sz;
         locate(g, cur, ix, iy, iz, sx, sy, sz);
-        const double a0 = mode[cur.type];
+        const double a0 = mode_of(s_mode, mode, (unsigned int)cur.type);
         const double a = a0 * tg.scale;
         double wx[3], wy[3], wz[3];
         tsc3(sx, wx);
@@ -738,10 +766,14 @@ __global__ __launch_bounds__(TP_THREADS) void k_tile_scatter(const MeshGeom g, c
                     atomicAdd(&s_t[row + i], (unsigned long long)(__double_as_longlong(shifted) - 0x4338000000000000ll));
                     }
                 }
+        if (q == q0 + threadIdx.x) TILE_STAMP(0, 2);                   // first particle of thread 0 done
         q = qn;
         }
+    TILE_STAMP(0, 3);
     __syncthreads();
+    TILE_STAMP(0, 4);
     for (unsigned int e = threadIdx.x; e < tg.hcells; e += TP_THREADS) tilebuf[(size_t)t * tg.hcells + e] = (long long)s_t[e];
+    TILE_STAMP(0, 5);
     }
 
 // Which entries of the per-tile buffers stand for a mesh cell: along one axis coordinate c is held by its own tile, by the
@@ -827,13 +859,16 @@ __global__ __launch_bounds__(TF_THREADS) void k_tile_forces(const MeshGeom g, co
                                                             const double *__restrict__ mode, const double4 *__restrict__ packed,
                                                             const double *__restrict__ inv, S4 *__restrict__ force,
                                                             const double *__restrict__ d_bias, const double bias_host,
-                                                            const double two_over_n)
+                                                            const double two_over_n, const unsigned int n_types)
     {
     typedef typename scalar4_traits<S4>::scalar scalar;
     __shared__ double s_inv[TP_HMAX];
+    __shared__ double s_mode[TP_MODE_LDS];
+    stage_modes(s_mode, mode, n_types);                              // (published by the barrier behind the staging of Re(inv))
     const unsigned int t = blockIdx.x;
     const unsigned int tix = t % tg.ntx, tiy = (t / tg.ntx) % tg.nty, tiz = t / (tg.ntx * tg.nty);
     const int x0 = tix * tg.tx, y0 = tiy * tg.ty, z0 = tiz * tg.tz;
+    TILE_STAMP(1, 0);
     const unsigned int q0 = tile_first[t], q1 = q0 + tile_total[t];
     if (q0 == q1) return;
     unsigned int q = q0 + threadIdx.x;
@@ -884,6 +919,7 @@ __global__ __launch_bounds__(TF_THREADS) void k_tile_forces(const MeshGeom g, co
     for (int r = 0; r < TF_ROWS; ++r)
         if (srow[r] != ~0u) s_inv[srow[r]] = v[r];
     __syncthreads();
+    TILE_STAMP(1, 1);
     const double bias = d_bias ? *d_bias : bias_host;
     const double s = two_over_n * bias;                                // :861
     while (q < q1)
@@ -893,7 +929,7 @@ __global__ __launch_bounds__(TF_THREADS) void k_tile_forces(const MeshGeom g, co
         if (qn < q1) pk = packed[qn];
         const unsigned int bt = (unsigned int)__double2hiint(cur.w);          // the record of k_tile_scatter
         const uint2 cib = make_uint2((unsigned int)__double2loint(cur.w), bt & 0xffffu);
-        const double a = mode[bt >> 16], sx = cur.x, sy = cur.y, sz = cur.z;
+        const double a = mode_of(s_mode, mode, bt >> 16), sx = cur.x, sy = cur.y, sz = cur.z;
         double wxv[3], wyv[3], wzv[3], dxv[3], dyv[3], dzv[3];
         tsc3_deriv(sx, wxv, dxv);
         tsc3_deriv(sy, wyv, dyv);
@@ -925,8 +961,10 @@ __global__ __launch_bounds__(TF_THREADS) void k_tile_forces(const MeshGeom g, co
         const double fy = (c1 * g.binv[0][1] + c2 * g.binv[1][1] + c3 * g.binv[2][1]) * s;
         const double fz = (c1 * g.binv[0][2] + c2 * g.binv[1][2] + c3 * g.binv[2][2]) * s;
         force[cib.x] = scalar4_traits<S4>::make((scalar)fx, (scalar)fy, (scalar)fz, (scalar)0);
+        if (q == q0 + threadIdx.x) TILE_STAMP(1, 2);
         q = qn;
         }
+    TILE_STAMP(1, 3);
     }
 
 // ---- 6/8. DFT of lines staged in LDS ---------------------------------------------------------------
@@ -2153,6 +2191,10 @@ bool xy_plan(const mtd_mesh *m, int inverse, XYPlan &pl, size_t &lds)
 } // namespace
 
 #ifdef MTD_STAMPS
+extern "C" int mtd_debug_read_tile_stamps(unsigned long long *host)
+    {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_tile_stamps), sizeof(unsigned long long) * 2 * 8 * 1024);
+    }
 extern "C" int mtd_debug_read_xy_stamps(unsigned long long *host)
     {
     return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_xy_stamps), sizeof(unsigned long long) * 2 * 16 * 256);
@@ -2390,9 +2432,9 @@ static int mesh_assign_local(mtd_mesh *m, unsigned int n_particles, const void *
         k_tile_place<<<pb, 256, sizeof(unsigned int) * tg.n_tiles, s>>>(tg, N, m->d_cell_of, m->d_slot_of, m->d_start, m->d_tile_total, m->d_ids, m->d_tile_first);
         MTD_LAUNCH_CHECK();
         if (dtype == MTD_F32)
-            k_tile_scatter<float4><<<tg.n_tiles, TP_THREADS, 0, s>>>(g, tg, (const float4 *)d_postype, m->d_mode, m->d_tile_total, m->d_tile_first, m->d_ids, m->d_tilebuf, m->d_packed);
+            k_tile_scatter<float4><<<tg.n_tiles, TP_THREADS, 0, s>>>(g, tg, (const float4 *)d_postype, m->d_mode, m->d_tile_total, m->d_tile_first, m->d_ids, m->d_tilebuf, m->d_packed, m->n_types);
         else
-            k_tile_scatter<double4><<<tg.n_tiles, TP_THREADS, 0, s>>>(g, tg, (const double4 *)d_postype, m->d_mode, m->d_tile_total, m->d_tile_first, m->d_ids, m->d_tilebuf, m->d_packed);
+            k_tile_scatter<double4><<<tg.n_tiles, TP_THREADS, 0, s>>>(g, tg, (const double4 *)d_postype, m->d_mode, m->d_tile_total, m->d_tile_first, m->d_ids, m->d_tilebuf, m->d_packed, m->n_types);
         MTD_LAUNCH_CHECK();
         {
         const unsigned int cthreads = m->nx >= 256 ? 256 : (m->nx > 64 ? 128 : 64);
@@ -2535,9 +2577,9 @@ int mtd_mesh_forces(mtd_mesh *m, unsigned int n_particles, const void *d_postype
     if (m->tile_path)
         {
         if (dtype == MTD_F32)
-            k_tile_forces<float4><<<m->tg.n_tiles, TF_THREADS, 0, s>>>(g, m->tg, m->d_tile_total, m->d_tile_first, m->d_mode, m->d_packed, m->d_inv, (float4 *)d_force, d_bias, bias_host, two_over_n);
+            k_tile_forces<float4><<<m->tg.n_tiles, TF_THREADS, 0, s>>>(g, m->tg, m->d_tile_total, m->d_tile_first, m->d_mode, m->d_packed, m->d_inv, (float4 *)d_force, d_bias, bias_host, two_over_n, m->n_types);
         else
-            k_tile_forces<double4><<<m->tg.n_tiles, TF_THREADS, 0, s>>>(g, m->tg, m->d_tile_total, m->d_tile_first, m->d_mode, m->d_packed, m->d_inv, (double4 *)d_force, d_bias, bias_host, two_over_n);
+            k_tile_forces<double4><<<m->tg.n_tiles, TF_THREADS, 0, s>>>(g, m->tg, m->d_tile_total, m->d_tile_first, m->d_mode, m->d_packed, m->d_inv, (double4 *)d_force, d_bias, bias_host, two_over_n, m->n_types);
         MTD_LAUNCH_CHECK();
         return MTD_SUCCESS;
         }

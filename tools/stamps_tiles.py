@@ -1,0 +1,37 @@
+#!/usr/bin/env python3
+"""Developer tool: where the 1024 blocks of k_tile_scatter / k_tile_forces (mesh.hip) spend their time; needs the -DMTD_STAMPS
+diagnostic library (tools/build_stamps.sh).  s_memrealtime, 10 ns ticks; thread 0 of every block."""
+import ctypes as C, os, sys
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+os.environ["MTD_LIB_OVERRIDE"] = os.path.join(root, "tools", "bin", "libmtd_hip_stamps.so")
+sys.path[:0] = [os.path.join(root, "metadynamics-plugin_amd"), os.path.join(root, "tests")]
+import numpy as np, torch
+import util
+from metadynamics import _abi
+lib = _abi.load()
+n, N, L = 128, 1_000_000, 100.0
+pos, types = util.snapshot_random(N, L, seed=12345, modulated=True, dtype=np.float32)
+pos = (np.mod(pos.astype(np.float64) + L / 2, L) - L / 2).astype(np.float32)
+pos[pos >= L / 2] = -L / 2
+d_pos = torch.from_numpy(util.pack_postype(pos, types, np.float32)).cuda()
+d_f = torch.zeros((N, 4), dtype=torch.float32, device="cuda")
+box = _abi.Box.make(L)
+h = C.c_void_p()
+_abi.check(lib.mtd_mesh_create(C.byref(h), n, n, n, (C.c_double * 2)(1.0, -1.0), 2, N))
+part, npart = C.c_void_p(), C.c_uint()
+for t in range(60):
+    _abi.check(lib.mtd_mesh_compute_cv(h, N, d_pos.data_ptr(), _abi.MTD_F32, C.byref(box), N, C.byref(part), C.byref(npart), None))
+    _abi.check(lib.mtd_mesh_forces(h, N, d_pos.data_ptr(), d_f.data_ptr(), _abi.MTD_F32, C.byref(box), N, None, C.c_double(-2.5), None))
+torch.cuda.synchronize()
+buf = (C.c_ulonglong * (2 * 8 * 1024))()
+lib.mtd_debug_read_tile_stamps.argtypes = [C.c_void_p]
+lib.mtd_debug_read_tile_stamps(buf)
+a = np.array(buf[:], dtype=np.float64).reshape(2, 8, 1024) * 0.01
+names = [["entry", "image cleared, first particle requested", "first particle added", "thread 0 out of the loop", "block out of the loop", "image stored (issued)"],
+         ["entry", "Re(inv) staged", "first particle done", "thread 0 out of the loop"]]
+for k, kn in enumerate(["k_tile_scatter", "k_tile_forces"]):
+    t0 = a[k, 0].min()
+    print(kn, "(1024 blocks; us after the first block's entry: min / median / max)")
+    for row, name in enumerate(names[k]):
+        x = a[k, row] - t0
+        print("  %-42s %6.2f %6.2f %6.2f" % (name, x.min(), np.median(x), x.max()))
