@@ -871,9 +871,11 @@ __global__ __launch_bounds__(TF_THREADS) void k_tile_forces(const MeshGeom g, co
     TILE_STAMP(1, 0);
     const unsigned int q0 = tile_first[t], q1 = q0 + tile_total[t];
     if (q0 == q1) return;
+    // (records are loaded unconditionally from clamped slots: behind a branch the compiler cannot count the load and waits
+    // for everything in flight — the previous particle's force store included — at the first use of the record)
     unsigned int q = q0 + threadIdx.x;
-    double4 pk = make_double4(0.0, 0.0, 0.0, 0.0);
-    if (q < q1) pk = packed[q];
+    const unsigned int q_last = q1 - 1;
+    double4 pk = packed[min(q, q_last)];
     // Re(inv) of the tile + halo, row by row (32 lanes per row of <= 18 entries: no divisions in the loop)
     const unsigned int wxn = min(tg.tx, g.nx - x0) + 2, wyn = min(tg.ty, g.ny - y0) + 2, wzn = min(tg.tz, g.nz - z0) + 2;
     const unsigned int lx = threadIdx.x & 31;
@@ -926,7 +928,7 @@ __global__ __launch_bounds__(TF_THREADS) void k_tile_forces(const MeshGeom g, co
         {
         const double4 cur = pk;
         const unsigned int qn = q + TF_THREADS;
-        if (qn < q1) pk = packed[qn];
+        pk = packed[min(qn, q_last)];
         const unsigned int bt = (unsigned int)__double2hiint(cur.w);          // the record of k_tile_scatter
         const uint2 cib = make_uint2((unsigned int)__double2loint(cur.w), bt & 0xffffu);
         const double a = mode_of(s_mode, mode, bt >> 16), sx = cur.x, sy = cur.y, sz = cur.z;
