@@ -551,6 +551,12 @@ __device__ unsigned long long g_tile_stamps[2][8][1024];
 #else
 #define TILE_STAMP(k, row) do { } while (0)
 #endif
+#ifdef MTD_STAMPS
+__device__ unsigned long long g_cnt_stamps[8][1024];
+#define CNT_STAMP(row) do { if (threadIdx.x == 0 && blockIdx.x < 1024) g_cnt_stamps[row][blockIdx.x] = wall_clock64(); } while (0)
+#else
+#define CNT_STAMP(row) do { } while (0)
+#endif
 
 // The mode coefficients of the first TP_MODE_LDS types in LDS: looked up by a type that has just arrived from memory, a global
 // table costs every trip of the particle loops another dependent round trip.
@@ -570,31 +576,46 @@ template<typename S4>
 __global__ __launch_bounds__(TC_THREADS) void k_tile_count(const MeshGeom g, const TileGeom tg, const S4 *__restrict__ postype, const unsigned int N,
                                                     const double *__restrict__ mode, unsigned int *__restrict__ tile_of,
                                                     unsigned int *__restrict__ slot_of, unsigned int *__restrict__ hist,
-                                                    double *__restrict__ modesq_partials)
+                                                    double *__restrict__ modesq_partials, const unsigned int n_types)
     {
     extern __shared__ unsigned int s_hist[];
     __shared__ double s_red[16];
-    for (unsigned int t = threadIdx.x; t < tg.n_tiles; t += blockDim.x) s_hist[t] = 0;
-    __syncthreads();
+    __shared__ double s_mode[TP_MODE_LDS];
     const unsigned int i0 = blockIdx.x * tg.chunk;
     const unsigned int i1 = min(N, i0 + tg.chunk);
+    // the mode coefficient comes from LDS — as a second, dependent global load it doubled the trip
+    // the thread's next particle is in flight (raw, from a clamped index, no branch: see k_tile_scatter) while this one is
+    // located.  (All four positions of a thread requested up front measured slower again, 10.1 against 9.1 us.)
+    const unsigned int i_last = i1 ? i1 - 1 : 0u;
+    CNT_STAMP(0);
+    S4 raw = scalar4_traits<S4>::make(0, 0, 0, 0);
+    if (i0 < i1) raw = postype[min(i0 + threadIdx.x, i_last)];     // (uniform over the block)
+    stage_modes(s_mode, mode, n_types);
+    for (unsigned int t = threadIdx.x; t < tg.n_tiles; t += blockDim.x) s_hist[t] = 0;
+    __syncthreads();
+    CNT_STAMP(1);
     double msq = 0.0;
     for (unsigned int i = i0 + threadIdx.x; i < i1; i += blockDim.x)
         {
-        const Particle p = scalar4_traits<S4>::load(postype, i);
+        const Particle p = scalar4_traits<S4>::unpack(raw);
+        raw = postype[min(i + blockDim.x, i_last)];
         int ix, iy, iz;
         double sx, sy, sz;
         locate(g, p, ix, iy, iz, sx, sy, sz);
         const unsigned int t = (unsigned int)ix / tg.tx + tg.ntx * ((unsigned int)iy / tg.ty + tg.nty * ((unsigned int)iz / tg.tz));
         tile_of[i] = t;
         slot_of[i] = atomicAdd(&s_hist[t], 1u);
-        const double a = mode[p.type];
+        const double a = mode_of(s_mode, mode, (unsigned int)p.type);
         msq += a * a;
         }
-    __syncthreads();
-    for (unsigned int t = threadIdx.x; t < tg.n_tiles; t += blockDim.x) hist[(size_t)t * tg.n_blocks + blockIdx.x] = s_hist[t];
-    msq = block_sum(msq, s_red);
+    CNT_STAMP(2);
+    lds_barrier();                                                   // (the tile / slot stores of the loop drain behind it)
+    // [block][tile]: one contiguous row per block (tile-major it was 1024 scattered 4-byte stores per block)
+    CNT_STAMP(3);
+    for (unsigned int t = threadIdx.x; t < tg.n_tiles; t += blockDim.x) hist[(size_t)blockIdx.x * tg.n_tiles + t] = s_hist[t];
+    msq = block_sum_lds(msq, s_red);
     if (threadIdx.x == 0) modesq_partials[blockIdx.x] = msq;
+    CNT_STAMP(4);
     }
 
 // 2b. where the particles of (tile, count block) go = [particles of the tiles in front] + [particles of this tile counted by
@@ -621,7 +642,7 @@ __global__ __launch_bounds__(256) void k_tile_rowscan(const unsigned int *__rest
     const unsigned int base = threadIdx.x * 4;                      // nb <= 1024 (tile_blocks_max)
     unsigned int v[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) v[j] = base + j < nb ? hist[row + base + j] : 0u;
+    for (int j = 0; j < 4; ++j) v[j] = base + j < nb ? hist[(size_t)(base + j) * n_tiles + blockIdx.x] : 0u;   // column of the [block][tile] table
     const unsigned int t = v[0] + v[1] + v[2] + v[3];
     unsigned int incl = t;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1325,13 +1346,6 @@ struct FastDiv
         }
     };
 
-// Block barrier that waits for this wave's LDS traffic only: __syncthreads() also drains the global loads in flight, and
-// the next batch is being prefetched into registers across the sweeps (the compiler waits for those where they are used)
-__device__ __forceinline__ void xy_barrier()
-    {
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    }
-
 // The radix-4 butterfly of fft_dit_pow2 on registers (a, b, c, d at ia, ia + half, ia + 2 half, ia + 3 half)
 __device__ __forceinline__ void bfly4(double2 &a, double2 &b, double2 &c, double2 &d, const double2 w1, const double2 w2, const int inverse)
     {
@@ -1384,7 +1398,7 @@ __device__ __forceinline__ void fft_dit_xy(double2 *s, const double2 *__restrict
 #pragma unroll
             for (int m = 0; m < 8; ++m) pa[m * stride] = e[m];
             }
-        xy_barrier();
+        lds_barrier();
         log2len = 4;
         }
     // two radix-4 stages (len = 2^log2len .. 8 len) on positions ib + m half, m < 16
@@ -1416,7 +1430,7 @@ __device__ __forceinline__ void fft_dit_xy(double2 *s, const double2 *__restrict
 #pragma unroll
             for (int m = 0; m < 16; ++m) pa[m * sh] = e[m];
             }
-        xy_barrier();
+        lds_barrier();
         }
     // a last radix-4 stage on its own
     for (; log2len < log2n + 1; log2len += 2)
@@ -1437,7 +1451,7 @@ __device__ __forceinline__ void fft_dit_xy(double2 *s, const double2 *__restrict
             pa[2 * sh] = c;
             pa[3 * sh] = d;
             }
-        xy_barrier();
+        lds_barrier();
         }
     }
 
@@ -1524,7 +1538,7 @@ __global__ __launch_bounds__(XY_THREADS) void k_fft_xy_forward(const double *__r
             const unsigned int idx = threadIdx.x + i * XY_THREADS;
             if (idx < nx * pb) X[(idx & (nx - 1)) * xs + (idx >> pl.log2nx)] = pre[i];
             }
-        xy_barrier();
+        lds_barrier();
         // rows to bit-reversed order, lanes along a row: written straight to their bit-reversed rows, the lanes of a wave
         // (consecutive positions of one line) would queue eight deep on the same banks
         for (unsigned int idx = threadIdx.x; idx < nx * pb; idx += XY_THREADS)
@@ -1539,7 +1553,7 @@ __global__ __launch_bounds__(XY_THREADS) void k_fft_xy_forward(const double *__r
                 X[r * xs + u] = a;
                 }
             }
-        xy_barrier();
+        lds_barrier();
         XY_STAMP(0, 1 + 3 * min(batch, 1u));
         if (batch + 1 < n_batches) fetch(batch + 1);             // in flight during the sweeps below
         fft_dit_xy(X, TX, pl.log2nx, pl.d_pb, 0, xs);
@@ -1555,7 +1569,7 @@ __global__ __launch_bounds__(XY_THREADS) void k_fft_xy_forward(const double *__r
             Y[lds_slot(ya, pl.log2ny) * ys + kl] = make_double2(0.5 * (zk.x + zm.x), 0.5 * (zk.y - zm.y));
             Y[lds_slot(ya + 1, pl.log2ny) * ys + kl] = make_double2(0.5 * (zk.y + zm.y), -0.5 * (zk.x - zm.x));
             }
-        xy_barrier();
+        lds_barrier();
         XY_STAMP(0, 3 + 3 * min(batch, 1u));
         }
     fft_dit_xy(Y, TY, pl.log2ny, dk, 0, ys);
@@ -1621,7 +1635,7 @@ __global__ __launch_bounds__(XY_THREADS) void k_fft_xy_inverse(const double2 *__
                 Y[lds_slot(ky, pl.log2ny) * ys + cl] = make_double2(pre[i].x, pre[i].y);
                 }
             }
-        xy_barrier();
+        lds_barrier();
         XY_STAMP(1, 1 + 3 * cpart);
         if (cpart + 1 < XY_PARTS) xy_fetch_columns(pre, half_in, pl, line_base, cpart + 1);   // in flight during the sweeps below
         fft_dit_xy(Y, TY, pl.log2ny, dc, 1, ys);
@@ -1636,7 +1650,7 @@ __global__ __launch_bounds__(XY_THREADS) void k_fft_xy_inverse(const double2 *__
             X[lds_slot(k, pl.log2nx) * xs + u] = make_double2(A.x - B.y, A.y + B.x);
             if (k != 0 && 2 * k != nx) X[lds_slot(nx - k, pl.log2nx) * xs + u] = make_double2(A.x + B.y, -A.y + B.x);
             }
-        xy_barrier();
+        lds_barrier();
         XY_STAMP(1, 3 + 3 * cpart);
         }
     fft_dit_xy(X, TX, pl.log2nx, pl.d_pb, 1, xs);
@@ -2193,6 +2207,10 @@ bool xy_plan(const mtd_mesh *m, int inverse, XYPlan &pl, size_t &lds)
 } // namespace
 
 #ifdef MTD_STAMPS
+extern "C" int mtd_debug_read_count_stamps(unsigned long long *host)
+    {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_cnt_stamps), sizeof(unsigned long long) * 8 * 1024);
+    }
 extern "C" int mtd_debug_read_tile_stamps(unsigned long long *host)
     {
     return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_tile_stamps), sizeof(unsigned long long) * 2 * 8 * 1024);
@@ -2423,9 +2441,9 @@ static int mesh_assign_local(mtd_mesh *m, unsigned int n_particles, const void *
         tg.inv_scale = std::ldexp(1.0, -k);
         const size_t lds = sizeof(unsigned int) * tg.n_tiles;
         if (dtype == MTD_F32)
-            k_tile_count<float4><<<nb, TC_THREADS, lds, s>>>(g, tg, (const float4 *)d_postype, N, m->d_mode, m->d_cell_of, m->d_slot_of, m->d_count, m->d_modesq_partials);
+            k_tile_count<float4><<<nb, TC_THREADS, lds, s>>>(g, tg, (const float4 *)d_postype, N, m->d_mode, m->d_cell_of, m->d_slot_of, m->d_count, m->d_modesq_partials, m->n_types);
         else
-            k_tile_count<double4><<<nb, TC_THREADS, lds, s>>>(g, tg, (const double4 *)d_postype, N, m->d_mode, m->d_cell_of, m->d_slot_of, m->d_count, m->d_modesq_partials);
+            k_tile_count<double4><<<nb, TC_THREADS, lds, s>>>(g, tg, (const double4 *)d_postype, N, m->d_mode, m->d_cell_of, m->d_slot_of, m->d_count, m->d_modesq_partials, m->n_types);
         MTD_LAUNCH_CHECK();
         k_tile_rowscan<<<tg.n_tiles + 1, 256, 0, s>>>(m->d_count, m->d_start, m->d_tile_total, tg.n_tiles, nb, m->d_modesq_partials, nb, m->d_mode_sq);
         MTD_LAUNCH_CHECK();

@@ -43,6 +43,14 @@ __device__ __forceinline__ float wave_sum(float v)
     return v;
     }
 
+// Block barrier that orders LDS traffic only: __syncthreads() also waits for every global load and STORE of the wave
+// (s_waitcnt vmcnt(0)) — a microsecond or more behind a batch of stores, and the end of any prefetch in flight.  Use where the
+// barrier publishes LDS data and nothing that went to global memory is read back by the block.
+__device__ __forceinline__ void lds_barrier()
+    {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+
 // Block sum of one double per thread; result valid in EVERY thread. blockDim.x multiple of 64, <= 1024.
 // s_red must hold >= 16 doubles.
 __device__ __forceinline__ double block_sum(double v, double *s_red)
@@ -54,6 +62,21 @@ __device__ __forceinline__ double block_sum(double v, double *s_red)
     __syncthreads(); // protect s_red from a previous use
     if (lane == 0) s_red[wave] = v;
     __syncthreads();
+    double r = 0.0;
+    for (int w = 0; w < n_waves; ++w) r += s_red[w];
+    return r;
+    }
+
+// the same with LDS-only barriers (same order of the adds: same bits)
+__device__ __forceinline__ double block_sum_lds(double v, double *s_red)
+    {
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int n_waves = blockDim.x >> 6;
+    v = wave_sum(v);
+    lds_barrier();
+    if (lane == 0) s_red[wave] = v;
+    lds_barrier();
     double r = 0.0;
     for (int w = 0; w < n_waves; ++w) r += s_red[w];
     return r;

@@ -35,3 +35,14 @@ for k, kn in enumerate(["k_tile_scatter", "k_tile_forces"]):
     for row, name in enumerate(names[k]):
         x = a[k, row] - t0
         print("  %-42s %6.2f %6.2f %6.2f" % (name, x.min(), np.median(x), x.max()))
+
+cb = (C.c_ulonglong * (8 * 1024))()
+lib.mtd_debug_read_count_stamps.argtypes = [C.c_void_p]
+lib.mtd_debug_read_count_stamps(cb)
+c = np.array(cb[:], dtype=np.float64).reshape(8, 1024) * 0.01
+used = c[0] > 0
+t0 = c[0][used].min()
+print("k_tile_count (%d blocks; us after the first block's entry: min / median / max)" % used.sum())
+for row, name in enumerate(["entry", "histogram cleared, first position in", "out of the particle loop (thread 0)", "block out of the loop", "histogram row and block sum written"]):
+    x = c[row][used] - t0
+    print("  %-42s %6.2f %6.2f %6.2f" % (name, x.min(), np.median(x), x.max()))
