@@ -518,8 +518,8 @@ __global__ __launch_bounds__(GT_THREADS) void k_mesh_gather(const MeshGeom g, co
 // stores and a per-cell gather loop per particle (bin 42 + scan 15 + place 40 + sortfix 18 + gather 78 us at 10^6 particles
 // on 128^3).  Here the particles are only grouped by TILE of 16x16x8 cells and the TSC weights are summed in LDS:
 //   1b k_tile_count    a block owns a contiguous chunk of particles: tile of every particle, its arrival slot in the
-//                      block's LDS histogram (LDS atomic), the histogram written tile-major [tile][block]; sum of mode^2
-//   2b scan            exclusive scan of the [tile][block] counts = where each block's particles of each tile go
+//                      block's LDS histogram (LDS atomic), the histogram written as one row per block, [block][tile]; sum of mode^2
+//   2b scan            exclusive scan over the blocks of every tile's counts = where each block's particles of each tile go
 //   3b k_tile_place    particle id -> start[tile][block] + slot (4-byte scattered store; no record is built)
 //   4b k_tile_scatter  a block owns a tile: the tile + one halo layer live in LDS as 64-bit FIXED-POINT sums, every particle
 //                      of the tile (position gathered through its id) adds its 27 weights with LDS atomics; integer sums
@@ -619,7 +619,7 @@ __global__ __launch_bounds__(TC_THREADS) void k_tile_count(const MeshGeom g, con
     }
 
 // 2b. where the particles of (tile, count block) go = [particles of the tiles in front] + [particles of this tile counted by
-// the blocks in front].  ONE launch forms the second term (a scan along each tile's row of the [tile][block] histogram, a
+// the blocks in front].  ONE launch forms the second term (a scan along each tile's column of the [block][tile] histogram, a
 // block per tile) and the tiles' totals; the first term — a prefix over <= 8192 totals — is formed by whoever needs it (the
 // place kernel once per block in LDS, the scatter / force kernels for their own tile): a second scan launch cost ~5 us of
 // pure latency in this chain of small kernels.  One extra block adds up sum mode^2 (:622).
@@ -791,7 +791,7 @@ __global__ __launch_bounds__(TP_THREADS) void k_tile_scatter(const MeshGeom g, c
         q = qn;
         }
     TILE_STAMP(0, 3);
-    __syncthreads();
+    lds_barrier();                                                   // (the record stores of the loop drain behind it)
     TILE_STAMP(0, 4);
     for (unsigned int e = threadIdx.x; e < tg.hcells; e += TP_THREADS) tilebuf[(size_t)t * tg.hcells + e] = (long long)s_t[e];
     TILE_STAMP(0, 5);
