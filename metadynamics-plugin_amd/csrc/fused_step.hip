@@ -400,7 +400,7 @@ __global__ __launch_bounds__(FS_THREADS, 1) void k_fused_step(const LamKArgs a, 
         if (has_extra) step_force_unscaled_one<NCV, FAST>(a, s_mt, X);
         }
     MTD_STAMP(6, blockIdx.x == 0 && threadIdx.x == 0); MTD_STAMP(22, blockIdx.x == gridDim.x - 1 && threadIdx.x == 0); MTD_STAMP(38, blockIdx.x == 0 && threadIdx.x == 64);
-    __syncthreads();
+    lds_barrier();                                                   // (publishes LDS data only: nothing drains behind it)
     MTD_STAMP(7, blockIdx.x == 0 && threadIdx.x == 0); MTD_STAMP(23, blockIdx.x == gridDim.x - 1 && threadIdx.x == 0); MTD_STAMP(39, blockIdx.x == 0 && threadIdx.x == 64);
 
     // ---- phase 3: scaled forces out.  On a deposit step the waves that own grid cells run the first grid pass BEFORE their
@@ -468,7 +468,7 @@ __global__ __launch_bounds__(FS_THREADS, 1) void k_fused_step(const LamKArgs a, 
             s_red[2 * wave] = s1;
             s_red[2 * wave + 1] = s2;
             }
-        __syncthreads();
+        lds_barrier();                                               // (not __syncthreads: it would wait for the force stores to drain)
         if (threadIdx.x < 2 * FS_LL_REPLICAS)
             {
             const unsigned int i = threadIdx.x & 1, rep = threadIdx.x >> 1;
@@ -494,7 +494,7 @@ __global__ __launch_bounds__(FS_THREADS, 1) void k_fused_step(const LamKArgs a, 
                 s_avg[1] = ex ? 1.0 : 0.0;
                 }
             }
-        __syncthreads();
+        lds_barrier();
         avg_dV = s_avg[0];
     MTD_STAMP(10, blockIdx.x == 0 && threadIdx.x == 0); MTD_STAMP(26, blockIdx.x == gridDim.x - 1 && threadIdx.x == 0); MTD_STAMP(42, blockIdx.x == 0 && threadIdx.x == 64);
         grid_expired = s_avg[1] != 0.0;
