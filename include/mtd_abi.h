@@ -449,6 +449,11 @@ int mtd_ql_finalize(int half_nlist, unsigned int lmax, const double *Ql_ref, uns
 /* SteinhardtQl::computeBiasForces (:203-339) with the Q_lm the last mtd_ql_accumulate left in d_scratch (Q20);
  * bias = *d_bias when d_bias != NULL, else bias_host.  Writes d_force[0..n_particles); with half lists the reaction force goes
  * to LOCAL partners only (j < n_particles, SteinhardtQl.cc:328), so particle-sharded runs use full lists. */
+/* Half lists: how the reaction forces of the pairs are summed into the partner particles (SteinhardtQl.cc:328-333; the
+ * reference's serial loop has one order, a GPU has none).  1 (default): as exact integers — bitwise reproducible, independent
+ * of the order; 0: floating-point atomics — sums in arrival order, about 2.5 x faster.  Full lists need neither. */
+int mtd_ql_set_half_list_exact(int enable);
+
 int mtd_ql_forces(unsigned int n_particles, const void *d_postype, void *d_force, int dtype, const mtd_box *box,
                   const unsigned int *d_head_list, const unsigned int *d_n_neigh, const unsigned int *d_nlist, int half_nlist,
                   double rcut, double ron, unsigned int lmax, unsigned int type, const double *Ql_ref, unsigned int n_global,

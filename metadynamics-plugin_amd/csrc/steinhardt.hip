@@ -512,13 +512,79 @@ __global__ __launch_bounds__(256) void k_ql_finalize(const QlArgs<LMAX> a, const
         }
     }
 
+// ---- half lists: order-independent (exact) sums of the pair forces ---------------------------------------------
+// With a half list a pair is visited once and its reaction force goes to the OTHER particle (SteinhardtQl.cc:328-333): many
+// blocks add to one particle in an order that changes from run to run.  Floating-point atomics made the half-list forces the
+// one result of this library that was not bitwise reproducible.  Now every contribution is split exactly into integers —
+// QL_BINS 64-bit accumulators per component, bin k holding the bits of weight 2^(QL_BIN_LOW + 48 k) .. 2^(QL_BIN_LOW + 48 (k + 1))
+// — and added with integer atomics: the sums are exact, so they cannot depend on the order, and a last pass converts them to
+// the caller's force array (one rounding per component).  Range: |x| < 2^72 per contribution, bits below 2^-120 are dropped
+// (forces of order 1: 1e-36 relative); 15 bits of headroom per bin = 32768 contributions at the top of a bin.  Non-finite
+// contributions (theta = 0, Q_l = 0: the reference produces inf / NaN there too) set flags that the conversion turns back into
+// what IEEE addition in any order would have given.
+constexpr int QL_BINS = 4;
+constexpr int QL_BIN_BITS = 48;
+constexpr int QL_BIN_LOW = -120;
+constexpr size_t QL_ACC_WORDS = 3 * QL_BINS + 1;                 // per particle: 3 components x QL_BINS bins + one flag word
+
+__device__ __forceinline__ void ql_exact_add(unsigned long long *acc /* this particle's words */, const int comp, double x)
+    {
+    if (!(fabs(x) < 4722366482869645213696.0))                     // 2^72: inf, NaN or out of range
+        {
+        const unsigned int bit = x != x ? 4u : (x > 0.0 ? 1u : 2u);  // NaN, +overflow, -overflow
+        atomicOr((unsigned int *)(acc + 3 * QL_BINS), bit << (4 * comp));
+        return;
+        }
+#pragma unroll
+    for (int k = QL_BINS - 1; k >= 0; --k)
+        {
+        const int w = QL_BIN_LOW + QL_BIN_BITS * k;
+        const double t = trunc(ldexp(x, -w));                       // |t| < 2^48 (k = top: |x| < 2^72), exact
+        if (t != 0.0)
+            {
+            atomicAdd(acc + comp * QL_BINS + k, (unsigned long long)(long long)t);
+            x -= ldexp(t, w);                                        // exact
+            }
+        }
+    }
+
+template<typename S4>
+__global__ __launch_bounds__(256) void k_ql_exact_to_force(const unsigned long long *__restrict__ acc, const double *__restrict__ own, const unsigned int N,
+                                                           S4 *__restrict__ force)
+    {
+    typedef typename scalar4_traits<S4>::scalar scalar;
+    const unsigned int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    const unsigned long long *a = acc + (size_t)i * QL_ACC_WORDS;
+    const unsigned int flags = (unsigned int)a[3 * QL_BINS];
+    double f[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+        {
+        double v = 0.0;
+#pragma unroll
+        for (int k = 0; k < QL_BINS; ++k) v += ldexp((double)(long long)a[c * QL_BINS + k], QL_BIN_LOW + QL_BIN_BITS * k);   // small to large
+        v += own[3 * (size_t)i + c];                                   // the particle's own pairs (inf / NaN arrive through it as they are)
+        const unsigned int fl = (flags >> (4 * c)) & 7u;
+        if (fl & 4u) v = nan("");
+        if (fl & 1u) v += INFINITY;                                     // (-inf + inf = NaN, like the additions themselves)
+        if (fl & 2u) v -= INFINITY;
+        f[c] = v;
+        }
+    force[i] = scalar4_traits<S4>::make((scalar)f[0], (scalar)f[1], (scalar)f[2], (scalar)0);
+    }
+
 // ---- forces ----------------------------------------------------------------------------------------------
-template<typename S4, int LMAX, bool HALF>
+// EXACT (half lists): reaction forces into the exact accumulators, the particle's own sum (formed by one thread in list order)
+// into own[i] — the conversion pass adds it; !EXACT: the floating-point atomics of round 1 (mtd_ql_set_half_list_exact(0):
+// 2.5 x faster, sums in arrival order).
+template<typename S4, int LMAX, bool HALF, bool EXACT>
 __global__ __launch_bounds__(QL_THREADS, (LMAX <= 6 ? 4 : 2)) void k_ql_forces(const QlArgs<LMAX> a, const S4 *__restrict__ postype,
                                                              const unsigned int *__restrict__ head_list,
                                                              const unsigned int *__restrict__ n_neigh,
                                                              const unsigned int *__restrict__ nlist, const double *__restrict__ qlm_full,
-                                                             S4 *__restrict__ force, const double *__restrict__ d_bias, const double bias_host)
+                                                             S4 *__restrict__ force, const double *__restrict__ d_bias, const double bias_host,
+                                                             unsigned long long *__restrict__ exact_acc, double *__restrict__ own)
     {
     typedef typename scalar4_traits<S4>::scalar scalar;
     constexpr int NLM = (LMAX + 1) * (LMAX + 2) / 2;
@@ -626,10 +692,20 @@ __global__ __launch_bounds__(QL_THREADS, (LMAX <= 6 ? 4 : 2)) void k_ql_forces(c
                         const unsigned int j = s_j[t];
                         if (j < a.N)
                             {
-                            scalar *fj = (scalar *)&force[j];
-                            atomicAdd(fj + 0, (scalar)(-fpx));
-                            atomicAdd(fj + 1, (scalar)(-fpy));
-                            atomicAdd(fj + 2, (scalar)(-fpz));
+                            if (EXACT)
+                                {
+                                unsigned long long *aj = exact_acc + (size_t)j * QL_ACC_WORDS;
+                                ql_exact_add(aj, 0, -fpx);
+                                ql_exact_add(aj, 1, -fpy);
+                                ql_exact_add(aj, 2, -fpz);
+                                }
+                            else
+                                {
+                                scalar *fj = (scalar *)&force[j];
+                                atomicAdd(fj + 0, (scalar)(-fpx));
+                                atomicAdd(fj + 1, (scalar)(-fpy));
+                                atomicAdd(fj + 2, (scalar)(-fpz));
+                                }
                             }
                         }
                     }
@@ -658,7 +734,13 @@ __global__ __launch_bounds__(QL_THREADS, (LMAX <= 6 ? 4 : 2)) void k_ql_forces(c
             const unsigned int i = chunk * QL_PPB + threadIdx.x;
             if (i < a.N)
                 {
-                if (HALF)
+                if (HALF && EXACT)
+                    {
+                    own[3 * (size_t)i + 0] = Fx;
+                    own[3 * (size_t)i + 1] = Fy;
+                    own[3 * (size_t)i + 2] = Fz;
+                    }
+                else if (HALF)
                     {
                     scalar *fi = (scalar *)&force[i];
                     atomicAdd(fi + 0, (scalar)Fx);
@@ -671,6 +753,8 @@ __global__ __launch_bounds__(QL_THREADS, (LMAX <= 6 ? 4 : 2)) void k_ql_forces(c
             }
         }
     }
+
+int g_half_exact = 1;        // mtd_ql_set_half_list_exact
 
 template<int LMAX>
 int fill_args(QlArgs<LMAX> &a, unsigned int N, const mtd_box *box, double rcut, double ron, unsigned int lmax, unsigned int type,
@@ -761,29 +845,64 @@ int forces_impl(unsigned int N, const void *d_postype, void *d_force, int dtype,
     int rc = fill_args<LMAX>(a, N, box, rcut, ron, lmax, type, ql_ref, n_global, half);
     if (rc) return rc;
     const unsigned int blocks = ql_blocks(N, QL_FRC_PPB, 1024);
+    // half lists: exact integer accumulators (memset of :236 = clearing them), stream-ordered scratch from the device's pool
+    unsigned long long *acc = nullptr;
+    double *own = nullptr;
+    const bool exact = half && g_half_exact;
+    const size_t acc_bytes = sizeof(unsigned long long) * QL_ACC_WORDS * (size_t)N, own_bytes = sizeof(double) * 3 * (size_t)N;
     const size_t s4 = dtype == MTD_F32 ? sizeof(float4) : sizeof(double4);
-    if (half) MTD_HIP_TRY(hipMemsetAsync(d_force, 0, s4 * N, s));            // memset of :236, the pair terms are then added atomically
+    if (exact && N)
+        {
+        MTD_HIP_TRY(hipMallocAsync((void **)&acc, acc_bytes + own_bytes, s));
+        own = (double *)((char *)acc + acc_bytes);
+        MTD_HIP_TRY(hipMemsetAsync(acc, 0, acc_bytes + own_bytes, s));
+        }
+    else if (half)
+        MTD_HIP_TRY(hipMemsetAsync(d_force, 0, s4 * N, s));               // memset of :236, the pair terms are then added atomically
     if (dtype == MTD_F32)
         {
-        if (half)
-            k_ql_forces<float4, LMAX, true><<<blocks, QL_THREADS, 0, s>>>(a, (const float4 *)d_postype, d_head, d_nneigh, d_nlist, d_qlm, (float4 *)d_force, d_bias, bias_host);
+        if (exact)
+            k_ql_forces<float4, LMAX, true, true><<<blocks, QL_THREADS, 0, s>>>(a, (const float4 *)d_postype, d_head, d_nneigh, d_nlist, d_qlm, (float4 *)d_force, d_bias, bias_host, acc, own);
+        else if (half)
+            k_ql_forces<float4, LMAX, true, false><<<blocks, QL_THREADS, 0, s>>>(a, (const float4 *)d_postype, d_head, d_nneigh, d_nlist, d_qlm, (float4 *)d_force, d_bias, bias_host, nullptr, nullptr);
         else
-            k_ql_forces<float4, LMAX, false><<<blocks, QL_THREADS, 0, s>>>(a, (const float4 *)d_postype, d_head, d_nneigh, d_nlist, d_qlm, (float4 *)d_force, d_bias, bias_host);
+            k_ql_forces<float4, LMAX, false, false><<<blocks, QL_THREADS, 0, s>>>(a, (const float4 *)d_postype, d_head, d_nneigh, d_nlist, d_qlm, (float4 *)d_force, d_bias, bias_host, nullptr, nullptr);
         }
     else
         {
-        if (half)
-            k_ql_forces<double4, LMAX, true><<<blocks, QL_THREADS, 0, s>>>(a, (const double4 *)d_postype, d_head, d_nneigh, d_nlist, d_qlm, (double4 *)d_force, d_bias, bias_host);
+        if (exact)
+            k_ql_forces<double4, LMAX, true, true><<<blocks, QL_THREADS, 0, s>>>(a, (const double4 *)d_postype, d_head, d_nneigh, d_nlist, d_qlm, (double4 *)d_force, d_bias, bias_host, acc, own);
+        else if (half)
+            k_ql_forces<double4, LMAX, true, false><<<blocks, QL_THREADS, 0, s>>>(a, (const double4 *)d_postype, d_head, d_nneigh, d_nlist, d_qlm, (double4 *)d_force, d_bias, bias_host, nullptr, nullptr);
         else
-            k_ql_forces<double4, LMAX, false><<<blocks, QL_THREADS, 0, s>>>(a, (const double4 *)d_postype, d_head, d_nneigh, d_nlist, d_qlm, (double4 *)d_force, d_bias, bias_host);
+            k_ql_forces<double4, LMAX, false, false><<<blocks, QL_THREADS, 0, s>>>(a, (const double4 *)d_postype, d_head, d_nneigh, d_nlist, d_qlm, (double4 *)d_force, d_bias, bias_host, nullptr, nullptr);
         }
-    MTD_LAUNCH_CHECK();
-    return MTD_SUCCESS;
+    hipError_t launch_err = hipGetLastError();
+    if (exact && N)
+        {
+        if (launch_err == hipSuccess)
+            {
+            if (dtype == MTD_F32)
+                k_ql_exact_to_force<float4><<<(N + 255) / 256, 256, 0, s>>>(acc, own, N, (float4 *)d_force);
+            else
+                k_ql_exact_to_force<double4><<<(N + 255) / 256, 256, 0, s>>>(acc, own, N, (double4 *)d_force);
+            launch_err = hipGetLastError();
+            }
+        const hipError_t free_err = hipFreeAsync(acc, s);
+        if (launch_err == hipSuccess) launch_err = free_err;
+        }
+    return launch_err == hipSuccess ? MTD_SUCCESS : (int)launch_err;
     }
 
 } // namespace
 
 extern "C" {
+
+int mtd_ql_set_half_list_exact(int enable)
+    {
+    g_half_exact = enable ? 1 : 0;
+    return MTD_SUCCESS;
+    }
 
 size_t mtd_ql_scratch_doubles(unsigned int lmax)
     {

@@ -179,6 +179,7 @@ _SIGNATURES = {
     "mtd_ql_finalize": (C.c_int, [C.c_int, C.c_uint, _dp, C.c_uint, _vp, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp), _vp]),
     "mtd_ql_accumulate": (C.c_int, [C.c_uint, _vp, C.c_int, C.POINTER(Box), _vp, _vp, _vp, C.c_int, C.c_double, C.c_double, C.c_uint,
                                      C.c_uint, _dp, C.c_uint, _vp, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp), _vp]),
+    "mtd_ql_set_half_list_exact": (C.c_int, [C.c_int]),
     "mtd_ql_forces": (C.c_int, [C.c_uint, _vp, _vp, C.c_int, C.POINTER(Box), _vp, _vp, _vp, C.c_int, C.c_double, C.c_double, C.c_uint,
                                  C.c_uint, _dp, C.c_uint, _vp, _vp, C.c_double, _vp]),
     "mtd_wte_scratch_doubles": (C.c_size_t, [C.c_uint]),

@@ -77,9 +77,42 @@ def test_ql_parity(abi, ref, dtype, lmax, Ql_ref, half):
     assert np.allclose(g[1], r[1], rtol=1e-10, atol=1e-13 * np.abs(r[1]).max())
     assert g[0] == pytest.approx(r[0], rel=1e-10)
     fs = np.abs(r[3][:, :3]).max()
-    tol = 1e-9 if dtype == np.float64 else (2e-7 if not half else 2e-6)   # fp32 force array; half list adds fp32 atomics
+    tol = 1e-9 if dtype == np.float64 else 2e-7    # fp32 force array: one rounding on store, half lists too (exact integer sums)
     assert np.abs(g[3][:, :3] - r[3][:, :3]).max() <= tol * fs
     assert np.all(g[3][:, 3] == 0.0)
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_ql_half_list_forces_bitwise_reproducible(abi, dtype):
+    """half lists: the reaction forces of a pair go to the other particle from whichever block holds the pair — summed as exact
+    integers (steinhardt.hip: ql_exact_add), so two runs give the same bits, and a list with its rows permuted (another
+    order of the adds) too"""
+    pos, L = noisy_fcc(6, seed=9)
+    pos = pos.astype(dtype)
+    N = len(pos)
+    types = np.zeros(N, dtype=np.int32)
+    nl = util.build_nlist(pos.astype(np.float64), L, 1.55, half=True)
+    args = (1.4, 1.2, 6, 0, [0, 0, 0, 0, 1, 0, 1])
+    runs = [run_gpu(abi, pos, types, L, nl, *args, dtype, half=True)[3] for _ in range(3)]
+    assert np.array_equal(runs[0], runs[1]) and np.array_equal(runs[0], runs[2])
+    assert np.abs(runs[0][:, :3]).max() > 0
+    # the same pairs listed in another order inside every row
+    head, nn, lst = [np.array(a).copy() for a in nl]
+    rng = np.random.default_rng(2)
+    for i in range(N):
+        seg = lst[head[i]:head[i] + nn[i]]
+        lst[head[i]:head[i] + nn[i]] = rng.permutation(seg)
+    shuffled = run_gpu(abi, pos, types, L, (head, nn, lst), *args, dtype, half=True)[3]
+    # own-role sums follow the list order (like the reference's loop), so only agreement to rounding is asked of them
+    assert np.abs(shuffled[:, :3] - runs[0][:, :3]).max() <= (1e-13 if dtype == np.float64 else 2e-7) * np.abs(runs[0][:, :3]).max()
+    # the floating-point atomics stay available (mtd_ql_set_half_list_exact(0)): same forces to rounding
+    lib = abi.load()
+    abi.check(lib.mtd_ql_set_half_list_exact(0))
+    try:
+        fast = run_gpu(abi, pos, types, L, nl, *args, dtype, half=True)[3]
+    finally:
+        abi.check(lib.mtd_ql_set_half_list_exact(1))
+    assert np.abs(fast[:, :3] - runs[0][:, :3]).max() <= (1e-12 if dtype == np.float64 else 2e-6) * np.abs(runs[0][:, :3]).max()
 
 
 def test_ql_two_types_and_shard(abi, ref):
