@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Developer tool: BASELINE.json configs[2] (10^6 particles, cv.mesh on 128^3 + 1 lamellar CV, 256^2 grid) through the
 reference-shaped API; prints us/step.  Run under rocprofv3 --kernel-trace --stats for the per-kernel table.
-usage: bench_mesh.py [steps] [sfc]   sfc: particle ids follow a Morton curve over 64^3 cells, as after HOOMD's SFCPack sorter
+usage: bench_mesh.py [steps] [sfc|-] [nx]   sfc: particle ids follow a Morton curve over 64^3 cells, as after HOOMD's SFCPack sorter
 (the default, ids uncorrelated with positions, is the worst case for the gathers and scattered stores by id)"""
 import os, sys, time
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -26,7 +26,8 @@ context.initialize(pos, types, ["A", "B"], L, dtype=np.float32)
 meta = integrate.mode_metadynamics(dt=0.005, stride=1, mode="well_tempered", W=1.0, deltaT=7.0, T=1.0)
 lam = cv.lamellar(sigma=0.02, mode=dict(A=1.0, B=-1.0), lattice_vectors=util.CV1_VECTORS)
 lam.set_grid(-1.0, 1.0, 256)
-mesh = cv.mesh(nx=128, mode={"A": 1.0, "B": -1.0})
+NX = int(sys.argv[3]) if len(sys.argv) > 3 else 128
+mesh = cv.mesh(nx=NX, mode={"A": 1.0, "B": -1.0})
 s0 = None
 context.run(0) if False else None
 # range for the mesh CV from its own value
@@ -40,4 +41,4 @@ t0 = time.perf_counter()
 context.current.system.run(steps - 1)
 torch.cuda.synchronize()
 dt = time.perf_counter() - t0
-print("config 3%s: %.1f us/step  (%.3e particle-CV-evals/s, 2 CVs)" % (" (ids along a space-filling curve)" if len(sys.argv) > 2 and sys.argv[2] == "sfc" else "", 1e6 * dt / steps, 2 * N * steps / dt))
+print("config 3%s%s: %.1f us/step  (%.3e particle-CV-evals/s, 2 CVs)" % (" (ids along a space-filling curve)" if len(sys.argv) > 2 and sys.argv[2] == "sfc" else "", "" if NX == 128 else " with a %d^3 mesh" % NX, 1e6 * dt / steps, 2 * N * steps / dt))
