@@ -853,7 +853,26 @@ int forces_impl(unsigned int N, const void *d_postype, void *d_force, int dtype,
     const size_t s4 = dtype == MTD_F32 ? sizeof(float4) : sizeof(double4);
     if (exact && N)
         {
-        MTD_HIP_TRY(hipMallocAsync((void **)&acc, acc_bytes + own_bytes, s));
+        // a pool of this library's own that keeps what it has handed out (the device's default pool returns everything to the
+        // driver at the next synchronise, and the next call pays a fresh allocation)
+        static hipMemPool_t pool = [] {
+            hipMemPool_t p = nullptr;
+            int dev = 0;
+            (void)hipGetDevice(&dev);
+            hipMemPoolProps props;
+            std::memset(&props, 0, sizeof(props));
+            props.allocType = hipMemAllocationTypePinned;
+            props.location.type = hipMemLocationTypeDevice;
+            props.location.id = dev;
+            if (hipMemPoolCreate(&p, &props) != hipSuccess) { (void)hipGetLastError(); return (hipMemPool_t) nullptr; }
+            unsigned long long keep = ~0ull;
+            (void)hipMemPoolSetAttribute(p, hipMemPoolAttrReleaseThreshold, &keep);
+            return p;
+        }();
+        if (pool)
+            MTD_HIP_TRY(hipMallocFromPoolAsync((void **)&acc, acc_bytes + own_bytes, pool, s));
+        else
+            MTD_HIP_TRY(hipMallocAsync((void **)&acc, acc_bytes + own_bytes, s));
         own = (double *)((char *)acc + acc_bytes);
         MTD_HIP_TRY(hipMemsetAsync(acc, 0, acc_bytes + own_bytes, s));
         }
