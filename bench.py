@@ -8,46 +8,59 @@ One "step" = one pass of the hot path over one synthetic particle snapshot (BASE
     -> bias forces of both CVs written for every particle (one fused pass).
 Inputs are resident in HBM before the timed region; nothing synchronises with the host inside it.
 
-    python bench.py --gpus N --steps K --warmup W
-N > 1: launched by torch.distributed.run, one rank per GPU; particles are sharded (10^6 per rank,
-weak scaling), the per-CV sums of a step travel through the xGMI mailbox (mtd_comm_*: direct stores between
-the GPUs, still two launches per step; RCCL all-reduce if the mailbox cannot be set up), the bias grid is
-replicated (every rank deposits the same hill, no grid collective).
+    python bench.py --gpus N --steps K --warmup W [--scaling weak|strong] [--walkers]
+
+N > 1: one rank per GPU.  Either the caller starts the ranks (`python -m torch.distributed.run --nproc-per-node N bench.py
+--gpus N ...`: WORLD_SIZE is set) or this script does: called plainly with --gpus N it starts that command ITSELF as a child
+process — before it has imported torch or touched the GPU in any way — and relays rank 0's single JSON line and the exit code.
+  weak (default)  10^6 particles per GPU (config 4 of BASELINE.json at N = 8: 8 x 10^6, L = 200), particles sharded, the
+                  per-CV sums of a step through the xGMI mailbox (mtd_comm_*: direct stores between the GPUs, still two
+                  launches per step; RCCL all-reduce if the mailbox cannot be set up — config.exchange says which one ran),
+                  bias grid replicated (every rank deposits the same hill, no grid collective)
+  strong          8 x 10^6 particles in all (L = 200), N_global / N per GPU, same exchange
+  --walkers       one independent 10^6-particle box per GPU sharing ONE bias grid: the packed increments
+                  {grid_delta, sigma_grid_delta | hist_delta, hist_gauss_delta} are summed over the walkers on every
+                  deposit (IntegratorMetaDynamics.cc:393-409) with RCCL (mtd_metad_update_bias_walkers)
 Rank 0 prints ONE JSON line.
 """
 import argparse
 import ctypes as C
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
+# The xGMI mailbox shares device buffers between the ranks of a node through HIP IPC handles.  On hosts whose driver only
+# supports dmabuf IPC the runtime has to be told so BEFORE it initialises (it reads the variable once); without it
+# hipIpcGetMemHandle fails with "invalid argument", the mailbox cannot map its peers and every rank takes the RCCL all-reduce
+# (~11 us per step more).  Set here, before anything loads HIP, unless the caller chose a value.
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
-for p in (os.path.join(ROOT, "metadynamics-plugin_amd"), os.path.join(ROOT, "tests")):
-    if p not in sys.path:
-        sys.path.insert(0, p)
-
-import numpy as np
-import torch
-
-import util
-from metadynamics import _abi
-
 N_PER_GPU = 1_000_000
+N_STRONG = 8_000_000      # SURVEY.md 8d config 4: 8 x 10^6 particles, L = 200
 BOX_L = 100.0
 GRID = dict(sigma=[1e-3, 1e-3], cv_min=[-0.02, -0.02], cv_max=[0.02, 0.02], num_points=[256, 256])
 W, DELTA_T, T = 1.0, 7.0, 1.0
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+FP64_VECTOR_PEAK_TFLOPS = 78.6   # MI355X_MICROARCH.md: fp64 vector (non-matrix) peak
+PROFILE_ROUND = "r3"
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="weak: 10^6 particles per GPU; strong: 8 x 10^6 particles in all (SURVEY.md 8d config 4)")
+    ap.add_argument("--walkers", action="store_true", help="one independent 10^6-particle box per GPU sharing one bias grid")
     ap.add_argument("--stride", type=int, default=1, help="hill deposition stride (headline: 1)")
-    ap.add_argument("--particles", type=int, default=N_PER_GPU, help="particles per GPU")
-    ap.add_argument("--fast-trig", type=int, default=int(os.environ.get("MTD_FAST_TRIG", "1")))
+    ap.add_argument("--particles", type=int, default=None, help="particles per GPU (weak / walkers) or in all (strong)")
+    ap.add_argument("--fast-trig", type=int, default=int(os.environ.get("MTD_FAST_TRIG", "1")),
+                    help="1 (library default): hardware sine / cosine on the phase in turns; 0: ocml sinpi / cospi")
     ap.add_argument("--path", choices=["fused", "generic"], default="fused",
                     help="fused: two launches per step (headline); generic: separate C-ABI calls per stage")
     ap.add_argument("--driver", choices=["host", "abi"], default=None,
@@ -58,41 +71,121 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=4)
     ap.add_argument("--no-sub-records", action="store_true", help="skip the config 3 / config 5 sub-records (N = 1)")
+    ap.add_argument("--no-variants", action="store_true", help="skip extra.steady_state / stride100 / f64 / accurate_trig (N = 1)")
     ap.add_argument("--sub-steps", type=int, default=200, help="steps timed for each sub-record")
-    return ap.parse_args()
+    return ap.parse_args(argv)
+
+
+def visible_gpus():
+    """GPUs this process could use, WITHOUT touching HIP: the KFD topology (nodes with SIMDs), capped by a visibility list"""
+    n = None
+    try:
+        base = "/sys/class/kfd/kfd/topology/nodes"
+        n = 0
+        for node in os.listdir(base):
+            props = dict(l.split() for l in open(os.path.join(base, node, "properties")) if len(l.split()) == 2)
+            if int(props.get("simd_count", "0")) > 0:
+                n += 1
+    except Exception:
+        n = None
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None and v.strip() != "":
+            k = len([x for x in v.split(",") if x.strip() != ""])
+            n = k if n is None else min(n, k)
+    return n
+
+
+def self_launch(args, argv):
+    """`python bench.py --gpus N` without a launcher: start one rank per GPU with torch.distributed.run as a CHILD process
+    (this process never imports torch and never touches the GPU), relay rank 0's JSON line and the exit code."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    n_vis = visible_gpus()
+    if n_vis is not None and n_vis < args.gpus and env.get("MTD_BENCH_REHEARSAL") is None:
+        # fewer GPUs than ranks (a one-GPU box): every rank on cuda:0, control plane gloo — a rehearsal of the code path whose
+        # numbers mean nothing; the line says so (config.rehearsal).  A GPU box admits few processes on its card at once.
+        if args.gpus > 4:
+            sys.stderr.write("bench.py: %d ranks asked for, %d GPU(s) visible: a rehearsal on one GPU is limited to 4 ranks\n" % (args.gpus, n_vis))
+            return 2
+        env["MTD_BENCH_REHEARSAL"] = "1"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    if os.environ.get("MTD_BENCH_DRY_LAUNCH") == "1":         # test hook (tests/test_bench_launcher.py): show the launch, start nothing
+        print(json.dumps({"cmd": cmd, "rehearsal": env.get("MTD_BENCH_REHEARSAL"), "ipc": env.get("HSA_ENABLE_IPC_MODE_LEGACY"),
+                          "torch_imported": "torch" in sys.modules, "visible_gpus": n_vis}))
+        return 0
+    p = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True, cwd=ROOT)
+    line = None
+    for l in p.stdout:
+        if l.startswith('{"metric"'):
+            line = l.strip()
+        else:
+            sys.stderr.write(l)
+    rc = p.wait()
+    if line is not None:
+        print(line, flush=True)
+    return rc if rc != 0 else (0 if line is not None else 1)
+
+
+if __name__ == "__main__" and "WORLD_SIZE" not in os.environ:
+    _args = parse()
+    if _args.gpus > 1:
+        sys.exit(self_launch(_args, sys.argv[1:]))
+
+for p in (os.path.join(ROOT, "metadynamics-plugin_amd"), os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np
+import torch
+
+import util
+from metadynamics import _abi
+
+CVS = [(util.CV1_VECTORS, util.MODE_AB), (util.CV2_VECTORS, util.MODE_AB)]
 
 
 class Engine:
     """The hot path through the C-ABI, device resident (metadynamics.sharded.HipLamellarBackend)."""
 
-    def __init__(self, n_local, n_global, rank, seed, stride, fast_trig, dist=None, path="fused", dtype=np.float32):
+    def __init__(self, n_local, n_global, rank, seed, stride, fast_trig, dist=None, path="fused", dtype=np.float32, shard=True,
+                 box_particles=None):
         from metadynamics.sharded import HipLamellarBackend, ShardedBiasStep
         self.dist = dist
-        L = BOX_L * (n_global / N_PER_GPU) ** (1.0 / 3.0)  # constant density (config 4: L = 200 at 8e6)
-        pos, types = util.snapshot_random(n_global, L, seed=seed, dtype=np.float32)
+        n_box = n_global if box_particles is None else box_particles
+        L = BOX_L * (n_box / N_PER_GPU) ** (1.0 / 3.0)  # constant density (config 4: L = 200 at 8e6)
+        pos, types = util.snapshot_random(n_box, L, seed=seed, dtype=np.float32)
         self.full = None
-        if dist is not None:
+        if dist is not None and shard:
             # every rank draws the same global snapshot and keeps its contiguous slice (lamellar CVs need no locality)
             if rank == 0:
                 self.full = (pos, types)           # rank 0 checks the global CV values against the oracle afterwards
             sl = slice(rank * n_local, (rank + 1) * n_local)
             pos, types = pos[sl].copy(), types[sl].copy()
         self.pos_np, self.types_np, self.L = pos, types, L
-        cvs = [(util.CV1_VECTORS, util.MODE_AB), (util.CV2_VECTORS, util.MODE_AB)]
         d_pos = torch.from_numpy(util.pack_postype(pos.astype(dtype), types, dtype)).cuda()
-        self.be = HipLamellarBackend(cvs, d_pos, n_global, L, GRID, W, DELTA_T, T, stride, "well_tempered",
+        self.be = HipLamellarBackend(CVS, d_pos, n_global, L, GRID, W, DELTA_T, T, stride, "well_tempered",
                                      fast_trig=bool(fast_trig), fused=(path == "fused"),
                                      exchange="partials")   # equal shards: the block partial sums travel (no reduce launch)
-        self.sharded = ShardedBiasStep(self.be, dist) if dist is not None else None
+        self.sharded = ShardedBiasStep(self.be, dist) if (dist is not None and shard) else None
         self.exchange = None
-        if dist is not None:
+        self.exchange_note = None
+        if dist is not None and shard:
             # the n_cv sums of a step travel through the xGMI mailbox (direct stores between the GPUs, no collective call);
             # RCCL all-reduce of the block partial sums if the mailbox cannot be set up on this node
             from metadynamics import xgmi
             box = xgmi.connect(dist, max_doubles=8)
             if box is not None:
                 self.be.attach_mailbox(box)
-            self.exchange = "xgmi-mailbox" if box is not None else ("rccl" if dist.get_backend() == "nccl" else dist.get_backend())
+            fallback = "rccl" if dist.get_backend() == "nccl" else dist.get_backend()
+            self.exchange = "xgmi-mailbox" if box is not None else fallback
+            if box is None:
+                self.exchange_note = ("FALLBACK: the xGMI mailbox could not be set up (%s); the per-step sums go through the %s "
+                                      "all-reduce (~11 us per step more)" % (xgmi.last_failure() or "no reason recorded", fallback))
         self.t = 0
         self.ev = None
 
@@ -100,7 +193,7 @@ class Engine:
         be = self.be
         if self.ev is None:
             if self.sharded is not None:
-                self.sharded.step(self.t)      # launch A, reduce, RCCL all-reduce of n_cv doubles, launch B
+                self.sharded.step(self.t)      # launch A, (mailbox | reduce + all-reduce of n_cv doubles), launch B
             else:
                 be.step_single(self.t)         # launch A, launch B
         else:
@@ -129,20 +222,28 @@ class Engine:
     def state(self):
         return self.be.state()
 
+    def close(self):
+        self.be.close()
+
 
 class HostEngine:
     """The same workload through the reference-shaped API: metadynamics.cv / metadynamics.integrate over the C++
     host classes; the step loop is System::run in C++ (what HOOMD's run loop does)."""
 
-    def __init__(self, pos, types, L, n_global, stride, fast_trig, path, dtype=np.float32, mailbox=None):
+    def __init__(self, pos, types, L, n_global, stride, fast_trig, path, dtype=np.float32, mailbox=None, walkers=None):
         """pos / types: this rank's particles (the whole snapshot at N = 1); mailbox: metadynamics.xgmi.Mailbox of a
-        particle-sharded run — it plays the role of HOOMD's MPI communicator in the execution configuration"""
+        particle-sharded run — it plays the role of HOOMD's MPI communicator in the execution configuration; walkers: an
+        mtd_rccl handle (the reference's partition communicator) of a multiple-walker run"""
         from metadynamics import context, cv, integrate
         self.pos_np, self.types_np, self.L = pos, types, L
         self.ctx = context.initialize(pos, types, ["A", "B"], L, dtype=dtype, n_global=n_global)
         if mailbox is not None:
             context.exec_conf.setMailbox(mailbox.handle.value)
+        if walkers is not None:
+            context.exec_conf.setWalkerCommunicator(walkers)
         self.meta = integrate.mode_metadynamics(dt=0.005, stride=stride, mode="well_tempered", W=W, deltaT=DELTA_T, T=T)
+        if walkers is not None:
+            self.meta.set_params(multiple_walkers=True)
         self.cvs = []
         for i, vecs in enumerate((util.CV1_VECTORS, util.CV2_VECTORS)):
             c = cv.lamellar(sigma=GRID["sigma"][i], mode=dict(A=1.0, B=-1.0), lattice_vectors=vecs, name="cv%d" % i)
@@ -164,6 +265,43 @@ class HostEngine:
         return dict(cv=list(integ.getCurrentValues()), V=integ.getLogValue("bias", t),
                     w=integ.getLogValue("weight", t), num_gaussians=integ.getNumGaussians(), fused=integ.usedFusedPath())
 
+    def grid_checksum(self):
+        """sum and sum of squares of the bias grid (walkers: identical on every rank after each exchange)"""
+        lib = _abi.load()
+        h = C.c_void_p(self.meta.cpp_integrator.getEngineHandle())
+        G = lib.mtd_metad_num_elements(h)
+        out = np.zeros(G, dtype=np.float64)
+        _abi.check(lib.mtd_metad_get_array(h, 0, out.ctypes.data, None))
+        return float(out.sum()), float((out * out).sum())
+
+
+class WalkerEngine:
+    """Multiple walkers through the C ABI from Python (rehearsals whose control plane is gloo — RCCL refuses two ranks on one
+    device; a real run takes the C++ host classes with an RCCL communicator): metadynamics.sharded.WalkerBiasStep over a
+    generic CV set, the packed increments summed by the process group."""
+
+    def __init__(self, pos, types, L, stride, fast_trig, dist, dtype=np.float32):
+        from metadynamics.sharded import HipCvSetBackend, LamellarPart, WalkerBiasStep
+        N = pos.shape[0]
+        self.d_pos = torch.from_numpy(util.pack_postype(pos.astype(dtype), types, dtype)).cuda()
+        _abi.check(_abi.load().mtd_lamellar_set_fast_trig(int(fast_trig)))
+        parts = [LamellarPart(v, m, self.d_pos, N, L) for v, m in CVS]
+        self.be = HipCvSetBackend(parts, GRID, W, DELTA_T, T, stride, "well_tempered")
+        self.walk = WalkerBiasStep(self.be, dist)
+        self.t = 0
+
+    def run(self, k):
+        for _ in range(k):
+            self.walk.step(self.t)
+            self.t += 1
+
+    def state(self):
+        return self.be.state()
+
+    def grid_checksum(self):
+        g = self.be.grid_array(0)
+        return float(g.sum()), float((g * g).sum())
+
 
 def cpu_baseline(pos, types, L, steps):
     """The CPU restatement (oracle, kind "port") of the same step on ONE host core: the reference CPU
@@ -173,18 +311,14 @@ def cpu_baseline(pos, types, L, steps):
     rbox = mtd_ref.Box.make(L)
     opt = util.oracle_postype(pos, types)
     r = mtd_ref.Metad(W=W, T_shift=DELTA_T, T=T, stride=1, mode="well_tempered", **GRID)
-    cvs = [(util.CV1_VECTORS, util.MODE_AB), (util.CV2_VECTORS, util.MODE_AB)]
     t0 = time.perf_counter()
     for t in range(steps):
-        s = [mtd_ref.lamellar_cv(v, opt, m, rbox) for v, m in cvs]
+        s = [mtd_ref.lamellar_cv(v, opt, m, rbox) for v, m in CVS]
         b = r.update_bias(t, s)
-        for c, (v, m) in enumerate(cvs):
+        for c, (v, m) in enumerate(CVS):
             mtd_ref.lamellar_forces(v, opt, m, rbox, b[c])
     dt = time.perf_counter() - t0
-    return pos.shape[0] * len(cvs) * steps / dt, dt
-
-
-FP64_VECTOR_PEAK_TFLOPS = 78.6   # MI355X_MICROARCH.md: fp64 vector (non-matrix) peak
+    return pos.shape[0] * len(CVS) * steps / dt, dt
 
 
 def _timed_host_steps(context, steps, repeats=3):
@@ -200,9 +334,21 @@ def _timed_host_steps(context, steps, repeats=3):
     return float(np.median(out))
 
 
+def _traffic_record(kernels):
+    """HBM bytes per launch of the named kernels from the PMC passes committed under profiles/ (None when absent)"""
+    path = os.path.join(ROOT, "profiles", PROFILE_ROUND, "pmc_mesh_ql_summary.json")
+    if not os.path.exists(path):
+        return None
+    rec = json.load(open(path))
+    out = {k: rec[k] for k in kernels if k in rec}
+    out["_source"] = "profiles/%s/pmc_mesh_ql_summary.json" % PROFILE_ROUND
+    return out
+
+
 def sub_record_config3(steps, fast_trig):
     """BASELINE.json configs[2] (SURVEY config 3): 10^6 particles, cv.mesh on 128^3 (bug-compatible) + one lamellar CV, 256^2 bias
-    grid, well-tempered, stride 1 — through the reference-shaped API (C++ host classes).  Bound: HBM.  Algorithmic bytes:
+    grid, well-tempered, stride 1 — through the reference-shaped API (C++ host classes).  The mesh CV's grid spans value x [0, 2]
+    (one untimed evaluation supplies the value), sigma = 1 % of the range.  Bound: HBM.  Algorithmic bytes:
     SURVEY 8d's definition for the reference's fp32 / C2C layout (191 MB) and this build's own count (fp64 meshes, half
     spectrum: DESIGN.md 4.4).  The mesh kernels are also timed on their own through the C ABI (events on the launch stream)."""
     from metadynamics import context, cv, integrate
@@ -211,15 +357,28 @@ def sub_record_config3(steps, fast_trig):
     pos = (np.mod(pos.astype(np.float64) + L / 2, L) - L / 2).astype(np.float32)       # an MD engine keeps its particles in the box
     pos[pos >= L / 2] = -L / 2
     _abi.check(_abi.load().mtd_lamellar_set_fast_trig(int(fast_trig)))
-    context.initialize(pos, types, ["A", "B"], L, dtype=np.float32)
-    integrate.mode_metadynamics(dt=0.005, stride=1, mode="well_tempered", W=W, deltaT=DELTA_T, T=T)
-    lam = cv.lamellar(sigma=0.02, mode=dict(A=1.0, B=-1.0), lattice_vectors=util.CV1_VECTORS)
-    lam.set_grid(-1.0, 1.0, 256)
-    mesh = cv.mesh(nx=128, mode={"A": 1.0, "B": -1.0})
-    mesh.set_grid(0.0, 1.0, 256)
+
+    def build(lo, hi, sigma):
+        context.initialize(pos, types, ["A", "B"], L, dtype=np.float32)
+        meta = integrate.mode_metadynamics(dt=0.005, stride=1, mode="well_tempered", W=W, deltaT=DELTA_T, T=T)
+        lam = cv.lamellar(sigma=0.02, mode=dict(A=1.0, B=-1.0), lattice_vectors=util.CV1_VECTORS)
+        lam.set_grid(-1.0, 1.0, 256)
+        mesh = cv.mesh(nx=128, mode={"A": 1.0, "B": -1.0}, sigma=sigma)
+        mesh.set_grid(lo, hi, 256)
+        return meta, mesh
+
+    meta, mesh = build(0.0, 1.0, 1.0)
+    context.run(1)                              # one untimed evaluation: the value the grid is centred on
+    s0 = mesh.cpp_force.getCurrentValue(context.current.system.getCurrentTimeStep())
+    context.current = None
+    lo, hi = (0.0, 2.0 * s0) if s0 > 0 else (2.0 * s0, 0.0)
+    meta, mesh = build(lo, hi, 0.01 * (hi - lo))
     context.run(150)                            # (the GPU idled during the CPU baseline: tens of milliseconds of work bring the clocks back)
     per_step = _timed_host_steps(context, steps)
-    s_mesh = mesh.cpp_force.getCurrentValue(context.current.system.getCurrentTimeStep())
+    t_now = context.current.system.getCurrentTimeStep()
+    s_mesh = mesh.cpp_force.getCurrentValue(t_now)
+    integ = meta.cpp_integrator
+    hills, bias_f, V_now = integ.getNumGaussians(), list(integ.getBiasFactors()), integ.getLogValue("bias", t_now)
     context.current = None
     # the mesh CV's own launches through the C ABI
     lib = _abi.load()
@@ -257,32 +416,50 @@ def sub_record_config3(steps, fast_trig):
     return {"workload": "1xMI355X: 10^6 particles, OrderParameterMesh CV on 128^3 mesh (bug-compatible) + 1 lamellar CV, 256^2 bias grid, well-tempered",
             "ms_per_step": 1e3 * per_step, "ms_per_step_runs": [1e3 * x for x in _timed_host_steps.last], "value": 2 * N / per_step,
             "unit": "particle-CV-evals/s", "steps": steps, "dtype": "f64 meshes, f32 particles",
-            "fast_trig": int(fast_trig), "mesh_cv": s_mesh,
+            "fast_trig": int(fast_trig), "mesh_cv": s_mesh, "mesh_grid": [lo, hi, 256], "mesh_sigma": 0.01 * (hi - lo),
+            "on_grid": bool(lo <= s_mesh < hi), "hills": hills, "bias_factors": bias_f, "V": V_now,
             "roofline": {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "step_algorithmic_bytes_survey_fp32_c2c": bytes_survey, "step_frac_survey": bytes_survey / per_step / 1e9 / HBM_PEAK_GBS,
                          "step_algorithmic_bytes_this_build_fp64_r2c": int(bytes_build), "step_frac": bytes_build / per_step / 1e9 / HBM_PEAK_GBS,
                          "mesh_compute_cv_us": cv_us, "mesh_forces_us": f_us,
-                         "dominant_kernels": "k_tile_scatter, k_tile_forces, k_fft_z_spectral (per-kernel table: profiles/r2/config3_mesh_kernel_stats.csv)",
+                         "traffic": _traffic_record(["k_tile_count", "k_tile_rowscan", "k_tile_place", "k_tile_scatter", "k_tile_combine_rows",
+                                                     "k_fft_xy_forward", "k_fft_z_spectral", "k_fft_xy_inverse", "k_tile_forces"]),
+                         "dominant_kernels": "k_tile_scatter, k_tile_forces, k_fft_z_spectral (per-kernel table: profiles/%s/config3_mesh_kernel_stats.csv)" % PROFILE_ROUND,
                          "timing": "host API: wall clock around System::run, synchronised on both sides; mesh calls: HIP events on the launch stream"}}
 
 
 def sub_record_config5(steps):
     """BASELINE.json configs[4] (SURVEY config 5): 256 000-particle noisy fcc crystal, cv.steinhardt lmax 6, full neighbour list
-    r_cut 1.4, 512-point grid — through the reference-shaped API.  Bound: fp64 vector ALU (no HBM roofline: ~40 B against
-    ~0.9 kflop per pair); flops per pair from DESIGN.md 4.5 (CV pass ~0.5 kflop, contracted force pass ~0.4 kflop)."""
+    r_cut 1.4, 512-point grid over [0, 2 s] with sigma = 1 % of the range (one untimed evaluation supplies s) —
+    through the reference-shaped API.  Bound: fp64 vector ALU (no HBM roofline: ~40 B against ~0.9 kflop per pair); flops per
+    pair from DESIGN.md 4.5 (CV pass ~0.5 kflop, contracted force pass ~0.4 kflop); the counter-based VALU utilisation of the
+    two kernels is under profiles/."""
     from metadynamics import context, cv, integrate
     pos, L = util.fcc_lattice(40)
     pos = pos + np.random.default_rng(777).normal(0, 0.05, pos.shape)
     N = len(pos)
-    context.initialize(pos, np.zeros(N, dtype=np.int32), ["A"], L, dtype=np.float64)
-    integrate.mode_metadynamics(dt=0.005, stride=1, mode="well_tempered", W=W, deltaT=DELTA_T, T=T)
-    nl = cv.nlist_cell(r_cut=1.4)
-    lists = nl.update()
-    st = cv.steinhardt(r_cut=1.4, r_on=1.2, lmax=6, Ql_ref=[0, 0, 0, 0, 1, 0, 1], nlist=nl, type="A", sigma=1.0)
-    st.set_grid(0.0, 1.0, 512)
+
+    def build(hi, sigma):
+        context.initialize(pos, np.zeros(N, dtype=np.int32), ["A"], L, dtype=np.float64)
+        meta = integrate.mode_metadynamics(dt=0.005, stride=1, mode="well_tempered", W=W, deltaT=DELTA_T, T=T)
+        nl = cv.nlist_cell(r_cut=1.4)
+        lists = nl.update()
+        st = cv.steinhardt(r_cut=1.4, r_on=1.2, lmax=6, Ql_ref=[0, 0, 0, 0, 1, 0, 1], nlist=nl, type="A", sigma=sigma)
+        st.set_grid(0.0, hi, 512)
+        return meta, st, lists
+
+    meta, st, lists = build(1.0, 1.0)
+    context.run(1)
+    s0 = st.cpp_force.getCurrentValue(context.current.system.getCurrentTimeStep())
+    context.current = None
+    hi = 2.0 * s0
+    meta, st, lists = build(hi, 0.01 * hi)
     context.run(150)
     per_step = _timed_host_steps(context, steps)
-    s = st.cpp_force.getCurrentValue(context.current.system.getCurrentTimeStep())
+    t_now = context.current.system.getCurrentTimeStep()
+    s = st.cpp_force.getCurrentValue(t_now)
+    integ = meta.cpp_integrator
+    hills, bias_f, V_now = integ.getNumGaussians(), list(integ.getBiasFactors()), integ.getLogValue("bias", t_now)
     context.current = None
     pairs = len(lists[2])
     flops = pairs * (500.0 / 2 + 400.0)       # symmetric full list: the CV pass visits a pair once, the force pass every entry
@@ -290,9 +467,11 @@ def sub_record_config5(steps):
             "ms_per_step": 1e3 * per_step, "ms_per_step_runs": [1e3 * x for x in _timed_host_steps.last], "value": N / per_step,
             "unit": "particle-CV-evals/s", "steps": steps, "dtype": "f64",
             "pair_entries": pairs, "pair_visits_per_s": 1.5 * pairs / per_step, "steinhardt_cv": s,
+            "grid": [0.0, hi, 512], "sigma": 0.01 * hi, "on_grid": bool(0.0 <= s < hi), "hills": hills, "bias_factors": bias_f, "V": V_now,
             "roofline": {"bound": "valu_fp64", "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s", "achieved": flops / per_step / 1e12,
                          "frac": flops / per_step / 1e12 / FP64_VECTOR_PEAK_TFLOPS, "flops_per_step_model": flops,
-                         "dominant_kernels": "k_ql_forces, k_ql_accumulate (per-kernel table: profiles/r2/config5_steinhardt_kernel_stats.csv)",
+                         "counters": _traffic_record(["k_ql_accumulate", "k_ql_forces"]),
+                         "dominant_kernels": "k_ql_forces, k_ql_accumulate (per-kernel table: profiles/%s/config5_steinhardt_kernel_stats.csv)" % PROFILE_ROUND,
                          "timing": "host API: wall clock around System::run, synchronised on both sides"}}
 
 
@@ -333,17 +512,65 @@ def self_check(st, stride):
             "V_rel_err": abs(st["V"] - v_ref) / max(abs(v_ref), 1e-300), "w_rel_err": abs(st["w"] - w_ref) / max(abs(w_ref), 1e-300)}
 
 
+def measured_copy_bandwidth():
+    """a measured ceiling beside the 8 TB/s of the data sheet: device-to-device copy of 512 MB (read + write counted) and a
+    read-only pass (sum) over the same buffer — HIP events, best of several"""
+    n = 128 * 1024 * 1024
+    src = torch.empty(n, dtype=torch.float32, device="cuda").normal_()
+    dst = torch.empty_like(src)
+
+    def best(fn, nbytes, reps=8):
+        out = []
+        for _ in range(reps):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            fn()
+            b.record()
+            torch.cuda.synchronize()
+            out.append(nbytes / (a.elapsed_time(b) * 1e-3) / 1e9)
+        return float(max(out))
+
+    dst.copy_(src)
+    copy = best(lambda: dst.copy_(src), 2 * 4 * n)
+    read = best(lambda: src.sum(), 4 * n)
+    fill = best(lambda: dst.fill_(1.0), 4 * n)
+    del src, dst
+    return {"copy_512MB_GBs": copy, "read_512MB_GBs": read, "write_512MB_GBs": fill,
+            "note": "torch copy_ / sum / fill_ of a 512 MB buffer, best of 8 (HIP events); copy counts bytes read + written"}
+
+
+def timed_variant(stride, dtype, fast_trig, steps, warmup=300, path="fused"):
+    """us per step of the headline workload with one thing changed (same kernels through the C ABI, Python loop: equal to the
+    C++ loop at these step counts, profiles/r2/timed_region_fixed_cost.log), synchronised on both sides"""
+    np_dtype = np.float32 if dtype == "f32" else np.float64
+    eng = Engine(N_PER_GPU, N_PER_GPU, 0, seed=12345, stride=stride, fast_trig=fast_trig, path=path, dtype=np_dtype)
+    for _ in range(warmup):
+        eng.step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        eng.step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    st = eng.state()
+    eng.close()
+    scalar4 = 16 if dtype == "f32" else 32
+    return {"ms_per_step": 1e3 * dt / steps, "steps": steps, "value": steps / dt * N_PER_GPU * 2, "hills": st["num_gaussians"],
+            "step_frac": N_PER_GPU * 4 * scalar4 / (dt / steps) / 1e9 / HBM_PEAK_GBS}
+
+
 def main():
     args = parse()
+    lib_default_trig = int(_abi.load().mtd_lamellar_get_fast_trig())     # before anything sets the process-wide switch
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)" % args.gpus)
+        raise SystemExit("bench.py --gpus %d inside a launch of %d rank(s): call it plainly (it starts its ranks itself) or with "
+                         "torch.distributed.run --nproc-per-node %d" % (args.gpus, world, args.gpus))
     dist = None
     # rehearsal of the N>1 code path on a one-GPU box: MTD_BENCH_REHEARSAL=1 puts every rank on cuda:0 and carries the
-    # all-reduce with gloo (RCCL refuses two ranks on one device); numbers from such a run mean nothing
+    # control plane with gloo (RCCL refuses two ranks on one device); numbers from such a run mean nothing
     rehearsal = os.environ.get("MTD_BENCH_REHEARSAL") == "1"
     if rehearsal:
         local_rank = 0
@@ -359,9 +586,19 @@ def main():
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
-    n_local = args.particles
-    n_global = n_local * world
+    walkers = bool(args.walkers)
+    if args.scaling == "strong" and walkers:
+        raise SystemExit("--walkers is a weak-scaling mode (one box per GPU)")
+    if args.scaling == "strong":
+        n_global = args.particles if args.particles is not None else N_STRONG
+        if n_global % world:
+            raise SystemExit("--scaling strong: %d particles do not divide over %d ranks" % (n_global, world))
+        n_local = n_global // world
+    else:
+        n_local = args.particles if args.particles is not None else N_PER_GPU
+        n_global = n_local if walkers else n_local * world
     driver = args.driver or "host"
+    path = "generic" if walkers else args.path          # the fused step is off in walker mode (the increments are summed between the grid passes)
 
     def barrier():
         # (plain synchronise: recording an event and polling it first measured ~1 us per step SLOWER at K = 20 —
@@ -371,10 +608,19 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    def ctl_device():
+        return "cuda" if dist.get_backend() == "nccl" else "cpu"
+
     np_dtype = np.float32 if args.dtype == "f32" else np.float64
     # the event-bracketed pass over the dominant kernel always goes through the C-ABI backend (same kernels)
-    eng = Engine(n_local, n_global, rank, seed=12345 if world == 1 else 12346, stride=args.stride,
-                 fast_trig=args.fast_trig, dist=dist, path=args.path, dtype=np_dtype)
+    if walkers:
+        seed = 12345 + rank                    # every walker its own box
+    elif world == 1 and args.scaling == "weak":
+        seed = 12345                           # config 2 of SURVEY.md 8d
+    else:
+        seed = 12346                           # config 4
+    eng = Engine(n_local, n_global, rank, seed=seed, stride=args.stride, fast_trig=args.fast_trig, dist=dist, path=path, dtype=np_dtype,
+                 shard=not walkers)
     if dist is not None and eng.be.mailbox is not None:
         # the mailbox passed its self test; a short rehearsal of the real step decides whether it carries the timed run: any
         # bounded wait that expired on any rank (a link that does not deliver) sends every rank back to the collective
@@ -384,23 +630,37 @@ def main():
             for _ in range(chunk):
                 eng.step()
             barrier()
-            tt = torch.tensor([eng.be.mailbox.timeouts()], dtype=torch.int64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
+            tt = torch.tensor([eng.be.mailbox.timeouts()], dtype=torch.int64, device=ctl_device())
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             if int(tt.item()) > 0:
                 break
         if int(tt.item()) > 0 or os.environ.get("MTD_BENCH_TEST_FALLBACK") == "1":      # (env: exercises this branch in a rehearsal)
             eng.be.attach_mailbox(None)
-            eng.exchange = "%s (mailbox gave %d timeouts in rehearsal)" % ("rccl" if dist.get_backend() == "nccl" else dist.get_backend(), int(tt.item()))
-    if driver == "host" and dist is not None and eng.be.mailbox is None:
+            fb = "rccl" if dist.get_backend() == "nccl" else dist.get_backend()
+            eng.exchange = fb
+            eng.exchange_note = "FALLBACK: the xGMI mailbox gave %d expired waits in the rehearsal steps; the per-step sums go through the %s all-reduce" % (int(tt.item()), fb)
+    if driver == "host" and dist is not None and not walkers and eng.be.mailbox is None:
         driver = "abi"                     # no mailbox on this node: the C-ABI backend with the RCCL all-reduce
+    if walkers and dist is not None and dist.get_backend() != "nccl":
+        driver = "abi"                     # rehearsal: the packed increments through the process group (gloo)
     host = None
+    walker_comm = None
+    if walkers and dist is not None and driver == "host":
+        from metadynamics.sharded import RcclAllReduce
+        walker_comm = RcclAllReduce(dist)   # the library's own RCCL binding; the host classes call mtd_metad_update_bias_walkers
+        eng.exchange = "rccl (mtd_metad_update_bias_walkers: packed grid increments, 4 G elements per deposit)"
+    elif walkers and dist is not None:
+        eng.exchange = "%s process group (packed grid increments, 4 G elements per deposit)" % dist.get_backend()
     if driver == "host":
         # every piece of set-up comes first — building the host-API system copies the snapshot again and leaves the GPU idle for
         # ~0.1 s, after which the first milliseconds of work run on lowered clocks (tools/ramp_probe.py: +6-8 % per step after
         # 20-200 ms of idling, and W = 5 warm-up steps are 0.1 ms of work)
         barrier()                          # ranks enter the first exchange (prepRun's deposit) together
-        host = HostEngine(eng.pos_np, eng.types_np, eng.L, n_global, args.stride, args.fast_trig, args.path, dtype=np_dtype,
-                          mailbox=eng.be.mailbox)
+        host = HostEngine(eng.pos_np, eng.types_np, eng.L, n_global, args.stride, args.fast_trig, path, dtype=np_dtype,
+                          mailbox=eng.be.mailbox, walkers=walker_comm.handle.value if walker_comm is not None else None)
+    elif walkers:
+        barrier()
+        host = WalkerEngine(eng.pos_np, eng.types_np, eng.L, args.stride, args.fast_trig, dist, dtype=np_dtype)
     # (measured BEFORE the timed region: the per-launch figures are then taken on a GPU in the same state as the timed steps
     # and the timed region starts on clocks that are already up)
     # dominant kernel (launch B, the force pass): per-launch durations over the same loop from HIP events on the launch stream.
@@ -408,7 +668,8 @@ def main():
     # the begin and end of that dispatch and nothing else — no subtraction.  Two cross-checks are reported beside it: the
     # differential (n whole steps) - (n launches of launch A alone), and a plain event pair around B minus the cost of an
     # empty pair (which subtracts one packet too many: low).  The rocprofv3 kernel trace of the same command is under
-    # profiles/ (13.4-13.7 us for this kernel; the in-process figures are 14.6-14.7 us — the roofline is priced with those).
+    # profiles/; its average is reported beside the in-process figure (roofline.rocprof_avg_launch_us) — the roofline is priced
+    # with the in-process one, the larger of the two.
     for _ in range(20):
         eng.step()
     n_ev = 300          # launches measured one by one (their own loops, outside the timed region: events per launch perturb the step)
@@ -418,7 +679,7 @@ def main():
         return torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 
     alt = {}
-    if args.path == "fused":
+    if path == "fused":
         timing = "start/stop events of each launch (hipExtLaunchKernelGGL) on the launch stream"
         _abi.check(lib.mtd_profile_force_begin(n_ev))
         for _ in range(n_ev):
@@ -460,82 +721,110 @@ def main():
     ev_overhead_us = float(np.median([a.elapsed_time(b) for a, b in empty]) * 1e3)
     pair = np.array([a.elapsed_time(b) for a, b in eng.ev]) * 1e3 - ev_overhead_us
     eng.ev = None
-    raw = direct if args.path == "fused" else pair
+    raw = direct if path == "fused" else pair
     # a sample more than 3x the median is a stall of the queue (clock ramp, host jitter), not a kernel duration: dropped, counted
     keep = raw <= 3.0 * np.median(raw)
     n_stalls = int((~keep).sum())
     force_us_mean, force_us = float(np.mean(raw[keep])), float(np.median(raw))
-    if args.path == "fused":
+    if path == "fused":
         alt["event_pair_minus_empty_pair_us"] = float(np.mean(pair[pair <= 3.0 * np.median(pair)]))
     alt["empty_event_pair_us"] = ev_overhead_us
+
+    def run_steps(k):
+        if host is not None:
+            if isinstance(host, HostEngine):
+                host.run(k - 1)             # run(k) = prepRun (one bias update) + k updates: exactly k bias steps
+            else:
+                host.run(k)
+        else:
+            for _ in range(k):
+                eng.step()
 
     # The per-launch measurements above put two events around every launch; the queue works through such traffic more slowly
     # for a while after it has stopped (tools/k20_barrier_probe.py).  A stretch of plain, untimed steps in front of the warm-up
     # lets the timed region start from the state a production run is in.
     for _ in range(8):
-        if driver == "host":
-            host.run(99)
-        else:
-            for _ in range(100):
-                eng.step()
+        run_steps(100)
         barrier()
-    if driver == "host":
-        # sharded: the C++ host classes take the mailbox as their communicator (fused lamellar step)
+    barrier()                              # ranks enter the first exchange together (the mailbox waits are bounded)
+    if args.warmup > 0:
+        run_steps(args.warmup)
+    barrier()
+    t0 = time.perf_counter()
+    run_steps(args.steps)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    st = host.state() if host is not None else eng.state()
+    # steady state: the same loop over >= 2000 steps in the same process (a timed region has a fixed cost of ~40 us —
+    # doorbell on an idle queue, completion signal — which is 2 us per step at K = 20 and nothing at K = 2000)
+    steady = None
+    if not args.no_variants:
+        k_steady = max(2000, args.steps)
         barrier()
-        host.run(max(args.warmup - 1, 0))  # run(k) = prepRun (one bias update) + k updates: args.warmup untimed bias steps
+        t1 = time.perf_counter()
+        run_steps(k_steady)
         barrier()
-        t0 = time.perf_counter()
-        host.run(args.steps - 1)        # run(k) = prepRun (one bias update) + k updates: exactly args.steps bias steps
-        barrier()
-        elapsed = time.perf_counter() - t0
-        st = host.state()
-    else:
-        barrier()                          # ranks enter the first exchange together (the mailbox waits are bounded)
-        for _ in range(args.warmup):
-            eng.step()
-        barrier()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            eng.step()
-        barrier()
-        elapsed = time.perf_counter() - t0
-        st = eng.state()
+        steady = (time.perf_counter() - t1, k_steady)
+        st = host.state() if host is not None else eng.state()
     if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
+        vals = [elapsed, steady[0] if steady else 0.0]
+        tt = torch.tensor(vals, dtype=torch.float64, device=ctl_device())
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+        elapsed = float(tt[0].item())
+        if steady:
+            steady = (float(tt[1].item()), steady[1])
     mailbox_timeouts = None
     if eng.be.mailbox is not None:
-        tt = torch.tensor([eng.be.mailbox.timeouts()], dtype=torch.int64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
+        tt = torch.tensor([eng.be.mailbox.timeouts()], dtype=torch.int64, device=ctl_device())
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         mailbox_timeouts = int(tt.item())
+    walker_check = None
+    if walkers and host is not None:
+        s1, s2 = host.grid_checksum()
+        if dist is not None:
+            lo = torch.tensor([s1, s2], dtype=torch.float64, device=ctl_device())
+            hi = lo.clone()
+            dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+            dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+            same = bool((lo == hi).all().item())
+        else:
+            same = True
+        walker_check = {"grid_sum": s1, "grid_sum_sq": s2, "grid_identical_on_all_ranks": same, "hills_rank0": int(st["num_gaussians"])}
 
     if rank == 0:
+        n_boxes = world if walkers else 1
         steps_per_s = args.steps / elapsed
-        value = steps_per_s * n_global * 2
+        value = steps_per_s * n_global * n_boxes * 2
         # dominant kernel's algorithmic bytes per launch: read Scalar4 positions + write one Scalar4
         # force per CV (48 B/particle); the fused kernel also carries the first grid pass of the deposit
         # (per cell: 8 B dV written, 8+8 B reweighted r/w, 4 B hist_delta read)
         scalar4 = 16 if args.dtype == "f32" else 32
         force_bytes = n_local * (scalar4 + 2 * scalar4)
-        if args.path == "fused" and args.stride == 1:
+        if path == "fused" and args.stride == 1:
             force_bytes += 256 * 256 * 28
         achieved = force_bytes / (force_us_mean * 1e-6) / 1e9
         # HBM traffic of the dominant kernel from the PMC passes committed under profiles/ (FETCH_SIZE / WRITE_SIZE
         # in separate rocprofv3 runs, gfx950 x2 correction on FETCH_SIZE); only valid for the default workload
         # (a profiler cannot be attached from inside the run; the figure is only reported while the kernel's sources are the
         # ones the counters were collected on — otherwise traffic is null and traffic_stale says so)
-        traffic, traffic_src, traffic_stale = None, None, None
-        pmc = os.path.join(ROOT, "profiles", "r2", "pmc_summary.json")
-        if os.path.exists(pmc) and args.path == "fused" and args.stride == 1 and n_local == N_PER_GPU and args.dtype == "f32":
+        traffic, traffic_src, traffic_stale, rocprof_us = None, None, None, None
+        pmc = os.path.join(ROOT, "profiles", PROFILE_ROUND, "pmc_summary.json")
+        if os.path.exists(pmc) and path == "fused" and args.stride == 1 and n_local == N_PER_GPU and args.dtype == "f32" and world == 1:
             rec = json.load(open(pmc))
             traffic_stale = rec.get("kernel_source_sha256") != kernel_source_sha()
             if not traffic_stale:
                 traffic = rec.get("k_fused_force", {}).get("hbm_bytes_per_launch")
-                traffic_src = "profiles/r2/pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command on these kernel sources)"
+                rocprof_us = rec.get("k_fused_force", {}).get("rocprof_avg_launch_us")
+                traffic_src = "profiles/%s/pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command on these kernel sources)" % PROFILE_ROUND
         # step level: N (P [CV pass read] + P [force pass read] + n_cv P [force writes]) over the measured step
         step_bytes = n_local * 4 * scalar4
-        step_frac = step_bytes * world / (elapsed / args.steps) / 1e9 / (HBM_PEAK_GBS * world)
+        step_frac = step_bytes / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS
+        if world == 1 and args.scaling == "weak":
+            workload = "1xMI355X: 10^6 particles, 2 lamellar CVs (8 Fourier modes each), 256^2 bias grid, well-tempered"
+        elif walkers:
+            workload = "%dxMI355X: %d walkers of %d particles each sharing one 256^2 bias grid, 2 lamellar CVs, packed increments summed over the walkers (%s)" % (world, world, n_local, eng.exchange)
+        else:
+            workload = "%dxMI355X: %d particles sharded (%s scaling), 2 lamellar CVs, all-reduce of the CV sums (%s), replicated 256^2 grid" % (world, n_global, args.scaling, eng.exchange)
         out = {
             "metric": "particle_cv_evals_per_s",
             "value": value,
@@ -546,17 +835,22 @@ def main():
             "ms_per_step": 1e3 * elapsed / args.steps,
             "md_bias_steps_per_s": steps_per_s,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": args.dtype,
             "data": "synthetic",
-            "config": {"workload": "1xMI355X: 10^6 particles, 2 lamellar CVs (8 Fourier modes each), 256^2 bias grid, well-tempered"
-                       if world == 1 else "%dxMI355X: %d particles sharded, 2 lamellar CVs, all-reduce of the CV sums (%s), replicated 256^2 grid" % (world, n_global, eng.exchange),
-                       "particles_per_gpu": n_local, "n_cv": 2, "modes_per_cv": 8, "grid": "256x256",
-                       "stride": args.stride, "fast_trig": int(args.fast_trig), "path": args.path, "driver": driver},
-            "roofline": {"bound": "hbm", "kernel": "k_fused_force" if args.path == "fused" else "k_lamellar_forces", "achieved": achieved, "peak": HBM_PEAK_GBS,
+            "config": {"workload": workload,
+                       "particles_per_gpu": n_local, "particles_global": n_global * n_boxes, "n_cv": 2, "modes_per_cv": 8, "grid": "256x256",
+                       "stride": args.stride, "fast_trig": int(args.fast_trig), "fast_trig_library_default": lib_default_trig,
+                       "path": path, "driver": driver, "mode": "walkers" if walkers else "sharded" if world > 1 else "single"},
+            "roofline": {"bound": "hbm", "kernel": "k_fused_force" if path == "fused" else "k_lamellar_forces", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_source": traffic_src, "traffic_stale": traffic_stale,
+                         "frac_definition": "algorithmic bytes per launch / avg_launch_us (in-process start/stop events of every launch) / 8 TB/s; "
+                                            "rocprof_avg_launch_us is the kernel-trace average of the same command under profiles/ (smaller: "
+                                            "the trace excludes the dispatch's own start-up), frac_rocprof prices the roofline with it",
+                         "rocprof_avg_launch_us": rocprof_us,
+                         "frac_rocprof": (force_bytes / (rocprof_us * 1e-6) / 1e9 / HBM_PEAK_GBS) if rocprof_us else None,
                          "step_frac": step_frac, "step_algorithmic_bytes": step_bytes,
                          "step_frac_definition": "N*(P + P + n_cv*P) bytes per step (SURVEY.md 8d: 64 B/particle in f32) / ms_per_step / 8 TB/s, per GPU",
                          "algorithmic_bytes_per_launch": force_bytes, "avg_launch_us": force_us_mean, "median_launch_us": force_us,
@@ -564,11 +858,27 @@ def main():
                          "stalled_samples_dropped": n_stalls},
             "state": st,
         }
+        if rehearsal:
+            out["config"]["rehearsal"] = "all %d ranks share cuda:0, control plane gloo: the code path is real, the numbers mean nothing" % world
         if eng.exchange is not None:
             out["config"]["exchange"] = eng.exchange
+            if eng.exchange_note:
+                out["config"]["exchange_note"] = eng.exchange_note
+            out["config"]["HSA_ENABLE_IPC_MODE_LEGACY"] = os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY")
             if mailbox_timeouts is not None:
                 out["config"]["mailbox_timeouts"] = mailbox_timeouts
-        if not args.no_cpu_baseline and st.get("num_gaussians") and args.stride == 1:      # any N: the grid is replicated
+        if walker_check is not None:
+            out["walker_check"] = walker_check
+        extra = {}
+        if steady is not None:
+            sdt, sk = steady
+            extra["steady_state"] = {"ms_per_step": 1e3 * sdt / sk, "steps": sk, "value": sk / sdt * n_global * n_boxes * 2,
+                                     "step_frac": step_bytes / (sdt / sk) / 1e9 / HBM_PEAK_GBS,
+                                     "note": "the same loop in the same process right after the timed region, synchronised on both sides: the "
+                                             "fixed cost of a timed region (~40 us: doorbell on an idle queue, completion signal) is 2 us per "
+                                             "step at K = 20 and < 0.03 us here"}
+            out["roofline"]["step_frac_steady_state"] = extra["steady_state"]["step_frac"]
+        if not args.no_cpu_baseline and st.get("num_gaussians") and args.stride == 1 and not walkers:      # any N: the grid is replicated
             out["self_check"] = self_check(st, args.stride)
         if not args.no_cpu_baseline and eng.full is not None:
             # sharded run: the CV values the ranks agreed on against the oracle on the whole snapshot (checker, untimed).
@@ -581,11 +891,31 @@ def main():
             ref_cv = [mtd_ref.lamellar_cv(v, opt, util.MODE_AB, rbox) for v in (util.CV1_VECTORS, util.CV2_VECTORS)]
             out["cv_check"] = {"cv_oracle": ref_cv, "abs_err": [abs(a - b) for a, b in zip(st["cv"], ref_cv)],
                                "tolerance": 1e-6 * 8 / np.sqrt(n_global)}
-        if not args.no_cpu_baseline and world == 1:
+        single = world == 1 and args.scaling == "weak" and not walkers and n_local == N_PER_GPU
+        if single and not args.no_variants:
+            # the same workload with one thing changed each (SURVEY.md 8d "Metric": stride 100, the fp64 build, and the trigonometry
+            # mode that is NOT the one timed above), and a measured bandwidth ceiling beside the data-sheet peak
+            try:
+                if host is not None and isinstance(host, HostEngine):
+                    host.context.current = None
+                extra["stride100"] = timed_variant(100, "f32", args.fast_trig, 2000)
+                extra["f64"] = timed_variant(1, "f64", args.fast_trig, 1000)
+                other = 0 if args.fast_trig else 1
+                extra["accurate_trig" if other == 0 else "fast_trig"] = timed_variant(1, "f32", other, 2000)
+                _abi.check(lib.mtd_lamellar_set_fast_trig(int(args.fast_trig)))
+                mp = measured_copy_bandwidth()
+                out["roofline"]["measured_peak"] = mp
+                out["roofline"]["frac_of_measured_copy"] = achieved / mp["copy_512MB_GBs"]
+                ss = extra.get("steady_state", {}).get("ms_per_step", 1e3 * elapsed / args.steps)
+                out["roofline"]["step_frac_of_measured_copy"] = step_bytes / (ss * 1e-3) / 1e9 / mp["copy_512MB_GBs"]
+            except Exception as e:                                      # never let a variant break the headline line
+                extra["variants_error"] = repr(e)
+        if not args.no_cpu_baseline and world == 1 and not walkers:
             pos, types = eng.pos_np, eng.types_np
-            v, dt = cpu_baseline(pos, types, eng.L, args.cpu_steps)
+            n_cpu = min(pos.shape[0], N_PER_GPU)                        # bounded sample (strong scaling at N = 1 holds 8 x 10^6)
+            v, dt = cpu_baseline(pos[:n_cpu], types[:n_cpu], eng.L, args.cpu_steps)
             out["cpu_baseline"] = {"value": v, "unit": "particle-CV-evals/s", "cores": 1, "kind": "port",
-                                   "sample": "%d full steps of the same 10^6-particle workload (%.1f s) with the oracle's C restatement, gcc -O2, double" % (args.cpu_steps, dt)}
+                                   "sample": "%d full steps of the same workload on %d particles (%.1f s) with the oracle's C restatement, gcc -O2, double" % (args.cpu_steps, n_cpu, dt)}
             # informational: the same loops with OpenMP over the particles on every host core ("idealised multi-rank";
             # the reference itself has no threading, one MPI rank per core is its only parallelism)
             try:
@@ -593,22 +923,25 @@ def main():
                 n_thr = host_cores()
                 os.environ["OMP_NUM_THREADS"] = str(n_thr)              # read by libgomp when the OpenMP build is loaded
                 mtd_ref.use_openmp(True)
-                cpu_baseline(pos, types, eng.L, 1)                      # thread pool start-up
-                v2, dt2 = cpu_baseline(pos, types, eng.L, 4 * args.cpu_steps)
+                cpu_baseline(pos[:n_cpu], types[:n_cpu], eng.L, 1)      # thread pool start-up
+                v2, dt2 = cpu_baseline(pos[:n_cpu], types[:n_cpu], eng.L, 4 * args.cpu_steps)
                 out["cpu_baseline_all_cores"] = {"value": v2, "unit": "particle-CV-evals/s", "cores": n_thr, "kind": "port",
                                                  "sample": "%d steps (%.1f s), OpenMP over particles" % (4 * args.cpu_steps, dt2)}
             except Exception as e:                                      # never let the informational leg break the bench line
                 out["cpu_baseline_all_cores"] = {"error": str(e)}
             finally:
                 mtd_ref.use_openmp(False)
-        if world == 1 and not args.no_sub_records and n_local == N_PER_GPU:
+        if single and not args.no_sub_records:
             # the other single-GPU configurations of BASELINE.json, bounded runs (not the headline: reported beside it)
             try:
-                if driver == "host":
+                if host is not None and isinstance(host, HostEngine):
                     host.context.current = None
-                out["extra"] = {"config3": sub_record_config3(args.sub_steps, args.fast_trig), "config5": sub_record_config5(args.sub_steps)}
+                extra["config3"] = sub_record_config3(args.sub_steps, args.fast_trig)
+                extra["config5"] = sub_record_config5(args.sub_steps)
             except Exception as e:                                      # never let a sub-record break the headline line
-                out["extra"] = {"error": repr(e)}
+                extra["error"] = repr(e)
+        if extra:
+            out["extra"] = extra
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

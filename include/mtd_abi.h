@@ -119,8 +119,10 @@ int mtd_lamellar_forces(const mtd_lamellar_set *set, unsigned int n_particles, c
                         void *const *d_force, int dtype, unsigned int n_global, const double *d_bias,
                         const mtd_box *global_box, mtd_stream_t stream);
 
-/* 0: accurate trig (ocml sinpi/cospi, default); 1: hardware v_sin_f32 / v_cos_f32 on the phase in turns */
+/* 1 (default): hardware v_sin_f32 / v_cos_f32 on the fractional phase in turns — what the reference's GPU kernels do
+ * (fast::sin / fast::cos, LamellarOrderParameterGPU.cu:36-37, 180); 0: ocml sinpi / cospi.  Process-wide switch. */
 int mtd_lamellar_set_fast_trig(int enable);
+int mtd_lamellar_get_fast_trig(void);
 
 /* ================================================================================================
  * Bias grid ("IntegratorMetaDynamics" grid engine), device resident
@@ -506,6 +508,19 @@ int mtd_sigma_products(unsigned int n_cv, const void *const *d_force, unsigned i
 
 /* sigma_inv = inverse(element-wise sqrt(sigmasq)) (:1273-1286), host arrays of n_cv^2 doubles */
 int mtd_sigma_inverse(unsigned int n_cv, const double *sigmasq, double *sigma_inv);
+
+/* ================================================================================================
+ * Diagnostic exports: the two pieces of device code whose reference counterparts COULD be compiled (oracle/_ref), exposed so
+ * that tests hold the kernels' own arithmetic — not only the oracle's — against the vectors the reference code produced
+ * (tests/golden/, tests/test_gpu_golden.py).  Host arrays in and out, synchronous; not part of the hot path.
+ * ============================================================================================== */
+
+/* Y_lm of n directions (h_separations: n x 3, any length) as the Steinhardt pair kernels evaluate them; h_out:
+ * n x (lmax+1)^2 x (re, im) in fsph's order (spherical_harmonics.hpp:229-246 with full_m) */
+int mtd_debug_sph_harmonics(unsigned int lmax, unsigned int n, const double *h_separations, double *h_out);
+/* IndexGrid::getCoordinates (IndexGrid.cc:46-58) and getIndex (:20-44) as the grid kernels compute them */
+int mtd_debug_index_decode(unsigned int n_cv, const unsigned int *lengths, unsigned int n, const unsigned int *h_indices,
+                           unsigned int *h_coords, unsigned int *h_index_back);
 
 #ifdef __cplusplus
 }

@@ -52,6 +52,7 @@ extern "C" int mtd_debug_read_stamps(unsigned long long *host)
 #include <cstring>
 #include <map>
 #include <mutex>
+#include <utility>
 #include <vector>
 
 namespace
@@ -66,7 +67,7 @@ constexpr int FF_UNROLL = 2;
 
 // COMM (particle-sharded step): the last CV block to finish adds up this rank's block partial sums (fixed order) and
 // stores the NCV totals into every rank's mailbox over xGMI (comm_device.hpp); launch B polls its local mailbox.
-template<typename S4, int NCV, bool FAST, bool COMM>
+template<typename S4, int NCV, bool FAST, bool COMM, int U = FCV_UNROLL>
 __global__ __launch_bounds__(FCV_THREADS) void k_fused_cv(const LamKArgs a, const S4 *__restrict__ postype, const unsigned int N,
                                                           double *partials, const MetadCfg c,
                                                           const unsigned int n_apply_blocks, const CommK ck)
@@ -89,8 +90,8 @@ __global__ __launch_bounds__(FCV_THREADS) void k_fused_cv(const LamKArgs a, cons
     const unsigned int n_blocks = gridDim.x - n_apply_blocks;
 
     // the first group of particles is requested before the tables are staged: one memory round trip instead of two
-    RawGroup<S4, FCV_UNROLL> first;
-    lam_load_group<S4, FCV_UNROLL>(postype, N, block_id * FCV_THREADS + threadIdx.x, n_blocks * FCV_THREADS, first);
+    RawGroup<S4, U> first;
+    lam_load_group<S4, U>(postype, N, block_id * FCV_THREADS + threadIdx.x, n_blocks * FCV_THREADS, first);
     load_coeff(a, s_coeff);
     load_modes_cv(a, s_mt);
     __syncthreads();
@@ -98,8 +99,8 @@ __global__ __launch_bounds__(FCV_THREADS) void k_fused_cv(const LamKArgs a, cons
     float acc[NCV];
 #pragma unroll
     for (int i = 0; i < NCV; ++i) acc[i] = 0.0f;
-    lam_cv_accumulate<S4, NCV, FAST, FCV_UNROLL>(a, postype, N, block_id * FCV_THREADS + threadIdx.x, n_blocks * FCV_THREADS,
-                                                 s_coeff, s_mt, first, acc);
+    lam_cv_accumulate<S4, NCV, FAST, U>(a, postype, N, block_id * FCV_THREADS + threadIdx.x, n_blocks * FCV_THREADS,
+                                        s_coeff, s_mt, first, acc);
     MTD_STAMP(5, block_id == 0 && threadIdx.x == 0);
     lam_cv_block_reduce<NCV>(acc, s_wave, partials, block_id);
     MTD_STAMP(6, block_id == 0 && threadIdx.x == 0);
@@ -392,19 +393,37 @@ bool force_profile_next(hipEvent_t &start, hipEvent_t &stop)
 unsigned int resident_capacity(const void *kernel, int threads)
     {
     static std::mutex mu;
-    static std::map<const void *, unsigned int> cache;
-    std::lock_guard<std::mutex> lock(mu);
-    auto it = cache.find(kernel);
-    if (it != cache.end()) return it->second;
+    static std::map<std::pair<int, const void *>, unsigned int> cache;      // per device: a process may drive several GPUs
     int per_cu = 0, dev = 0, n_cu = 0;
+    if (hipGetDevice(&dev) != hipSuccess)
+        {
+        (void)hipGetLastError();
+        return 0;
+        }
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = cache.find(std::make_pair(dev, kernel));
+    if (it != cache.end()) return it->second;
     unsigned int cap = 0;
-    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess &&
+    if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess &&
         hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, threads, 0) == hipSuccess)
         cap = (unsigned int)per_cu * (unsigned int)n_cu;
     else
         (void)hipGetLastError();
-    cache[kernel] = cap;
+    cache[std::make_pair(dev, kernel)] = cap;
     return cap;
+    }
+
+template<typename S4, bool FAST> const void *fused_cv_comm_kernel_of(unsigned int n_cv)
+    {
+    return n_cv == 1 ? (const void *)k_fused_cv<S4, 1, FAST, true>
+                     : (n_cv == 2 ? (const void *)k_fused_cv<S4, 2, FAST, true> : (const void *)k_fused_cv<S4, 3, FAST, true>);
+    }
+
+// the instantiation a sharded CV pass launches (mtd_fused_cv_pass asks for its residency before it takes an exchange number)
+const void *fused_cv_comm_kernel(int dtype, unsigned int n_cv, bool fast)
+    {
+    if (dtype == MTD_F32) return fast ? fused_cv_comm_kernel_of<float4, true>(n_cv) : fused_cv_comm_kernel_of<float4, false>(n_cv);
+    return fast ? fused_cv_comm_kernel_of<double4, true>(n_cv) : fused_cv_comm_kernel_of<double4, false>(n_cv);
     }
 
 template<typename S4, bool FAST>
@@ -415,9 +434,7 @@ int launch_fused_cv(const LamKArgs &k, unsigned int N, const void *d_postype, do
     const unsigned int grid = cv_blocks + n_apply;
     if (ck)
         {
-        const void *kern = k.n_cv == 1 ? (const void *)k_fused_cv<S4, 1, FAST, true>
-                                       : (k.n_cv == 2 ? (const void *)k_fused_cv<S4, 2, FAST, true> : (const void *)k_fused_cv<S4, 3, FAST, true>);
-        if (grid > resident_capacity(kern, FCV_THREADS)) return MTD_ERR_UNSUPPORTED;
+        if (grid > resident_capacity(fused_cv_comm_kernel_of<S4, FAST>(k.n_cv), FCV_THREADS)) return MTD_ERR_UNSUPPORTED;
         switch (k.n_cv)
             {
             case 1: k_fused_cv<S4, 1, FAST, true><<<grid, FCV_THREADS, 0, s>>>(k, p, N, d_partials, cfg, n_apply, *ck); break;
@@ -469,6 +486,10 @@ int mtd_fused_cv_pass(mtd_metad *m, const mtd_lamellar_set *set, unsigned int n_
     if (m->comm)
         {
         if (set->n_cv > (unsigned int)CHAIN_MAX_CV || set->n_cv != m->cfg.n_cv) return MTD_ERR_UNSUPPORTED;
+        // every refusal comes BEFORE the exchange number advances: a call that sends nothing must not consume a number
+        // (the peers would wait for an exchange that never happens)
+        const void *kern = fused_cv_comm_kernel(dtype, set->n_cv, fast);
+        if (blocks + n_apply > resident_capacity(kern, FCV_THREADS)) return MTD_ERR_UNSUPPORTED;
         rc = comm_next(m->comm, ckv);                           // this launch sends exchange seq, launch B receives it
         if (rc) return rc;
         ck = &ckv;

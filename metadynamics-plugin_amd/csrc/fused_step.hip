@@ -65,6 +65,7 @@ extern "C" int mtd_debug_read_step_stamps(unsigned long long *host)
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <utility>
 #include <mutex>
 
 namespace
@@ -569,18 +570,23 @@ __global__ __launch_bounds__(FS_THREADS, 1) void k_fused_step(const LamKArgs a, 
 unsigned int step_capacity(const void *kernel)
     {
     static std::mutex mu;
-    static std::map<const void *, unsigned int> cache;
-    std::lock_guard<std::mutex> lock(mu);
-    auto it = cache.find(kernel);
-    if (it != cache.end()) return it->second;
+    static std::map<std::pair<int, const void *>, unsigned int> cache;      // per device
     int per_cu = 0, dev = 0, n_cu = 0;
+    if (hipGetDevice(&dev) != hipSuccess)
+        {
+        (void)hipGetLastError();
+        return 0;
+        }
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = cache.find(std::make_pair(dev, kernel));
+    if (it != cache.end()) return it->second;
     unsigned int cap = 0;
-    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess &&
+    if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess &&
         hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, FS_THREADS, 0) == hipSuccess)
         cap = (unsigned int)per_cu * (unsigned int)n_cu;
     else
         (void)hipGetLastError();
-    cache[kernel] = cap;
+    cache[std::make_pair(dev, kernel)] = cap;
     return cap;
     }
 

@@ -31,7 +31,9 @@ constexpr int CV_UNROLL = 4;
 constexpr int FORCE_THREADS = 256;
 constexpr int FORCE_UNROLL = 2;
 
-int g_fast_trig = 0;
+// default: the hardware sine / cosine on the phase in turns, as the reference's GPU kernels (fast::sin / fast::cos,
+// LamellarOrderParameterGPU.cu:36-37, 180); parity at 10^6 particles is tested in both modes
+int g_fast_trig = 1;
 
 // ---------------------------------------------------------------------------------------------
 // Hot path: per-CV sums  partials[b][c] = sum_{j in block b} a_c(type_j) sum_k cos(q_k . r_j)
@@ -315,6 +317,8 @@ int mtd_lamellar_set_fast_trig(int enable)
     g_fast_trig = enable ? 1 : 0;
     return MTD_SUCCESS;
     }
+
+int mtd_lamellar_get_fast_trig(void) { return g_fast_trig; }
 
 size_t mtd_lamellar_scratch_doubles(unsigned int n_particles)
     {

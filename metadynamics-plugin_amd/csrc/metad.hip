@@ -224,6 +224,27 @@ int metad_flush(mtd_metad *m, hipStream_t s)
     }
 }
 
+namespace
+{
+// Diagnostic: IndexGrid::getCoordinates / the linear index (IndexGrid.cc:20-58) as the kernels compute them (decode,
+// coord * factors) — tests/test_gpu_golden.py holds them against the tables the reference's own IndexGrid.cc produced
+__global__ void k_debug_index(const MetadCfg c, const unsigned int n, const unsigned int *__restrict__ idx, unsigned int *__restrict__ coords,
+                              unsigned int *__restrict__ back)
+    {
+    const unsigned int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    unsigned int co[MAXCV];
+    decode(c, idx[t], co);
+    unsigned int r = 0;
+    for (unsigned int i = 0; i < c.n_cv; ++i)
+        {
+        coords[(size_t)t * c.n_cv + i] = co[i];
+        r += co[i] * c.factors[i];
+        }
+    back[t] = r;
+    }
+} // namespace
+
 extern "C" {
 
 int mtd_update_grid(unsigned int num_elements, const unsigned int *lengths, unsigned int dim,
@@ -300,6 +321,20 @@ int mtd_metad_create(mtd_metad **out, unsigned int n_cv, const double *sigma, co
     c.mode = mode;
     c.det_sigma = host_determinant(c.sigma_inv, n_cv);
     c.n_gblocks = (c.len + GRID_THREADS - 1) / GRID_THREADS;
+    // host reciprocals for the chain's quotients (metad_device.hpp::chain_div); every divisor has to qualify
+    {
+    const ExactDivisor dT = make_exact_divisor(T_shift);
+    int ok = dT.fast;
+    c.rT_shift = dT.y;
+    for (unsigned int i = 0; i < n_cv && i < 3; ++i)
+        {
+        const ExactDivisor d1 = make_exact_divisor(c.delta[i]), d2 = make_exact_divisor(2.0 * c.delta[i]);
+        c.rdelta[i] = d1.y;
+        c.rdelta2[i] = d2.y;
+        ok = ok && d1.fast && d2.fast;
+        }
+    c.fastdiv = ok;
+    }
     m->stride = stride;
     m->add_bias = add_bias ? 1 : 0;
     m->pending_apply = 0;
@@ -364,6 +399,37 @@ int mtd_metad_create(mtd_metad **out, unsigned int n_cv, const double *sigma, co
     // default CV source: a host-provided value (mtd_metad_set_cv_value), initially 0
     *out = m;
     return MTD_SUCCESS;
+    }
+
+int mtd_debug_index_decode(unsigned int n_cv, const unsigned int *lengths, unsigned int n, const unsigned int *h_indices,
+                           unsigned int *h_coords, unsigned int *h_index_back)
+    {
+    if (!lengths || !h_indices || !h_coords || !h_index_back || n == 0 || n_cv == 0) return MTD_ERR_INVALID_ARGUMENT;
+    if (n_cv > (unsigned int)MAXCV) return MTD_ERR_UNSUPPORTED;
+    MetadCfg c;
+    std::memset(&c, 0, sizeof(c));
+    c.n_cv = n_cv;
+    for (unsigned int i = 0; i < n_cv; ++i)
+        {
+        c.lengths[i] = lengths[i];
+        c.factors[i] = (i == 0) ? 1 : c.lengths[i - 1] * c.factors[i - 1];       // as mtd_metad_create
+        }
+    unsigned int *d_idx = nullptr, *d_co = nullptr, *d_back = nullptr;
+    hipError_t e = hipMalloc(&d_idx, n * sizeof(unsigned int));
+    if (e == hipSuccess) e = hipMalloc(&d_co, (size_t)n * n_cv * sizeof(unsigned int));
+    if (e == hipSuccess) e = hipMalloc(&d_back, n * sizeof(unsigned int));
+    if (e == hipSuccess) e = hipMemcpy(d_idx, h_indices, n * sizeof(unsigned int), hipMemcpyHostToDevice);
+    if (e == hipSuccess)
+        {
+        k_debug_index<<<(n + 63) / 64, 64>>>(c, n, d_idx, d_co, d_back);
+        e = hipGetLastError();
+        }
+    if (e == hipSuccess) e = hipMemcpy(h_coords, d_co, (size_t)n * n_cv * sizeof(unsigned int), hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(h_index_back, d_back, n * sizeof(unsigned int), hipMemcpyDeviceToHost);
+    (void)hipFree(d_idx);
+    (void)hipFree(d_co);
+    (void)hipFree(d_back);
+    return (int)e;
     }
 
 int mtd_metad_destroy(mtd_metad *m)

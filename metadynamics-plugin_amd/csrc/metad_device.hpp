@@ -7,6 +7,7 @@
 
 #include "mtd_device.hpp"
 #include "comm_device.hpp"
+#include "exact_div.hpp"
 
 #ifndef MTD_STAMP
 #define MTD_STAMP(slot, cond) do { } while (0)
@@ -56,7 +57,12 @@ struct MetadCfg
     unsigned int *hist, *hist_delta, *hist_gauss, *hist_gauss_delta;
     MetadState *st;
     double *gpart;
-    unsigned int n_gblocks, _pad2;
+    unsigned int n_gblocks;
+    // chain_wave: quotients by the grid spacing, twice the grid spacing and the well-tempered temperature as correctly rounded
+    // FMA sequences from host reciprocals (exact_div.hpp: bit-identical to the division, a fifth of its instructions on the one
+    // wave whose latency every block of launch B waits for); 0 when any of the divisors does not qualify
+    int fastdiv;
+    double rdelta[3], rdelta2[3], rT_shift;
     CvSource src[MAXCV];
     };
 
@@ -422,6 +428,17 @@ __device__ __forceinline__ GridPatch chain_prefetch(const MetadCfg &c)
 // rx != nullptr: particle-sharded step — the sums over ranks come out of the xGMI mailbox (comm_device.hpp) instead
 // of the registered partial sums.  given != nullptr: the (global) sums are handed in (k_fused_step collected them itself);
 // a NaN among them marks an expired wait.  want_weight: also read the weight grid at the corners of s (closed form).
+// a / (the divisor whose reciprocal is y), correctly rounded (exact_div.hpp) when the grid qualifies, else the division
+__device__ __forceinline__ double chain_div(const MetadCfg &c, const double a, const double b, const double y)
+    {
+    if (!c.fastdiv) return a / b;                                    // (uniform)
+    const double q0 = a * y;
+    const double r0 = __builtin_fma(-b, q0, a);
+    const double q1 = __builtin_fma(r0, y, q0);
+    const double r1 = __builtin_fma(-b, q1, a);
+    return __builtin_fma(r1, y, q1);
+    }
+
 __device__ __forceinline__ ChainResult chain_wave(const MetadCfg &c, const bool deposit, const bool closed_form,
                                                   const CommK *rx = nullptr, const double *given = nullptr,
                                                   const bool want_weight = false, const GridPatch *patch = nullptr)
@@ -493,12 +510,13 @@ __device__ __forceinline__ ChainResult chain_wave(const MetadCfg &c, const bool 
         const double delta = i == 0 ? c.delta[0] : (i == 1 ? c.delta[1] : c.delta[2]);
         const double cmin = i == 0 ? c.cv_min[0] : (i == 1 ? c.cv_min[1] : c.cv_min[2]);
         const double cmax = i == 0 ? c.cv_max[0] : (i == 1 ? c.cv_max[1] : c.cv_max[2]);
+        const double rdel = i == 0 ? c.rdelta[0] : (i == 1 ? c.rdelta[1] : c.rdelta[2]);
         const int len = (int)(i == 0 ? c.lengths[0] : (i == 1 ? c.lengths[1] : c.lengths[2]));
         double val = si;
         if (v == 0) val = si - delta;
         if (v == 2) val = si + delta;
         g_ok = val >= cmin && val < cmax;             // (:677-683; a NaN value is off the grid too)
-        int lower = (int)((val - cmin) / delta);
+        int lower = (int)chain_div(c, val - cmin, delta, rdel);
         int upper = lower + 1;
         if (upper >= len)
             {
@@ -580,16 +598,9 @@ __device__ __forceinline__ ChainResult chain_wave(const MetadCfg &c, const bool 
     r.c_wold = (want_weight && ok && p == 0) ? c.weight[cell] : 0.0;
     r.c_dV = 0.0;
 
-    MTD_STAMP(42, blockIdx.x == 0 && threadIdx.x == 0 && closed_form);
-    // 4. V_old(s): corner terms of point 0 summed in the reference's order (:711-733)
-    double term = ok ? wt * val : 0.0;
-    double V_old = 0.0;
-    for (int b = 0; b < n_term; ++b) V_old += __shfl(term, b, MTD_WAVE);
-    r.scal = 1.0;
-    if (deposit && c.mode == MTD_MODE_WELL_TEMPERED) r.scal = exp(-V_old / c.T_shift);   // :377-378
-
-    MTD_STAMP(43, blockIdx.x == 0 && threadIdx.x == 0 && closed_form);
-    // 5. post-deposit node values in closed form on the stencil
+    // ---- everything that does not need the grid values runs while they are on their way:
+    // the Gaussian of this deposit at the lane's stencil cell (closed form, step 5) ...
+    double e_g = 0.0;
     if (closed_form && deposit && ok)
         {
         double gauss_exp = 0.0;
@@ -602,44 +613,9 @@ __device__ __forceinline__ ChainResult chain_wave(const MetadCfg &c, const bool 
                     const double sij = c.sigma_inv[i * n + j];
                     gauss_exp += d[i] * d[j] * (1.0 / 2.0) * (sij * sij);
                     }
-        r.c_dV = (c.W * r.scal) * exp(-gauss_exp);
-        val += r.c_dV;
-        term = wt * val;
+        e_g = exp(-gauss_exp);
         }
-    if (!ok) r.c_wt = 0.0;
-
-    MTD_STAMP(44, blockIdx.x == 0 && threadIdx.x == 0 && closed_form);
-    // 6. every lane: the interpolated value of its own point, corners in order
-    const int base = (p < n_pts ? p : 0) * n_term;
-    double res = 0.0;
-    for (int b = 0; b < n_term; ++b) res += __shfl(term, base + b, MTD_WAVE);
-
-    // 7. finite differences (:738-776); all lanes execute the shuffles, every lane keeps all n results
-    const double res0 = __shfl(res, 0, MTD_WAVE);
-    r.V = res0;
-    r.w = closed_form ? 1.0 : __shfl(res, (1 + 2 * (int)n) * n_term, MTD_WAVE);
-    r.oob = !__shfl((int)ok, 0, MTD_WAVE);
-#pragma unroll
-    for (int i = 0; i < CHAIN_MAX_CV; ++i)
-        {
-        if (i < (int)n)
-            {
-            const double rm = __shfl(res, (1 + 2 * i) * n_term, MTD_WAVE);
-            const double rp = __shfl(res, (2 + 2 * i) * n_term, MTD_WAVE);
-            const double s = r.cv[i];
-            const double delta = c.delta[i];
-            double b;
-            if (s - delta < c.cv_min[i])
-                b = (rp - res0) / delta;                          // forward  (:746-755)
-            else if (s + delta > c.cv_max[i])
-                b = (res0 - rm) / delta;                          // backward (:756-764)
-            else
-                b = (rp - rm) / (2.0 * delta);                    // central  (:765-775)
-            r.bias[i] = b;
-            }
-        }
-    MTD_STAMP(45, blockIdx.x == 0 && threadIdx.x == 0 && closed_form);
-    // histogram bin (updateHistogram :1092-1119), statically unrolled (no private-memory arrays)
+    // ... and the histogram bin (updateHistogram :1092-1119), statically unrolled (no private-memory arrays)
     bool on_grid = true;
     unsigned int bin = 0;
 #pragma unroll
@@ -647,7 +623,7 @@ __device__ __forceinline__ ChainResult chain_wave(const MetadCfg &c, const bool 
         {
         if (i < (int)n)
             {
-            const double q = (r.cv[i] - c.cv_min[i]) / c.delta[i];
+            const double q = chain_div(c, r.cv[i] - c.cv_min[i], c.delta[i], c.rdelta[i]);
             if (!(q > -1.0) || !(q < 4294967296.0))
                 on_grid = false;
             else
@@ -660,6 +636,77 @@ __device__ __forceinline__ ChainResult chain_wave(const MetadCfg &c, const bool 
         }
     r.on_grid = on_grid ? 1 : 0;
     r.bin = bin;
+
+    MTD_STAMP(42, blockIdx.x == 0 && threadIdx.x == 0 && closed_form);
+    // 4. V_old(s): corner terms of point 0 summed in the reference's order (:711-733); the corners sit in lanes 0 .. 2^n - 1:
+    //    v_readlane, not a trip through the LDS crossbar
+    double term = ok ? wt * val : 0.0;
+    double V_old = 0.0;
+    for (int b = 0; b < n_term; ++b) V_old += wave_read(term, b);
+    r.scal = 1.0;
+    if (deposit && c.mode == MTD_MODE_WELL_TEMPERED) r.scal = exp(chain_div(c, -V_old, c.T_shift, c.rT_shift));   // :377-378
+
+    MTD_STAMP(43, blockIdx.x == 0 && threadIdx.x == 0 && closed_form);
+    // 5. post-deposit node values in closed form on the stencil
+    if (closed_form && deposit && ok)
+        {
+        r.c_dV = (c.W * r.scal) * e_g;
+        val += r.c_dV;
+        term = wt * val;
+        }
+    if (!ok) r.c_wt = 0.0;
+
+    MTD_STAMP(44, blockIdx.x == 0 && threadIdx.x == 0 && closed_form);
+    // 6. every lane: the interpolated value of its own point, corners in order.  The 2^n corner lanes of a point are a pair
+    //    (n = 1) or a quad (n = 2): DPP broadcasts inside the quad; n = 3 goes through the crossbar, all eight in flight
+    double res = 0.0;
+    if (n == 2)
+        {
+        res += dpp_move<0x00>(term);          // quad_perm:[0,0,0,0]
+        res += dpp_move<0x55>(term);          // [1,1,1,1]
+        res += dpp_move<0xAA>(term);          // [2,2,2,2]
+        res += dpp_move<0xFF>(term);          // [3,3,3,3]
+        }
+    else if (n == 1)
+        {
+        res += dpp_move<0xA0>(term);          // [0,0,2,2]
+        res += dpp_move<0xF5>(term);          // [1,1,3,3]
+        }
+    else
+        {
+        const int base = (p < n_pts ? p : 0) * n_term;
+        double t8[8];
+#pragma unroll
+        for (int b = 0; b < 8; ++b) t8[b] = __shfl(term, (base + b) & 63, MTD_WAVE);
+#pragma unroll
+        for (int b = 0; b < 8; ++b) res += t8[b];
+        }
+
+    // 7. finite differences (:738-776); the points sit in wave-uniform lanes: v_readlane
+    const double res0 = wave_read(res, 0);
+    r.V = res0;
+    r.w = closed_form ? 1.0 : wave_read(res, (1 + 2 * (int)n) * n_term);
+    r.oob = !wave_read((int)ok, 0);
+#pragma unroll
+    for (int i = 0; i < CHAIN_MAX_CV; ++i)
+        {
+        if (i < (int)n)
+            {
+            const double rm = wave_read(res, (1 + 2 * i) * n_term);
+            const double rp = wave_read(res, (2 + 2 * i) * n_term);
+            const double s = r.cv[i];
+            const double delta = c.delta[i];
+            double b;
+            if (s - delta < c.cv_min[i])
+                b = chain_div(c, rp - res0, delta, c.rdelta[i]);                  // forward  (:746-755)
+            else if (s + delta > c.cv_max[i])
+                b = chain_div(c, res0 - rm, delta, c.rdelta[i]);                  // backward (:756-764)
+            else
+                b = chain_div(c, rp - rm, 2.0 * delta, c.rdelta2[i]);             // central  (:765-775)
+            r.bias[i] = b;
+            }
+        }
+    MTD_STAMP(45, blockIdx.x == 0 && threadIdx.x == 0 && closed_form);
     r.failed = 0;
     if (handed)
         {

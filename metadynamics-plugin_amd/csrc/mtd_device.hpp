@@ -26,19 +26,65 @@ namespace mtd
 {
 
 // ---- wave64 reductions (fixed butterfly order => bitwise reproducible) -------------------------
+// The sum of the xor butterfly with ASCENDING offsets (1, 2, 4, 8, 16, 32), without its twelve dependent trips through the LDS crossbar
+// (__shfl_xor is ds_bpermute_b32: ~100 cycles each, two per double — a chain of wave sums was most of the latency of
+// chain_wave): the four stages inside a row of 16 lanes are DPP moves (quad_perm for 1 and 2; after those a quad is uniform,
+// so row_half_mirror pairs each quad with the other quad of its half row exactly as xor 4 does, and row_mirror the half rows as
+// xor 8), the two stages across rows are v_readlane of the four row sums added as (r0 + r1) + (r2 + r3) — the same pairs in
+// the same grouping as the butterfly, addition being commutative: the SAME BITS in every lane.
+// Every lane of the wave must take part (EXEC all ones): a lane that is switched off contributes garbage, not zero.
+#define MTD_DPP_QUAD_XOR1 0xB1        /* quad_perm:[1,0,3,2] */
+#define MTD_DPP_QUAD_XOR2 0x4E        /* quad_perm:[2,3,0,1] */
+#define MTD_DPP_ROW_HALF_MIRROR 0x141
+#define MTD_DPP_ROW_MIRROR 0x140
 
-__device__ __forceinline__ double wave_sum(double v)
+template<int CTRL> __device__ __forceinline__ float dpp_move(const float v)
     {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1)
-        v += __shfl_xor(v, off, MTD_WAVE);
-    return v;
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
     }
 
-__device__ __forceinline__ float wave_sum(float v)
+template<int CTRL> __device__ __forceinline__ double dpp_move(const double v)
+    {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+    }
+
+// value of lane `lane` (wave-uniform index) in every lane: v_readlane_b32, no LDS trip
+__device__ __forceinline__ float wave_read(const float v, const int lane)
+    {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
+    }
+
+__device__ __forceinline__ double wave_read(const double v, const int lane)
+    {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+    return __hiloint2double(hi, lo);
+    }
+
+__device__ __forceinline__ int wave_read(const int v, const int lane) { return __builtin_amdgcn_readlane(v, lane); }
+
+template<typename T> __device__ __forceinline__ T wave_sum_dpp(T v)
+    {
+    v += dpp_move<MTD_DPP_QUAD_XOR1>(v);
+    v += dpp_move<MTD_DPP_QUAD_XOR2>(v);
+    v += dpp_move<MTD_DPP_ROW_HALF_MIRROR>(v);
+    v += dpp_move<MTD_DPP_ROW_MIRROR>(v);
+    const T r0 = wave_read(v, 0), r1 = wave_read(v, 16), r2 = wave_read(v, 32), r3 = wave_read(v, 48);
+    return (r0 + r1) + (r2 + r3);
+    }
+
+__device__ __forceinline__ double wave_sum(double v) { return wave_sum_dpp(v); }
+__device__ __forceinline__ float wave_sum(float v) { return wave_sum_dpp(v); }
+
+// the butterfly itself (reference form of the above; tools/probe_wave_sum.hip compares the two bit for bit).  Rounds 1 and 2 of
+// this library ran it with descending offsets (32 ... 1): the same sum in another grouping, so sums of this build differ from
+// theirs in the last bits — every rank and every path of one build uses the same one.
+template<typename T> __device__ __forceinline__ T wave_sum_butterfly(T v)
     {
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1)
+    for (int off = 1; off < MTD_WAVE; off <<= 1)
         v += __shfl_xor(v, off, MTD_WAVE);
     return v;
     }

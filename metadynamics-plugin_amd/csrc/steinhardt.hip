@@ -915,12 +915,80 @@ int forces_impl(unsigned int N, const void *d_postype, void *d_force, int dtype,
 
 } // namespace
 
+namespace
+{
+// Diagnostic: the spherical harmonics exactly as the pair kernels evaluate them — pair_geom's unit-vector trigonometry from a
+// separation, amplitude_column's Jacobi recurrence with the prefactors folded to literals, e^{i m phi} by repeated
+// multiplication, sin^m(theta) / sqrt(2 pi) by repeated multiplication (ql_accumulate_pairs with f = 1) — one thread per
+// direction, written in fsph's order (spherical_harmonics.hpp:229-246, full_m: per degree l the orders 0..l, then -1..-l as
+// plain conjugates).  tests/test_gpu_golden.py holds it against the vectors the reference's own header produced.
+template<int LMAX>
+__global__ void k_debug_sph(const unsigned int n, const unsigned int lmax, const double *__restrict__ sep, double *__restrict__ out)
+    {
+    const unsigned int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    QlArgs<LMAX> a;
+    a.lmax = lmax;
+    const double dx = sep[3 * t], dy = sep[3 * t + 1], dz = sep[3 * t + 2];
+    const PairGeom g = pair_geom(dx, dy, dz, dx * dx + dy * dy + dz * dz);
+    double *o = out + (size_t)t * 2 * (lmax + 1) * (lmax + 1);
+    double sinpow = 0.3989422804014326779399460599343818684758586311649;   // 1 / sqrt(2 pi)
+    cplx harm = {1.0, 0.0};
+#pragma unroll
+    for (int m = 0; m <= LMAX; ++m)
+        {
+        double col[LMAX + 1];
+        amplitude_column<LMAX>(a, m, g.ct, 1.0, col);
+        const double hr = sinpow * harm.re, hi = sinpow * harm.im;
+#pragma unroll
+        for (int l = m; l <= LMAX; ++l)
+            if (l <= (int)lmax)
+                {
+                const double re = col[l] * hr, im = col[l] * hi;
+                o[2 * (l * l + m)] = re;
+                o[2 * (l * l + m) + 1] = im;
+                if (m > 0)
+                    {
+                    o[2 * (l * l + l + m)] = re;
+                    o[2 * (l * l + l + m) + 1] = -im;
+                    }
+                }
+        sinpow *= g.st;
+        harm = cmul(harm, {g.cp, g.sp});
+        }
+    }
+} // namespace
+
 extern "C" {
 
 int mtd_ql_set_half_list_exact(int enable)
     {
     g_half_exact = enable ? 1 : 0;
     return MTD_SUCCESS;
+    }
+
+int mtd_debug_sph_harmonics(unsigned int lmax, unsigned int n, const double *h_separations, double *h_out)
+    {
+    if (!h_separations || !h_out || n == 0) return MTD_ERR_INVALID_ARGUMENT;
+    if (lmax > 12) return MTD_ERR_UNSUPPORTED;
+    const size_t n_out = (size_t)n * 2 * (lmax + 1) * (lmax + 1);
+    double *d_sep = nullptr, *d_out = nullptr;
+    MTD_HIP_TRY(hipMalloc(&d_sep, (size_t)n * 3 * sizeof(double)));
+    hipError_t e = hipMalloc(&d_out, n_out * sizeof(double));
+    if (e == hipSuccess) e = hipMemcpy(d_sep, h_separations, (size_t)n * 3 * sizeof(double), hipMemcpyHostToDevice);
+    if (e == hipSuccess)
+        {
+        const unsigned int blocks = (n + 63) / 64;
+        if (lmax <= 4) k_debug_sph<4><<<blocks, 64>>>(n, lmax, d_sep, d_out);
+        else if (lmax <= 6) k_debug_sph<6><<<blocks, 64>>>(n, lmax, d_sep, d_out);
+        else if (lmax <= 8) k_debug_sph<8><<<blocks, 64>>>(n, lmax, d_sep, d_out);
+        else k_debug_sph<12><<<blocks, 64>>>(n, lmax, d_sep, d_out);
+        e = hipGetLastError();
+        }
+    if (e == hipSuccess) e = hipMemcpy(h_out, d_out, n_out * sizeof(double), hipMemcpyDeviceToHost);
+    (void)hipFree(d_sep);
+    (void)hipFree(d_out);
+    return (int)e;
     }
 
 size_t mtd_ql_scratch_doubles(unsigned int lmax)

@@ -1,6 +1,7 @@
 // metadynamics_host.cc — see metadynamics_host.h.  Reference citations are file:line under
 // /root/reference/metadynamics/.
 #include "metadynamics_host.h"
+#include "grid_file.h"
 #include "prof.h"
 
 #include <algorithm>
@@ -1046,19 +1047,13 @@ void IntegratorMetaDynamics::updateBiasPotential(unsigned int timestep)
         double V = 0.0;
         mtd_check(mtd_metad_get_state(m_engine, cv.data(), nullptr, &V, nullptr, nullptr, nullptr, s), "mtd_metad_get_state");
         const double W = m_W * std::exp(-V / m_T_shift);               // :528 (written even in standard mode, Q16)
-        m_file << std::setprecision(10) << timestep << m_delimiter;
-        m_file << std::setprecision(10) << W << m_delimiter;
+        // row i of h_sigma_inv (:536-541): diag(1 / sigma) (:177) until computeSigma overwrites it in adaptive mode (:1271-1290)
+        std::vector<double> sinv(cv.size() * cv.size(), 0.0);
         for (size_t i = 0; i < cv.size(); ++i)
-            {
-            m_file << std::setprecision(10) << cv[i] << m_delimiter;
-            // row of h_sigma_inv (:536-541), no delimiter (Q16): diag(1 / sigma) (:177) until computeSigma overwrites it in
-            // adaptive mode (:1271-1290)
             for (size_t j = 0; j < cv.size(); ++j)
-                m_file << std::setprecision(10)
-                       << (m_sigma_inv.size() == cv.size() * cv.size() ? m_sigma_inv[i * cv.size() + j] : (i == j ? 1.0 / m_variables[i].m_sigma : 0.0));
-            if (i != cv.size() - 1) m_file << m_delimiter;
-            }
-        m_file << std::endl;
+                sinv[i * cv.size() + j] = m_sigma_inv.size() == cv.size() * cv.size() ? m_sigma_inv[i * cv.size() + j]
+                                                                                      : (i == j ? 1.0 / m_variables[i].m_sigma : 0.0);
+        format_hills_line(m_file, timestep, W, cv, sinv, m_delimiter);  // grid_file.h
         }
 
     // dump grid information if required using alternating scheme (:555-565)
@@ -1140,40 +1135,25 @@ void IntegratorMetaDynamics::writeGrid(const std::string &filename, unsigned int
 
     std::ofstream file;
     file.open((filename + "_" + std::to_string(timestep)).c_str(), std::ios_base::out);
-    const size_t dim = m_variables.size();
-    file << "#n_cv: " << dim << std::endl;
-    file << "#dim: ";
-    for (size_t i = 0; i < dim; i++) file << " " << m_variables[i].m_num_points;
-    file << std::endl;
-    file << "#num_gaussians: " << num_gaussians << std::endl;
-    for (size_t i = 0; i < dim; i++) file << m_variables[i].m_cv->getName() << m_delimiter;
-    file << "grid_value" << m_delimiter << "det_sigma" << m_delimiter << "num_gaussians" << m_delimiter << "hist" << m_delimiter
-         << "hist_reweight" << m_delimiter << "weight" << std::endl;
-
-    std::vector<unsigned int> coords(dim);
-    for (unsigned int grid_idx = 0; grid_idx < len; grid_idx++)
+    GridFileData d;
+    d.num_gaussians = num_gaussians;
+    d.grid.swap(grid);
+    d.sigma_grid.swap(sigma_grid);
+    d.rew.swap(rew);
+    d.weight.swap(weight);
+    d.hist.swap(hist);
+    d.hist_gauss.swap(hist_gauss);
+    std::vector<std::string> names;
+    std::vector<double> lo, hi;
+    std::vector<unsigned int> pts;
+    for (const auto &v : m_variables)
         {
-        unsigned int rest = grid_idx;                                  // IndexGrid::getCoordinates, first CV fastest
-        for (size_t i = 0; i < dim; ++i)
-            {
-            coords[i] = rest % m_variables[i].m_num_points;
-            rest /= m_variables[i].m_num_points;
-            }
-        for (size_t i = 0; i < dim; ++i)
-            {
-            double delta = (m_variables[i].m_cv_max - m_variables[i].m_cv_min) / (m_variables[i].m_num_points - 1);
-            double val = m_variables[i].m_cv_min + coords[i] * delta;
-            file << std::setprecision(10) << val << m_delimiter;
-            }
-        file << std::setprecision(10) << grid[grid_idx];
-        double val = hist_gauss[grid_idx] > 0 ? sigma_grid[grid_idx] / (double)hist_gauss[grid_idx] : 0.0;   // :909-914
-        file << m_delimiter << std::setprecision(10) << val;
-        file << m_delimiter << hist_gauss[grid_idx];
-        file << m_delimiter << hist[grid_idx];
-        file << m_delimiter << std::setprecision(10) << rew[grid_idx];
-        file << m_delimiter << std::setprecision(10) << weight[grid_idx];
-        file << std::endl;
+        names.push_back(v.m_cv->getName());
+        lo.push_back(v.m_cv_min);
+        hi.push_back(v.m_cv_max);
+        pts.push_back(v.m_num_points);
         }
+    format_grid_file(file, names, lo, hi, pts, m_delimiter, d);        // grid_file.h: the text format, host only
     file.close();
     }
 
@@ -1182,33 +1162,12 @@ void IntegratorMetaDynamics::readGrid(const std::string &filename)
     {
     if (!m_use_grid || !m_engine) throw std::runtime_error("Error reading grid.");
     std::ifstream file(filename.c_str());
-    std::string line, tmp;
-    getline(file, line);
-    getline(file, line);
-    getline(file, line);
-    unsigned int num_gaussians = 0;
-        {
-        std::istringstream iss(line);
-        iss >> tmp >> num_gaussians;
-        }
-    getline(file, line);
     const unsigned int len = mtd_metad_num_elements(m_engine);
-    std::vector<double> grid(len), sigma_grid(len), rew(len), weight(len);
-    std::vector<unsigned int> hist(len), hist_gauss(len);
-    for (unsigned int grid_idx = 0; grid_idx < len; grid_idx++)
-        {
-        if (!file.good()) throw std::runtime_error("Error reading grid.");   // premature end (:973-977)
-        getline(file, line);
-        std::istringstream iss(line);
-        for (size_t i = 0; i < m_variables.size(); i++) iss >> tmp;
-        iss >> grid[grid_idx];
-        iss >> sigma_grid[grid_idx];
-        iss >> hist_gauss[grid_idx];
-        iss >> hist[grid_idx];
-        sigma_grid[grid_idx] *= hist_gauss[grid_idx];                  // :992
-        iss >> rew[grid_idx];
-        iss >> weight[grid_idx];
-        }
+    GridFileData d;
+    parse_grid_file(file, m_variables.size(), len, d);                 // grid_file.h: the text format, host only
+    std::vector<double> &grid = d.grid, &sigma_grid = d.sigma_grid, &rew = d.rew, &weight = d.weight;
+    std::vector<unsigned int> &hist = d.hist, &hist_gauss = d.hist_gauss;
+    const unsigned int num_gaussians = d.num_gaussians;
     hipStream_t s = m_exec_conf->getStream();
     mtd_check(mtd_metad_set_array(m_engine, 0, grid.data(), s), "set grid");
     mtd_check(mtd_metad_set_array(m_engine, 4, sigma_grid.data(), s), "set sigma_grid");

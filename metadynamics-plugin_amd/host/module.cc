@@ -8,6 +8,10 @@
 #include <pybind11/stl_bind.h>
 
 #include "metadynamics_host.h"
+#include "grid_file.h"
+
+#include <fstream>
+#include <sstream>
 
 namespace py = pybind11;
 using namespace mtdhost;
@@ -96,6 +100,40 @@ PYBIND11_MODULE(_metadynamics, m)
     m.def("make_int3", [](int x, int y, int z) { return make_int3(x, y, z); });
     py::bind_vector<std::vector<int3>>(m, "std_vector_int3");          // module.cc:25
     m.def("pack_postype", &pack_postype);
+    // the text formats of the grid dump and the hills log as host-only functions (grid_file.h): reachable without a GPU
+    m.def("parse_grid_file", [](const std::string &path, size_t n_cv, size_t len)
+        {
+        std::ifstream f(path.c_str());
+        GridFileData d;
+        parse_grid_file(f, n_cv, len, d);
+        py::dict out;
+        out["num_gaussians"] = d.num_gaussians;
+        out["grid"] = py::array_t<double>(d.grid.size(), d.grid.data());
+        out["sigma_grid"] = py::array_t<double>(d.sigma_grid.size(), d.sigma_grid.data());
+        out["reweighted"] = py::array_t<double>(d.rew.size(), d.rew.data());
+        out["weight"] = py::array_t<double>(d.weight.size(), d.weight.data());
+        out["hist"] = py::array_t<unsigned int>(d.hist.size(), d.hist.data());
+        out["hist_gauss"] = py::array_t<unsigned int>(d.hist_gauss.size(), d.hist_gauss.data());
+        return out;
+        });
+    m.def("format_grid_file", [](const std::string &path, const std::vector<std::string> &names, const std::vector<double> &cv_min,
+                                 const std::vector<double> &cv_max, const std::vector<unsigned int> &num_points, unsigned int num_gaussians,
+                                 const std::vector<double> &grid, const std::vector<double> &sigma_grid, const std::vector<double> &rew,
+                                 const std::vector<double> &weight, const std::vector<unsigned int> &hist,
+                                 const std::vector<unsigned int> &hist_gauss)
+        {
+        GridFileData d;
+        d.num_gaussians = num_gaussians;
+        d.grid = grid; d.sigma_grid = sigma_grid; d.rew = rew; d.weight = weight; d.hist = hist; d.hist_gauss = hist_gauss;
+        std::ofstream f(path.c_str());
+        format_grid_file(f, names, cv_min, cv_max, num_points, "\t", d);
+        });
+    m.def("format_hills_line", [](unsigned int timestep, double W, const std::vector<double> &cv, const std::vector<double> &sigma_inv)
+        {
+        std::ostringstream o;
+        format_hills_line(o, timestep, W, cv, sigma_inv, "\t");
+        return o.str();
+        });
 
     py::class_<BoxDim>(m, "BoxDim")
         .def(py::init<double, double, double, double, double, double>(), py::arg("Lx") = 1.0, py::arg("Ly") = 1.0, py::arg("Lz") = 1.0,

@@ -101,6 +101,9 @@ _SIGNATURES = {
     "mtd_lamellar_forces": (C.c_int, [C.POINTER(LamellarSet), C.c_uint, _vp, C.POINTER(_vp), C.c_int, C.c_uint,
                                        _vp, C.POINTER(Box), _vp]),
     "mtd_lamellar_set_fast_trig": (C.c_int, [C.c_int]),
+    "mtd_lamellar_get_fast_trig": (C.c_int, []),
+    "mtd_debug_sph_harmonics": (C.c_int, [C.c_uint, C.c_uint, _vp, _vp]),
+    "mtd_debug_index_decode": (C.c_int, [C.c_uint, _vp, C.c_uint, _vp, _vp, _vp]),
     "mtd_update_grid": (C.c_int, [C.c_uint, _up, C.c_uint, _vp, _vp, _dp, _dp, _dp, C.c_double, C.c_double, _vp]),
     "mtd_metad_create": (C.c_int, [C.POINTER(_vp), C.c_uint, _dp, _dp, _dp, _up, C.c_double, C.c_double,
                                     C.c_double, C.c_uint, C.c_int, C.c_int]),
@@ -207,6 +210,12 @@ def load():
         # so torch tensors, streams and RCCL buffers and our kernels share one runtime; loaded the other
         # way round two runtimes would coexist.
         # (torch is never imported from here: a process without it loads the HIP runtime libmtd_hip.so links against)
+        # The xGMI mailbox and the slab mesh share device buffers between the processes of a node with hipIpcGetMemHandle; on
+        # hosts whose driver only supports dmabuf IPC the runtime must be told BEFORE it initialises (it reads the variable
+        # once), or the export fails with "invalid argument" and every rank falls back to the RCCL all-reduce.  Set here when
+        # nobody chose a value (a process that initialised HIP before importing this module has to export it itself:
+        # xgmi.connect reports the value it ran with).
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         lib = C.CDLL(LIB_PATH)
         for name, (res, args) in _SIGNATURES.items():
             if not hasattr(lib, name):

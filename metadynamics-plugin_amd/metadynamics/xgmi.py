@@ -56,6 +56,14 @@ class Mailbox:
             self.handle = None
 
 
+_last_failure = None
+
+
+def last_failure():
+    """why the last :func:`connect` of this process handed back ``None`` (a short sentence), or ``None``"""
+    return _last_failure
+
+
 def _control_device(dist):
     return "cuda" if dist.get_backend() == "nccl" else "cpu"
 
@@ -66,6 +74,8 @@ def connect(dist, max_doubles=64, self_test=True):
     different hosts, a peer that cannot be mapped, a failed self test, or MTD_XGMI_MAILBOX=0)."""
     import torch
     from . import _abi
+    global _last_failure
+    _last_failure = None
     lib = _abi.load()
     rank, world = dist.get_rank(), dist.get_world_size()
     dev = _control_device(dist)
@@ -83,6 +93,8 @@ def connect(dist, max_doubles=64, self_test=True):
     names = bytes(names.cpu().numpy().tobytes())
     usable = usable and all(names[64 * r:64 * r + 64] == host for r in range(world))
     if not agree(usable):
+        _last_failure = ("switched off (MTD_XGMI_MAILBOX=0)" if os.environ.get("MTD_XGMI_MAILBOX", "1") == "0"
+                         else "more than 8 ranks or ranks on different hosts")
         return None
 
     h = C.c_void_p()
@@ -102,6 +114,10 @@ def connect(dist, max_doubles=64, self_test=True):
     if ok and self_test:
         ok = agree(_self_test(box, torch))
     if not ok:
+        # HIP IPC needs HSA_ENABLE_IPC_MODE_LEGACY=0 on hosts with dmabuf-only IPC, set before the runtime initialises
+        # (metadynamics._abi.load does when nobody chose a value; a process that initialised HIP earlier has to export it)
+        _last_failure = ("a rank could not export or map a peer's mailbox (status %d on rank %d; HSA_ENABLE_IPC_MODE_LEGACY=%s)"
+                         % (rc, rank, os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY"))) if rc != 0 or box is None else "the self test failed"
         # every rank leaves the same way (the barrier is collective: ranks whose mailbox never came up take part too)
         torch.cuda.synchronize()
         dist.barrier()

@@ -1,10 +1,11 @@
-"""GPU: bench.py's N > 1 code path (what the driver's scaling run launches with torch.distributed.run) rehearsed with two ranks
-sharing cuda:0 — MTD_BENCH_REHEARSAL=1: control plane gloo, particles sharded, the per-step sums through the xGMI mailbox between
-the two processes, C++ host classes as the step loop.  Numbers from such a run mean nothing; the JSON contract, the exchange
-chosen, zero expired waits and the global CV values against the oracle do."""
+"""GPU: bench.py's N > 1 code paths rehearsed on the one-GPU box through the SAME entry the driver uses — plain
+`python bench.py --gpus 2` (no launcher: bench.py starts its own ranks before it touches the GPU; with fewer GPUs than ranks it
+flags the run as a rehearsal: every rank on cuda:0, control plane gloo).  Particles sharded (weak and strong scaling: the
+per-step sums through the xGMI mailbox between the two processes, C++ host classes as the step loop) and multiple walkers (packed
+grid increments summed over the walkers).  Numbers from such runs mean nothing; the JSON contract, the exchange chosen, zero expired
+waits, the global CV values against the oracle and identical grids on all walkers do."""
 import json
 import os
-import socket
 import subprocess
 import sys
 
@@ -13,27 +14,73 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+        "data", "config", "roofline")
 
 
-def test_bench_two_ranks_rehearsal():
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
-    env = dict(os.environ, MTD_BENCH_REHEARSAL="1", HSA_ENABLE_IPC_MODE_LEGACY="0", MTD_FUSED_STEP="0")
-    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                        "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--particles", "200000", "--steps", "40",
-                        "--warmup", "5"], env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+def _bench(args, **env):
+    e = dict(os.environ, MTD_FUSED_STEP="0", **env)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MTD_BENCH_REHEARSAL", "HSA_ENABLE_IPC_MODE_LEGACY"):
+        e.pop(k, None)                      # bench.py sets what it needs itself: that is what is being tested
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=e, capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     line = [l for l in r.stdout.splitlines() if l.startswith('{"metric"')]
-    assert len(line) == 1, r.stdout[-2000:]                     # rank 0 prints ONE line
+    assert len(line) == 1, r.stdout[-2000:]                     # ONE line
     d = json.loads(line[0])
-    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
-                "data", "config", "roofline"):
+    for key in KEYS:
         assert key in d, key
-    assert d["n_gpus"] == 2 and d["steps"] == 40 and d["scaling"] == "weak" and d["vs_baseline"] is None
+    return d
+
+
+def _sharded_checks(d, n_global):
+    assert d["n_gpus"] == 2 and d["vs_baseline"] is None
+    assert "rehearsal" in d["config"]
     assert d["config"]["exchange"] == "xgmi-mailbox" and d["config"]["mailbox_timeouts"] == 0, d["config"]
-    assert d["value"] == pytest.approx(40 / (d["ms_per_step"] * 40e-3) * 400000 * 2, rel=1e-6)
+    assert "exchange_note" not in d["config"]
+    assert d["config"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    assert d["config"]["particles_global"] == n_global
+    assert d["value"] == pytest.approx(d["steps"] / (d["ms_per_step"] * d["steps"] * 1e-3) * n_global * 2, rel=1e-6)
     assert max(d["cv_check"]["abs_err"]) <= d["cv_check"]["tolerance"], d["cv_check"]
     assert d["self_check"]["V_rel_err"] < 1e-10 and d["self_check"]["w_rel_err"] < 1e-10
     assert "step_frac" in d["roofline"] and d["roofline"]["bound"] == "hbm"
+    assert d["extra"]["steady_state"]["steps"] >= 2000
+
+
+def test_bench_two_ranks_weak():
+    d = _bench(["--gpus", "2", "--particles", "200000", "--steps", "40", "--warmup", "5"])
+    assert d["scaling"] == "weak" and d["steps"] == 40 and d["config"]["mode"] == "sharded"
+    _sharded_checks(d, 400000)
+
+
+def test_bench_two_ranks_strong():
+    d = _bench(["--gpus", "2", "--scaling", "strong", "--particles", "400000", "--steps", "40", "--warmup", "5"])
+    assert d["scaling"] == "strong" and d["config"]["particles_per_gpu"] == 200000
+    _sharded_checks(d, 400000)
+
+
+def test_bench_two_walkers():
+    d = _bench(["--gpus", "2", "--walkers", "--particles", "100000", "--steps", "30", "--warmup", "5"])
+    assert d["scaling"] == "weak" and d["config"]["mode"] == "walkers" and d["config"]["particles_global"] == 200000
+    wc = d["walker_check"]
+    assert wc["grid_identical_on_all_ranks"] is True and wc["grid_sum"] > 0.0, wc
+    # every deposit of a walker step adds the increments of BOTH walkers: more than one hill's worth of bias per counted hill
+    assert wc["hills_rank0"] >= 30
+    assert d["value"] == pytest.approx(30 / (d["ms_per_step"] * 30e-3) * 200000 * 2, rel=1e-6)
+
+
+def test_bench_fallback_is_loud():
+    """a mailbox that cannot be used (here: switched off) sends the ranks to the collective, and the line says so"""
+    d = _bench(["--gpus", "2", "--particles", "100000", "--steps", "20", "--warmup", "5", "--no-variants"], MTD_XGMI_MAILBOX="0")
+    assert d["config"]["exchange"] == "gloo" and d["config"]["exchange_note"].startswith("FALLBACK"), d["config"]
+    assert max(d["cv_check"]["abs_err"]) <= d["cv_check"]["tolerance"], d["cv_check"]
+
+
+def test_bench_single_gpu_through_the_same_entry():
+    d = _bench(["--gpus", "1", "--steps", "20", "--warmup", "5", "--no-sub-records", "--cpu-steps", "1"])
+    assert d["n_gpus"] == 1 and d["scaling"] == "weak" and d["config"]["mode"] == "single" and "exchange" not in d["config"]
+    assert d["config"]["fast_trig"] == d["config"]["fast_trig_library_default"] == 1
+    assert d["self_check"]["V_rel_err"] < 1e-10
+    for k in ("steady_state", "stride100", "f64", "accurate_trig"):
+        assert d["extra"][k]["ms_per_step"] > 0, k
+    assert d["roofline"]["measured_peak"]["copy_512MB_GBs"] > 1000.0
+    assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] == 1
