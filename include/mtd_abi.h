@@ -456,6 +456,19 @@ int mtd_ql_finalize(int half_nlist, unsigned int lmax, const double *Ql_ref, uns
  * of the order; 0: floating-point atomics — sums in arrival order, about 2.5 x faster.  Full lists need neither. */
 int mtd_ql_set_half_list_exact(int enable);
 
+/* Half lists without atomics.  Builds — once per neighbour-list update, synchronous — the symmetric full list a half list stands
+ * for: every pair at both of its particles, each particle's partners in ascending order (so the result does not depend on any
+ * arrival order), into caller-provided device arrays d_full_head[n], d_full_n_neigh[n], d_full_nlist[full_capacity].
+ * *n_full_entries (host) receives the number of entries (twice the pairs); when it exceeds full_capacity nothing is written and
+ * MTD_ERR_INVALID_ARGUMENT comes back (call again with room).  Then pass the full arrays with half_nlist = 2 to
+ * mtd_ql_accumulate / mtd_ql_forces: the CV pass visits every pair once and scales like the half-list branch
+ * (SteinhardtQl.cc:173-179), the force pass gathers like the full-list pass — the third-law sum of :328-333 with no atomics,
+ * bitwise reproducible, at the full-list pass's cost (two pair visits instead of one visit + atomics).  A half list that
+ * indexes ghost particles (j >= n_particles) is refused (MTD_ERR_UNSUPPORTED): its reaction forces would be lost (:328). */
+int mtd_ql_symmetrize_half_list(unsigned int n_particles, const unsigned int *d_head_list, const unsigned int *d_n_neigh,
+                                const unsigned int *d_nlist, unsigned int *d_full_head, unsigned int *d_full_n_neigh,
+                                unsigned int *d_full_nlist, size_t full_capacity, size_t *n_full_entries, mtd_stream_t stream);
+
 int mtd_ql_forces(unsigned int n_particles, const void *d_postype, void *d_force, int dtype, const mtd_box *box,
                   const unsigned int *d_head_list, const unsigned int *d_n_neigh, const unsigned int *d_nlist, int half_nlist,
                   double rcut, double ron, unsigned int lmax, unsigned int type, const double *Ql_ref, unsigned int n_global,

@@ -917,6 +917,106 @@ int forces_impl(unsigned int N, const void *d_postype, void *d_force, int dtype,
 
 namespace
 {
+// ---- half list -> the symmetric full list it stands for (mtd_ql_symmetrize_half_list) -------------------------------------
+// counts[i] = own entries + the times i is listed by somebody else (integer atomics: the count does not depend on their order)
+__global__ void k_sym_count(const unsigned int n, const unsigned int *__restrict__ head, const unsigned int *__restrict__ n_neigh,
+                            const unsigned int *__restrict__ nlist, unsigned int *__restrict__ counts, unsigned int *__restrict__ flag)
+    {
+    const unsigned int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const unsigned int h = head[i], c = n_neigh[i];
+    unsigned int own = 0;
+    for (unsigned int k = 0; k < c; ++k)
+        {
+        const unsigned int j = nlist[h + k];
+        if (j >= n || j == i)
+            {
+            atomicOr(flag, 1u);                       // a ghost particle (or a self pair): the reaction would be lost (SteinhardtQl.cc:328)
+            continue;
+            }
+        atomicAdd(&counts[j], 1u);
+        own++;
+        }
+    atomicAdd(&counts[i], own);
+    }
+
+// exclusive scan of counts[0..n) by ONE block (once per neighbour-list update: 250 tiles at 256 000 particles), total behind it
+__global__ __launch_bounds__(1024) void k_sym_scan(const unsigned int n, const unsigned int *__restrict__ counts, unsigned int *__restrict__ head,
+                                                   unsigned int *__restrict__ total)
+    {
+    __shared__ unsigned int s_wave[16];
+    __shared__ unsigned int s_carry;
+    const unsigned int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) s_carry = 0;
+    __syncthreads();
+    for (unsigned int base = 0; base < n; base += 1024)
+        {
+        const unsigned int i = base + threadIdx.x;
+        const unsigned int v = i < n ? counts[i] : 0u;
+        unsigned int incl = v;
+#pragma unroll
+        for (int d = 1; d < MTD_WAVE; d <<= 1)
+            {
+            const unsigned int up = __shfl_up(incl, d, MTD_WAVE);
+            if ((int)lane >= d) incl += up;
+            }
+        if (lane == 63) s_wave[wave] = incl;
+        __syncthreads();
+        unsigned int before = s_carry;
+        for (unsigned int w = 0; w < wave; ++w) before += s_wave[w];
+        if (i < n) head[i] = before + incl - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) s_carry = before + incl;
+        __syncthreads();
+        }
+    if (threadIdx.x == 0) *total = s_carry;
+    }
+
+// every pair into both segments (arrival order: sorted afterwards)
+__global__ void k_sym_fill(const unsigned int n, const unsigned int *__restrict__ head, const unsigned int *__restrict__ n_neigh,
+                           const unsigned int *__restrict__ nlist, const unsigned int *__restrict__ full_head,
+                           unsigned int *__restrict__ cursor, unsigned int *__restrict__ full_nlist, const size_t capacity)
+    {
+    const unsigned int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const unsigned int h = head[i], c = n_neigh[i];
+    for (unsigned int k = 0; k < c; ++k)
+        {
+        const unsigned int j = nlist[h + k];
+        if (j >= n || j == i) continue;
+        const size_t a = (size_t)full_head[i] + atomicAdd(&cursor[i], 1u), b = (size_t)full_head[j] + atomicAdd(&cursor[j], 1u);
+        if (a < capacity) full_nlist[a] = j;
+        if (b < capacity) full_nlist[b] = i;
+        }
+    }
+
+// a particle's partners in ascending order: the list — and with it the order of every per-particle sum of the force pass — no
+// longer depends on the order the atomics of the fill were served in
+__global__ void k_sym_sort(const unsigned int n, const unsigned int *__restrict__ full_head, const unsigned int *__restrict__ counts,
+                           unsigned int *__restrict__ full_nlist, unsigned int *__restrict__ full_n_neigh, const size_t capacity)
+    {
+    const unsigned int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const unsigned int c = counts[i];
+    full_n_neigh[i] = c;
+    if ((size_t)full_head[i] + c > capacity) return;
+    unsigned int *seg = full_nlist + full_head[i];
+    for (unsigned int a = 1; a < c; ++a)
+        {
+        const unsigned int v = seg[a];
+        unsigned int b = a;
+        while (b > 0 && seg[b - 1] > v)
+            {
+            seg[b] = seg[b - 1];
+            --b;
+            }
+        seg[b] = v;
+        }
+    }
+} // namespace
+
+namespace
+{
 // Diagnostic: the spherical harmonics exactly as the pair kernels evaluate them — pair_geom's unit-vector trigonometry from a
 // separation, amplitude_column's Jacobi recurrence with the prefactors folded to literals, e^{i m phi} by repeated
 // multiplication, sin^m(theta) / sqrt(2 pi) by repeated multiplication (ql_accumulate_pairs with f = 1) — one thread per
@@ -965,6 +1065,56 @@ int mtd_ql_set_half_list_exact(int enable)
     {
     g_half_exact = enable ? 1 : 0;
     return MTD_SUCCESS;
+    }
+
+int mtd_ql_symmetrize_half_list(unsigned int n_particles, const unsigned int *d_head_list, const unsigned int *d_n_neigh,
+                                const unsigned int *d_nlist, unsigned int *d_full_head, unsigned int *d_full_n_neigh,
+                                unsigned int *d_full_nlist, size_t full_capacity, size_t *n_full_entries, mtd_stream_t stream)
+    {
+    if (!n_full_entries || (n_particles && (!d_head_list || !d_n_neigh || !d_full_head || !d_full_n_neigh)))
+        return MTD_ERR_INVALID_ARGUMENT;
+    *n_full_entries = 0;
+    if (n_particles == 0) return MTD_SUCCESS;
+    hipStream_t s = (hipStream_t)stream;
+    unsigned int *work = nullptr;                                     // counts[n] | cursor[n] | total | flag
+    MTD_HIP_TRY(hipMalloc(&work, (2 * (size_t)n_particles + 2) * sizeof(unsigned int)));
+    unsigned int *counts = work, *cursor = work + n_particles, *total = work + 2 * (size_t)n_particles, *flag = total + 1;
+    hipError_t e = hipMemsetAsync(work, 0, (2 * (size_t)n_particles + 2) * sizeof(unsigned int), s);
+    const unsigned int blocks = (n_particles + 255) / 256;
+    unsigned int host[2] = {0, 0};
+    if (e == hipSuccess)
+        {
+        k_sym_count<<<blocks, 256, 0, s>>>(n_particles, d_head_list, d_n_neigh, d_nlist, counts, flag);
+        k_sym_scan<<<1, 1024, 0, s>>>(n_particles, counts, d_full_head, total);
+        e = hipGetLastError();
+        }
+    if (e == hipSuccess) e = hipMemcpyAsync(host, total, 2 * sizeof(unsigned int), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    int rc = (int)e;
+    if (e == hipSuccess)
+        {
+        *n_full_entries = host[0];
+        if (host[1])
+            rc = MTD_ERR_UNSUPPORTED;                                 // ghost particles in a half list: use the third-law pass (or a full list)
+        else if (host[0] > full_capacity || (host[0] && !d_full_nlist))
+            rc = MTD_ERR_INVALID_ARGUMENT;                            // *n_full_entries tells the caller what to provide
+        else if (host[0])
+            {
+            k_sym_fill<<<blocks, 256, 0, s>>>(n_particles, d_head_list, d_n_neigh, d_nlist, d_full_head, cursor, d_full_nlist, full_capacity);
+            k_sym_sort<<<blocks, 256, 0, s>>>(n_particles, d_full_head, counts, d_full_nlist, d_full_n_neigh, full_capacity);
+            e = hipGetLastError();
+            if (e == hipSuccess) e = hipStreamSynchronize(s);         // `work` is released below
+            rc = (int)e;
+            }
+        else
+            {
+            e = hipMemsetAsync(d_full_n_neigh, 0, (size_t)n_particles * sizeof(unsigned int), s);
+            if (e == hipSuccess) e = hipStreamSynchronize(s);
+            rc = (int)e;
+            }
+        }
+    (void)hipFree(work);
+    return rc;
     }
 
 int mtd_debug_sph_harmonics(unsigned int lmax, unsigned int n, const double *h_separations, double *h_out)

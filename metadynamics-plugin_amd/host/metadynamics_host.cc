@@ -456,12 +456,51 @@ SteinhardtQl::SteinhardtQl(std::shared_ptr<SystemDefinition> sysdef, double rcut
                            const std::string &log_suffix)
     : CollectiveVariable(sysdef, "steinhardt" + log_suffix), m_rcut(rcut), m_ron(ron), m_lmax(lmax), m_nlist(nlist), m_type(type),
       m_Ql_ref(Ql_ref), m_Ql(lmax + 1, 0.0), m_cv_last_updated(0), m_have_computed(false), m_value(0.0), m_d_value(nullptr),
-      m_d_Ql(nullptr), m_d_Qlm(nullptr)
+      m_d_Ql(nullptr), m_d_Qlm(nullptr), m_sym_version(0), m_sym_ok(false)
     {
     if (Ql_ref.size() != lmax + 1) throw std::runtime_error("Error setting up Steinhardt CV");   // SteinhardtQl.cc:25-29
     if (lmax > 12) throw std::runtime_error("cv.steinhardt: lmax <= 12 in this build");
     if (!nlist) throw std::runtime_error("cv.steinhardt: a neighbour list is required");
     m_scratch.resize(sizeof(double) * mtd_ql_scratch_doubles(lmax));
+    }
+
+// the arrays and the list mode of this step's mtd_ql_* calls.  A half list (NeighborList::half: every pair once, reaction force by
+// Newton's third law, SteinhardtQl.cc:80, 173-179, 328-333) is turned ONCE PER LIST UPDATE into the symmetric full list it
+// stands for; the symmetric-full-list mode then gives the half-list result (each pair counted once in the CV pass, even degrees
+// doubled, odd ones zero) with a force pass that gathers instead of scattering reaction forces with atomics.  A half list with
+// ghost particles keeps the third-law pass.
+SteinhardtQl::Lists SteinhardtQl::lists()
+    {
+    Lists l;
+    l.head = (const unsigned int *)m_nlist->getHeadList().data();
+    l.n_neigh = (const unsigned int *)m_nlist->getNNeighArray().data();
+    l.nlist = (const unsigned int *)m_nlist->getNListArray().data();
+    l.mode = m_nlist->getStorageMode() == NeighborList::half ? 1 : (m_nlist->isSymmetricFull() ? 2 : 0);
+    static const bool keep_third_law = std::getenv("MTD_QL_HALF_THIRD_LAW") != nullptr;    // diagnostic: the atomic pass
+    if (l.mode != 1 || keep_third_law) return l;
+    if (m_sym_version != m_nlist->getVersion())
+        {
+        const unsigned int N = m_pdata->getN();
+        const size_t cap = 2 * (m_nlist->getNListArray().bytes() / sizeof(unsigned int));
+        m_sym_head.resize(sizeof(unsigned int) * (N ? N : 1));
+        m_sym_nneigh.resize(sizeof(unsigned int) * (N ? N : 1));
+        m_sym_nlist.resize(sizeof(unsigned int) * (cap ? cap : 1));
+        size_t n_full = 0;
+        const int rc = mtd_ql_symmetrize_half_list(N, l.head, l.n_neigh, l.nlist, (unsigned int *)m_sym_head.data(),
+                                                   (unsigned int *)m_sym_nneigh.data(), (unsigned int *)m_sym_nlist.data(), cap, &n_full,
+                                                   m_exec_conf->getStream());
+        if (rc != MTD_SUCCESS && rc != MTD_ERR_UNSUPPORTED) mtd_check(rc, "mtd_ql_symmetrize_half_list");
+        m_sym_ok = rc == MTD_SUCCESS;
+        m_sym_version = m_nlist->getVersion();
+        }
+    if (m_sym_ok)
+        {
+        l.head = (const unsigned int *)m_sym_head.data();
+        l.n_neigh = (const unsigned int *)m_sym_nneigh.data();
+        l.nlist = (const unsigned int *)m_sym_nlist.data();
+        l.mode = 2;
+        }
+    return l;
     }
 
 void SteinhardtQl::computeCV(unsigned int timestep)
@@ -470,9 +509,8 @@ void SteinhardtQl::computeCV(unsigned int timestep)
     if (m_cv_last_updated == timestep && m_have_computed) return;    // :64-65
     m_nlist->compute(timestep);                                      // :68
     const mtd_box box = m_pdata->getBox().toMtd();
-    mtd_check(mtd_ql_accumulate(m_pdata->getN(), m_pdata->positionsPtr(), m_pdata->getDtype(), &box,
-                                (const unsigned int *)m_nlist->getHeadList().data(), (const unsigned int *)m_nlist->getNNeighArray().data(),
-                                (const unsigned int *)m_nlist->getNListArray().data(), m_nlist->getStorageMode() == NeighborList::half ? 1 : (m_nlist->isSymmetricFull() ? 2 : 0),
+    const Lists l = lists();
+    mtd_check(mtd_ql_accumulate(m_pdata->getN(), m_pdata->positionsPtr(), m_pdata->getDtype(), &box, l.head, l.n_neigh, l.nlist, l.mode,
                                 m_rcut, m_ron, m_lmax, m_type, m_Ql_ref.data(), m_pdata->getNGlobal(), (double *)m_scratch.data(),
                                 &m_d_value, &m_d_Ql, &m_d_Qlm, m_exec_conf->getStream()),
               "mtd_ql_accumulate");
@@ -502,9 +540,8 @@ void SteinhardtQl::computeBiasForces(unsigned int timestep)
     // the reference relies on the Q_lm of the computeCV the integrator triggered earlier in the step (Q20); make sure one exists
     if (!m_have_computed) computeCV(timestep);
     const mtd_box box = m_pdata->getBox().toMtd();
-    mtd_check(mtd_ql_forces(m_pdata->getN(), m_pdata->positionsPtr(), m_force.data(), m_pdata->getDtype(), &box,
-                            (const unsigned int *)m_nlist->getHeadList().data(), (const unsigned int *)m_nlist->getNNeighArray().data(),
-                            (const unsigned int *)m_nlist->getNListArray().data(), m_nlist->getStorageMode() == NeighborList::half ? 1 : (m_nlist->isSymmetricFull() ? 2 : 0),
+    const Lists l = lists();
+    mtd_check(mtd_ql_forces(m_pdata->getN(), m_pdata->positionsPtr(), m_force.data(), m_pdata->getDtype(), &box, l.head, l.n_neigh, l.nlist, l.mode,
                             m_rcut, m_ron, m_lmax, m_type, m_Ql_ref.data(), m_pdata->getNGlobal(), (const double *)m_scratch.data(),
                             m_bias_device, m_bias, m_exec_conf->getStream()),
               "mtd_ql_forces");

@@ -261,6 +261,17 @@ class SteinhardtQl : public CollectiveVariable
         double m_value;
         DeviceBuffer m_scratch;
         const double *m_d_value, *m_d_Ql, *m_d_Qlm;
+        // half lists: the symmetric full list the half list stands for (mtd_ql_symmetrize_half_list), rebuilt when the
+        // neighbour list changes; the passes then run in the symmetric-full-list mode (no atomics in the force pass)
+        struct Lists
+            {
+            const unsigned int *head, *n_neigh, *nlist;
+            int mode;                                                 // half_nlist of the mtd_ql_* calls
+            };
+        Lists lists();
+        DeviceBuffer m_sym_head, m_sym_nneigh, m_sym_nlist;
+        unsigned int m_sym_version;
+        bool m_sym_ok;
     };
 
 //! AspectRatio.h / AspectRatio.cc:5-130 — box-shape CV, external virial only

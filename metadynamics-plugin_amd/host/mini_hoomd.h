@@ -345,6 +345,7 @@ class NeighborList
             if (n) m_nneigh.upload(n_neigh, sizeof(unsigned int) * n);
             if (n_list) m_nlist.upload(nlist, sizeof(unsigned int) * n_list);
             m_has = true;
+            m_version++;
             // a full list of HOOMD is symmetric by construction ((i, j) listed <=> (j, i) listed) and, on one rank, indexes
             // local particles only; the stand-in checks what it is handed, since SteinhardtQl's CV pass then visits every pair once
             m_symmetric = true;
@@ -366,6 +367,8 @@ class NeighborList
             if (!m_has) throw std::runtime_error("NeighborList: no neighbour list supplied (nlist.set_lists)");
             m_last = timestep;
             }
+        //! counts the lists handed in (HOOMD: a rebuild of the list): consumers that derive something from a list redo it then
+        unsigned int getVersion() const { return m_version; }
         DeviceBuffer &getHeadList() { return m_head; }
         DeviceBuffer &getNNeighArray() { return m_nneigh; }
         DeviceBuffer &getNListArray() { return m_nlist; }
@@ -376,6 +379,7 @@ class NeighborList
         unsigned int m_last;
         bool m_has;
         bool m_symmetric = false;
+        unsigned int m_version = 0;
         DeviceBuffer m_head, m_nneigh, m_nlist;
     };
 

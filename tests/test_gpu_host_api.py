@@ -308,6 +308,52 @@ def test_steinhardt_through_api(api, ref):
         cv.steinhardt(r_cut=1.4, r_on=1.2, lmax=6, Ql_ref=Ql_ref, nlist=nl, type="Z")         # cv.py:591-593
 
 
+def test_steinhardt_half_storage_through_host_classes(api, ref):
+    """a NeighborList in HALF storage mode (HOOMD's CPU default; cv.steinhardt asks for full storage like the reference does on a
+    GPU, so the mode is set on the C++ object as a C++ caller would): the host class turns the half list into the symmetric full
+    list it stands for once per list update (mtd_ql_symmetrize_half_list) — CV and forces are the reference's HALF-list results
+    (SteinhardtQl.cc:80, 173-179, 328-333), the force pass uses no atomics"""
+    context, cv, integrate = api
+    from metadynamics import _metadynamics
+    pos, L = util.fcc_lattice(5)
+    pos = pos + np.random.default_rng(21).normal(0, 0.05, pos.shape)
+    N = len(pos)
+    types = np.zeros(N, dtype=np.int32)
+    context.initialize(pos, types, ["A"], L, dtype=np.float64)
+    meta = integrate.mode_metadynamics(dt=0.005, stride=1, mode="well_tempered", W=1.0, deltaT=7.0, T=1.0)
+    nl = cv.nlist_cell(r_cut=1.5)
+    half = util.build_nlist(pos, L, 1.5, half=True)
+    Ql_ref = [0, 0, 0, 0, 1, 0, 1]
+    rbox = ref.Box.make(L)
+    pt = util.oracle_postype(pos, types)
+    val, Qlm, Ql = ref.ql_compute_cv(pt, rbox, *half, 1.4, 1.2, 6, 0, Ql_ref, half=True)
+    st = cv.steinhardt(r_cut=1.4, r_on=1.2, lmax=6, Ql_ref=Ql_ref, nlist=nl, type="A", sigma=0.02 * val)
+    nl.cpp_nlist.setStorageMode(_metadynamics.NeighborList.storageMode.half)
+    nl.set_lists(*half)
+    st.set_grid(0.55 * val, 1.3 * val, 64)
+    context.run(2)
+    t = context.current.system.getCurrentTimeStep()
+    assert st.cpp_force.getCurrentValue(t) == pytest.approx(val, rel=1e-10)
+    b = meta.cpp_integrator.getBiasFactors()
+    F = st.cpp_force.getForceArray()
+    F_ref = ref.ql_compute_forces(pt, rbox, *half, 1.4, 1.2, 6, 0, Ql_ref, Qlm, b[0], half=True)
+    assert np.abs(F_ref[:, :3]).max() > 0
+    assert np.abs(F[:, :3] - F_ref[:, :3]).max() <= 1e-7 * np.abs(F_ref[:, :3]).max()
+    # a new list (the pairs stored at their other end) is picked up: same result, bit for bit
+    i_of = np.repeat(np.arange(N), half[1])
+    a, bb = half[2].astype(np.int64), i_of
+    order = np.lexsort((bb, a))
+    a, bb = a[order], bb[order]
+    nn2 = np.bincount(a, minlength=N).astype(np.uint32)
+    head2 = np.zeros(N, dtype=np.uint32)
+    head2[1:] = np.cumsum(nn2)[:-1]
+    nl.set_lists(head2, nn2, bb.astype(np.uint32))
+    context.current.system.run(0)
+    st.cpp_force.compute(context.current.system.getCurrentTimeStep()) if hasattr(st.cpp_force, "compute") else None
+    context.run(1)
+    assert st.cpp_force.getCurrentValue(context.current.system.getCurrentTimeStep()) == pytest.approx(val, rel=1e-12)
+
+
 def test_wrap_through_api(api, ref):
     """cv.wrap around a prescribed force: energy CV incl. the external energy, grid evolution, and the wrapped
     compute's own arrays scaled by the bias factor (CollectiveWrapper.cc:136-179)"""

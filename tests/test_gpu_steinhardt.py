@@ -208,3 +208,70 @@ def test_ql_symmetric_full_list_visits_each_pair_once(abi, ref, dtype):
     fs = np.abs(r[3][:, :3]).max()
     tol = 1e-9 if dtype == np.float64 else 2e-7
     assert np.abs(out[2][3][:, :3] - r[3][:, :3]).max() <= tol * fs
+
+
+def _symmetrize(abi, N, nl, capacity=None):
+    lib = abi.load()
+    d_head, d_nn, d_nl = (torch.from_numpy(np.ascontiguousarray(x).astype(np.int32)).cuda() for x in nl)
+    cap = 2 * len(nl[2]) if capacity is None else capacity
+    f_head = torch.zeros(max(N, 1), dtype=torch.int32, device="cuda")
+    f_nn = torch.zeros(max(N, 1), dtype=torch.int32, device="cuda")
+    f_nl = torch.zeros(max(cap, 1), dtype=torch.int32, device="cuda")
+    n_full = C.c_size_t()
+    rc = lib.mtd_ql_symmetrize_half_list(N, abi.ptr(d_head), abi.ptr(d_nn), abi.ptr(d_nl), abi.ptr(f_head), abi.ptr(f_nn), abi.ptr(f_nl), cap,
+                                         C.byref(n_full), None)
+    torch.cuda.synchronize()
+    return rc, n_full.value, (f_head.cpu().numpy().astype(np.uint32), f_nn.cpu().numpy().astype(np.uint32), f_nl.cpu().numpy().astype(np.uint32))
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_ql_half_list_symmetrized(abi, ref, dtype):
+    """mtd_ql_symmetrize_half_list: the symmetric full list a half list stands for, built on the device once per list update; the
+    passes in the symmetric-full-list mode (half_nlist = 2) then give the reference's HALF-list result (SteinhardtQl.cc:80,
+    173-179, 328-333) — the force pass gathers, no atomics: bitwise reproducible, and independent of which end of a pair the
+    half list happens to store it at"""
+    pos, L = noisy_fcc(6, seed=9)
+    pos = pos.astype(dtype)
+    N = len(pos)
+    types = np.zeros(N, dtype=np.int32)
+    p64 = pos.astype(np.float64)
+    half = util.build_nlist(p64, L, 1.55, half=True)
+    full = util.build_nlist(p64, L, 1.55, half=False)
+    rc, n_full, sym = _symmetrize(abi, N, half)
+    assert rc == 0 and n_full == 2 * len(half[2]) == len(full[2])
+    # exactly the full list, every particle's partners ascending
+    assert np.array_equal(sym[0], full[0]) and np.array_equal(sym[1], full[1]) and np.array_equal(sym[2][:n_full], full[2])
+    args = (1.4, 1.2, 6, 0, [0, 0, 0, 0, 1, 0, 1])
+    g = run_gpu(abi, pos, types, L, sym, *args, dtype, half=2)
+    r = run_ref(ref, p64 if dtype == np.float64 else pos.astype(np.float64), types, L, half, *args, half=True)
+    assert g[0] == pytest.approx(r[0], rel=1e-10 if dtype == np.float64 else 1e-6)
+    tol = 1e-9 if dtype == np.float64 else 2e-7
+    scale = np.abs(r[3][:, :3]).max()
+    assert scale > 0 and np.abs(g[3][:, :3] - r[3][:, :3]).max() <= tol * scale
+    # the same pairs stored at their OTHER end, rows in another order: the same symmetric list, so the same bits
+    rng = np.random.default_rng(4)
+    i_of = np.repeat(np.arange(N), half[1])
+    flip = rng.random(len(i_of)) < 0.5
+    a = np.where(flip, half[2], i_of)
+    b = np.where(flip, i_of, half[2])
+    order = rng.permutation(len(a))
+    a, b = a[order], b[order]
+    order = np.argsort(a, kind="stable")
+    a, b = a[order], b[order]
+    nn2 = np.bincount(a, minlength=N).astype(np.uint32)
+    head2 = np.zeros(N, dtype=np.uint32)
+    head2[1:] = np.cumsum(nn2)[:-1]
+    rc2, n2, sym2 = _symmetrize(abi, N, (head2, nn2, b.astype(np.uint32)))
+    assert rc2 == 0 and np.array_equal(sym2[2][:n2], full[2])
+    g2 = run_gpu(abi, pos, types, L, sym2, *args, dtype, half=2)
+    assert np.array_equal(g2[3], g[3]) and g2[0] == g[0]
+    # too little room: nothing written, the size needed comes back; a ghost particle in the half list: refused
+    rc3, n3, _ = _symmetrize(abi, N, half, capacity=len(half[2]))
+    assert rc3 == -1 and n3 == n_full
+    ghost = [np.array(x).copy() for x in half]
+    ghost[2][3] = N + 5
+    rc4, _, _ = _symmetrize(abi, N, ghost)
+    assert rc4 == -2
+    # an empty list
+    rc5, n5, sym5 = _symmetrize(abi, N, (np.zeros(N, dtype=np.uint32), np.zeros(N, dtype=np.uint32), np.zeros(0, dtype=np.uint32)))
+    assert rc5 == 0 and n5 == 0 and not sym5[1].any()

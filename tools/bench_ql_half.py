@@ -38,3 +38,26 @@ for half in (0, 1):
         forces()
     torch.cuda.synchronize()
     print("%s list (%d entries): force pass %.1f us" % ("half" if half else "full", len(lst), (time.perf_counter() - t0) / reps * 1e6))
+    if half:
+        # the same half list turned into the symmetric full list it stands for (once per list update), passes in mode 2
+        f_head, f_nn = torch.zeros(N, dtype=torch.int32, device="cuda"), torch.zeros(N, dtype=torch.int32, device="cuda")
+        f_l = torch.zeros(2 * len(lst), dtype=torch.int32, device="cuda")
+        n_full = C.c_size_t()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        _abi.check(lib.mtd_ql_symmetrize_half_list(N, d_head.data_ptr(), d_nn.data_ptr(), d_l.data_ptr(), f_head.data_ptr(), f_nn.data_ptr(), f_l.data_ptr(),
+                                                   2 * len(lst), C.byref(n_full), None))
+        t_sym = time.perf_counter() - t0
+        _abi.check(lib.mtd_ql_accumulate(N, d_pos.data_ptr(), _abi.MTD_F64, C.byref(box), f_head.data_ptr(), f_nn.data_ptr(), f_l.data_ptr(), 2, 1.4, 1.2, 6, 0,
+                                         Ql_ref, N, scratch.data_ptr(), C.byref(p_val), C.byref(p_ql), C.byref(p_qlm), None))
+        def forces2():
+            _abi.check(lib.mtd_ql_forces(N, d_pos.data_ptr(), d_f.data_ptr(), _abi.MTD_F64, C.byref(box), f_head.data_ptr(), f_nn.data_ptr(), f_l.data_ptr(),
+                                         2, 1.4, 1.2, 6, 0, Ql_ref, N, scratch.data_ptr(), d_bias.data_ptr(), 0.0, None))
+        for _ in range(5):
+            forces2()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            forces2()
+        torch.cuda.synchronize()
+        print("half list symmetrized (%d entries, built in %.0f us, once per list update): force pass %.1f us" % (n_full.value, t_sym * 1e6, (time.perf_counter() - t0) / reps * 1e6))

@@ -1,27 +1,59 @@
 #!/bin/bash
-# Developer tool (GPU box): re-collect everything under profiles/r2 that bench.py's line refers to, into gpurun_out/profiles_r2/
-# (copy what is to be judged into profiles/r2 afterwards).  Every rocprofv3 run has the python program itself after `--`.
+# Developer tool (GPU box): re-collect everything under profiles/r3 that bench.py's line refers to, into gpurun_out/profiles_r3/
+# (copy what is to be judged into profiles/r3 afterwards).  Every rocprofv3 run has the python program itself after `--`;
+# counters are collected in runs of their own (--pmc with --kernel-trace only), one counter set per pass.
+# usage: tools/refresh_profiles.sh [bench|mesh|ql|sharded ...]   (default: all)
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-O=gpurun_out/profiles_r2; rm -rf $O; mkdir -p $O
+O=gpurun_out/profiles_r3; mkdir -p $O
+WHAT="${*:-bench mesh ql sharded}"
+rocprofv3 -L > $O/counters_list.txt 2>&1 || true
+pmc_pass() {   # pmc_pass <tag> <counters...> -- <program...>
+  local tag=$1; shift; local ctr=(); while [ "$1" != "--" ]; do ctr+=("$1"); shift; done; shift
+  rm -rf $O/pmc_$tag
+  timeout -k 10 400 rocprofv3 --kernel-trace --pmc "${ctr[@]}" --output-format csv -d $O/pmc_$tag -o pmc -- "$@" > $O/pmc_$tag.log 2>&1
+  local f="$(find $O/pmc_$tag -name '*counter_collection.csv' | head -1)"
+  if [ -n "$f" ]; then cp "$f" $O/pmc_${tag}_counter_collection.csv; rm -rf $O/pmc_$tag; else echo "pmc pass $tag produced no counters (see $O/pmc_$tag.log)"; fi
+}
 set -x
-timeout -k 10 400 python3 bench.py > $O/bench_default.log 2>&1 && tail -1 $O/bench_default.log > $O/bench_default.json
-timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -o bench -- python3 bench.py --no-cpu-baseline --no-sub-records > $O/bench_under_rocprof.log 2>&1
-grep '^{"metric"' $O/bench_under_rocprof.log | tail -1 > $O/bench_default_under_rocprof.json
-cp $(find $O/kt -name "*kernel_stats.csv" | head -1) $O/bench_default_kernel_stats.csv
-cp $(find $O/kt -name "*agent_info.csv" | head -1) $O/agent_info.csv
-for c in FETCH_SIZE WRITE_SIZE; do
-  timeout -k 10 400 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/pmc_$c -o pmc -- python3 bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-sub-records --driver abi > $O/pmc_$c.log 2>&1
-  cp $(find $O/pmc_$c -name "*counter_collection.csv" | head -1) $O/pmc_${c}_counter_collection.csv
-done
-python3 tools/pmc_summary.py $O/pmc_FETCH_SIZE_counter_collection.csv $O/pmc_WRITE_SIZE_counter_collection.csv $O/pmc_summary.json > /dev/null
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/c3 -o mesh -- python3 tools/bench_mesh.py 60 > $O/config3.log 2>&1
-cp $(find $O/c3 -name "*kernel_stats.csv" | head -1) $O/config3_mesh_kernel_stats.csv
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/c5 -o ql -- python3 tools/bench_ql.py 60 > $O/config5.log 2>&1
-cp $(find $O/c5 -name "*kernel_stats.csv" | head -1) $O/config5_steinhardt_kernel_stats.csv
-# the particle-sharded code path with one rank (mailbox to itself) and with two ranks sharing this GPU (rehearsal: software path only)
-MTD_BENCH_FORCE_DIST=1 timeout -k 10 300 python3 bench.py --no-cpu-baseline --no-sub-records > $O/mailbox_1rank.log 2>&1; grep '^{"metric"' $O/mailbox_1rank.log | tail -1 > $O/bench_mailbox_1rank.json
-MTD_XGMI_MAILBOX=0 MTD_BENCH_FORCE_DIST=1 timeout -k 10 300 python3 bench.py --no-cpu-baseline --no-sub-records > $O/rccl_1rank.log 2>&1; grep '^{"metric"' $O/rccl_1rank.log | tail -1 > $O/bench_rccl_1rank.json
-MTD_BENCH_REHEARSAL=1 timeout -k 10 300 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29561 bench.py --gpus 2 --particles 500000 > $O/rehearsal2.log 2>&1; grep '^{"metric"' $O/rehearsal2.log | tail -1 > $O/bench_rehearsal_2ranks_one_gpu.json
+if [[ " $WHAT " == *" bench "* ]]; then
+  timeout -k 10 600 python3 bench.py > $O/bench_default.log 2>&1 && tail -1 $O/bench_default.log > $O/bench_default.json
+  timeout -k 10 300 python3 bench.py --steps 20 --warmup 5 > $O/bench_k20.log 2>&1 && tail -1 $O/bench_k20.log > $O/bench_driver_call_k20.json
+  rm -rf $O/kt
+  timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -o bench -- python3 bench.py --no-cpu-baseline --no-sub-records --no-variants > $O/bench_under_rocprof.log 2>&1
+  grep '^{"metric"' $O/bench_under_rocprof.log | tail -1 > $O/bench_default_under_rocprof.json
+  cp "$(find $O/kt -name '*kernel_stats.csv' | head -1)" $O/bench_default_kernel_stats.csv
+  cp "$(find $O/kt -name '*agent_info.csv' | head -1)" $O/agent_info.csv; rm -rf $O/kt
+  for c in FETCH_SIZE WRITE_SIZE; do
+    pmc_pass $c $c -- python3 bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-sub-records --no-variants --driver abi
+  done
+  python3 tools/pmc_summary.py fused $O/pmc_FETCH_SIZE_counter_collection.csv $O/pmc_WRITE_SIZE_counter_collection.csv $O/bench_default_kernel_stats.csv $O/pmc_summary.json > /dev/null
+fi
+if [[ " $WHAT " == *" mesh "* ]]; then
+  rm -rf $O/c3
+  timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/c3 -o mesh -- python3 tools/bench_mesh.py 60 > $O/config3.log 2>&1
+  cp "$(find $O/c3 -name '*kernel_stats.csv' | head -1)" $O/config3_mesh_kernel_stats.csv; rm -rf $O/c3
+  for c in FETCH_SIZE WRITE_SIZE; do pmc_pass mesh_$c $c -- python3 tools/bench_mesh.py 20; done
+  pmc_pass mesh_SQ SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT -- python3 tools/bench_mesh.py 12
+  pmc_pass mesh_SQ2 SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES SQ_BUSY_CYCLES SQ_WAIT_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR -- python3 tools/bench_mesh.py 12
+fi
+if [[ " $WHAT " == *" ql "* ]]; then
+  rm -rf $O/c5
+  timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/c5 -o ql -- python3 tools/bench_ql.py 60 > $O/config5.log 2>&1
+  cp "$(find $O/c5 -name '*kernel_stats.csv' | head -1)" $O/config5_steinhardt_kernel_stats.csv; rm -rf $O/c5
+  for c in FETCH_SIZE WRITE_SIZE; do pmc_pass ql_$c $c -- python3 tools/bench_ql.py 20; done
+  pmc_pass ql_SQ SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT -- python3 tools/bench_ql.py 12
+  pmc_pass ql_SQ2 SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES SQ_BUSY_CYCLES SQ_WAIT_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR -- python3 tools/bench_ql.py 12
+fi
+if [[ " $WHAT " == *" mesh "* || " $WHAT " == *" ql "* ]]; then
+  python3 tools/pmc_summary.py kernels $O $O/pmc_mesh_ql_summary.json > $O/pmc_mesh_ql_summary.txt
+fi
+if [[ " $WHAT " == *" sharded "* ]]; then
+  # the particle-sharded code path with one rank (mailbox to itself) and with two ranks sharing this GPU (rehearsal: software path only)
+  MTD_BENCH_FORCE_DIST=1 timeout -k 10 300 python3 bench.py --no-cpu-baseline --no-sub-records --no-variants > $O/mailbox_1rank.log 2>&1; grep '^{"metric"' $O/mailbox_1rank.log | tail -1 > $O/bench_mailbox_1rank.json
+  MTD_XGMI_MAILBOX=0 MTD_BENCH_FORCE_DIST=1 timeout -k 10 300 python3 bench.py --no-cpu-baseline --no-sub-records --no-variants > $O/rccl_1rank.log 2>&1; grep '^{"metric"' $O/rccl_1rank.log | tail -1 > $O/bench_rccl_1rank.json
+  timeout -k 10 400 python3 bench.py --gpus 2 --particles 500000 > $O/rehearsal2.log 2>&1; grep '^{"metric"' $O/rehearsal2.log | tail -1 > $O/bench_rehearsal_2ranks_weak.json
+  timeout -k 10 400 python3 bench.py --gpus 2 --scaling strong --particles 1000000 > $O/rehearsal2s.log 2>&1; grep '^{"metric"' $O/rehearsal2s.log | tail -1 > $O/bench_rehearsal_2ranks_strong.json
+  timeout -k 10 400 python3 bench.py --gpus 2 --walkers --particles 500000 --steps 500 --warmup 50 > $O/rehearsal2w.log 2>&1; grep '^{"metric"' $O/rehearsal2w.log | tail -1 > $O/bench_rehearsal_2walkers.json
+fi
 set +x
-rm -rf $O/kt $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE $O/c3 $O/c5
-ls -la $O; cat $O/pmc_summary.json | head -20; grep "config" $O/config3.log $O/config5.log
+ls -la $O
