@@ -690,6 +690,7 @@ int fused_grid_step(mtd_metad *m, unsigned int timestep, hipStream_t s)
         }
     MTD_LAUNCH_CHECK();
     m->pending_apply = dep;
+    if (dep) announce_pending_apply(m, s);              // a later kernel of the step may take the deferred pass along (metad.hip)
     return MTD_SUCCESS;
     }
 } // namespace mtd

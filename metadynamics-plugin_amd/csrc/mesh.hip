@@ -37,6 +37,8 @@
 #include "mtd_device.hpp"
 #include "comm_host.hpp"
 #include "exact_div.hpp"
+#include "lamellar_host.hpp"
+#include "metad_host.hpp"
 
 #include <algorithm>
 #include <cmath>
@@ -572,15 +574,64 @@ __device__ __forceinline__ double mode_of(const double *s_mode, const double *__
 
 constexpr int TC_THREADS = 1024;       // one block per CU at 10^6 particles: 16 waves hide the load -> locate -> LDS atomic chain
 
-template<typename S4>
+// RIDER: two things that want the same pass over the positions, or merely a launch, ride along (mtd_mesh_set_lamellar_rider):
+// the block partial sums of a set of lamellar CVs — what the CV blocks of k_fused_cv (fused.hip) form, here from the particle
+// the block is binning anyway: one read of the 16 MB position array and one launch less per step of a mixed lamellar + mesh
+// set — and, in blocks behind the counting ones, the deferred second grid pass of the bias-grid engine's previous deposit.
+struct CountRider
+    {
+    mtd::LamKArgs k;
+    mtd::MetadCfg cfg;
+    double *partials;              // [count block][n_cv]
+    unsigned int n_apply;          // blocks behind the counting ones that run apply_cells
+    };
+
+// one particle's contribution to every CV of the set: the arithmetic of lam_cv_accumulate (lamellar_device.hpp), one particle at
+// a time — the same operations on the same operands per particle, only the grouping of the sums differs
+template<bool FAST>
+__device__ __forceinline__ void lam_cv_particle(const mtd::LamKArgs &a, const mtd::ModeTables &mt, const float *s_coeff, const mtd::Particle &p,
+                                                float (&acc)[3])
+    {
+    float g0, g1, g2;
+    mtd::project(a, p, g0, g1, g2);
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+        if (c < (int)a.n_cv)
+            {
+            float sum = 0.0f;
+            const unsigned int k1 = a.first[c] + a.nact[c];
+            for (unsigned int k = a.first[c]; k < k1; ++k)
+                {
+                const float4 h = mt.h[k];
+                const float cs = mtd::cos2pi<FAST>(h.x * g0 + h.y * g1 + h.z * g2);
+                sum += cs;
+                sum += h.w * ((cs * cs) * 2.0f - (FAST ? 0.99999994f : 1.0f));
+                }
+            acc[c] += s_coeff[c * MTD_MAX_TYPES + p.type] * sum;
+            }
+    }
+
+template<typename S4, bool RIDER, bool FAST>
 __global__ __launch_bounds__(TC_THREADS) void k_tile_count(const MeshGeom g, const TileGeom tg, const S4 *__restrict__ postype, const unsigned int N,
                                                     const double *__restrict__ mode, unsigned int *__restrict__ tile_of,
                                                     unsigned int *__restrict__ slot_of, unsigned int *__restrict__ hist,
-                                                    double *__restrict__ modesq_partials, const unsigned int n_types)
+                                                    double *__restrict__ modesq_partials, const unsigned int n_types,
+                                                    const CountRider *__restrict__ rider)
     {
     extern __shared__ unsigned int s_hist[];
     __shared__ double s_red[16];
     __shared__ double s_mode[TP_MODE_LDS];
+    __shared__ float s_coeff[RIDER ? 3 * MTD_MAX_TYPES : 1];
+    __shared__ mtd::ModeTables s_mt;
+    __shared__ double s_wave[RIDER ? (TC_THREADS / 64) * 3 : 1];
+    if (RIDER && blockIdx.x >= tg.n_blocks)
+        {
+        // the deferred second grid pass (updateReweightedEstimator's second loop + accumulate): TC_THREADS cells per block
+        const unsigned int b = blockIdx.x - tg.n_blocks;
+        const unsigned int c0 = b * TC_THREADS;
+        mtd::apply_cells(rider->cfg, c0, min(rider->cfg.len, c0 + TC_THREADS), b == 0, s_red);
+        return;
+        }
     const unsigned int i0 = blockIdx.x * tg.chunk;
     const unsigned int i1 = min(N, i0 + tg.chunk);
     // the mode coefficient comes from LDS — as a second, dependent global load it doubled the trip
@@ -591,10 +642,17 @@ __global__ __launch_bounds__(TC_THREADS) void k_tile_count(const MeshGeom g, con
     S4 raw = scalar4_traits<S4>::make(0, 0, 0, 0);
     if (i0 < i1) raw = postype[min(i0 + threadIdx.x, i_last)];     // (uniform over the block)
     stage_modes(s_mode, mode, n_types);
+    if (RIDER)
+        {
+        const mtd::LamKArgs &a = rider->k;
+        for (unsigned int q = threadIdx.x; q < 3 * MTD_MAX_TYPES; q += blockDim.x) s_coeff[q] = a.coeff[q / MTD_MAX_TYPES][q % MTD_MAX_TYPES];
+        for (unsigned int q = threadIdx.x; q < a.n_modes; q += blockDim.x) s_mt.h[q] = a.h[a.corder[q]];
+        }
     for (unsigned int t = threadIdx.x; t < tg.n_tiles; t += blockDim.x) s_hist[t] = 0;
     __syncthreads();
     CNT_STAMP(1);
     double msq = 0.0;
+    float acc[3] = { 0.0f, 0.0f, 0.0f };
     for (unsigned int i = i0 + threadIdx.x; i < i1; i += blockDim.x)
         {
         const Particle p = scalar4_traits<S4>::unpack(raw);
@@ -607,6 +665,7 @@ __global__ __launch_bounds__(TC_THREADS) void k_tile_count(const MeshGeom g, con
         slot_of[i] = atomicAdd(&s_hist[t], 1u);
         const double a = mode_of(s_mode, mode, (unsigned int)p.type);
         msq += a * a;
+        if (RIDER) lam_cv_particle<FAST>(rider->k, s_mt, s_coeff, p, acc);
         }
     CNT_STAMP(2);
     lds_barrier();                                                   // (the tile / slot stores of the loop drain behind it)
@@ -615,6 +674,25 @@ __global__ __launch_bounds__(TC_THREADS) void k_tile_count(const MeshGeom g, con
     for (unsigned int t = threadIdx.x; t < tg.n_tiles; t += blockDim.x) hist[(size_t)blockIdx.x * tg.n_tiles + t] = s_hist[t];
     msq = block_sum_lds(msq, s_red);
     if (threadIdx.x == 0) modesq_partials[blockIdx.x] = msq;
+    if (RIDER)
+        {
+        // fp32 wave sums -> fp64 across the waves in a fixed order, as lam_cv_block_reduce
+        const unsigned int n_cv = rider->k.n_cv;
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+            {
+            const float v = wave_sum(acc[c]);
+            if (lane == 0) s_wave[wave * 3 + c] = (double)v;
+            }
+        lds_barrier();
+        if (threadIdx.x < n_cv)
+            {
+            double r = 0.0;
+            for (int w = 0; w < TC_THREADS / 64; ++w) r += s_wave[w * 3 + threadIdx.x];
+            rider->partials[(size_t)blockIdx.x * n_cv + threadIdx.x] = r;
+            }
+        }
     CNT_STAMP(4);
     }
 
@@ -2105,6 +2183,12 @@ struct mtd_mesh
     const void *slab_rho[MTD_COMM_MAX_RANKS], *slab_f[MTD_COMM_MAX_RANKS], *slab_g[MTD_COMM_MAX_RANKS], *slab_inv[MTD_COMM_MAX_RANKS];
     double *d_slab_rho;        // this rank's reduced slab (device memory of its own)
     double *d_slab_sum;        // [0] CV integrand of this rank's pencils -> sum over ranks, [1] barrier token
+    // riders of the next assignment's first kernel (mtd_mesh_set_lamellar_rider): device copy of the arguments, host bookkeeping
+    CountRider *d_rider;
+    CountRider *h_rider;       // what d_rider holds (copied again only when something changed: a box, a grid, a mode set)
+    int rider_armed;
+    unsigned int rider_n_apply;
+    struct mtd_metad *rider_engine;
     };
 
 namespace
@@ -2385,9 +2469,59 @@ int mtd_mesh_destroy(mtd_mesh *m)
     if (m->d_slab_sum) (void)hipFree(m->d_slab_sum);
     if (m->d_table) (void)hipFree(m->d_table);
     if (m->d_log_scratch) (void)hipFree(m->d_log_scratch);
+    if (m->d_rider) (void)hipFree(m->d_rider);
+    delete m->h_rider;
     hipError_t e = hipFree(m->slab);
     delete m;
     return (int)e;
+    }
+
+int mtd_mesh_set_lamellar_rider(mtd_mesh *mesh, mtd_metad *engine, const mtd_lamellar_set *set, const mtd_box *global_box,
+                                unsigned int n_particles, double *d_partials, unsigned int *n_partials, mtd_stream_t stream)
+    {
+    if (!mesh || !set || !d_partials || !n_partials) return MTD_ERR_INVALID_ARGUMENT;
+    if (!mesh->tile_path) return MTD_ERR_UNSUPPORTED;              // the cell-level pipeline has no such pass: mtd_fused_cv_pass
+    if (set->n_cv == 0 || set->n_cv > 3) return MTD_ERR_UNSUPPORTED;
+    if (engine && engine->comm) return MTD_ERR_UNSUPPORTED;         // a sharded step sends its sums from launch A of the fused step
+    CountRider r;
+    std::memset(&r, 0, sizeof(r));
+    int rc = mtd::fill_kargs(r.k, set, global_box);
+    if (rc) return rc;
+    unsigned int nb = (n_particles + 4095) / 4096;                  // as mesh_assign_local
+    nb = nb < 1 ? 1 : (nb > mesh->tile_blocks_max ? mesh->tile_blocks_max : nb);
+    r.partials = d_partials;
+    r.n_apply = 0;
+    if (engine)
+        {
+        r.cfg = engine->cfg;
+        std::memset(r.cfg.src, 0, sizeof(r.cfg.src));               // (not read by apply_cells; keeps the comparison below quiet)
+        if (engine->pending_apply) r.n_apply = (engine->cfg.len + TC_THREADS - 1) / TC_THREADS;
+        }
+    if (!mesh->d_rider)
+        {
+        MTD_HIP_TRY(hipMalloc(&mesh->d_rider, sizeof(CountRider)));
+        mesh->h_rider = new (std::nothrow) CountRider();
+        if (!mesh->h_rider) return (int)hipErrorOutOfMemory;
+        std::memset(mesh->h_rider, 0xff, sizeof(CountRider));
+        }
+    if (std::memcmp(mesh->h_rider, &r, sizeof(r)) != 0)
+        {
+        *mesh->h_rider = r;
+        MTD_HIP_TRY(hipMemcpyAsync(mesh->d_rider, mesh->h_rider, sizeof(CountRider), hipMemcpyHostToDevice, (hipStream_t)stream));
+        }
+    mesh->rider_armed = 1;
+    mesh->rider_n_apply = r.n_apply;
+    mesh->rider_engine = engine;
+    *n_partials = nb;
+    return MTD_SUCCESS;
+    }
+
+int mtd_mesh_clear_rider(mtd_mesh *mesh, int *was_armed)
+    {
+    if (!mesh) return MTD_ERR_INVALID_ARGUMENT;
+    if (was_armed) *was_armed = mesh->rider_armed;
+    mesh->rider_armed = 0;
+    return MTD_SUCCESS;
     }
 
 int mtd_mesh_set_cv_event(mtd_mesh *m, void *hip_event)
@@ -2453,10 +2587,24 @@ static int mesh_assign_local(mtd_mesh *m, unsigned int n_particles, const void *
         tg.scale = std::ldexp(1.0, k);
         tg.inv_scale = std::ldexp(1.0, -k);
         const size_t lds = sizeof(unsigned int) * tg.n_tiles;
-        if (dtype == MTD_F32)
-            k_tile_count<float4><<<nb, TC_THREADS, lds, s>>>(g, tg, (const float4 *)d_postype, N, m->d_mode, m->d_cell_of, m->d_slot_of, m->d_count, m->d_modesq_partials, m->n_types);
+#define MTD_TILE_COUNT(S4, RIDER, FAST, GRID) \
+        k_tile_count<S4, RIDER, FAST><<<GRID, TC_THREADS, lds, s>>>(g, tg, (const S4 *)d_postype, N, m->d_mode, m->d_cell_of, m->d_slot_of, \
+                                                                    m->d_count, m->d_modesq_partials, m->n_types, m->d_rider)
+        if (m->rider_armed)
+            {
+            // (the rider's arguments were copied to the device on this stream by mtd_mesh_set_lamellar_rider)
+            const unsigned int grid = nb + m->rider_n_apply;
+            const bool fast = mtd::lam_fast_trig() != 0;
+            if (dtype == MTD_F32) { if (fast) MTD_TILE_COUNT(float4, true, true, grid); else MTD_TILE_COUNT(float4, true, false, grid); }
+            else { if (fast) MTD_TILE_COUNT(double4, true, true, grid); else MTD_TILE_COUNT(double4, true, false, grid); }
+            m->rider_armed = 0;
+            if (m->rider_engine && m->rider_n_apply) m->rider_engine->pending_apply = 0;
+            }
+        else if (dtype == MTD_F32)
+            MTD_TILE_COUNT(float4, false, false, nb);
         else
-            k_tile_count<double4><<<nb, TC_THREADS, lds, s>>>(g, tg, (const double4 *)d_postype, N, m->d_mode, m->d_cell_of, m->d_slot_of, m->d_count, m->d_modesq_partials, m->n_types);
+            MTD_TILE_COUNT(double4, false, false, nb);
+#undef MTD_TILE_COUNT
         MTD_LAUNCH_CHECK();
         k_tile_rowscan<<<tg.n_tiles + 1, 256, 0, s>>>(m->d_count, m->d_start, m->d_tile_total, tg.n_tiles, nb, m->d_modesq_partials, nb, m->d_mode_sq);
         MTD_LAUNCH_CHECK();

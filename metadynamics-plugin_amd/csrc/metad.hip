@@ -19,6 +19,7 @@
 
 #include <cmath>
 #include <cstring>
+#include <mutex>
 #include <new>
 
 #include "metad_host.hpp"
@@ -221,6 +222,46 @@ int metad_flush(mtd_metad *m, hipStream_t s)
         m->pending_apply = 0;
         }
     return MTD_SUCCESS;
+    }
+
+// ---- the deferred pass as a passenger ------------------------------------------------------------------------------
+// The second reweighting pass + accumulate of a deposit (k_apply) depends on nothing but that deposit's own grid launch and has to
+// be complete before the NEXT grid launch: a 5 us kernel of pure latency when it runs on its own.  The engine whose grid launch
+// left one pending announces it here together with the stream it ran on; a kernel of this library that is launched on the same
+// stream before the next grid launch and has room for passengers (Steinhardt's finalize step) takes it along as extra blocks —
+// stream order puts it after the deposit and before the next chain.  Nobody taking it is fine: metad_flush runs it as before.
+namespace
+{
+std::mutex g_deferred_mutex;
+mtd_metad *g_deferred_engine = nullptr;
+hipStream_t g_deferred_stream = nullptr;
+}
+
+void announce_pending_apply(mtd_metad *m, hipStream_t s)
+    {
+    std::lock_guard<std::mutex> lock(g_deferred_mutex);
+    g_deferred_engine = m;
+    g_deferred_stream = s;
+    }
+
+void withdraw_pending_apply(mtd_metad *m)
+    {
+    std::lock_guard<std::mutex> lock(g_deferred_mutex);
+    if (g_deferred_engine == m) g_deferred_engine = nullptr;
+    }
+
+bool take_pending_apply(hipStream_t s, MetadCfg &cfg)
+    {
+    static const bool off = std::getenv("MTD_NO_APPLY_PASSENGER") != nullptr;      // diagnostic: every deferred pass as its own launch
+    if (off) return false;
+    std::lock_guard<std::mutex> lock(g_deferred_mutex);
+    mtd_metad *m = g_deferred_engine;
+    if (!m || g_deferred_stream != s) return false;
+    g_deferred_engine = nullptr;
+    if (!m->pending_apply || m->comm) return false;
+    cfg = m->cfg;
+    m->pending_apply = 0;
+    return true;
     }
 }
 
@@ -435,6 +476,7 @@ int mtd_debug_index_decode(unsigned int n_cv, const unsigned int *lengths, unsig
 int mtd_metad_destroy(mtd_metad *m)
     {
     if (!m) return MTD_SUCCESS;
+    mtd::withdraw_pending_apply(m);
     mtd::fused_step_release(m);
     hipError_t e = hipFree(m->slab);
     delete m;

@@ -31,6 +31,11 @@ namespace mtd
 int metad_flush(mtd_metad *m, hipStream_t s);
 // fused.hip: deferred apply + one launch for the whole update (n_cv <= 3), MTD_ERR_UNSUPPORTED otherwise
 int fused_grid_step(mtd_metad *m, unsigned int timestep, hipStream_t s);
+// the deferred pass as a passenger of another kernel of this library on the same stream (metad.hip): the engine announces a
+// pending pass, a kernel with room takes it (cfg copied out, pending flag cleared) and runs apply_cells in extra blocks
+void announce_pending_apply(mtd_metad *m, hipStream_t s);
+void withdraw_pending_apply(mtd_metad *m);
+bool take_pending_apply(hipStream_t s, MetadCfg &cfg);
 // fused_step.hip: release the one-launch step's buffers (mtd_metad_destroy)
 void fused_step_release(mtd_metad *m);
 }

@@ -25,6 +25,7 @@
 //                     a fixed order through LDS (deterministic, no atomics for full lists).
 // Double precision throughout.
 #include "mtd_device.hpp"
+#include "metad_host.hpp"
 
 #include <cmath>
 #include <cstring>
@@ -460,9 +461,21 @@ __global__ __launch_bounds__(QL_THREADS, (LMAX <= 6 ? 4 : 2)) void k_ql_accumula
     }
 
 // ---- finalize: full Q_lm table (reference order), Q_l, CV --------------------------------------------
+// the bias-grid engine's deferred pass riding in the finalize launch (metad.hip: take_pending_apply): blocks 1 .. n run
+// apply_cells on 256 grid cells each; kept apart from the plain kernel so that a step without a passenger carries no extra
+// kernel arguments
 template<int LMAX>
 __global__ __launch_bounds__(256) void k_ql_finalize(const QlArgs<LMAX> a, const double *__restrict__ qprime,
-                                                     double *__restrict__ qlm_full, double *__restrict__ ql, double *__restrict__ value)
+                                                     double *__restrict__ qlm_full, double *__restrict__ ql, double *__restrict__ value);
+
+template<int LMAX>
+__global__ __launch_bounds__(256) void k_ql_finalize_carrier(const QlArgs<LMAX> a, const double *__restrict__ qprime,
+                                                             double *__restrict__ qlm_full, double *__restrict__ ql,
+                                                             double *__restrict__ value, const mtd::MetadCfg cfg);
+
+template<int LMAX>
+__device__ __forceinline__ void ql_finalize_body(const QlArgs<LMAX> &a, const double *__restrict__ qprime,
+                                                 double *__restrict__ qlm_full, double *__restrict__ ql, double *__restrict__ value)
     {
     // one thread per entry of the full table (<= 169 at lmax = 12), the sums over m and l in the serial order of the reference
     __shared__ double s_sq[(LMAX + 1) * (LMAX + 1)];
@@ -510,6 +523,28 @@ __global__ __launch_bounds__(256) void k_ql_finalize(const QlArgs<LMAX> a, const
         for (int l = 0; l <= (int)a.lmax; ++l) val += a.ql_ref[l] * s_ql[l];   // :190-194
         *value = val;
         }
+    }
+
+template<int LMAX>
+__global__ __launch_bounds__(256) void k_ql_finalize(const QlArgs<LMAX> a, const double *__restrict__ qprime,
+                                                     double *__restrict__ qlm_full, double *__restrict__ ql, double *__restrict__ value)
+    {
+    ql_finalize_body<LMAX>(a, qprime, qlm_full, ql, value);
+    }
+
+template<int LMAX>
+__global__ __launch_bounds__(256) void k_ql_finalize_carrier(const QlArgs<LMAX> a, const double *__restrict__ qprime,
+                                                             double *__restrict__ qlm_full, double *__restrict__ ql,
+                                                             double *__restrict__ value, const mtd::MetadCfg cfg)
+    {
+    if (blockIdx.x > 0)
+        {
+        __shared__ double s_red[16];
+        const unsigned int c0 = (blockIdx.x - 1) * 256;
+        mtd::apply_cells(cfg, c0, min(cfg.len, c0 + 256u), blockIdx.x == 1, s_red);
+        return;
+        }
+    ql_finalize_body<LMAX>(a, qprime, qlm_full, ql, value);
     }
 
 // ---- half lists: order-independent (exact) sums of the pair forces ---------------------------------------------
@@ -791,6 +826,17 @@ unsigned int ql_blocks(unsigned int N, int ppb, unsigned int resident)
 // the recurrence index in f0/f1 is the DEGREE n = l - m in the reference's tables (index2d(lmax, m, l-1) with l the
 // degree counter of compute_jacobis), which is what ylm_table uses (a.f0[m][n]).
 
+// the finalize launch, with the bias-grid engine's deferred pass as a passenger when one is waiting on this stream
+template<int LMAX>
+void launch_finalize(const QlArgs<LMAX> &a, const double *d_qprime, double *d_qlm, double *d_ql, double *d_value, hipStream_t s)
+    {
+    mtd::MetadCfg cfg;
+    if (mtd::take_pending_apply(s, cfg))
+        k_ql_finalize_carrier<LMAX><<<1 + (cfg.len + 255) / 256, 256, 0, s>>>(a, d_qprime, d_qlm, d_ql, d_value, cfg);
+    else
+        k_ql_finalize<LMAX><<<1, 256, 0, s>>>(a, d_qprime, d_qlm, d_ql, d_value);
+    }
+
 template<int LMAX>
 int accumulate_impl(unsigned int N, const void *d_postype, int dtype, const mtd_box *box, const unsigned int *d_head,
                     const unsigned int *d_nneigh, const unsigned int *d_nlist, int half, double rcut, double ron, unsigned int lmax,
@@ -804,7 +850,7 @@ int accumulate_impl(unsigned int N, const void *d_postype, int dtype, const mtd_
     if (rc) return rc;
     if (!accumulate)
         {
-        k_ql_finalize<LMAX><<<1, 256, 0, s>>>(a, d_qprime, d_qlm, d_ql, d_value);
+        launch_finalize<LMAX>(a, d_qprime, d_qlm, d_ql, d_value, s);
         MTD_LAUNCH_CHECK();
         return MTD_SUCCESS;
         }
@@ -829,7 +875,7 @@ int accumulate_impl(unsigned int N, const void *d_postype, int dtype, const mtd_
     rc = mtd_reduce_partials(d_partials, blocks, n_out, n_out, 1.0, 0.0, d_qprime, (mtd_stream_t)s);
     if (rc) return rc;
     if (!finalize) return MTD_SUCCESS;
-    k_ql_finalize<LMAX><<<1, 256, 0, s>>>(a, d_qprime, d_qlm, d_ql, d_value);
+    launch_finalize<LMAX>(a, d_qprime, d_qlm, d_ql, d_value, s);
     MTD_LAUNCH_CHECK();
     return MTD_SUCCESS;
     }

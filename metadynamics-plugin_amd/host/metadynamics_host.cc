@@ -351,6 +351,24 @@ void OrderParameterMeshGPU::computeVirial()
     for (unsigned int i = 0; i < 6; ++i) m_external_virial[i] = v[i];
     }
 
+bool OrderParameterMeshGPU::armLamellarRider(unsigned int timestep, mtd_metad *engine, const mtd_lamellar_set *set, double *d_partials,
+                                             unsigned int *n_partials)
+    {
+    if (m_cv_last_updated == timestep && !m_is_first_step) return false;    // enqueueCV would not launch anything this step
+    const mtd_box box = m_pdata->getGlobalBox().toMtd();
+    const int rc = mtd_mesh_set_lamellar_rider(m_mesh, engine, set, &box, m_pdata->getN(), d_partials, n_partials, m_exec_conf->getStream());
+    if (rc == MTD_ERR_UNSUPPORTED) return false;
+    mtd_check(rc, "mtd_mesh_set_lamellar_rider");
+    return true;
+    }
+
+bool OrderParameterMeshGPU::clearRider()
+    {
+    int was = 0;
+    mtd_check(mtd_mesh_clear_rider(m_mesh, &was), "mtd_mesh_clear_rider");
+    return was != 0;
+    }
+
 void OrderParameterMeshGPU::enqueueCV(unsigned int timestep)
     {
     ProfRange prof_range("Mesh");
@@ -945,7 +963,7 @@ std::vector<unsigned int> IntegratorMetaDynamics::mixedLamellarSlots() const
     return slots;
     }
 
-void IntegratorMetaDynamics::mixedLamellarCvPass(const std::vector<unsigned int> &slots, hipStream_t stream)
+void IntegratorMetaDynamics::buildMixedLamellarSet(const std::vector<unsigned int> &slots)
     {
     std::memset(&m_fused_set, 0, sizeof(m_fused_set));
     m_fused_set.n_cv = (unsigned int)slots.size();
@@ -969,15 +987,25 @@ void IntegratorMetaDynamics::mixedLamellarCvPass(const std::vector<unsigned int>
     m_fused_set.first[slots.size()] = k;
     m_fused_set.n_modes = k;
     if (m_fused_partials.bytes() == 0) m_fused_partials.resize(sizeof(double) * mtd_lamellar_scratch_doubles(m_pdata->getN()));
+    }
+
+void IntegratorMetaDynamics::setMixedLamellarSources(const std::vector<unsigned int> &slots, unsigned int n_partials)
+    {
+    for (unsigned int c = 0; c < slots.size(); ++c)
+        mtd_check(mtd_metad_set_cv_source(m_engine, slots[c], (const double *)m_fused_partials.data(), n_partials,
+                                          (unsigned int)slots.size(), c, 1.0 / (double)m_pdata->getNGlobal(), 0.0),
+                  "mtd_metad_set_cv_source");
+    }
+
+void IntegratorMetaDynamics::mixedLamellarCvPass(const std::vector<unsigned int> &slots, hipStream_t stream)
+    {
+    buildMixedLamellarSet(slots);
     const mtd_box box = m_pdata->getGlobalBox().toMtd();
     unsigned int n_partials = 0;
     mtd_check(mtd_fused_cv_pass(m_engine, &m_fused_set, m_pdata->getN(), m_pdata->positionsPtr(), m_pdata->getDtype(), &box,
                                 (double *)m_fused_partials.data(), &n_partials, stream),
               "mtd_fused_cv_pass");
-    for (unsigned int c = 0; c < slots.size(); ++c)
-        mtd_check(mtd_metad_set_cv_source(m_engine, slots[c], (const double *)m_fused_partials.data(), n_partials,
-                                          (unsigned int)slots.size(), c, 1.0 / (double)m_pdata->getNGlobal(), 0.0),
-                  "mtd_metad_set_cv_source");
+    setMixedLamellarSources(slots, n_partials);
     }
 
 void IntegratorMetaDynamics::mixedLamellarForcePass(const std::vector<unsigned int> &slots, unsigned int timestep, hipStream_t stream)
@@ -1036,10 +1064,37 @@ void IntegratorMetaDynamics::updateBiasPotential(unsigned int timestep)
                         hooked = std::dynamic_pointer_cast<OrderParameterMeshGPU>(m_variables[i].m_cv);
             if (hooked) hooked->setCvEvent(m_exec_conf->getEvent(1));
             }
-        if (!lam_slots.empty()) mixedLamellarCvPass(lam_slots, ls);
+        // One mesh CV beside the lamellar ones (BASELINE.json's config 3): the lamellar sums and the deferred grid pass RIDE in the
+        // mesh's own pass over the positions (the kernel that bins the particles, mtd_mesh_set_lamellar_rider) instead of taking
+        // a launch and a second read of the position array of their own (launch A of the fused step).
+        std::shared_ptr<OrderParameterMeshGPU> carrier;
+        static const bool no_rider = std::getenv("MTD_NO_MESH_RIDER") != nullptr;       // diagnostic: launch A as before
+        if (!lam_slots.empty() && !side && !no_rider && lam_slots.size() <= 3)
+            {
+            unsigned int n_mesh = 0;
+            for (unsigned int i = 0; i < m_variables.size(); ++i)
+                if (std::find(lam_slots.begin(), lam_slots.end(), i) == lam_slots.end())
+                    if (auto mesh = std::dynamic_pointer_cast<OrderParameterMeshGPU>(m_variables[i].m_cv))
+                        {
+                        carrier = mesh;
+                        ++n_mesh;
+                        }
+            if (n_mesh != 1) carrier.reset();
+            }
+        bool ridden = false;
+        if (carrier)
+            {
+            buildMixedLamellarSet(lam_slots);
+            unsigned int n_partials = 0;
+            ridden = carrier->armLamellarRider(timestep, m_engine, &m_fused_set, (double *)m_fused_partials.data(), &n_partials);
+            if (ridden) setMixedLamellarSources(lam_slots, n_partials);
+            }
+        if (!lam_slots.empty() && !ridden) mixedLamellarCvPass(lam_slots, ls);
         for (unsigned int i = 0; i < m_variables.size(); ++i)
             if (std::find(lam_slots.begin(), lam_slots.end(), i) == lam_slots.end())
                 m_variables[i].m_cv->enqueueCurrentValue(timestep, m_engine, i);
+        if (ridden && carrier->clearRider())
+            mixedLamellarCvPass(lam_slots, ls);                        // (nothing consumed the riders: the sums are formed by launch A after all)
         if (side)
             {
             if (hooked)

@@ -180,6 +180,12 @@ class OrderParameterMeshGPU : public CollectiveVariable
         void setBugCompatible(bool on);
         //! event recorded when the CV partial sums of the next compute are complete (mtd_mesh_set_cv_event); nullptr clears
         void setCvEvent(hipEvent_t e) { mtd_mesh_set_cv_event(m_mesh, (void *)e); }
+        //! the lamellar CVs of a mixed set (and the engine's deferred grid pass) ride in this mesh's next particle pass
+        //! (mtd_mesh_set_lamellar_rider); false when the mesh cannot carry them or is already up to date for `timestep`
+        bool armLamellarRider(unsigned int timestep, mtd_metad *engine, const mtd_lamellar_set *set, double *d_partials,
+                              unsigned int *n_partials);
+        //! true when riders armed earlier are still waiting (nothing consumed them): they are disarmed
+        bool clearRider();
         std::vector<std::string> getProvidedLogQuantities() override
             {
             auto l = CollectiveVariable::getProvidedLogQuantities();
@@ -368,6 +374,8 @@ class IntegratorMetaDynamics
         bool fusedLamellarPossible() const;
         void fusedLamellarStep(unsigned int timestep);
         std::vector<unsigned int> mixedLamellarSlots() const;
+        void buildMixedLamellarSet(const std::vector<unsigned int> &slots);
+        void setMixedLamellarSources(const std::vector<unsigned int> &slots, unsigned int n_partials);
         void mixedLamellarCvPass(const std::vector<unsigned int> &slots, hipStream_t stream);
         void mixedLamellarForcePass(const std::vector<unsigned int> &slots, unsigned int timestep, hipStream_t stream);
 

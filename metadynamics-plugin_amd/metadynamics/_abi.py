@@ -103,6 +103,8 @@ _SIGNATURES = {
     "mtd_lamellar_set_fast_trig": (C.c_int, [C.c_int]),
     "mtd_lamellar_get_fast_trig": (C.c_int, []),
     "mtd_debug_sph_harmonics": (C.c_int, [C.c_uint, C.c_uint, _vp, _vp]),
+    "mtd_mesh_clear_rider": (C.c_int, [_vp, C.POINTER(C.c_int)]),
+    "mtd_mesh_set_lamellar_rider": (C.c_int, [_vp, _vp, _vp, _vp, C.c_uint, _vp, C.POINTER(C.c_uint), _vp]),
     "mtd_ql_symmetrize_half_list": (C.c_int, [C.c_uint, _vp, _vp, _vp, _vp, _vp, _vp, C.c_size_t, C.POINTER(C.c_size_t), _vp]),
     "mtd_debug_index_decode": (C.c_int, [C.c_uint, _vp, C.c_uint, _vp, _vp, _vp]),
     "mtd_update_grid": (C.c_int, [C.c_uint, _up, C.c_uint, _vp, _vp, _dp, _dp, _dp, C.c_double, C.c_double, _vp]),

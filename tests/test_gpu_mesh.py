@@ -356,3 +356,72 @@ def test_mesh_256_cubed_tile_path_against_cell_path(abi, monkeypatch):
     assert np.abs(out["tiles"][1] - out["cells"][1]).max() <= 1e-11 * scale
     fm = np.abs(out["cells"][2]).max()
     assert fm > 0 and np.abs(out["tiles"][2] - out["cells"][2]).max() <= 5e-7 * fm
+
+
+@pytest.mark.parametrize("dtype,fast", [(np.float32, 1), (np.float32, 0), (np.float64, 1)])
+def test_lamellar_and_deferred_grid_pass_ride_in_the_binning_kernel(abi, ref, dtype, fast):
+    """mtd_mesh_set_lamellar_rider: the kernel that bins the particles for the mesh also forms the block partial sums of a set of
+    lamellar CVs (LamellarOrderParameter.cc:143-179 beside OrderParameterMesh.cc:517-640: one pass over the positions) and carries
+    the bias-grid engine's deferred second pass.  The lamellar sums against the oracle (1e-6) and against the stand-alone CV pass
+    (another grouping of the same fp32 terms: 1e-7), the mesh bit for bit what it is without riders, the grid arrays after the
+    ridden deferred pass against the oracle's."""
+    from test_gpu_metad import GpuMetad, compare
+    lib = abi.load()
+    N, L = 30011, 28.0
+    pos, types = util.snapshot_random(N, L, seed=77, modulated=True, dtype=np.float32)
+    pos = (np.mod(pos.astype(np.float64) + L / 2, L) - L / 2).astype(np.float32)
+    pos[pos >= L / 2] = -L / 2
+    dt = abi.MTD_F32 if dtype == np.float32 else abi.MTD_F64
+    d_pos = torch.from_numpy(util.pack_postype(pos.astype(dtype), types, dtype)).cuda()
+    box, rbox = abi.Box.make(L), ref.Box.make(L)
+    cvs = [(util.CV1_VECTORS, util.MODE_AB), (util.CV2_VECTORS, util.MODE_AB)]
+    lset = abi.LamellarSet.make(cvs)
+    abi.check(lib.mtd_lamellar_set_fast_trig(fast))
+    plain, ridden = GpuMesh(abi, (32, 32, 32), [1.0, -1.0], N), GpuMesh(abi, (32, 32, 32), [1.0, -1.0], N)
+    kw = dict(sigma=[0.05], cv_min=[-1.0], cv_max=[1.0], num_points=[300], W=1.0, T_shift=7.0, T=1.0, stride=1, mode="well_tempered")
+    g, r = GpuMetad(abi, **kw), ref.Metad(**kw)
+    try:
+        s_plain = plain.cv(d_pos, dt, box, N)
+        rho_plain = plain.array(0).copy()
+        # a deposit through the generic entry point leaves its second grid pass pending ...
+        g.step(0, [0.3])
+        b_ref = r.update_bias(0, [0.3])
+        # ... which rides, with the lamellar sums, in the mesh's binning kernel
+        partials = torch.zeros(lib.mtd_lamellar_scratch_doubles(N), dtype=torch.float64, device="cuda")
+        n_part = C.c_uint()
+        abi.check(lib.mtd_mesh_set_lamellar_rider(ridden.h, g.h, C.byref(lset), C.byref(box), N, abi.ptr(partials), C.byref(n_part), None))
+        s_ridden = ridden.cv(d_pos, dt, box, N)
+        was = C.c_int(-1)
+        abi.check(lib.mtd_mesh_clear_rider(ridden.h, C.byref(was)))
+        assert was.value == 0                                        # consumed by the assignment
+        assert s_ridden == s_plain and np.array_equal(ridden.array(0), rho_plain)
+        sums = partials[: n_part.value * 2].cpu().numpy().reshape(n_part.value, 2).sum(axis=0) / N
+        opt = util.oracle_postype(pos.astype(np.float64) if dtype == np.float64 else pos, types)
+        s_ref = [ref.lamellar_cv(v, opt, m, rbox) for v, m in cvs]
+        tol = [1e-6 * max(abs(s), 8 / np.sqrt(N)) for s in s_ref]
+        assert abs(sums[0] - s_ref[0]) <= tol[0] and abs(sums[1] - s_ref[1]) <= tol[1], (sums, s_ref)
+        scratch = torch.zeros(lib.mtd_lamellar_scratch_doubles(N), dtype=torch.float64, device="cuda")
+        n2 = C.c_uint()
+        abi.check(lib.mtd_lamellar_cv_partials(C.byref(lset), N, abi.ptr(d_pos), dt, C.byref(box), abi.ptr(scratch), C.byref(n2), None))
+        alone = scratch[: n2.value * 2].cpu().numpy().reshape(n2.value, 2).sum(axis=0) / N
+        assert np.allclose(sums, alone, rtol=1e-7, atol=1e-7 * 8 / np.sqrt(N))
+        # the deferred pass ran as a passenger: the arrays are final WITHOUT another launch (nothing is pending any more)
+        compare(g, r, b_ref, label="after the ridden deferred pass")
+        # riders are one-shot: the next assignment carries nothing, and an armed rider nobody consumes is reported
+        partials.zero_()
+        assert ridden.cv(d_pos, dt, box, N) == s_plain and float(partials.abs().sum()) == 0.0
+        abi.check(lib.mtd_mesh_set_lamellar_rider(ridden.h, None, C.byref(lset), C.byref(box), N, abi.ptr(partials), C.byref(n_part), None))
+        abi.check(lib.mtd_mesh_clear_rider(ridden.h, C.byref(was)))
+        assert was.value == 1
+        assert ridden.cv(d_pos, dt, box, N) == s_plain and float(partials.abs().sum()) == 0.0
+        # a second deposit + ridden pass, this time with an engine only partly busy (no pending pass: no apply blocks)
+        abi.check(lib.mtd_mesh_set_lamellar_rider(ridden.h, g.h, C.byref(lset), C.byref(box), N, abi.ptr(partials), C.byref(n_part), None))
+        assert ridden.cv(d_pos, dt, box, N) == s_plain
+        sums2 = partials[: n_part.value * 2].cpu().numpy().reshape(n_part.value, 2).sum(axis=0) / N
+        assert np.array_equal(sums2, sums)
+        g.step(1, [0.31])
+        compare(g, r, r.update_bias(1, [0.31]), label="second deposit")
+    finally:
+        abi.check(lib.mtd_lamellar_set_fast_trig(0))
+        for x in (plain, ridden, g):
+            x.close()

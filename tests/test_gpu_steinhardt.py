@@ -275,3 +275,33 @@ def test_ql_half_list_symmetrized(abi, ref, dtype):
     # an empty list
     rc5, n5, sym5 = _symmetrize(abi, N, (np.zeros(N, dtype=np.uint32), np.zeros(N, dtype=np.uint32), np.zeros(0, dtype=np.uint32)))
     assert rc5 == 0 and n5 == 0 and not sym5[1].any()
+
+
+def test_deferred_grid_pass_rides_in_the_finalize_launch(abi, ref):
+    """the bias-grid engine's deferred second pass (updateReweightedEstimator's second loop + accumulate, IntegratorMetaDynamics.cc:
+    1077-1087, 426-437) is announced by the generic grid launch and taken along by the next mtd_ql_accumulate on the same stream
+    (extra blocks of its finalize launch) instead of a 5 us launch of its own: the grid arrays are the oracle's either way"""
+    from test_gpu_metad import GpuMetad, compare
+    pos, L = noisy_fcc(5, seed=3)
+    N = len(pos)
+    types = np.zeros(N, dtype=np.int32)
+    nl = util.build_nlist(pos, L, 1.5)
+    kw = dict(sigma=[0.4], cv_min=[0.0], cv_max=[80.0], num_points=[700], W=1.0, T_shift=7.0, T=1.0, stride=1, mode="well_tempered")
+    g, r = GpuMetad(abi, **kw), ref.Metad(**kw)
+    try:
+        vals = []
+        for t in range(4):
+            val = run_gpu(abi, pos, types, L, nl, 1.4, 1.2, 6, 0, [0, 0, 0, 0, 1, 0, 1], np.float64)[0]      # accumulate (+ passenger), forces
+            vals.append(val)
+            g.step(t, [val])                                          # generic grid launch: leaves a pass pending, announces it
+            compare(g, r, r.update_bias(t, [val]), label="step %d" % t)      # (get_array flushes what nobody took)
+        # without a flush in between: three steps whose deferred passes can only have run as passengers
+        for t in range(4, 7):
+            val = run_gpu(abi, pos, types, L, nl, 1.4, 1.2, 6, 0, [0, 0, 0, 0, 1, 0, 1], np.float64)[0]
+            g.abi.check(g.lib.mtd_metad_set_cv_value(g.h, 0, float(val)))
+            g.abi.check(g.lib.mtd_metad_update_bias(g.h, t, None))
+            b = r.update_bias(t, [val])
+        compare(g, r, b, label="after three unflushed steps")
+        assert vals[0] == pytest.approx(vals[-1], rel=1e-14)
+    finally:
+        g.close()
