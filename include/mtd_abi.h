@@ -40,7 +40,9 @@ enum mtd_status
     MTD_ERR_INVALID_ARGUMENT = -1, /* the reference throws std::runtime_error for these */
     MTD_ERR_UNSUPPORTED = -2,
     MTD_ERR_NO_DEVICE = -3,
-    MTD_ERR_COMM_TIMEOUT = -4      /* a mailbox wait expired: the step is poisoned (NaN), sticky until the mailbox is destroyed */
+    MTD_ERR_COMM_TIMEOUT = -4,     /* a mailbox wait expired: the step is poisoned (NaN), sticky until the mailbox is destroyed */
+    MTD_ERR_COLLECTIVE = -5        /* an RCCL call failed (mtd_rccl_last_error says which and why), or the walkers of a multiple-walker
+                                      run disagree on stride / add_hills / timestep (they would enter different collectives) */
     };
 
 /* HOOMD BoxDim as a POD (reference: hoomd/BoxDim.h, passed by const-ref to every driver) */
@@ -281,6 +283,8 @@ int mtd_comm_allreduce_large(mtd_rccl *r, void *d_buffer, size_t count, int elem
 unsigned int mtd_rccl_world(const mtd_rccl *r);
 unsigned int mtd_rccl_rank(const mtd_rccl *r);
 int mtd_rccl_destroy(mtd_rccl *r);
+/* text of the last RCCL failure of this process ("ncclAllReduce: unhandled system error", ...), "" when there was none */
+const char *mtd_rccl_last_error(void);
 /* Multiple walkers in one call (IntegratorMetaDynamics.cc:363-451 with m_multiple_walkers): histogram / Gaussian increments
  * of this walker (mtd_metad_update_phase_a), sum of {grid_delta, sigma_grid_delta} and {hist_delta, hist_gauss_delta} over
  * the walkers (two all-reduces: the delta groups are contiguous), reweighting + accumulate + evaluation

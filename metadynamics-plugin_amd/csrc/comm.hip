@@ -49,13 +49,18 @@ __global__ __launch_bounds__(AR_THREADS) void k_comm_allreduce(const CommK k, do
         {
         if (s_failed)                                   // an expired wait: NaN, never a stale or partial sum
             {
-            values[j] = __longlong_as_double(0x7ff8000000000000ll);
+            values[j] = comm_poison();
             continue;
             }
         double t = 0.0;
+        bool remote = false;                            // a rank handed its own failure on
         for (unsigned int r = 0; r < k.world; ++r)
-            t += __hiloint2double((int)s_half[r * nw + 2 * j + 1], (int)s_half[r * nw + 2 * j]);
-        values[j] = t;
+            {
+            const double x = __hiloint2double((int)s_half[r * nw + 2 * j + 1], (int)s_half[r * nw + 2 * j]);
+            remote = remote || is_comm_poison(x);
+            t += x;
+            }
+        values[j] = remote ? comm_poison() : t;
         }
     }
 

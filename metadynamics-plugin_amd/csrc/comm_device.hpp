@@ -29,6 +29,19 @@
 namespace mtd
 {
 
+// What an expired wait hands on instead of a sum: a quiet NaN with a payload of its own, so that it travels in band — through the
+// sums over blocks and ranks, and through the mailbox to ranks whose own waits were fine — and can still be told from an
+// ARITHMETIC NaN.  A diverged simulation (NaN positions) produces NaN sums with the default payload: that is not a communication
+// failure, and it goes through the step exactly as without a mailbox (the reference deposits the NaN too).  Nothing relies on
+// an adder carrying the payload along: every hand-over tests its operands and sets the value again.
+constexpr unsigned long long MTD_COMM_POISON_BITS = 0x7ff8c0de00000000ull;
+__device__ __forceinline__ double comm_poison() { return __longlong_as_double((long long)MTD_COMM_POISON_BITS); }
+__device__ __forceinline__ bool is_comm_poison(const double x)
+    {
+    return (((unsigned long long)__double_as_longlong(x) >> 32) & 0x7fffffffull) == (MTD_COMM_POISON_BITS >> 32);
+    }
+
+
 constexpr int COMM_MAX_RANKS = MTD_COMM_MAX_RANKS;
 
 struct CommK
@@ -159,7 +172,7 @@ __device__ __forceinline__ bool ll_collect_strided(const CommK &k, const unsigne
     if (any_expired)
         {
 #pragma unroll
-        for (int i = 0; i < NS; ++i) v[i] = __longlong_as_double(0x7ff8000000000000ll);     // NaN: poisons the totals
+        for (int i = 0; i < NS; ++i) v[i] = comm_poison();                                  // poisons the totals
         }
     return any_expired;
     }
@@ -235,7 +248,7 @@ __device__ __forceinline__ bool ll_collect_columns(const CommK &k, const unsigne
     if (any_expired)
         {
 #pragma unroll
-        for (int i = 0; i < NS; ++i) v[i] = __longlong_as_double(0x7ff8000000000000ll);     // NaN: poisons the totals
+        for (int i = 0; i < NS; ++i) v[i] = comm_poison();                                  // poisons the totals
         }
     return any_expired;
     }
@@ -286,18 +299,24 @@ __device__ __forceinline__ void comm_recv_sum_wave(const CommK &k, double (&tota
     bool ok = true;
     if (lane < k.world * nw) half = comm_recv_word(k, lane / nw, lane % nw, ok);
     const bool failed = __any(!ok);                                  // wave-uniform: any expired wait poisons every total
+    bool remote = false;                                             // a rank whose own collection expired sent the poison value
 #pragma unroll
     for (int i = 0; i < 3; ++i)
         {
-        total[i] = failed ? __longlong_as_double(0x7ff8000000000000ll) : 0.0;
+        total[i] = 0.0;
         if (i < (int)n)
             for (unsigned int r = 0; r < k.world; ++r)
                 {
                 const unsigned int lo = __shfl(half, (int)(r * nw + 2 * i), MTD_WAVE);
                 const unsigned int hi = __shfl(half, (int)(r * nw + 2 * i + 1), MTD_WAVE);
-                total[i] += __hiloint2double((int)hi, (int)lo);
+                const double x = __hiloint2double((int)hi, (int)lo);
+                remote = remote || is_comm_poison(x);
+                total[i] += x;
                 }
         }
+    if (failed || remote)
+#pragma unroll
+        for (int i = 0; i < 3; ++i) total[i] = comm_poison();
     }
 
 } // namespace mtd

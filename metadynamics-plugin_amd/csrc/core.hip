@@ -14,6 +14,7 @@ const char *mtd_status_string(int status)
         case MTD_ERR_UNSUPPORTED: return "unsupported configuration";
         case MTD_ERR_NO_DEVICE: return "no HIP device";
         case MTD_ERR_COMM_TIMEOUT: return "xGMI mailbox: a peer did not answer in time (step poisoned, communicator dead)";
+        case MTD_ERR_COLLECTIVE: return "RCCL call failed (mtd_rccl_last_error has the text), or the walkers disagree on stride / add_hills / time step";
         }
     if (status > 0) return hipGetErrorString((hipError_t)status);
     return "unknown mtd status";

@@ -114,11 +114,15 @@ __global__ __launch_bounds__(FCV_THREADS) void k_fused_cv(const LamKArgs a, cons
             ll_store(ck.ll + ((size_t)block_id * NS + threadIdx.x) * 2, ck.seq, partials[block_id * NCV + threadIdx.x]);
         if (block_id != 0 || threadIdx.x >= MTD_WAVE) return;
         double v[3] = { 0.0, 0.0, 0.0 };
-        ll_collect_wave<NS>(ck, n_blocks, v);
+        const bool expired = ll_collect_wave<NS>(ck, n_blocks, v);
         MTD_STAMP(7, threadIdx.x == 0);
         double tot[3] = { 0.0, 0.0, 0.0 };
 #pragma unroll
-        for (int i = 0; i < NS; ++i) tot[i] = wave_sum(v[i]);
+        for (int i = 0; i < NS; ++i)
+            {
+            const double t = wave_sum(v[i]);                        // (every lane takes part, whatever it collected)
+            tot[i] = expired ? comm_poison() : t;
+            }
         MTD_STAMP(8, threadIdx.x == 0);
         comm_send_wave(ck, tot, NS);                            // this rank's totals into every rank's mailbox over xGMI
         MTD_STAMP(9, threadIdx.x == 0);
@@ -611,6 +615,7 @@ int mtd_fused_force_pass_slots(mtd_metad *m, const mtd_lamellar_set *set, const 
         }
     MTD_LAUNCH_CHECK();
     m->pending_apply = dep;
+    m->w_stale = dep;
     return MTD_SUCCESS;
     }
 
@@ -690,6 +695,7 @@ int fused_grid_step(mtd_metad *m, unsigned int timestep, hipStream_t s)
         }
     MTD_LAUNCH_CHECK();
     m->pending_apply = dep;
+    m->w_stale = dep;
     if (dep) announce_pending_apply(m, s);              // a later kernel of the step may take the deferred pass along (metad.hip)
     return MTD_SUCCESS;
     }

@@ -371,7 +371,7 @@ __global__ __launch_bounds__(FS_THREADS, 1) void k_fused_step(const LamKArgs a, 
             for (int i = 0; i < NS; ++i) tot[i] = wave_sum(v[i]);
             if (expired)
 #pragma unroll
-                for (int i = 0; i < 3; ++i) tot[i] = __longlong_as_double(0x7ff8000000000000ll);
+                for (int i = 0; i < 3; ++i) tot[i] = comm_poison();
             }
         MTD_STAMP(4, blockIdx.x == 0 && threadIdx.x == 0); MTD_STAMP(20, blockIdx.x == gridDim.x - 1 && threadIdx.x == 0);
         if (lane == 0) MTD_BSTAMP(2);
@@ -769,6 +769,7 @@ int mtd_fused_step(mtd_metad *m, const mtd_lamellar_set *set, unsigned int n_par
 #undef MTD_LAUNCH_FS
     MTD_LAUNCH_CHECK();
     m->pending_apply = 0;
+    m->w_stale = 0;                                             // (w(s) comes out of the launch in closed form)
     m->last_launches = 1;
     return MTD_SUCCESS;
     }

@@ -611,8 +611,11 @@ __device__ __forceinline__ void lam_cv_particle(const mtd::LamKArgs &a, const mt
             }
     }
 
+// (with riders two blocks have to fit a compute unit — 8 waves per SIMD, at most 64 registers — so that the blocks of the
+// deferred grid pass run BESIDE the counting blocks: at one 1024-thread block per CU they formed a second generation behind
+// them, 163 us per step of config 3 against 159 without riders)
 template<typename S4, bool RIDER, bool FAST>
-__global__ __launch_bounds__(TC_THREADS) void k_tile_count(const MeshGeom g, const TileGeom tg, const S4 *__restrict__ postype, const unsigned int N,
+__global__ __launch_bounds__(TC_THREADS, RIDER ? 8 : 4) void k_tile_count(const MeshGeom g, const TileGeom tg, const S4 *__restrict__ postype, const unsigned int N,
                                                     const double *__restrict__ mode, unsigned int *__restrict__ tile_of,
                                                     unsigned int *__restrict__ slot_of, unsigned int *__restrict__ hist,
                                                     double *__restrict__ modesq_partials, const unsigned int n_types,

@@ -379,6 +379,7 @@ int mtd_metad_create(mtd_metad **out, unsigned int n_cv, const double *sigma, co
     m->stride = stride;
     m->add_bias = add_bias ? 1 : 0;
     m->pending_apply = 0;
+    m->w_stale = 0;
     m->comm = nullptr;
     m->d_ll = nullptr;
     m->d_step_err = nullptr;
@@ -387,6 +388,9 @@ int mtd_metad_create(mtd_metad **out, unsigned int n_cv, const double *sigma, co
     m->step_seq = 0;
     m->last_launches = 0;
     m->step_mode = -1;
+    m->walkers_checked = nullptr;
+    m->walkers_stride = 0;
+    m->walkers_add_bias = 0;
 
     const size_t G = c.len;
     const size_t bytes_d = 6 * G * sizeof(double);
@@ -586,8 +590,36 @@ int mtd_metad_update_phase_b(mtd_metad *m, int deposited, mtd_stream_t stream)
 int mtd_metad_update_bias_walkers(mtd_metad *m, mtd_rccl *walkers, unsigned int timestep, mtd_stream_t stream)
     {
     if (!m) return MTD_ERR_INVALID_ARGUMENT;
+    int rc;
+    if (walkers && (m->walkers_checked != (const void *)walkers || m->walkers_stride != m->stride || m->walkers_add_bias != m->add_bias))
+        {
+        // Whether a step deposits — and with it whether this walker enters the two all-reduces below — follows from stride,
+        // add_hills and the time step.  Walkers that disagree would wait in different collectives for ever (RCCL has no bound,
+        // unlike the mailbox).  Checked once per (communicator, stride, add_hills): sum and sum of squares of each quantity over
+        // the walkers equal W x and W x^2 only when all are equal.  One small all-reduce and a synchronisation, at set-up.
+        double *d_chk = nullptr;
+        MTD_HIP_TRY(hipMalloc(&d_chk, 6 * sizeof(double)));
+        const double mine[3] = { (double)m->stride, (double)m->add_bias, (double)timestep };
+        double h[6] = { mine[0], mine[0] * mine[0], mine[1], mine[1] * mine[1], mine[2], mine[2] * mine[2] };
+        hipError_t e = hipMemcpyAsync(d_chk, h, sizeof(h), hipMemcpyHostToDevice, (hipStream_t)stream);
+        rc = e == hipSuccess ? mtd_comm_allreduce_large(walkers, d_chk, 6, MTD_ELEM_F64, stream) : (int)e;
+        if (!rc)
+            {
+            e = hipMemcpyAsync(h, d_chk, sizeof(h), hipMemcpyDeviceToHost, (hipStream_t)stream);
+            if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
+            rc = (int)e;
+            }
+        (void)hipFree(d_chk);
+        if (rc) return rc;
+        const double W = (double)mtd_rccl_world(walkers);
+        for (int q = 0; q < 3; ++q)
+            if (h[2 * q] != W * mine[q] || h[2 * q + 1] != W * mine[q] * mine[q]) return MTD_ERR_COLLECTIVE;
+        m->walkers_checked = (const void *)walkers;
+        m->walkers_stride = m->stride;
+        m->walkers_add_bias = m->add_bias;
+        }
     int deposited = 0;
-    int rc = mtd_metad_update_phase_a(m, timestep, &deposited, stream);
+    rc = mtd_metad_update_phase_a(m, timestep, &deposited, stream);
     if (rc) return rc;
     if (deposited && walkers)                                    // walkers == NULL: a single walker, the sum is its own increments
         {
@@ -635,12 +667,13 @@ int mtd_metad_get_state(mtd_metad *m, double *cv, double *bias, double *bias_pot
                         unsigned int *num_gaussians, unsigned int *num_out_of_bounds, mtd_stream_t stream)
     {
     if (!m) return MTD_ERR_INVALID_ARGUMENT;
-    if (m->pending_apply)
+    if (m->pending_apply || m->w_stale)
         {
-        int frc = mtd::metad_flush(m, (hipStream_t)stream);
+        int frc = mtd::metad_flush(m, (hipStream_t)stream);                // (nothing to do when launch A or a passenger ran the pass)
         if (frc) return frc;
         k_evaluate<<<1, GRID_THREADS, 0, (hipStream_t)stream>>>(m->cfg);   // w(s) of the now-final weight grid
         MTD_LAUNCH_CHECK();
+        m->w_stale = 0;
         }
     MetadState st;
     MTD_HIP_TRY(hipMemcpyAsync(&st, m->cfg.st, sizeof(st), hipMemcpyDeviceToHost, (hipStream_t)stream));

@@ -712,7 +712,7 @@ __device__ __forceinline__ ChainResult chain_wave(const MetadCfg &c, const bool 
         {
         bool bad = false;
 #pragma unroll
-        for (int i = 0; i < CHAIN_MAX_CV; ++i) bad = bad || (i < (int)n && rx_total[i] != rx_total[i]);
+        for (int i = 0; i < CHAIN_MAX_CV; ++i) bad = bad || (i < (int)n && is_comm_poison(rx_total[i]));   // (an arithmetic NaN is not a failure)
         if (bad)
             {
             // poisoned step: NaN CV values, bias factors (=> NaN forces), V and w; no hill, no histogram count

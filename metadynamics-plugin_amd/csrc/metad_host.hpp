@@ -12,6 +12,9 @@ struct mtd_metad
     // fused path (fused.hip): the second reweighting pass + accumulate of the last deposit is deferred
     // into the next CV launch; pending_apply != 0 means the grid arrays are one k_apply behind.
     int pending_apply;
+    // the last grid launch deposited a hill and left w(s) to whoever reads it: mtd_metad_get_state evaluates it on the final
+    // weight grid (whoever ran the deferred pass — a flush, launch A, a passenger — the read-out is still owed)
+    int w_stale;
     // particle-sharded fused step: the per-rank CV totals travel through this xGMI mailbox (comm.hip); not owned
     struct mtd_comm *comm;
     // one-launch step (fused_step.hip): block sums of the launch in the mailbox's wire format (hand-off between the blocks of
@@ -23,6 +26,10 @@ struct mtd_metad
     unsigned int step_seq;
     unsigned int last_launches;     // launches the last mtd_fused_step took (1: the persistent kernel, 2: the two-launch form)
     int step_mode;                  // mtd_fused_step_set_mode: -1 environment / default, 0 two launches, 1 one launch where possible
+    // multiple walkers: the (communicator, stride, add_hills) for which all walkers were found to agree (mtd_metad_update_bias_walkers)
+    const void *walkers_checked;
+    unsigned int walkers_stride;
+    int walkers_add_bias;
     };
 
 namespace mtd

@@ -13,6 +13,7 @@
 
 #include <dlfcn.h>
 
+#include <cstdio>
 #include <cstring>
 #include <mutex>
 #include <new>
@@ -33,8 +34,13 @@ struct RcclApi
     ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
     bool ok = false;
     };
+
+// the last failure in words (the ABI returns MTD_ERR_COLLECTIVE; the cause would otherwise be lost)
+std::mutex g_err_mutex;
+char g_last_error[256] = "";
 
 RcclApi &rccl_api()
     {
@@ -52,9 +58,18 @@ RcclApi &rccl_api()
         api.CommInitRank = (decltype(api.CommInitRank))dlsym(api.handle, "ncclCommInitRank");
         api.AllReduce = (decltype(api.AllReduce))dlsym(api.handle, "ncclAllReduce");
         api.CommDestroy = (decltype(api.CommDestroy))dlsym(api.handle, "ncclCommDestroy");
+        api.GetErrorString = (decltype(api.GetErrorString))dlsym(api.handle, "ncclGetErrorString");
         api.ok = api.GetUniqueId && api.CommInitRank && api.AllReduce && api.CommDestroy;
         });
     return api;
+    }
+
+int rccl_failed(const char *call, ncclResult_t r)
+    {
+    RcclApi &api = rccl_api();
+    std::lock_guard<std::mutex> lock(g_err_mutex);
+    std::snprintf(g_last_error, sizeof(g_last_error), "%s: %s (ncclResult %d)", call, api.GetErrorString ? api.GetErrorString(r) : "?", (int)r);
+    return MTD_ERR_COLLECTIVE;
     }
 
 } // namespace
@@ -68,7 +83,8 @@ int mtd_rccl_unique_id(void *out_id)
     RcclApi &api = rccl_api();
     if (!api.ok) return MTD_ERR_UNSUPPORTED;
     ncclUniqueId id;
-    if (api.GetUniqueId(&id) != ncclSuccess) return MTD_ERR_UNSUPPORTED;
+    const ncclResult_t res = api.GetUniqueId(&id);
+    if (res != ncclSuccess) return rccl_failed("ncclGetUniqueId", res);
     std::memcpy(out_id, &id, sizeof(id));
     return MTD_SUCCESS;
     }
@@ -84,10 +100,11 @@ int mtd_rccl_create(mtd_rccl **out, const void *unique_id, unsigned int rank, un
     std::memcpy(&id, unique_id, sizeof(id));
     r->rank = rank;
     r->world = world;
-    if (api.CommInitRank(&r->comm, (int)world, id, (int)rank) != ncclSuccess)
+    const ncclResult_t res = api.CommInitRank(&r->comm, (int)world, id, (int)rank);
+    if (res != ncclSuccess)
         {
         delete r;
-        return MTD_ERR_UNSUPPORTED;
+        return rccl_failed("ncclCommInitRank", res);
         }
     *out = r;
     return MTD_SUCCESS;
@@ -100,8 +117,17 @@ int mtd_comm_allreduce_large(mtd_rccl *r, void *d_buffer, size_t count, int elem
     RcclApi &api = rccl_api();
     if (!api.ok) return MTD_ERR_UNSUPPORTED;
     const ncclDataType_t t = elem == MTD_ELEM_F64 ? ncclFloat64 : ncclUint32;
-    if (api.AllReduce(d_buffer, d_buffer, count, t, ncclSum, r->comm, (hipStream_t)stream) != ncclSuccess) return MTD_ERR_UNSUPPORTED;
+    const ncclResult_t res = api.AllReduce(d_buffer, d_buffer, count, t, ncclSum, r->comm, (hipStream_t)stream);
+    if (res != ncclSuccess) return rccl_failed("ncclAllReduce", res);
     return MTD_SUCCESS;
+    }
+
+const char *mtd_rccl_last_error(void)
+    {
+    static thread_local char copy[256];
+    std::lock_guard<std::mutex> lock(g_err_mutex);
+    std::memcpy(copy, g_last_error, sizeof(copy));
+    return copy;
     }
 
 unsigned int mtd_rccl_world(const mtd_rccl *r) { return r ? r->world : 0; }

@@ -29,6 +29,8 @@
 
 #include <cmath>
 #include <cstring>
+#include <map>
+#include <mutex>
 
 namespace
 {
@@ -901,26 +903,48 @@ int forces_impl(unsigned int N, const void *d_postype, void *d_force, int dtype,
         {
         // a pool of this library's own that keeps what it has handed out (the device's default pool returns everything to the
         // driver at the next synchronise, and the next call pays a fresh allocation)
-        static hipMemPool_t pool = [] {
+        // (one pool per device: a process may drive several GPUs)
+        static std::mutex pool_mutex;
+        static std::map<int, hipMemPool_t> pools;
+        hipMemPool_t pool = nullptr;
+        {
+        int dev = 0;
+        MTD_HIP_TRY(hipGetDevice(&dev));
+        std::lock_guard<std::mutex> lock(pool_mutex);
+        auto it = pools.find(dev);
+        if (it == pools.end())
+            {
             hipMemPool_t p = nullptr;
-            int dev = 0;
-            (void)hipGetDevice(&dev);
             hipMemPoolProps props;
             std::memset(&props, 0, sizeof(props));
             props.allocType = hipMemAllocationTypePinned;
             props.location.type = hipMemLocationTypeDevice;
             props.location.id = dev;
-            if (hipMemPoolCreate(&p, &props) != hipSuccess) { (void)hipGetLastError(); return (hipMemPool_t) nullptr; }
-            unsigned long long keep = ~0ull;
-            (void)hipMemPoolSetAttribute(p, hipMemPoolAttrReleaseThreshold, &keep);
-            return p;
-        }();
+            if (hipMemPoolCreate(&p, &props) != hipSuccess)
+                {
+                (void)hipGetLastError();
+                p = nullptr;
+                }
+            else
+                {
+                unsigned long long keep = ~0ull;
+                (void)hipMemPoolSetAttribute(p, hipMemPoolAttrReleaseThreshold, &keep);
+                }
+            it = pools.emplace(dev, p).first;
+            }
+        pool = it->second;
+        }
         if (pool)
             MTD_HIP_TRY(hipMallocFromPoolAsync((void **)&acc, acc_bytes + own_bytes, pool, s));
         else
             MTD_HIP_TRY(hipMallocAsync((void **)&acc, acc_bytes + own_bytes, s));
         own = (double *)((char *)acc + acc_bytes);
-        MTD_HIP_TRY(hipMemsetAsync(acc, 0, acc_bytes + own_bytes, s));
+        const hipError_t me = hipMemsetAsync(acc, 0, acc_bytes + own_bytes, s);
+        if (me != hipSuccess)
+            {
+            (void)hipFreeAsync(acc, s);                              // nothing was launched on it
+            return (int)me;
+            }
         }
     else if (half)
         MTD_HIP_TRY(hipMemsetAsync(d_force, 0, s4 * N, s));               // memset of :236, the pair terms are then added atomically

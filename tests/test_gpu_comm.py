@@ -89,6 +89,43 @@ def test_mailbox_single_rank_matches_plain_fused_step(abi, n_cv, dtype):
     a.close(); b.close(); box.close()
 
 
+def test_nan_positions_are_not_a_communication_failure(abi):
+    """a diverged simulation (a NaN position) gives NaN CV sums; with a mailbox attached that used to be read as an expired wait
+    (poisoned step, nothing deposited, the cause misreported).  An expired wait hands on a NaN with a payload of its own
+    (comm_device.hpp); an arithmetic NaN goes through the step exactly as without a mailbox — the reference deposits it too"""
+    import ctypes as C
+    from metadynamics import xgmi
+    from metadynamics.sharded import HipLamellarBackend
+    lib = abi.load()
+    h = C.c_void_p()
+    abi.check(lib.mtd_comm_create(C.byref(h), 0, 1, 8))
+    box = xgmi.Mailbox(h, 0, 1)
+    N, L = 20000, 30.0
+    pos, types = util.snapshot_random(N, L, seed=9, modulated=True, dtype=np.float32)
+    pos[1234, 1] = np.nan
+    grid = dict(sigma=[0.02, 0.02], cv_min=[-1.0] * 2, cv_max=[1.0] * 2, num_points=[64, 48])
+    kw = dict(W=1.0, T_shift=7.0, T=1.0, stride=1, mode="well_tempered")
+    cvs = [(util.CV1_VECTORS, util.MODE_AB), (util.CV2_VECTORS, util.MODE_AB)]
+    d = torch.from_numpy(util.pack_postype(pos, types, np.float32)).cuda()
+    a = HipLamellarBackend(cvs, d, N, L, grid, fast_trig=False, **kw)
+    b = HipLamellarBackend(cvs, d, N, L, grid, fast_trig=False, **kw)
+    b.attach_mailbox(box)
+    for t in range(3):
+        a.step_single(t)
+        b.step_single(t)                                              # (raises on MTD_ERR_COMM_TIMEOUT)
+    sa, sb = a.state(), b.state()
+    assert all(np.isnan(x) for x in sa["cv"]) and all(np.isnan(x) for x in sb["cv"])
+    assert sb["num_gaussians"] == sa["num_gaussians"] == 3            # deposited like the plain path (and the reference)
+    assert box.timeouts() == 0
+    G = lib.mtd_metad_num_elements(a.h)
+    ga, gb = np.zeros(G), np.zeros(G)
+    abi.check(lib.mtd_metad_get_array(a.h, 0, ga.ctypes.data, None))
+    abi.check(lib.mtd_metad_get_array(b.h, 0, gb.ctypes.data, None))
+    assert np.array_equal(np.isnan(ga), np.isnan(gb)) and np.isnan(ga).any()
+    b.attach_mailbox(None)
+    a.close(); b.close(); box.close()
+
+
 def test_mailbox_rejects_bad_arguments(abi):
     import ctypes as C
     lib = abi.load()
