@@ -574,16 +574,20 @@ __device__ __forceinline__ double mode_of(const double *s_mode, const double *__
 
 constexpr int TC_THREADS = 1024;       // one block per CU at 10^6 particles: 16 waves hide the load -> locate -> LDS atomic chain
 
-// RIDER: two things that want the same pass over the positions, or merely a launch, ride along (mtd_mesh_set_lamellar_rider):
-// the block partial sums of a set of lamellar CVs — what the CV blocks of k_fused_cv (fused.hip) form, here from the particle
-// the block is binning anyway: one read of the 16 MB position array and one launch less per step of a mixed lamellar + mesh
-// set — and, in blocks behind the counting ones, the deferred second grid pass of the bias-grid engine's previous deposit.
+// RIDER (mtd_mesh_set_lamellar_rider): the block partial sums of a set of lamellar CVs — what the CV blocks of k_fused_cv
+// (fused.hip) form — are formed here from the particle the block is binning anyway: one read of the 16 MB position array and
+// one launch less per step of a mixed lamellar + mesh set.  The deferred second grid pass of the bias-grid engine's previous
+// deposit, which launch A used to carry, rides in the next launch (k_tile_rowscan: latency-bound, nearly empty).  (First form:
+// the grid pass as extra 1024-thread blocks of THIS kernel — a second generation behind the counting blocks at one block per
+// CU, 163 us per step of config 3 against 159 without riders; with two blocks per CU 158.5 against 158.6: the counting blocks
+// keep the vector units busy — locate() is ~110 fp64 instructions per particle — and the grid pass beside them cost what it
+// costs as a launch of its own.)
 struct CountRider
     {
     mtd::LamKArgs k;
     mtd::MetadCfg cfg;
     double *partials;              // [count block][n_cv]
-    unsigned int n_apply;          // blocks behind the counting ones that run apply_cells
+    unsigned int n_apply;          // blocks of the row-scan launch that run apply_cells (256 cells each)
     };
 
 // one particle's contribution to every CV of the set: the arithmetic of lam_cv_accumulate (lamellar_device.hpp), one particle at
@@ -611,11 +615,8 @@ __device__ __forceinline__ void lam_cv_particle(const mtd::LamKArgs &a, const mt
             }
     }
 
-// (with riders two blocks have to fit a compute unit — 8 waves per SIMD, at most 64 registers — so that the blocks of the
-// deferred grid pass run BESIDE the counting blocks: at one 1024-thread block per CU they formed a second generation behind
-// them, 163 us per step of config 3 against 159 without riders)
 template<typename S4, bool RIDER, bool FAST>
-__global__ __launch_bounds__(TC_THREADS, RIDER ? 8 : 4) void k_tile_count(const MeshGeom g, const TileGeom tg, const S4 *__restrict__ postype, const unsigned int N,
+__global__ __launch_bounds__(TC_THREADS) void k_tile_count(const MeshGeom g, const TileGeom tg, const S4 *__restrict__ postype, const unsigned int N,
                                                     const double *__restrict__ mode, unsigned int *__restrict__ tile_of,
                                                     unsigned int *__restrict__ slot_of, unsigned int *__restrict__ hist,
                                                     double *__restrict__ modesq_partials, const unsigned int n_types,
@@ -627,14 +628,6 @@ __global__ __launch_bounds__(TC_THREADS, RIDER ? 8 : 4) void k_tile_count(const 
     __shared__ float s_coeff[RIDER ? 3 * MTD_MAX_TYPES : 1];
     __shared__ mtd::ModeTables s_mt;
     __shared__ double s_wave[RIDER ? (TC_THREADS / 64) * 3 : 1];
-    if (RIDER && blockIdx.x >= tg.n_blocks)
-        {
-        // the deferred second grid pass (updateReweightedEstimator's second loop + accumulate): TC_THREADS cells per block
-        const unsigned int b = blockIdx.x - tg.n_blocks;
-        const unsigned int c0 = b * TC_THREADS;
-        mtd::apply_cells(rider->cfg, c0, min(rider->cfg.len, c0 + TC_THREADS), b == 0, s_red);
-        return;
-        }
     const unsigned int i0 = blockIdx.x * tg.chunk;
     const unsigned int i1 = min(N, i0 + tg.chunk);
     // the mode coefficient comes from LDS — as a second, dependent global load it doubled the trip
@@ -707,9 +700,20 @@ __global__ __launch_bounds__(TC_THREADS, RIDER ? 8 : 4) void k_tile_count(const 
 __global__ __launch_bounds__(256) void k_tile_rowscan(const unsigned int *__restrict__ hist, unsigned int *__restrict__ rowscan,
                                                       unsigned int *__restrict__ tile_total, const unsigned int n_tiles, const unsigned int nb,
                                                       const double *__restrict__ modesq_partials, const unsigned int n_partials,
-                                                      double *__restrict__ mode_sq)
+                                                      double *__restrict__ mode_sq, const CountRider *__restrict__ rider)
     {
     __shared__ unsigned int s_wave[4];
+    if (blockIdx.x > n_tiles)
+        {
+        // passenger (mtd_mesh_set_lamellar_rider): the bias-grid engine's deferred second pass, 256 cells per block — this
+        // launch is latency-bound and nearly empty, the pass overlaps with it (in the counting kernel, which keeps the vector
+        // units busy, the same blocks cost what they cost as a launch of their own)
+        __shared__ double s_red2[16];
+        const unsigned int b = blockIdx.x - n_tiles - 1;
+        const unsigned int c0 = b * 256;
+        mtd::apply_cells(rider->cfg, c0, min(rider->cfg.len, c0 + 256u), b == 0, s_red2);
+        return;
+        }
     if (blockIdx.x >= n_tiles)
         {
         __shared__ double s_red[16];
@@ -2498,7 +2502,7 @@ int mtd_mesh_set_lamellar_rider(mtd_mesh *mesh, mtd_metad *engine, const mtd_lam
         {
         r.cfg = engine->cfg;
         std::memset(r.cfg.src, 0, sizeof(r.cfg.src));               // (not read by apply_cells; keeps the comparison below quiet)
-        if (engine->pending_apply) r.n_apply = (engine->cfg.len + TC_THREADS - 1) / TC_THREADS;
+        if (engine->pending_apply) r.n_apply = (engine->cfg.len + 255) / 256;
         }
     if (!mesh->d_rider)
         {
@@ -2590,14 +2594,16 @@ static int mesh_assign_local(mtd_mesh *m, unsigned int n_particles, const void *
         tg.scale = std::ldexp(1.0, k);
         tg.inv_scale = std::ldexp(1.0, -k);
         const size_t lds = sizeof(unsigned int) * tg.n_tiles;
+        unsigned int n_apply_blocks = 0;
 #define MTD_TILE_COUNT(S4, RIDER, FAST, GRID) \
         k_tile_count<S4, RIDER, FAST><<<GRID, TC_THREADS, lds, s>>>(g, tg, (const S4 *)d_postype, N, m->d_mode, m->d_cell_of, m->d_slot_of, \
                                                                     m->d_count, m->d_modesq_partials, m->n_types, m->d_rider)
         if (m->rider_armed)
             {
             // (the rider's arguments were copied to the device on this stream by mtd_mesh_set_lamellar_rider)
-            const unsigned int grid = nb + m->rider_n_apply;
+            const unsigned int grid = nb;
             const bool fast = mtd::lam_fast_trig() != 0;
+            n_apply_blocks = m->rider_n_apply;
             if (dtype == MTD_F32) { if (fast) MTD_TILE_COUNT(float4, true, true, grid); else MTD_TILE_COUNT(float4, true, false, grid); }
             else { if (fast) MTD_TILE_COUNT(double4, true, true, grid); else MTD_TILE_COUNT(double4, true, false, grid); }
             m->rider_armed = 0;
@@ -2609,7 +2615,7 @@ static int mesh_assign_local(mtd_mesh *m, unsigned int n_particles, const void *
             MTD_TILE_COUNT(double4, false, false, nb);
 #undef MTD_TILE_COUNT
         MTD_LAUNCH_CHECK();
-        k_tile_rowscan<<<tg.n_tiles + 1, 256, 0, s>>>(m->d_count, m->d_start, m->d_tile_total, tg.n_tiles, nb, m->d_modesq_partials, nb, m->d_mode_sq);
+        k_tile_rowscan<<<tg.n_tiles + 1 + n_apply_blocks, 256, 0, s>>>(m->d_count, m->d_start, m->d_tile_total, tg.n_tiles, nb, m->d_modesq_partials, nb, m->d_mode_sq, m->d_rider);
         MTD_LAUNCH_CHECK();
         unsigned int pb = (N + 1023) / 1024;                        // >= four particles per thread: the LDS prefix of the tile totals is formed once per block
         pb = pb < 1 ? 1 : (pb > 512 ? 512 : pb);

@@ -76,9 +76,10 @@ while time.time() - t0 < budget:
         assert abs(a["V"] - b["V"]) <= 1e-4 * abs(b["V"]), ("V", spec, a["V"], b["V"])
     one_launch = os.environ.get("MTD_FUSED_STEP") == "1"
     for c, (fa, fb) in enumerate(zip(a["F"], b["F"])):
-        if one_launch and spec[c][0].startswith("lam") and abs(a["bias"][c]) > 1e-300 and abs(b["bias"][c]) > 1e-300:
+        if spec[c][0].startswith("lam") and abs(a["bias"][c]) > 1e-300 and abs(b["bias"][c]) > 1e-300:
             # The particles do not move, so every hill lands on the same point and dV/ds there is a cancelling difference: the
-            # one-launch step groups its fp32 sums differently, its CV value differs by ~1e-9 and the bias FACTOR by up to 1e-3 of
+            # one-launch step — and, since round 3, a mixed set whose lamellar sums ride in the mesh's binning kernel — groups its
+            # fp32 sums differently, its CV value differs by ~1e-9 and the bias FACTOR by up to 1e-3 of
             # itself.  What the force kernels contribute is the force per unit bias factor: compared on that.
             fa, fb = fa / a["bias"][c], fb / b["bias"][c]
         sc = np.abs(fb).max()
