@@ -164,15 +164,62 @@ __global__ __launch_bounds__(FF_THREADS, 4) void k_fused_force(const LamKArgs a,
     ForceRegs<NCV, FF_U> R, R1;
     MTD_STAMP(16, blockIdx.x == 0 && threadIdx.x == 0);
     MTD_STAMP(24, blockIdx.x == n_grid_blocks && threadIdx.x == 0);
+    // The chain's wave asks for everything it reads — the partial sums and the grid patch around the last CV values — at entry,
+    // right behind the mode tables it stages (the vector L1 of a CU answers in order: the tables come back first, after the
+    // ~0.8 us they always took, and the barrier that publishes them orders LDS traffic only, so the chain's loads stay in flight
+    // across it): one memory round trip for everything, overlapped with the table staging.  (Tables through scalar loads by
+    // another wave: sixteen dependent trips, 2.3 us; tables by another wave through vector loads: they queue behind the chain's
+    // requests, the streaming waves start 1.4 us late — both measured.)
+    constexpr int NCH = CHAIN_MAX_CV;                  // (a mixed set's grid has more variables than this launch has lamellar CVs)
+    ChainPre<NCH> pre;
+    constexpr bool early = !COMM;                      // (sharded step: the sums come out of the mailbox, the chain polls for them)
+    float4 th = make_float4(0.f, 0.f, 0.f, 0.f), tq = th;
+    float tc = 0.0f;
+    if (wave == 0)
+        {
+        if (!grid_block)
+            {
+            // first in the queue: the mode tables and this lane's mode coefficient (for the weights formed right behind the chain)
+            if (lane < (int)a.n_modes)
+                {
+                th = a.h[lane];
+                tq = a.q[lane];
+                }
+            if (lane < NCV * MTD_MAX_TYPES) tc = a.coeff[lane / MTD_MAX_TYPES][lane % MTD_MAX_TYPES];
+            }
+        if (early) chain_preload<NCH>(c, pre);
+        }
+    // the streaming waves ask for their particles now: the loads need no table, and the barrier below does not wait for them
+    // (the first group only: the registers of both groups, live across the barrier beside the chain's preloaded sums — the
+    // allocator cannot know that different waves hold them —, spilled)
+    RawGroup<S4, FF_U> raw0;
+    if (wave != 0 && !grid_block && N) lam_force_request<S4, FF_U>(postype, N, first, stride, raw0);
     if (!grid_block)
         {
-        load_modes(a, s_mt, true);
-        __syncthreads();
+        if (wave == 0)
+            {
+            if (lane < (int)a.n_modes)
+                {
+                s_mt.h[lane] = th;
+                s_mt.q[lane] = tq;
+                }
+            if (lane < NCV * MTD_MAX_TYPES) s_wcoef[lane] = tc;        // raw coefficient; scaled in place behind the chain
+            }
+        lds_barrier();
         }
     MTD_STAMP(25, blockIdx.x == n_grid_blocks && threadIdx.x == 0);
     if (wave == 0)
         {
-        const ChainResult r = chain_wave(c, deposit != 0, true, COMM ? &ck : nullptr);
+        ChainResult r;
+        if constexpr (early)
+            {
+            double vi[3];
+#pragma unroll
+            for (int i = 0; i < NCH; ++i) vi[i] = (pre.x[i][0] + pre.x[i][1]) + (pre.x[i][2] + pre.x[i][3]);
+            r = chain_wave(c, deposit != 0, true, nullptr, nullptr, false, &pre.patch, pre.patch_ok != 0, true, vi[0], vi[1], vi[2]);
+            }
+        else
+            r = chain_wave(c, deposit != 0, true, &ck);
         MTD_STAMP(17, blockIdx.x == 0 && threadIdx.x == 0);
         MTD_STAMP(26, blockIdx.x == n_grid_blocks && threadIdx.x == 0);
         if (lane == 0)
@@ -182,19 +229,20 @@ __global__ __launch_bounds__(FF_THREADS, 4) void k_fused_force(const LamKArgs a,
             s_chain.scal = r.scal; s_chain.V = r.V; s_chain.w = r.w;
             s_chain.bin = r.bin; s_chain.on_grid = r.on_grid; s_chain.oob = r.oob; s_chain.failed = r.failed;
             }
-        if (!grid_block)
-            for (unsigned int i = lane; i < NCV * MTD_MAX_TYPES; i += MTD_WAVE)
-                {
-                const unsigned int cv = i / MTD_MAX_TYPES;
-                const unsigned int gs = cv < a.n_cv ? a.slot[cv] : 0u;                 // the grid's variable behind CV cv of the set
-                const double b = gs == 0 ? r.bias[0] : (gs == 1 ? r.bias[1] : r.bias[2]);
-                s_wcoef[i] = (cv < a.n_cv) ? (float)((double)a.coeff[cv][i % MTD_MAX_TYPES] * b * two_over_n) : 0.0f;
-                }
+        if (!grid_block && lane < NCV * MTD_MAX_TYPES)
+            {
+            const unsigned int cv = lane / MTD_MAX_TYPES;
+            const unsigned int gs = cv < a.n_cv ? a.slot[cv] : 0u;                 // the grid's variable behind CV cv of the set
+            const double b = gs == 0 ? r.bias[0] : (gs == 1 ? r.bias[1] : r.bias[2]);
+            s_wcoef[lane] = (cv < a.n_cv) ? (float)((double)s_wcoef[lane] * b * two_over_n) : 0.0f;
+            }
         }
     else if (!grid_block && N)                      // N == 0: the grid engine on its own (mtd_metad_update_bias), no particles
         {
-        lam_force_unscaled<S4, NCV, FAST, FF_U>(a, postype, N, first, stride, s_mt, R);
-        if (GROUPS > 1) lam_force_unscaled<S4, NCV, FAST, FF_U>(a, postype, N, first1, stride, s_mt, R1);
+        RawGroup<S4, FF_U> raw1;
+        if (GROUPS > 1) lam_force_request<S4, FF_U>(postype, N, first1, stride, raw1);     // in flight while group 0 is summed
+        lam_force_unscaled_from<S4, NCV, FAST, FF_U>(a, N, first, stride, s_mt, raw0, R);
+        if (GROUPS > 1) lam_force_unscaled_from<S4, NCV, FAST, FF_U>(a, N, first1, stride, s_mt, raw1, R1);
         MTD_STAMP(27, blockIdx.x == n_grid_blocks && threadIdx.x == 64);
         }
     __syncthreads();
@@ -261,8 +309,17 @@ __global__ __launch_bounds__(FF_THREADS, 4) void k_fused_force(const LamKArgs a,
         if (!deposit) w_now = chain_wave(c, false, false, COMM ? &ck : nullptr).w;     // w(s) from the (final) weight grid
         if (lane < (int)c.n_cv)
             {
-            c.st->cv[lane] = lane == 0 ? s_chain.cv[0] : (lane == 1 ? s_chain.cv[1] : s_chain.cv[2]);
+            const double s_l = lane == 0 ? s_chain.cv[0] : (lane == 1 ? s_chain.cv[1] : s_chain.cv[2]);
+            c.st->cv[lane] = s_l;
             c.st->bias[lane] = lane == 0 ? s_chain.bias[0] : (lane == 1 ? s_chain.bias[1] : s_chain.bias[2]);
+            // where the grid patch of the next step should sit (apply_cells fills it at this origin): the cell of s, minus 2
+            const double dl = lane == 0 ? c.delta[0] : (lane == 1 ? c.delta[1] : c.delta[2]);
+            const double ml = lane == 0 ? c.cv_min[0] : (lane == 1 ? c.cv_min[1] : c.cv_min[2]);
+            const double ll = (double)(lane == 0 ? c.lengths[0] : (lane == 1 ? c.lengths[1] : c.lengths[2]));
+            double q = (s_l - ml) / dl;
+            if (!(q > 0.0)) q = 0.0;                                   // (NaN too)
+            if (q > ll) q = ll;
+            c.st->guess_org[lane] = (int)q - 2;
             }
         if (lane == 0)
             {

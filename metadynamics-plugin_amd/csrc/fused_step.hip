@@ -515,6 +515,8 @@ __global__ __launch_bounds__(FS_THREADS, 1) void k_fused_step(const LamKArgs a, 
                 c.hist_delta[g] = 0;
                 c.hist_gauss_delta[g] = 0;
                 }
+        // (this kernel changes the grid without keeping the two-launch step's grid patch, MetadState::patch_v, current)
+        if (blockIdx.x == 0 && threadIdx.x == 0) c.st->patch_valid = 0;
         }
 
     if (threadIdx.x == 0) MTD_BSTAMP(5);

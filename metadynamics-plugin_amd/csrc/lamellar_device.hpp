@@ -278,31 +278,73 @@ __device__ __forceinline__ void lam_force_pass(const LamKArgs &a, const S4 *__re
 // registers (lam_force_unscaled) and scales + stores them once the bias is known (lam_force_store).
 template<int NCV, int U> struct ForceRegs
     {
-    float f[U][NCV][3];
+    v2f f[U / 2][NCV][3];          // particles 2 p and 2 p + 1 of the group in the two halves
     int type[U];
     bool ok[U];
     };
 
+template<typename S4, int U>
+__device__ __forceinline__ void lam_force_request(const S4 *__restrict__ postype, const unsigned int N, const unsigned int first,
+                                                  const unsigned int stride, RawGroup<S4, U> &raw);
+template<typename S4, int NCV, bool FAST, int U>
+__device__ __forceinline__ void lam_force_unscaled_from(const LamKArgs &a, const unsigned int N, const unsigned int first,
+                                                        const unsigned int stride, const ModeTables &mt, const RawGroup<S4, U> &raw,
+                                                        ForceRegs<NCV, U> &R);
+
+// Two particles per <2 x float> lane like the CV pass: the phase and the three force components are v_pk_mul / v_pk_fma (one
+// instruction per two particles; v_fract / v_sin have no packed form) — the compiler packed some of the scalar form on its own
+// and paid a v_mov per pair for it (16 modes x 4 particles: 173 issue slots, now 128).
 template<typename S4, int NCV, bool FAST, int U>
 __device__ __forceinline__ void lam_force_unscaled(const LamKArgs &a, const S4 *__restrict__ postype, const unsigned int N,
                                                    const unsigned int first, const unsigned int stride, const ModeTables &mt,
                                                    ForceRegs<NCV, U> &R)
     {
-    float g0[U], g1[U], g2[U];
+    RawGroup<S4, U> raw;
+    lam_force_request<S4, U>(postype, N, first, stride, raw);
+    lam_force_unscaled_from<S4, NCV, FAST, U>(a, N, first, stride, mt, raw, R);
+    }
+
+// the particle records of a group requested without being looked at (launch B asks for them before the barrier that publishes
+// the mode tables: the loads need no table, and the first memory round trip of a launch is its longest)
+template<typename S4, int U>
+__device__ __forceinline__ void lam_force_request(const S4 *__restrict__ postype, const unsigned int N, const unsigned int first,
+                                                  const unsigned int stride, RawGroup<S4, U> &raw)
+    {
+    if (N == 0) return;
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+        {
+        const unsigned int i = first + u * stride;
+        raw.v[u] = postype[i < N ? i : N - 1];
+        }
+    }
+
+template<typename S4, int NCV, bool FAST, int U>
+__device__ __forceinline__ void lam_force_unscaled_from(const LamKArgs &a, const unsigned int N, const unsigned int first,
+                                                        const unsigned int stride, const ModeTables &mt, const RawGroup<S4, U> &raw,
+                                                        ForceRegs<NCV, U> &R)
+    {
+    static_assert(U % 2 == 0, "particles are processed in pairs");
+    constexpr int P = U / 2;
+    v2f g0[P], g1[P], g2[P];
 #pragma unroll
     for (int u = 0; u < U; ++u)
         {
         const unsigned int i = first + u * stride;
         R.ok[u] = i < N;
-        const Particle p = scalar4_traits<S4>::load(postype, R.ok[u] ? i : (N ? N - 1 : 0));
-        project(a, p, g0[u], g1[u], g2[u]);
+        const Particle p = scalar4_traits<S4>::unpack(raw.v[u]);
+        float x0, x1, x2;
+        project(a, p, x0, x1, x2);
+        g0[u / 2][u % 2] = x0;
+        g1[u / 2][u % 2] = x1;
+        g2[u / 2][u % 2] = x2;
         R.type[u] = p.type;
         }
 #pragma unroll
     for (int c = 0; c < NCV; ++c)
         {
 #pragma unroll
-        for (int u = 0; u < U; ++u) R.f[u][c][0] = R.f[u][c][1] = R.f[u][c][2] = 0.0f;
+        for (int pp = 0; pp < P; ++pp) R.f[pp][c][0] = R.f[pp][c][1] = R.f[pp][c][2] = (v2f)(0.0f);
         if (c < (int)a.n_cv)
             {
             const unsigned int k1 = a.first[c + 1];
@@ -312,12 +354,15 @@ __device__ __forceinline__ void lam_force_unscaled(const LamKArgs &a, const S4 *
                 const float4 h = mt.h[k];
                 const float4 q = mt.q[k];
 #pragma unroll
-                for (int u = 0; u < U; ++u)
+                for (int pp = 0; pp < P; ++pp)
                     {
-                    const float s = sin2pi<FAST>(h.x * g0[u] + h.y * g1[u] + h.z * g2[u]);
-                    R.f[u][c][0] += q.x * s;
-                    R.f[u][c][1] += q.y * s;
-                    R.f[u][c][2] += q.z * s;
+                    const v2f t = h.x * g0[pp] + h.y * g1[pp] + h.z * g2[pp];
+                    v2f sn;
+                    sn.x = sin2pi<FAST>(t.x);
+                    sn.y = sin2pi<FAST>(t.y);
+                    R.f[pp][c][0] += q.x * sn;
+                    R.f[pp][c][1] += q.y * sn;
+                    R.f[pp][c][2] += q.z * sn;
                     }
                 }
             }
@@ -341,8 +386,8 @@ __device__ __forceinline__ void lam_force_store(const LamKArgs &a, const ForcePt
                 if (R.ok[u])
                     {
                     const float w = s_wcoef[c * MTD_MAX_TYPES + R.type[u]];
-                    const S4 v = scalar4_traits<S4>::make((scalar)(R.f[u][c][0] * w), (scalar)(R.f[u][c][1] * w),
-                                                          (scalar)(R.f[u][c][2] * w), (scalar)0);
+                    const S4 v = scalar4_traits<S4>::make((scalar)(R.f[u / 2][c][0][u % 2] * w), (scalar)(R.f[u / 2][c][1][u % 2] * w),
+                                                          (scalar)(R.f[u / 2][c][2][u % 2] * w), (scalar)0);
                     nt_store(v, &f[first + u * stride]);
                     }
                 }

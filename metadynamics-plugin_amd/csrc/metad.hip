@@ -715,6 +715,12 @@ static void *array_ptr(mtd_metad *m, int which, size_t *elem)
 void *mtd_metad_device_array(mtd_metad *m, int which)
     {
     size_t e;
+    if (m && which == 0)
+        {
+        // the caller may write the grid through the pointer: the patch around the last CV values (MetadState::patch_v) is
+        // no longer known to be the grid's until the next deferred pass has rewritten it
+        (void)hipMemset(&m->cfg.st->patch_valid, 0, sizeof(int));
+        }
     return m ? array_ptr(m, which, &e) : nullptr;
     }
 
@@ -738,6 +744,8 @@ int mtd_metad_set_array(mtd_metad *m, int which, const void *host_in, mtd_stream
     void *p = array_ptr(m, which, &e);
     if (!p) return MTD_ERR_INVALID_ARGUMENT;
     MTD_HIP_TRY(hipMemcpyAsync(p, host_in, e * m->cfg.len, hipMemcpyHostToDevice, (hipStream_t)stream));
+    if (which == 0)                                                  // the grid itself: the patch around the last CV values is stale
+        MTD_HIP_TRY(hipMemsetAsync(&m->cfg.st->patch_valid, 0, sizeof(int), (hipStream_t)stream));
     MTD_HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
     return MTD_SUCCESS;
     }

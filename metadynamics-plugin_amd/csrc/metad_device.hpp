@@ -42,6 +42,16 @@ struct MetadState
     unsigned int on_grid;
     unsigned int failed;   // a mailbox wait expired in the last step (comm_device.hpp): nothing was deposited, the deferred pass is skipped
     unsigned int _pad;
+    // The bias grid around the collective variables' last values (6 cells per variable, <= 3 variables), kept current by
+    // whoever changes the grid (apply_cells).  The chain of the next step reads its stencil cells from here in the SAME memory
+    // round trip as the CV sums — the grid load that depends on the CV values (~0.8 us on the path every block of launch B
+    // waits for) becomes a shuffle whenever the variables moved by at most one cell since the origin was set.
+    int patch_valid;       // the values below are the grid's (0: the host wrote the grid, or nothing has run the deferred pass yet)
+    int patch_org[3];      // grid coordinates of patch slot 0 (may be negative / beyond the grid at its edges)
+    int guess_org[3];      // where the next patch should sit: the cell of the values the last grid launch evaluated at, minus 2
+    int _pad2;
+    double zero;           // always 0.0: where chain_preload's lanes without a partial sum load from (no select behind the load)
+    double patch_v[216];   // slot o0 + 6 (o1 + 6 o2)
     };
 
 struct MetadCfg
@@ -331,7 +341,25 @@ __device__ __forceinline__ void apply_cells(const MetadCfg &c, const unsigned in
         const double fac = exp(-(dV - avg_dV) / c.temp);                     // T, not deltaT (:1084)
         c.rew[g] *= fac;
         c.weight[g] /= fac;
-        c.grid[g] += dV;
+        const double g_new = c.grid[g] + dV;
+        c.grid[g] = g_new;
+        if (c.n_cv <= 3)
+            {
+            // the patch around the last CV values follows the grid (MetadState::patch_v)
+            unsigned int rest = g;
+            int slot = 0, mul = 1;
+            bool in = true;
+            for (int i = (int)c.n_cv - 1; i >= 0; --i)
+                {
+                const unsigned int co = rest / c.factors[i];
+                rest -= co * c.factors[i];
+                const int o = (int)co - c.st->guess_org[i];
+                in = in && o >= 0 && o < 6;
+                slot += o * (i == 0 ? 1 : (i == 1 ? 6 : 36));
+                }
+            (void)mul;
+            if (in) c.st->patch_v[slot] = g_new;
+            }
         c.sigma_grid[g] += c.sigma_grid_delta[g];
         c.hist[g] += c.hist_delta[g];
         c.hist_gauss[g] += c.hist_gauss_delta[g];
@@ -342,6 +370,11 @@ __device__ __forceinline__ void apply_cells(const MetadCfg &c, const unsigned in
         }
     if (first && threadIdx.x == 0)
         {
+        // (every cell of the region has just been written by the block that owns it: the patch is the grid at guess_org)
+        c.st->patch_org[0] = c.st->guess_org[0];
+        c.st->patch_org[1] = c.st->guess_org[1];
+        c.st->patch_org[2] = c.st->guess_org[2];
+        c.st->patch_valid = c.n_cv <= 3 ? 1 : 0;
         c.st->avg_dV = avg_dV;
         c.st->num_gaussians += 1;                                            // :440
         }
@@ -428,6 +461,57 @@ __device__ __forceinline__ GridPatch chain_prefetch(const MetadCfg &c)
 // rx != nullptr: particle-sharded step — the sums over ranks come out of the xGMI mailbox (comm_device.hpp) instead
 // of the registered partial sums.  given != nullptr: the (global) sums are handed in (k_fused_step collected them itself);
 // a NaN among them marks an expired wait.  want_weight: also read the weight grid at the corners of s (closed form).
+// What the chain's wave can ask for before anything else of the launch has happened (k_fused_force: before the barrier that
+// publishes the mode tables): the first 512 partial sums of every CV source and the grid patch around the last CV values — one
+// memory round trip for everything the chain reads.
+// NCH: collective variables of the bias grid the caller is compiled for (the arrays stay in registers: static indices only).
+template<int NCH> struct ChainPre
+    {
+    double x[NCH][4];              // partial sums lane, lane + 64, lane + 128, lane + 192 of every CV source
+    GridPatch patch;
+    int patch_ok;
+    };
+
+template<int NCH>
+__device__ __forceinline__ void chain_preload(const MetadCfg &c, ChainPre<NCH> &p)
+    {
+    const unsigned int lane = threadIdx.x & 63;
+    // every scalar the loads need first, in one batch (fetched field by field inside predicated loads they were ~25 dependent
+    // scalar-load round trips: 2 us before the first vector load left), then branch-free loads from clamped addresses
+    const double *ptr[NCH];
+    unsigned int cnt[NCH], str[NCH], off[NCH];
+    const double *safe = &c.st->zero;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i)
+        {
+        const bool on = i < (int)c.n_cv && c.src[i].partials != nullptr;
+        ptr[i] = on ? c.src[i].partials : safe;
+        cnt[i] = on ? c.src[i].n_partials : 0u;
+        str[i] = on ? c.src[i].stride : 0u;
+        off[i] = on ? c.src[i].offset : 0u;
+        }
+    const int ok = c.st->patch_valid;
+    int org[CHAIN_MAX_CV];
+#pragma unroll
+    for (int i = 0; i < CHAIN_MAX_CV; ++i) org[i] = c.st->patch_org[i];
+#pragma unroll
+    for (int i = 0; i < NCH; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            {
+            // (a lane without a partial sum reads the 0.0 of MetadState::zero: nothing behind the load has to wait for it)
+            const unsigned int b = lane + j * MTD_WAVE;
+            const double *q = b < cnt[i] ? ptr[i] + ((size_t)b * str[i] + off[i]) : safe;
+            p.x[i][j] = *q;
+            }
+    p.patch_ok = ok;
+#pragma unroll
+    for (int i = 0; i < CHAIN_MAX_CV; ++i) p.patch.org[i] = org[i];
+    p.patch.v[0] = c.st->patch_v[lane];                              // 36 slots (two variables) sit in the first 64
+#pragma unroll
+    for (int r = 1; r < 4; ++r) p.patch.v[r] = NCH == 3 ? c.st->patch_v[min(lane + 64 * r, 215u)] : 0.0;
+    }
+
 // a / (the divisor whose reciprocal is y), correctly rounded (exact_div.hpp) when the grid qualifies, else the division
 __device__ __forceinline__ double chain_div(const MetadCfg &c, const double a, const double b, const double y)
     {
@@ -441,7 +525,9 @@ __device__ __forceinline__ double chain_div(const MetadCfg &c, const double a, c
 
 __device__ __forceinline__ ChainResult chain_wave(const MetadCfg &c, const bool deposit, const bool closed_form,
                                                   const CommK *rx = nullptr, const double *given = nullptr,
-                                                  const bool want_weight = false, const GridPatch *patch = nullptr)
+                                                  const bool want_weight = false, const GridPatch *patch = nullptr,
+                                                  const bool patch_ok = true, const bool have_init = false,
+                                                  const double v_init0 = 0.0, const double v_init1 = 0.0, const double v_init2 = 0.0)
     {
     const int lane = threadIdx.x & 63;
     const unsigned int n = c.n_cv;
@@ -469,7 +555,15 @@ __device__ __forceinline__ ChainResult chain_wave(const MetadCfg &c, const bool 
         n_part_max = 0;
         }
     const bool handed = rx != nullptr || given != nullptr;
-    for (unsigned int b0 = lane; b0 < n_part_max; b0 += 8 * MTD_WAVE)
+    // v_init0..2: this lane's sum of partial sums lane, lane + 64, lane + 128, lane + 192 of every source, loaded ahead of time
+    // (chain_preload); the loop goes on behind them
+    if (have_init && n_part_max)
+        {
+        v[0] = v_init0;
+        v[1] = v_init1;
+        v[2] = v_init2;
+        }
+    for (unsigned int b0 = lane + ((have_init && n_part_max) ? 4 * MTD_WAVE : 0); b0 < n_part_max; b0 += 8 * MTD_WAVE)
         {
 #pragma unroll
         for (int i = 0; i < CHAIN_MAX_CV; ++i)
@@ -541,7 +635,7 @@ __device__ __forceinline__ ChainResult chain_wave(const MetadCfg &c, const bool 
     unsigned int cell = 0;
     double d[CHAIN_MAX_CV];
     int pslot = 0, pmul = 1;                 // slot of this lane's cell in the prefetched patch; in_patch: it lies inside
-    bool in_patch = patch != nullptr;
+    bool in_patch = patch != nullptr && patch_ok;
 #pragma unroll
     for (int i = 0; i < CHAIN_MAX_CV; ++i)
         {
