@@ -90,6 +90,8 @@ __global__ __launch_bounds__(FCV_THREADS) void k_fused_cv(const LamKArgs a, cons
     const unsigned int n_blocks = gridDim.x - n_apply_blocks;
 
     // the first group of particles is requested before the tables are staged: one memory round trip instead of two
+    // (both groups of a thread requested here — the whole position array in the launch's first microsecond — measured SLOWER,
+    // launch A 7.4 against 6.9 us: the table loads below queue behind twice the requests in the CU's in-order vector L1)
     RawGroup<S4, U> first;
     lam_load_group<S4, U>(postype, N, block_id * FCV_THREADS + threadIdx.x, n_blocks * FCV_THREADS, first);
     load_coeff(a, s_coeff);
@@ -187,6 +189,8 @@ __global__ __launch_bounds__(FF_THREADS, 4) void k_fused_force(const LamKArgs a,
                 }
             if (lane < NCV * MTD_MAX_TYPES) tc = a.coeff[lane / MTD_MAX_TYPES][lane % MTD_MAX_TYPES];
             }
+        // (asking here for one field of every 64-byte line of the grid's configuration, so that the chain finds them in the scalar
+        // cache, measured 0.15 us SLOWER per step: the chain's stalls are not scalar-cache misses)
         if (early) chain_preload<NCH>(c, pre);
         }
     // the streaming waves ask for their particles now: the loads need no table, and the barrier below does not wait for them

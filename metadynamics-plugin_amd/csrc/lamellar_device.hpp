@@ -123,70 +123,78 @@ __device__ __forceinline__ void lam_load_group(const S4 *__restrict__ postype, c
 // `first` holds the group at base = tid (lam_load_group, issued by the caller before it staged the tables); every further
 // group is requested before the current one is summed, so only the very first memory round trip of the launch is exposed
 // (measured: 2.6 us per exposed round trip, more than summing a group)
+// one group's terms: acc[c] += sum over the U particles of `cur` (at base, base + n_threads, ...) of a_c(type_j) sum_k cos(q_k . r_j)
+template<typename S4, int NCV, bool FAST, int U>
+__device__ __forceinline__ void lam_cv_group(const LamKArgs &a, const unsigned int N, const unsigned int base, const unsigned int n_threads,
+                                             const float *s_coeff, const ModeTables &mt, const RawGroup<S4, U> &cur, float (&acc)[NCV])
+    {
+    static_assert(U % 2 == 0, "particles are processed in pairs");
+    constexpr int P = U / 2;
+    v2f g0[P], g1[P], g2[P];
+    int type[U];
+    bool ok[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+        {
+        ok[u] = base + u * n_threads < N;
+        const Particle p = scalar4_traits<S4>::unpack(cur.v[u]);
+        float x0, x1, x2;
+        project(a, p, x0, x1, x2);
+        g0[u / 2][u % 2] = x0;
+        g1[u / 2][u % 2] = x1;
+        g2[u / 2][u % 2] = x2;
+        type[u] = p.type;
+        }
+#pragma unroll
+    for (int c = 0; c < NCV; ++c)
+        {
+        if (c < (int)a.n_cv)
+            {
+            v2f sum[P];
+#pragma unroll
+            for (int q = 0; q < P; ++q) sum[q] = (v2f)(0.0f);
+            const unsigned int k1 = a.first[c] + a.nact[c];
+#pragma unroll 4
+            for (unsigned int k = a.first[c]; k < k1; ++k)
+                {
+                const float4 h = mt.h[k];                         // staged by load_modes_cv: dense, fold flag in w
+#pragma unroll
+                for (int q = 0; q < P; ++q)
+                    {
+                    const v2f t = h.x * g0[q] + h.y * g1[q] + h.z * g2[q];
+                    v2f cs;
+                    cs.x = cos2pi<FAST>(t.x);
+                    cs.y = cos2pi<FAST>(t.y);
+                    sum[q] += cs;
+                    // the second harmonic of this mode when folded (w = 1), branch-free.  The hardware cosine of the FAST
+                    // path truncates: |c| is low by 3.2e-8 on average, which cancels in sums of c but leaves 2 c^2 - 1 low by
+                    // 6.5e-8 on average — a bias of that size times sum_j a_j / N in the CV, whatever N (tools/probe_cos.hip;
+                    // found by tools/fuzz_fused.py on a one-type system).  One float ulp off the constant takes 92 % of it out.
+                    sum[q] += h.w * ((cs * cs) * 2.0f - (FAST ? 0.99999994f : 1.0f));
+                    }
+                }
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                {
+                const float w = ok[u] ? s_coeff[c * MTD_MAX_TYPES + type[u]] : 0.0f;
+                acc[c] += w * sum[u / 2][u % 2];
+                }
+            }
+        }
+    }
+
 template<typename S4, int NCV, bool FAST, int U>
 __device__ __forceinline__ void lam_cv_accumulate(const LamKArgs &a, const S4 *__restrict__ postype, const unsigned int N,
                                                   const unsigned int tid, const unsigned int n_threads,
                                                   const float *s_coeff, const ModeTables &mt, RawGroup<S4, U> cur,
                                                   float (&acc)[NCV])
     {
-    static_assert(U % 2 == 0, "particles are processed in pairs");
-    constexpr int P = U / 2;
     for (unsigned int base = tid; base < N; base += U * n_threads)
         {
         const unsigned int next = base + U * n_threads;
         RawGroup<S4, U> nxt = cur;
         if (next < N) lam_load_group<S4, U>(postype, N, next, n_threads, nxt);
-        v2f g0[P], g1[P], g2[P];
-        int type[U];
-        bool ok[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u)
-            {
-            ok[u] = base + u * n_threads < N;
-            const Particle p = scalar4_traits<S4>::unpack(cur.v[u]);
-            float x0, x1, x2;
-            project(a, p, x0, x1, x2);
-            g0[u / 2][u % 2] = x0;
-            g1[u / 2][u % 2] = x1;
-            g2[u / 2][u % 2] = x2;
-            type[u] = p.type;
-            }
-#pragma unroll
-        for (int c = 0; c < NCV; ++c)
-            {
-            if (c < (int)a.n_cv)
-                {
-                v2f sum[P];
-#pragma unroll
-                for (int q = 0; q < P; ++q) sum[q] = (v2f)(0.0f);
-                const unsigned int k1 = a.first[c] + a.nact[c];
-#pragma unroll 4
-                for (unsigned int k = a.first[c]; k < k1; ++k)
-                    {
-                    const float4 h = mt.h[k];                         // staged by load_modes_cv: dense, fold flag in w
-#pragma unroll
-                    for (int q = 0; q < P; ++q)
-                        {
-                        const v2f t = h.x * g0[q] + h.y * g1[q] + h.z * g2[q];
-                        v2f cs;
-                        cs.x = cos2pi<FAST>(t.x);
-                        cs.y = cos2pi<FAST>(t.y);
-                        sum[q] += cs;
-                        // the second harmonic of this mode when folded (w = 1), branch-free.  The hardware cosine of the FAST
-                        // path truncates: |c| is low by 3.2e-8 on average, which cancels in sums of c but leaves 2 c^2 - 1 low by
-                        // 6.5e-8 on average — a bias of that size times sum_j a_j / N in the CV, whatever N (tools/probe_cos.hip;
-                        // found by tools/fuzz_fused.py on a one-type system).  One float ulp off the constant takes 92 % of it out.
-                        sum[q] += h.w * ((cs * cs) * 2.0f - (FAST ? 0.99999994f : 1.0f));
-                        }
-                    }
-#pragma unroll
-                for (int u = 0; u < U; ++u)
-                    {
-                    const float w = ok[u] ? s_coeff[c * MTD_MAX_TYPES + type[u]] : 0.0f;
-                    acc[c] += w * sum[u / 2][u % 2];
-                    }
-                }
-            }
+        lam_cv_group<S4, NCV, FAST, U>(a, N, base, n_threads, s_coeff, mt, cur, acc);
         cur = nxt;
         }
     }
