@@ -249,7 +249,7 @@ __global__ __launch_bounds__(FF_THREADS, 4) void k_fused_force(const LamKArgs a,
         if (GROUPS > 1) lam_force_unscaled_from<S4, NCV, FAST, FF_U>(a, N, first1, stride, s_mt, raw1, R1);
         MTD_STAMP(27, blockIdx.x == n_grid_blocks && threadIdx.x == 64);
         }
-    __syncthreads();
+    lds_barrier();                 // publishes s_chain / s_wcoef (LDS only: nothing that went to global memory is read back)
     MTD_STAMP(18, blockIdx.x == 0 && threadIdx.x == 0);
     MTD_STAMP(28, blockIdx.x == n_grid_blocks && threadIdx.x == 64);
 

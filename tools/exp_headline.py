@@ -22,7 +22,7 @@ def worker():
     scratch = torch.zeros(lib.mtd_lamellar_scratch_doubles(N), dtype=torch.float64, device="cuda")
     forces = [torch.zeros((N, 4), dtype=torch.float32, device="cuda") for _ in cvs]
     fptr = (C.c_void_p * 2)(*[f.data_ptr() for f in forces])
-    lib.mtd_lamellar_set_fast_trig(1)
+    lib.mtd_lamellar_set_fast_trig(int(os.environ.get("EXP_TRIG", "1")))
     dbl = lambda v: (C.c_double * len(v))(*v)
     h = C.c_void_p()
     _abi.check(lib.mtd_metad_create(C.byref(h), 2, dbl([1e-3, 1e-3]), dbl([-0.02, -0.02]), dbl([0.02, 0.02]), (C.c_uint * 2)(256, 256),
