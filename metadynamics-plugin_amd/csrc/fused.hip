@@ -191,7 +191,10 @@ __global__ __launch_bounds__(FF_THREADS, 4) void k_fused_force(const LamKArgs a,
             }
         // (asking here for one field of every 64-byte line of the grid's configuration, so that the chain finds them in the scalar
         // cache, measured 0.15 us SLOWER per step: the chain's stalls are not scalar-cache misses)
-        if (early) chain_preload<NCH>(c, pre);
+        if (early)
+            chain_preload<NCH>(c, pre);
+        else
+            chain_preload<NCH, false>(c, pre);         // sharded step: the grid patch alone
         }
     // the streaming waves ask for their particles now: the loads need no table, and the barrier below does not wait for them
     // (the first group only: the registers of both groups, live across the barrier beside the chain's preloaded sums — the
@@ -223,7 +226,7 @@ __global__ __launch_bounds__(FF_THREADS, 4) void k_fused_force(const LamKArgs a,
             r = chain_wave(c, deposit != 0, true, nullptr, nullptr, false, &pre.patch, pre.patch_ok != 0, true, vi[0], vi[1], vi[2]);
             }
         else
-            r = chain_wave(c, deposit != 0, true, &ck);
+            r = chain_wave(c, deposit != 0, true, &ck, nullptr, false, &pre.patch, pre.patch_ok != 0);
         MTD_STAMP(17, blockIdx.x == 0 && threadIdx.x == 0);
         MTD_STAMP(26, blockIdx.x == n_grid_blocks && threadIdx.x == 0);
         if (lane == 0)

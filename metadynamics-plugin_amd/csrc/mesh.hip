@@ -752,10 +752,16 @@ __global__ __launch_bounds__(256) void k_tile_rowscan(const unsigned int *__rest
     }
 
 // 3b. place: particle id -> its tile's segment.  A block keeps the prefix over the tile totals in LDS.
+// POSCOPY: the particle's raw position record travels with its id into tile order — into the first bytes of the 32-byte slot the
+// scatter pass will overwrite with the record for the force pass (no buffer of its own).  The scatter pass then reads ids and
+// positions side by side, coalesced, in ONE memory round trip; gathered by id the 16-byte records arrived in 128-byte requests
+// (96 MB fetched for 20 MB of payload, profiles/r3/pmc_mesh_ql_summary.txt) behind a dependent id -> position chain.
+template<typename S4, bool POSCOPY>
 __global__ __launch_bounds__(256) void k_tile_place(const TileGeom tg, const unsigned int N, const unsigned int *__restrict__ tile_of,
                                                     const unsigned int *__restrict__ slot_of, const unsigned int *__restrict__ rowscan,
                                                     const unsigned int *__restrict__ tile_total, unsigned int *__restrict__ ids,
-                                                    unsigned int *__restrict__ tile_first)
+                                                    unsigned int *__restrict__ tile_first, const S4 *__restrict__ postype,
+                                                    double4 *__restrict__ packed)
     {
     extern __shared__ unsigned int s_first[];                    // [n_tiles]: first slot of every tile
     __shared__ unsigned int s_wsum[4];
@@ -796,7 +802,9 @@ __global__ __launch_bounds__(256) void k_tile_place(const TileGeom tg, const uns
     for (unsigned int i = blockIdx.x * blockDim.x + threadIdx.x; i < N; i += gridDim.x * blockDim.x)
         {
         const unsigned int t = tile_of[i];
-        ids[s_first[t] + rowscan[(size_t)t * tg.n_blocks + i / tg.chunk] + slot_of[i]] = i;
+        const unsigned int slot = s_first[t] + rowscan[(size_t)t * tg.n_blocks + i / tg.chunk] + slot_of[i];
+        ids[slot] = i;
+        if (POSCOPY) *(S4 *)(packed + slot) = postype[i];
         }
     }
 
@@ -805,7 +813,7 @@ __global__ __launch_bounds__(TP_THREADS) void k_tile_scatter(const MeshGeom g, c
                                                              const double *__restrict__ mode, const unsigned int *__restrict__ tile_total,
                                                              const unsigned int *__restrict__ tile_first,
                                                              const unsigned int *__restrict__ ids, long long *__restrict__ tilebuf,
-                                                             double4 *__restrict__ packed, const unsigned int n_types)
+                                                             double4 *__restrict__ packed, const unsigned int n_types, const int poscopy)
     {
     __shared__ unsigned long long s_t[TP_HMAX];
     __shared__ double s_mode[TP_MODE_LDS];
@@ -823,11 +831,13 @@ __global__ __launch_bounds__(TP_THREADS) void k_tile_scatter(const MeshGeom g, c
     const unsigned int q_last = q1 ? q1 - 1 : 0u;
     unsigned int id = 0, id_next = 0;
     S4 raw = scalar4_traits<S4>::make(0, 0, 0, 0);
+    // poscopy: k_tile_place left the raw position in the particle's slot of `packed` (this kernel overwrites the slot with the
+    // record once the position is in registers): ids and positions come side by side, no id -> position chain
     if (q0 < q1)                                                     // (uniform over the block; an empty tile — or no particles at
         {                                                            // all, and then no position array either — loads nothing)
         id = ids[min(q, q_last)];
         id_next = ids[min(q + TP_THREADS, q_last)];
-        raw = postype[id];
+        raw = poscopy ? *(const S4 *)(packed + min(q, q_last)) : postype[id];
         }
     stage_modes(s_mode, mode, n_types);
     for (unsigned int e = threadIdx.x; e < tg.hcells; e += TP_THREADS) s_t[e] = 0ull;
@@ -838,7 +848,7 @@ __global__ __launch_bounds__(TP_THREADS) void k_tile_scatter(const MeshGeom g, c
         const Particle cur = scalar4_traits<S4>::unpack(raw);
         const unsigned int cur_id = id;
         const unsigned int qn = q + TP_THREADS;
-        raw = postype[id_next];
+        raw = poscopy ? *(const S4 *)(packed + min(qn, q_last)) : postype[id_next];
         id = id_next;
         id_next = ids[min(qn + TP_THREADS, q_last)];
         int ix, iy, iz;
@@ -2619,12 +2629,28 @@ static int mesh_assign_local(mtd_mesh *m, unsigned int n_particles, const void *
         MTD_LAUNCH_CHECK();
         unsigned int pb = (N + 1023) / 1024;                        // >= four particles per thread: the LDS prefix of the tile totals is formed once per block
         pb = pb < 1 ? 1 : (pb > 512 ? 512 : pb);
-        k_tile_place<<<pb, 256, sizeof(unsigned int) * tg.n_tiles, s>>>(tg, N, m->d_cell_of, m->d_slot_of, m->d_start, m->d_tile_total, m->d_ids, m->d_tile_first);
+        // MEASURED SLOWER and therefore opt-in (MTD_MESH_POSCOPY=1): 167.3 against 160.0 us per step of config 3 — the 10^6
+        // scattered 16-byte stores of the place kernel cost more than the gather they save the scatter pass
+        static const bool poscopy = std::getenv("MTD_MESH_POSCOPY") != nullptr;
+        if (dtype == MTD_F32)
+            {
+            if (poscopy)
+                k_tile_place<float4, true><<<pb, 256, sizeof(unsigned int) * tg.n_tiles, s>>>(tg, N, m->d_cell_of, m->d_slot_of, m->d_start, m->d_tile_total, m->d_ids, m->d_tile_first, (const float4 *)d_postype, m->d_packed);
+            else
+                k_tile_place<float4, false><<<pb, 256, sizeof(unsigned int) * tg.n_tiles, s>>>(tg, N, m->d_cell_of, m->d_slot_of, m->d_start, m->d_tile_total, m->d_ids, m->d_tile_first, (const float4 *)d_postype, m->d_packed);
+            }
+        else
+            {
+            if (poscopy)
+                k_tile_place<double4, true><<<pb, 256, sizeof(unsigned int) * tg.n_tiles, s>>>(tg, N, m->d_cell_of, m->d_slot_of, m->d_start, m->d_tile_total, m->d_ids, m->d_tile_first, (const double4 *)d_postype, m->d_packed);
+            else
+                k_tile_place<double4, false><<<pb, 256, sizeof(unsigned int) * tg.n_tiles, s>>>(tg, N, m->d_cell_of, m->d_slot_of, m->d_start, m->d_tile_total, m->d_ids, m->d_tile_first, (const double4 *)d_postype, m->d_packed);
+            }
         MTD_LAUNCH_CHECK();
         if (dtype == MTD_F32)
-            k_tile_scatter<float4><<<tg.n_tiles, TP_THREADS, 0, s>>>(g, tg, (const float4 *)d_postype, m->d_mode, m->d_tile_total, m->d_tile_first, m->d_ids, m->d_tilebuf, m->d_packed, m->n_types);
+            k_tile_scatter<float4><<<tg.n_tiles, TP_THREADS, 0, s>>>(g, tg, (const float4 *)d_postype, m->d_mode, m->d_tile_total, m->d_tile_first, m->d_ids, m->d_tilebuf, m->d_packed, m->n_types, poscopy ? 1 : 0);
         else
-            k_tile_scatter<double4><<<tg.n_tiles, TP_THREADS, 0, s>>>(g, tg, (const double4 *)d_postype, m->d_mode, m->d_tile_total, m->d_tile_first, m->d_ids, m->d_tilebuf, m->d_packed, m->n_types);
+            k_tile_scatter<double4><<<tg.n_tiles, TP_THREADS, 0, s>>>(g, tg, (const double4 *)d_postype, m->d_mode, m->d_tile_total, m->d_tile_first, m->d_ids, m->d_tilebuf, m->d_packed, m->n_types, poscopy ? 1 : 0);
         MTD_LAUNCH_CHECK();
         {
         const unsigned int cthreads = m->nx >= 256 ? 256 : (m->nx > 64 ? 128 : 64);

@@ -486,7 +486,8 @@ template<int NCH> struct ChainPre
     int patch_ok;
     };
 
-template<int NCH>
+// SUMS = false: the grid patch only (sharded step: the sums come out of the mailbox)
+template<int NCH, bool SUMS = true>
 __device__ __forceinline__ void chain_preload(const MetadCfg &c, ChainPre<NCH> &p)
     {
     const unsigned int lane = threadIdx.x & 63;
@@ -515,8 +516,8 @@ __device__ __forceinline__ void chain_preload(const MetadCfg &c, ChainPre<NCH> &
             {
             // (a lane without a partial sum reads the 0.0 of MetadState::zero: nothing behind the load has to wait for it)
             const unsigned int b = lane + j * MTD_WAVE;
-            const double *q = b < cnt[i] ? ptr[i] + ((size_t)b * str[i] + off[i]) : safe;
-            p.x[i][j] = *q;
+            const double *q = (SUMS && b < cnt[i]) ? ptr[i] + ((size_t)b * str[i] + off[i]) : safe;
+            p.x[i][j] = SUMS ? *q : 0.0;
             }
     p.patch_ok = ok;
 #pragma unroll
