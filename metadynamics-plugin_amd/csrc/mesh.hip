@@ -1804,7 +1804,14 @@ struct SlabArgs
     unsigned int world, nz_loc, ny_loc, y0;
     };
 
-template<bool DIST>
+// TPB tiles per block (non-distributed path; default 1): with TPB > 1 the lines of the block's NEXT tile are requested — into
+// registers — before this tile's transforms, so that a block is loading while it is sweeping and its stores drain under the next
+// tile's sweeps.  The idea: with one tile per block every block of the launch is resident at once and in the same phase — a burst
+// that loads the whole mesh, the sweeps, a burst that stores it (round 2's stamps): 15.9 us for 38 MB, 30 % of the HBM peak.  It
+// did not pay (fft_z_tpb).  Needs n * tile <= FFT_ZPRE * FFT_THREADS.
+constexpr int FFT_ZPRE = 4;
+
+template<bool DIST, int TPB>
 __global__ __launch_bounds__(FFT_THREADS) void k_fft_z_spectral(const MeshGeom g, double2 *__restrict__ fmesh, double2 *__restrict__ gmesh,
                                                                 const double2 *__restrict__ twiddle, const unsigned int log2n,
                                                                 const unsigned int tile, const unsigned int tiles_per_row,
@@ -1814,40 +1821,11 @@ __global__ __launch_bounds__(FFT_THREADS) void k_fft_z_spectral(const MeshGeom g
     {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ double s_red[16];
-    double2 *s = (double2 *)smem;
     const unsigned int n = g.nz;
     const unsigned int plane = g.hxp * g.ny;                             // half-spectrum arrays: rows of pitch hxp
-    const unsigned int wy = (DIST ? sl.y0 : 0u) + blockIdx.x / tiles_per_row;   // row = y index (global)
-    const unsigned int x_first = (blockIdx.x % tiles_per_row) * tile;
-    const size_t base = (size_t)wy * g.hxp + x_first;
     const unsigned int total = n * tile;
     const unsigned int nxh = g.nx / 2;
-
-    for (unsigned int idx = threadIdx.x; idx < total; idx += FFT_THREADS)
-        {
-        const unsigned int p = idx >> ilog2_dev(tile), t = idx & (tile - 1);
-        if (DIST)
-            {
-            const unsigned int q = p / sl.nz_loc, zl = p - q * sl.nz_loc;
-            s[lds_slot(p, log2n) * tile + t] = ld_exported(sl.f[q] + base + t + (size_t)zl * plane);
-            }
-        else
-            s[lds_slot(p, log2n) * tile + t] = fmesh[base + t + (size_t)p * plane];
-        }
-    __syncthreads();
-    double2 *const s_first = s;
-    if (!log2n)
-        {
-        dft_direct(s, s + total, twiddle, n, tile, 0);               // forward, natural order, into the second buffer
-        s += total;
-        }
     const unsigned int log2tile = ilog2_dev(tile);
-    if (log2n) fft_dit_pow2(s, twiddle, log2n, log2tile, 0, tile);    // forward, decimation in time
-
-    // spectral step in place: updateMeshes :697-712 + computeCV :896-905 on the stored half of the spectrum.
-    // f(-k) = conj f(k), so the cell -k (not stored for 0 < k_x < nx/2) has the same |f|^2 and its own interpolation factor
-    // I(-k) (they differ in bug-compatible mode, Q6).  Stored for the inverse transform: the Hermitian part
-    // G_H(k) = (G(k) + conj G(-k)) / 2 = f (|f|^2 - (I(k)^2 + I(-k)^2) / 2 * sum mode^2 / 2 N^2), whose inverse is Re(inv).
     double term = 0.0;
     const double msq = *mode_sq;
     // loop invariants of the spectral step, formed once per thread: sum mode^2 / N^2 and 1 / N.  (Left in the loop, every point
@@ -1856,61 +1834,123 @@ __global__ __launch_bounds__(FFT_THREADS) void k_fft_z_spectral(const MeshGeom g
     // different order than the reference's expressions: a relative 1e-16, against 1e-11 asked of the meshes.)
     const double inv_n = 1.0 / n_global;
     const double msq_nn = msq / n_global / n_global;
-    const unsigned int my = wy ? g.ny - wy : 0u;                       // mirror row (-k_y as an array index)
-    const double Iy = itab[g.nx + wy], Imy = itab[g.nx + my];
-    for (unsigned int idx = threadIdx.x; idx < total; idx += FFT_THREADS)
-        {
-        const unsigned int p = idx >> log2tile, t = idx & (tile - 1);  // p = k_z index
-        const unsigned int wx = x_first + t;
-        if (wx > nxh)                                                  // padding column of the half-spectrum rows
-            {
-            s[p * tile + t] = make_double2(0.0, 0.0);
-            if (!DIST && keep_f) fmesh[base + t + (size_t)p * plane] = make_double2(0.0, 0.0);
-            continue;
-            }
-        const unsigned int mx = wx ? g.nx - wx : 0u, mz = p ? g.nz - p : 0u;
-        const double I = itab[wx] * Iy * itab[g.nx + g.ny + p];
-        const double Im = itab[mx] * Imy * itab[g.nx + g.ny + mz];
-        double2 f = s[p * tile + t];
-        f.x *= inv_n;
-        f.y *= inv_n;
-        const double val = f.x * f.x + f.y * f.y;
-        const double diagonal_term = 0.25 * (I * I + Im * Im) * msq_nn;
-        double2 G = make_double2(f.x * val, f.y * val);
-        G.x -= f.x * diagonal_term;
-        G.y -= f.y * diagonal_term;
-        // the normalised Fourier mesh is only read by the log quantities (q_max) and the virial: written when asked for
-        // (mtd_mesh_set_keep_fourier; 18.9 MB per step at 128^3).  Slab runs keep none.
-        if (!DIST && keep_f) fmesh[base + t + (size_t)p * plane] = f;
-        s[p * tile + t] = G;
-        if (wx != 0 || wy != 0 || p != 0)                              // exclude the DC bin (:889-894)
-            {
-            // Re(G f*) - |f|^2 I^2 sum mode^2 / 2 N^2 (:896-905) = |f|^4 - I^2 |f|^2 sum mode^2 / N^2 for the cell itself ...
-            double tk = val * val - val * (I * I) * msq_nn;
-            // ... plus the same for its mirror image when that one is not stored (k_x = 0 and, for even nx, nx/2 mirror
-            // into their own plane)
-            if (wx != 0 && 2 * wx != g.nx) tk += val * val - val * (Im * Im) * msq_nn;
-            term += tk;
-            }
-        }
-    __syncthreads();
+    double2 pre[FFT_ZPRE];
 
-    if (!log2n)
+    for (int it = 0; it < TPB; ++it)
         {
-        dft_direct(s, s_first, twiddle, n, tile, 1);                 // inverse, natural order, back into the first buffer
-        s = s_first;
-        }
-    if (log2n) fft_dif_pow2_inverse(s, twiddle, log2n, log2tile);        // inverse, decimation in frequency
-    for (unsigned int idx = threadIdx.x; idx < total; idx += FFT_THREADS)
-        {
-        const unsigned int q = idx >> log2tile, t = idx & (tile - 1);  // LDS slot q holds position z = bitrev(q) (radix-2 path)
-        const unsigned int z = lds_slot(q, log2n);
-        if (DIST)
-            gmesh[((size_t)z * sl.ny_loc + (wy - sl.y0)) * g.hxp + x_first + t] = s[q * tile + t];
-        else
+        double2 *s = (double2 *)smem;
+        const unsigned int tile_id = blockIdx.x * TPB + it;
+        const unsigned int wy = (DIST ? sl.y0 : 0u) + tile_id / tiles_per_row;      // row = y index (global)
+        const unsigned int x_first = (tile_id % tiles_per_row) * tile;
+        const size_t base = (size_t)wy * g.hxp + x_first;
+
+        if (TPB > 1 && it > 0)
             {
-            nt_store(s[q * tile + t], gmesh + base + t + (size_t)z * plane);
+            // the lines requested during the previous tile's transforms
+#pragma unroll
+            for (int k = 0; k < FFT_ZPRE; ++k)
+                {
+                const unsigned int idx = threadIdx.x + k * FFT_THREADS;
+                if (idx < total) s[lds_slot(idx >> log2tile, log2n) * tile + (idx & (tile - 1))] = pre[k];
+                }
             }
+        else
+            for (unsigned int idx = threadIdx.x; idx < total; idx += FFT_THREADS)
+                {
+                const unsigned int p = idx >> log2tile, t = idx & (tile - 1);
+                if (DIST)
+                    {
+                    const unsigned int q = p / sl.nz_loc, zl = p - q * sl.nz_loc;
+                    s[lds_slot(p, log2n) * tile + t] = ld_exported(sl.f[q] + base + t + (size_t)zl * plane);
+                    }
+                else
+                    s[lds_slot(p, log2n) * tile + t] = fmesh[base + t + (size_t)p * plane];
+                }
+        lds_barrier();
+        if (TPB > 1 && it + 1 < TPB)
+            {
+            // the next tile's lines: in flight during the sweeps below (clamped, not predicated: every load is issued before
+            // the first is waited for)
+            const unsigned int nid = tile_id + 1;
+            const size_t nbase = (size_t)(nid / tiles_per_row) * g.hxp + (nid % tiles_per_row) * tile;
+#pragma unroll
+            for (int k = 0; k < FFT_ZPRE; ++k)
+                {
+                const unsigned int idx = min(threadIdx.x + k * FFT_THREADS, total - 1);
+                const double2 v = fmesh[nbase + (idx & (tile - 1)) + (size_t)(idx >> log2tile) * plane];
+                pre[k].x = v.x;
+                pre[k].y = v.y;
+                }
+            }
+        double2 *const s_first = s;
+        if (!log2n)
+            {
+            dft_direct(s, s + total, twiddle, n, tile, 0);               // forward, natural order, into the second buffer
+            s += total;
+            }
+        if (log2n) fft_dit_pow2(s, twiddle, log2n, log2tile, 0, tile);    // forward, decimation in time
+
+        // spectral step in place: updateMeshes :697-712 + computeCV :896-905 on the stored half of the spectrum.
+        // f(-k) = conj f(k), so the cell -k (not stored for 0 < k_x < nx/2) has the same |f|^2 and its own interpolation factor
+        // I(-k) (they differ in bug-compatible mode, Q6).  Stored for the inverse transform: the Hermitian part
+        // G_H(k) = (G(k) + conj G(-k)) / 2 = f (|f|^2 - (I(k)^2 + I(-k)^2) / 2 * sum mode^2 / 2 N^2), whose inverse is Re(inv).
+        const unsigned int my = wy ? g.ny - wy : 0u;                       // mirror row (-k_y as an array index)
+        const double Iy = itab[g.nx + wy], Imy = itab[g.nx + my];
+        for (unsigned int idx = threadIdx.x; idx < total; idx += FFT_THREADS)
+            {
+            const unsigned int p = idx >> log2tile, t = idx & (tile - 1);  // p = k_z index
+            const unsigned int wx = x_first + t;
+            if (wx > nxh)                                                  // padding column of the half-spectrum rows
+                {
+                s[p * tile + t] = make_double2(0.0, 0.0);
+                if (!DIST && keep_f) fmesh[base + t + (size_t)p * plane] = make_double2(0.0, 0.0);
+                continue;
+                }
+            const unsigned int mx = wx ? g.nx - wx : 0u, mz = p ? g.nz - p : 0u;
+            const double I = itab[wx] * Iy * itab[g.nx + g.ny + p];
+            const double Im = itab[mx] * Imy * itab[g.nx + g.ny + mz];
+            double2 f = s[p * tile + t];
+            f.x *= inv_n;
+            f.y *= inv_n;
+            const double val = f.x * f.x + f.y * f.y;
+            const double diagonal_term = 0.25 * (I * I + Im * Im) * msq_nn;
+            double2 G = make_double2(f.x * val, f.y * val);
+            G.x -= f.x * diagonal_term;
+            G.y -= f.y * diagonal_term;
+            // the normalised Fourier mesh is only read by the log quantities (q_max) and the virial: written when asked for
+            // (mtd_mesh_set_keep_fourier; 18.9 MB per step at 128^3).  Slab runs keep none.
+            if (!DIST && keep_f) fmesh[base + t + (size_t)p * plane] = f;
+            s[p * tile + t] = G;
+            if (wx != 0 || wy != 0 || p != 0)                              // exclude the DC bin (:889-894)
+                {
+                // Re(G f*) - |f|^2 I^2 sum mode^2 / 2 N^2 (:896-905) = |f|^4 - I^2 |f|^2 sum mode^2 / N^2 for the cell itself ...
+                double tk = val * val - val * (I * I) * msq_nn;
+                // ... plus the same for its mirror image when that one is not stored (k_x = 0 and, for even nx, nx/2 mirror
+                // into their own plane)
+                if (wx != 0 && 2 * wx != g.nx) tk += val * val - val * (Im * Im) * msq_nn;
+                term += tk;
+                }
+            }
+        lds_barrier();
+
+        if (!log2n)
+            {
+            dft_direct(s, s_first, twiddle, n, tile, 1);                 // inverse, natural order, back into the first buffer
+            s = s_first;
+            }
+        if (log2n) fft_dif_pow2_inverse(s, twiddle, log2n, log2tile);        // inverse, decimation in frequency
+        for (unsigned int idx = threadIdx.x; idx < total; idx += FFT_THREADS)
+            {
+            const unsigned int q = idx >> log2tile, t = idx & (tile - 1);  // LDS slot q holds position z = bitrev(q) (radix-2 path)
+            const unsigned int z = lds_slot(q, log2n);
+            if (DIST)
+                gmesh[((size_t)z * sl.ny_loc + (wy - sl.y0)) * g.hxp + x_first + t] = s[q * tile + t];
+            else
+                {
+                nt_store(s[q * tile + t], gmesh + base + t + (size_t)z * plane);
+                }
+            }
+        if (TPB > 1 && it + 1 < TPB) lds_barrier();                      // the image is free for the next tile (its stores drain meanwhile)
         }
     term = block_sum(term, s_red);
     if (threadIdx.x == 0) cv_partials[blockIdx.x] = term;
@@ -2250,6 +2290,19 @@ FftPass fft_y_pass(const mtd_mesh *m)
     return py;
     }
 
+// tiles per block of the fused z pass of the whole-mesh path (k_fft_z_spectral<false, TPB>)
+unsigned int fft_z_tpb(const FftPass &pz)
+    {
+    // MEASURED SLOWER, opt-in (MTD_FFT_Z_TPB=2|3): config 3 at 128^3 takes 163.9 / 167.0 us per step with two / three tiles per
+    // block against 159.4 with one — the pass wants its 1152 small blocks all resident (4.5 per CU) more than it wants each block
+    // to overlap its own phases
+    static const int forced = [] { const char *e = std::getenv("MTD_FFT_Z_TPB"); return e && *e ? std::atoi(e) : 1; }();
+    const bool fits = pz.n * pz.tile <= (unsigned int)FFT_ZPRE * FFT_THREADS;
+    if (forced <= 1 || !fits) return 1;
+    if (forced == 3 && pz.n_blocks % 3 == 0) return 3;
+    return pz.n_blocks % 2 == 0 ? 2 : 1;
+    }
+
 FftPass fft_z_pass(const mtd_mesh *m)
     {
     FftPass pz;
@@ -2351,7 +2404,8 @@ int mtd_mesh_create(mtd_mesh **out, unsigned int nx, unsigned int ny, unsigned i
     m->hxp = (hx + unit - 1) / unit * unit;                    // 72 at nx = 128
     }
     const size_t MH = (size_t)m->hxp * ny * nz;
-    m->n_cv_partials = fft_z_pass(m).n_blocks;                 // one partial sum per block of the fused z pass
+    m->n_cv_partials = fft_z_pass(m).n_blocks;                 // one partial sum per block of the fused z pass (an upper bound: the
+                                                               // whole-mesh path puts several tiles into a block, fft_z_tpb)
     // tile path (k_tile_*): tiles of 16x16x8 cells clamped to the mesh; MTD_MESH_ASSIGN=cells keeps the cell-level pipeline
     {
     TileGeom &tg = m->tg;
@@ -2744,8 +2798,17 @@ int mtd_mesh_spectral(mtd_mesh *m, const mtd_box *box, unsigned int n_global, co
     const FftPass pz = fft_z_pass(m);
     SlabArgs none;
     std::memset(&none, 0, sizeof(none));
-    k_fft_z_spectral<false><<<pz.n_blocks, FFT_THREADS, fft_lds_bytes(pz.n, pz.tile), s>>>(
-        g, m->d_f, m->d_g, pz.tw, ilog2(pz.n), pz.tile, pz.tiles_per_row, m->d_mode_sq, (double)n_global, m->d_itab, m->d_cv_partials, none, m->keep_fourier);
+    const unsigned int tpb = fft_z_tpb(pz);
+    const unsigned int z_blocks_whole = pz.n_blocks / tpb;
+    if (tpb == 3)
+        k_fft_z_spectral<false, 3><<<z_blocks_whole, FFT_THREADS, fft_lds_bytes(pz.n, pz.tile), s>>>(
+            g, m->d_f, m->d_g, pz.tw, ilog2(pz.n), pz.tile, pz.tiles_per_row, m->d_mode_sq, (double)n_global, m->d_itab, m->d_cv_partials, none, m->keep_fourier);
+    else if (tpb == 2)
+        k_fft_z_spectral<false, 2><<<z_blocks_whole, FFT_THREADS, fft_lds_bytes(pz.n, pz.tile), s>>>(
+            g, m->d_f, m->d_g, pz.tw, ilog2(pz.n), pz.tile, pz.tiles_per_row, m->d_mode_sq, (double)n_global, m->d_itab, m->d_cv_partials, none, m->keep_fourier);
+    else
+        k_fft_z_spectral<false, 1><<<z_blocks_whole, FFT_THREADS, fft_lds_bytes(pz.n, pz.tile), s>>>(
+            g, m->d_f, m->d_g, pz.tw, ilog2(pz.n), pz.tile, pz.tiles_per_row, m->d_mode_sq, (double)n_global, m->d_itab, m->d_cv_partials, none, m->keep_fourier);
     m->fourier_valid = m->keep_fourier;
     if (m->cv_event) MTD_HIP_TRY(hipEventRecord(m->cv_event, s));          // the CV partial sums are complete from here on
     MTD_LAUNCH_CHECK();
@@ -2762,7 +2825,7 @@ int mtd_mesh_spectral(mtd_mesh *m, const mtd_box *box, unsigned int n_global, co
         MTD_LAUNCH_CHECK();
         }
     *d_partials = m->d_cv_partials;
-    *n_partials = m->n_cv_partials;
+    *n_partials = z_blocks_whole;
     return MTD_SUCCESS;
     }
 
@@ -2898,7 +2961,7 @@ int mtd_mesh_slab_compute_cv(mtd_mesh *m, unsigned int n_particles, const void *
     for (unsigned int q = 0; q < W; ++q) sl.f[q] = (const double2 *)m->slab_f[q];
     sl.world = W; sl.nz_loc = nzl; sl.ny_loc = nyl; sl.y0 = r * nyl;
     const unsigned int z_blocks = pz.tiles_per_row * nyl;
-    k_fft_z_spectral<true><<<z_blocks, FFT_THREADS, fft_lds_bytes(pz.n, pz.tile), s>>>(
+    k_fft_z_spectral<true, 1><<<z_blocks, FFT_THREADS, fft_lds_bytes(pz.n, pz.tile), s>>>(
         g, nullptr, g_x, pz.tw, ilog2(pz.n), pz.tile, pz.tiles_per_row, m->d_mode_sq, (double)n_global, m->d_itab, m->d_cv_partials, sl, 0);
     m->fourier_valid = 0;
     MTD_LAUNCH_CHECK();
