@@ -20,6 +20,11 @@
 //                                            R += hist_delta, block sums of R*dV and R   (first pass)
 //                            [force blocks]  forces of every CV for every particle (one pass)
 //
+// Round 3: launch B's critical path starts at its first instruction — wave 0 of every block requests the mode tables, the CV
+// partial sums and a 6^n-cell patch of the bias grid around the last CV values (kept current by the deferred pass) before
+// anything else, the streaming waves their first particles; the barrier that publishes the tables orders LDS traffic only
+// (k_fused_force below).
+//
 // The second reweighting pass needs <dV> = sum(R dV)/sum(R) over the whole grid, i.e. a grid-wide
 // dependency on the first pass: it is deferred into the next launch A (or mtd_metad_get_state /
 // get_array, which flush it), so the grid arrays are "one apply behind" between B and the next A.
@@ -538,6 +543,7 @@ int mtd_fused_cv_pass(mtd_metad *m, const mtd_lamellar_set *set, unsigned int n_
                       mtd_stream_t stream)
     {
     if (!m) return MTD_ERR_INVALID_ARGUMENT;
+    if (m->h_step_err && *m->h_step_err) return MTD_ERR_COMM_TIMEOUT;      // an earlier one-launch step left the grid half-updated
     LamKArgs k;
     int rc = fill_kargs(k, set, global_box);
     if (rc) return rc;

@@ -689,6 +689,9 @@ int mtd_metad_get_state(mtd_metad *m, double *cv, double *bias, double *bias_pot
     if (num_out_of_bounds) *num_out_of_bounds = st.n_oob;
     // a poisoned step (expired mailbox wait): the NaN state above is what the step left; the status says why
     if (m->comm && mtd::comm_failed(m->comm)) return MTD_ERR_COMM_TIMEOUT;
+    // the one-launch step's own hand-off between its blocks expired (fused_step.hip): sticky, whether or not a mailbox is attached —
+    // blocks that did not time out may have run their grid pass, the arrays are not to be trusted
+    if (m->h_step_err && *m->h_step_err) return MTD_ERR_COMM_TIMEOUT;
     return MTD_SUCCESS;
     }
 
@@ -727,6 +730,7 @@ void *mtd_metad_device_array(mtd_metad *m, int which)
 int mtd_metad_get_array(mtd_metad *m, int which, void *host_out, mtd_stream_t stream)
     {
     if (!m || !host_out) return MTD_ERR_INVALID_ARGUMENT;
+    if (m->h_step_err && *m->h_step_err) return MTD_ERR_COMM_TIMEOUT;      // (one-launch step: an expired in-kernel hand-off, see get_state)
     { int frc = mtd::metad_flush(m, (hipStream_t)stream); if (frc) return frc; }
     size_t e;
     void *p = array_ptr(m, which, &e);
