@@ -56,15 +56,15 @@ template<int LMAX> struct QlArgs
 // Jacobi recurrence prefactors (spherical_harmonics.hpp:151-175) and jacobi[m][0] (:197-201).  They depend on (m, n) only,
 // so in the fully unrolled loops they fold to literals: no table in the kernel arguments, no scalar registers tied up
 // (a [m][n] table in the argument segment cost ~340 v_readlane per pair in spilled scalars)
-__device__ __forceinline__ double jac_f0(const int m, const int n)
+__host__ __device__ __forceinline__ double jac_f0(const int m, const int n)
     {
     return 2 * sqrt(1 + (m - 0.5) / n) * sqrt(1 - (m - 0.5) / (n + 2 * m));
     }
-__device__ __forceinline__ double jac_f1(const int m, const int n)
+__host__ __device__ __forceinline__ double jac_f1(const int m, const int n)
     {
     return -sqrt(1.0 + 4.0 / (2 * n + 2 * m - 3)) * sqrt(1 - 1.0 / n) * sqrt(1.0 - 1.0 / (n + 2 * m));
     }
-__device__ __forceinline__ double jac_0(const int m)
+__host__ __device__ __forceinline__ double jac_0(const int m)
     {
     double v = 0.70710678118654752440084436210484903928483593768847;    // 1 / sqrt(2)
     for (int k = 1; k <= m; ++k) v *= sqrt(1 + 1.0 / 2 / k);
@@ -135,6 +135,141 @@ __device__ __forceinline__ void smoothing(const QlArgs<LMAX> &a, const double rs
         {
         double sn, cs;
         sincospi_unit((rsq * inv_r - a.r_on) * a.inv_width, sn, cs);
+        f = 0.5 * (cs + 1.0);
+        fprime_divr = -(0.5 * M_PI) * inv_r * a.inv_width * sn;
+        }
+    }
+
+// ---- constants of the force pass, read through the scalar cache -------------------------------------------------------------
+// Counters of round 3 (profiles/r3): the pair kernels are bound by instruction ISSUE — vector + scalar + LDS + branch
+// instructions times four cycles add up to the launch time.  A 64-bit literal is two s_mov_b32, and the ~100 literals of a pair
+// (recurrence prefactors, derivative factors, the smoothing polynomial) were a quarter of all issue slots (or, where the
+// compiler kept them in VGPRs, a v_mov per use and 44 registers).  They now sit in a small table in device memory that the
+// kernel reads with s_load_dwordx8/x16 (eight constants per issue slot) right where they are used; the table pointer carries an
+// offset the compiler cannot see through (always zero), or it would hoist ~90 loads out of the pair loop and spill them.
+//   [SM_SIN, +10)  [SM_COS, +10)   Taylor coefficients of sincospi_unit, highest order first
+//   beta(m, n)     monic form of the Jacobi recurrence of spherical_harmonics.hpp:203-211 in the degree n = l - m:
+//                  J_m(n) = kappa(m, n) p_mn(x), p_m0 = 1, p_m1 = x, p_mn = x p_m,n-1 - beta(m, n) p_m,n-2
+//                  (kappa(m, 0) = jacobi[m][0], kappa(m, n) = f0(m, n) kappa(m, n - 1), beta = -f1(m, n) / (f0(m, n) f0(m, n - 1)))
+//   nrm(l, m)      (-1)^m kappa(m, l - m) / sqrt(2 pi): Y_lm = nrm(l, m) p_m,l-m(cos theta) (sin theta e^{i phi})^m
+//   d(l, m)        sqrt((l - m)(l + m + 1)) nrm(l, m + 1) / nrm(l, m): the A_l,m+1 term of dY_lm/dtheta (:305-309)
+template<int LMAX> struct QlTab
+    {
+    static constexpr int SM_SIN = 0, SM_COS = 10, BETA = 24;
+    static constexpr int N_BETA = (LMAX - 1) * LMAX / 2;
+    static constexpr int D = (BETA + N_BETA + 7) / 8 * 8;
+    static constexpr int N_D = LMAX * (LMAX + 1) / 2;
+    static constexpr int NRM = (D + N_D + 7) / 8 * 8;
+    static constexpr int SIZE = NRM + (LMAX + 1) * (LMAX + 2) / 2;
+    __host__ __device__ static constexpr int beta(const int m, const int n)         // n >= 2, m + n <= LMAX
+        {
+        return BETA + m * (LMAX - 1) - m * (m - 1) / 2 + (n - 2);
+        }
+    __host__ __device__ static constexpr int d(const int l, const int m) { return D + l * (l - 1) / 2 + m; }       // m < l
+    __host__ __device__ static constexpr int nrm(const int l, const int m) { return NRM + l * (l + 1) / 2 + m; }
+    };
+
+template<int LMAX> void ql_build_table(double *t)
+    {
+    typedef QlTab<LMAX> T;
+    for (int i = 0; i < T::SIZE; ++i) t[i] = 0.0;
+    // sin: -1/21!, 1/19!, ..., 1/3! ; cos: 1/20!, -1/18!, ..., -1/2!   (sincospi_unit)
+    double fact = 1.0;                                       // k!
+    double inv[22];
+    inv[0] = 1.0;
+    for (int k = 1; k <= 21; ++k)
+        {
+        fact *= k;
+        inv[k] = 1.0 / fact;
+        }
+    for (int i = 0; i < 10; ++i)
+        {
+        const int ks = 21 - 2 * i, kc = 20 - 2 * i;
+        t[T::SM_SIN + i] = (i % 2 == 0 ? -1.0 : 1.0) * inv[ks];
+        t[T::SM_COS + i] = (i % 2 == 0 ? 1.0 : -1.0) * inv[kc];
+        }
+    double kappa[LMAX + 1][LMAX + 1];
+    for (int m = 0; m <= LMAX; ++m)
+        {
+        kappa[m][0] = jac_0(m);
+        for (int n = 1; m + n <= LMAX; ++n) kappa[m][n] = jac_f0(m, n) * kappa[m][n - 1];
+        for (int n = 2; m + n <= LMAX; ++n) t[T::beta(m, n)] = -jac_f1(m, n) / (jac_f0(m, n) * jac_f0(m, n - 1));
+        }
+    for (int l = 0; l <= LMAX; ++l)
+        for (int m = 0; m <= l; ++m)
+            t[T::nrm(l, m)] = ((m % 2) ? -1.0 : 1.0) * 0.3989422804014326779399460599343818684758586311649 * kappa[m][l - m];
+    for (int l = 1; l <= LMAX; ++l)
+        for (int m = 0; m < l; ++m)
+            t[T::d(l, m)] = std::sqrt((double)((l - m) * (l + m + 1))) * t[T::nrm(l, m + 1)] / t[T::nrm(l, m)];
+    }
+
+// the table of this LMAX on the current device (built and uploaded once per device)
+template<int LMAX> const double *ql_device_table(hipStream_t s, int &rc)
+    {
+    static std::mutex mtx;
+    static std::map<int, double *> tables;
+    rc = MTD_SUCCESS;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess)
+        {
+        rc = MTD_ERR_INVALID_ARGUMENT;
+        return nullptr;
+        }
+    std::lock_guard<std::mutex> lock(mtx);
+    auto it = tables.find(dev);
+    if (it != tables.end()) return it->second;
+    static double host[QlTab<LMAX>::SIZE];
+    ql_build_table<LMAX>(host);
+    double *d = nullptr;
+    hipError_t e = hipMalloc((void **)&d, sizeof(host));
+    if (e == hipSuccess) e = hipMemcpy(d, host, sizeof(host), hipMemcpyHostToDevice);      // once per device: synchronous
+    if (e != hipSuccess)
+        {
+        (void)hipGetLastError();
+        if (d) (void)hipFree(d);
+        rc = (int)e;
+        return nullptr;
+        }
+    (void)s;
+    tables.emplace(dev, d);
+    return d;
+    }
+
+// a * b + c with c a wave-uniform constant in scalar registers: ONE v_fma_f64.  Left to itself the compiler selects the
+// two-operand v_fmac_f64 and first copies the constant into the destination (two v_mov_b32 per Horner step).
+__device__ __forceinline__ double fma_uniform_addend(const double a, const double b, const double c)
+    {
+    double r;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(c));
+    return r;
+    }
+
+// sincospi_unit with its coefficients from the table (c = table + SM_SIN; same operations, same results)
+__device__ __forceinline__ void sincospi_unit_tab(const double *__restrict__ c, const double x, double &sn, double &cs)
+    {
+    const double z = M_PI * (x - 0.5), z2 = z * z;
+    double s = c[0];
+#pragma unroll
+    for (int i = 1; i < 10; ++i) s = fma_uniform_addend(s, z2, c[i]);
+    const double sin_z = z - z * z2 * s;
+    double k = c[10];
+#pragma unroll
+    for (int i = 1; i < 10; ++i) k = fma_uniform_addend(k, z2, c[10 + i]);
+    const double cos_z = 1.0 + z2 * k;
+    cs = -sin_z;
+    sn = cos_z;
+    }
+
+template<int LMAX>
+__device__ __forceinline__ void smoothing_tab(const QlArgs<LMAX> &a, const double *__restrict__ tab, const double rsq, const double inv_r,
+                                              double &f, double &fprime_divr)
+    {
+    f = 1.0;
+    fprime_divr = 0.0;
+    if (rsq > a.ronsq)
+        {
+        double sn, cs;
+        sincospi_unit_tab(tab + QlTab<LMAX>::SM_SIN, (rsq * inv_r - a.r_on) * a.inv_width, sn, cs);
         f = 0.5 * (cs + 1.0);
         fprime_divr = -(0.5 * M_PI) * inv_r * a.inv_width * sn;
         }
@@ -260,31 +395,8 @@ template<typename CS> __device__ __forceinline__ unsigned int chunk_owner(const 
     return p;
     }
 
-// phase 1: gather the separations of entries [base, base + QL_CAP) of the chunk into LDS
-template<typename S4, int LMAX, typename CS>
-__device__ __forceinline__ void chunk_gather(const QlArgs<LMAX> &a, const S4 *__restrict__ postype,
-                                             const unsigned int *__restrict__ nlist, const unsigned int base, const unsigned int n,
-                                             CS &cs, unsigned int *s_j)
-    {
-#pragma unroll 4
-    for (unsigned int t = threadIdx.x; t < n; t += QL_THREADS)
-        {
-        const unsigned int e = base + t;
-        const unsigned int p = chunk_owner(cs, e);
-        const unsigned int j = nlist[cs.start[p] + (e - cs.off[p])];
-        const Particle pj = scalar4_traits<S4>::load(postype, j);
-        double dx = cs.px[p] - pj.x, dy = cs.py[p] - pj.y, dz = cs.pz[p] - pj.z;
-        min_image(a, dx, dy, dz);
-        if ((unsigned int)pj.type != a.type) dx = INFINITY;                    // :126 -> fails the cut-off test
-        cs.dx[t] = dx;
-        cs.dy[t] = dy;
-        cs.dz[t] = dz;
-        if (s_j) s_j[t] = j;
-        }
-    __syncthreads();
-    }
-
-// CV pass: the same gather, but only the pairs that take part are stored, densely: every wave appends the pairs it keeps
+// CV pass: the separations of entries [base, base + QL_CAP) of the chunk are gathered into LDS, but only the pairs that take
+// part are stored, densely: every wave appends the pairs it keeps
 // of its share of the batch (entries w*64 + lane + k*256) to its own segment [w * CAP/4, ...) of the LDS arrays, in entry
 // order (ballot + popcount: deterministic), and publishes the count.  Pairs beyond the cut-off (a neighbour list is built
 // with a buffer) or of another type no longer idle a lane of the arithmetic phase.  SYM (symmetric full list without ghost
@@ -340,7 +452,6 @@ __device__ __forceinline__ void chunk_gather_compact(const QlArgs<LMAX> &a, cons
 __host__ __device__ constexpr bool ql_role_has(const int m, const int role) { return ((m % 4 == 0 || m % 4 == 3) ? 0 : 1) == role; }
 
 typedef ChunkShared<QL_ACC_PPB, QL_ACC_CAP> AccChunk;
-typedef ChunkShared<QL_FRC_PPB, QL_FRC_CAP> FrcChunk;
 
 template<int LMAX, int ROLE>
 __device__ __forceinline__ void ql_accumulate_pairs(const QlArgs<LMAX> &a, const AccChunk &cs, const unsigned int n,
@@ -612,30 +723,159 @@ __global__ __launch_bounds__(256) void k_ql_exact_to_force(const unsigned long l
     }
 
 // ---- forces ----------------------------------------------------------------------------------------------
-// EXACT (half lists): reaction forces into the exact accumulators, the particle's own sum (formed by one thread in list order)
-// into own[i] — the conversion pass adds it; !EXACT: the floating-point atomics of round 1 (mtd_ql_set_half_list_exact(0):
-// 2.5 x faster, sums in arrival order).
+// Round 3: a pipeline over the block's batches of pairs instead of load-everything / compute-everything phases.  The counters
+// of round 3's first half (profiles/r3: 486 vector instructions per list entry, VALU busy 56 % of the launch, every wave
+// waiting half of its cycles) said the three dependent memory trips of a chunk — (own particle, list head, count) -> list
+// entries -> neighbour positions — were paid in full per chunk with four waves per SIMD to hide them.  Now every thread keeps
+// the SAME list entries in both roles (it fetches the neighbour of entry t and computes the pair of entry t), so the
+// separations no longer pass through LDS, and every trip is requested one stage ahead and left in flight across the
+// arithmetic (the block barriers are LDS-only: lds_barrier):
+//   unit n      = one batch of <= QL_FRC_CAP list entries of one chunk of QL_FRC_PPB central particles
+//   arithmetic  of unit n, entry k of the thread: the neighbour position of entry k + 1 is requested first; the last entry
+//               requests the first neighbour of unit n + 1 (its list entries are in registers since the end of unit n - 1)
+//   wave 3      (the wave with the fewest entries in a partly filled batch) publishes unit n + 2's prefix table and own
+//               positions to LDS from registers loaded during unit n - 1's arithmetic, then requests unit n + 3's
+//   after the barrier: per-particle sums of unit n's pair forces (four threads per particle, fixed order), the list entries of
+//               unit n + 2 are requested
+// Three unit tables rotate in LDS (unit n in use, n + 1 referenced by the requests, n + 2 being written).
+// EXACT (half lists): reaction forces into the exact accumulators, the particle's own sum into own[i] — the conversion pass
+// adds it; !EXACT: the floating-point atomics of round 1 (mtd_ql_set_half_list_exact(0): 2.5 x faster, sums in arrival order).
+template<int PPB> struct FrcUnit
+    {
+    unsigned int start[PPB];          // head_list of the particle
+    unsigned int off[PPB + 1];        // exclusive prefix of the neighbour counts inside the chunk
+    double px[PPB], py[PPB], pz[PPB]; // the central particles' own positions
+    unsigned int chunk, base, total, valid;
+    };
+
+template<typename S4> struct FrcSetupRegs
+    {
+    S4 pos;
+    unsigned int start, cnt;
+    };
+
+template<typename S4> __device__ __forceinline__ S4 zero_s4();
+template<> __device__ __forceinline__ float4 zero_s4<float4>() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+template<> __device__ __forceinline__ double4 zero_s4<double4>() { return make_double4(0.0, 0.0, 0.0, 0.0); }
+
+// the pair force of one list entry (SteinhardtQl.cc:287-333 contracted as the header describes), in the monic amplitudes:
+// with h = sin(theta) e^{i phi} = (dx + i dy) / r, P = p_m,l-m(cos theta) and Z_lm = h^m q_lm (q_lm = nrm(l, m) w_l conj(Q_lm)
+// from LDS),
+//   U = sum P Re Z,   V = cot(theta) sum m P Re Z + sin(theta) sum_{m < l} d(l, m) p_m+1,l-m-1 Re Z,   W = -sum m P Im Z
+// and the force is -(f'/r U d + f/r V e_theta + f/rho W e_phi).  Degrees with Ql_ref[l] = 0 are skipped as a whole (one scalar
+// branch per degree); per order m the sums over l are kept apart (U_m, W_m) so that the factor m is applied once.
+// On the z axis 1/rho is infinite and the force comes out NaN, as from the reference's 0 * (1 / tan(0)).
+template<int LMAX>
+__device__ __forceinline__ void ql_pair_force(const QlArgs<LMAX> &a, const double *__restrict__ tab, const double *s_qw, const unsigned int act,
+                                              const unsigned int opaque0, const double dx, const double dy, const double dz, const double rsq,
+                                              double &fpx, double &fpy, double &fpz)
+    {
+    typedef QlTab<LMAX> T;
+    const double inv_r = rsqrt(rsq);
+    const double rho2 = dx * dx + dy * dy;
+    const double inv_rho = rsqrt(rho2);
+    const double ct = dz * inv_r, ex = dx * inv_r, ey = dy * inv_r;
+    double f, fprime_divr;
+    smoothing_tab<LMAX>(a, tab, rsq, inv_r, f, fprime_divr);
+    // monic amplitudes p[m][n], n = l - m (n = 0: 1, n = 1: cos theta)
+    double p[LMAX + 1][LMAX + 1];
+#pragma unroll
+    for (int m = 0; m <= LMAX; ++m)
+        {
+        p[m][0] = 1.0;
+        if (m + 1 <= LMAX) p[m][1] = ct;
+#pragma unroll
+        for (int n = 2; m + n <= LMAX; ++n) p[m][n] = ct * p[m][n - 1] - tab[T::beta(m, n)] * p[m][n - 2];
+        }
+    // h^m
+    cplx h[LMAX + 1];
+    h[0] = {1.0, 0.0};
+    if (LMAX >= 1) h[1] = {ex, ey};
+#pragma unroll
+    for (int m = 2; m <= LMAX; ++m) h[m] = cmul(h[m - 1], {ex, ey});
+    double Um[LMAX + 1], Wm[LMAX + 1], VB = 0.0;
+#pragma unroll
+    for (int m = 0; m <= LMAX; ++m) Um[m] = Wm[m] = 0.0;
+#pragma unroll
+    for (int l = 0; l <= LMAX; ++l)
+        {
+        if (act & (1u << l))                                     // degrees with Ql_ref[l] != 0 (and l <= lmax)
+            {
+#pragma unroll
+            for (int m = 0; m <= l; ++m)
+                {
+                const int idx = l * (l + 1) / 2 + m;
+                // `opaque0` (always 0, but derived from the pair slot) keeps these reads inside the pair loop: hoisted, the
+                // loop-invariant table takes ~110 registers
+                const cplx q = {s_qw[2 * idx + opaque0], s_qw[2 * idx + 1 + opaque0]};
+                const cplx Z = m == 0 ? q : cmul(h[m], q);
+                if (m == l)
+                    Um[m] += Z.re;
+                else
+                    Um[m] += p[m][l - m] * Z.re;
+                if (m > 0)
+                    {
+                    if (m == l)
+                        Wm[m] += Z.im;
+                    else
+                        Wm[m] += p[m][l - m] * Z.im;
+                    }
+                if (m < l)
+                    {
+                    if (l - m - 1 == 0)
+                        VB += tab[T::d(l, m)] * Z.re;
+                    else
+                        VB += (tab[T::d(l, m)] * p[m + 1][l - m - 1]) * Z.re;
+                    }
+                }
+            }
+        }
+    double U = Um[0], VA = 0.0, W = 0.0;
+#pragma unroll
+    for (int m = 1; m <= LMAX; ++m)
+        {
+        U += Um[m];
+        VA += (double)m * Um[m];
+        W -= (double)m * Wm[m];
+        }
+    const double st = rho2 * inv_rho * inv_r, cot = dz * inv_rho;      // sin(theta) = rho / r, 1 / tan(theta)
+    const double cp = dx * inv_rho, sp = dy * inv_rho;
+    const double V = cot * VA + st * VB;
+    const double fa = fprime_divr * U, fb = f * inv_r * V, fc = f * inv_rho * W;   // 1/(r sin theta) = 1/rho
+    fpx = -(fa * dx + fb * (ct * cp) - fc * sp);                                  // e_theta = (ct cp, ct sp, -st), e_phi = (-sp, cp, 0)  (:288)
+    fpy = -(fa * dy + fb * (ct * sp) + fc * cp);
+    fpz = -(fa * dz - fb * st);
+    }
+
 template<typename S4, int LMAX, bool HALF, bool EXACT>
-__global__ __launch_bounds__(QL_THREADS, (LMAX <= 6 ? 4 : 2)) void k_ql_forces(const QlArgs<LMAX> a, const S4 *__restrict__ postype,
+__global__ __launch_bounds__(QL_THREADS, (LMAX <= 6 ? 3 : 2)) void k_ql_forces(const QlArgs<LMAX> a, const S4 *__restrict__ postype,
                                                              const unsigned int *__restrict__ head_list,
                                                              const unsigned int *__restrict__ n_neigh,
                                                              const unsigned int *__restrict__ nlist, const double *__restrict__ qlm_full,
                                                              S4 *__restrict__ force, const double *__restrict__ d_bias, const double bias_host,
-                                                             unsigned long long *__restrict__ exact_acc, double *__restrict__ own)
+                                                             unsigned long long *__restrict__ exact_acc, double *__restrict__ own,
+                                                             const double *__restrict__ tab)
     {
     typedef typename scalar4_traits<S4>::scalar scalar;
+    typedef FrcUnit<QL_FRC_PPB> Unit;
     constexpr int NLM = (LMAX + 1) * (LMAX + 2) / 2;
-    constexpr int QL_PPB = QL_FRC_PPB, QL_CAP = QL_FRC_CAP;
+    constexpr unsigned int PPB = QL_FRC_PPB, CAP = QL_FRC_CAP;
+    constexpr int K = QL_FRC_CAP / QL_THREADS;                 // list entries per thread and unit
+    static_assert(QL_FRC_PPB == MTD_WAVE, "one wave scans the neighbour counts of a chunk");
+    static_assert(K == 4 && QL_THREADS == 4 * QL_FRC_PPB, "owner bytes packed in one register; four summing threads per particle");
     __shared__ double s_qw[2 * NLM];                 // w_l (2 or 4) conj(Q_lm), m >= 0, index l(l+1)/2 + m
-    __shared__ FrcChunk cs;
-    __shared__ unsigned int s_j[HALF ? QL_CAP : 1];
+    __shared__ Unit su[3];
+    __shared__ double s_fx[CAP], s_fy[CAP], s_fz[CAP];          // pair forces of the unit, by list entry
+    const unsigned int tid = threadIdx.x, lane = tid & 63u;
+    const bool setup_wave = (tid >> 6) == QL_THREADS / MTD_WAVE - 1;
     const double bias = d_bias ? *d_bias : bias_host;
     const double ng = (double)a.n_global;
     unsigned int active_l = 0;
 #pragma unroll
     for (int l = 0; l <= LMAX; ++l)
         if (l <= (int)a.lmax && a.ql_ref[l] != 0.0) active_l |= 1u << l;
-    for (unsigned int q = threadIdx.x; q < (unsigned int)NLM; q += blockDim.x)
+    active_l = __builtin_amdgcn_readfirstlane(active_l);          // a scalar: one s_bitcmp + branch per degree in the pair loop
+    for (unsigned int q = tid; q < (unsigned int)NLM; q += blockDim.x)
         {
         // (l, m) of the packed index
         int l = 0;
@@ -644,7 +884,8 @@ __global__ __launch_bounds__(QL_THREADS, (LMAX <= 6 ? 4 : 2)) void k_ql_forces(c
         double re = 0.0, im = 0.0;
         if (l <= (int)a.lmax)
             {
-            const double w = bias * (4.0 * M_PI / (2 * l + 1)) / (ng * ng) * a.ql_ref[l] * (m > 0 ? 4.0 : 2.0);   // :316-321
+            // :316-321, times the normalisation of the monic amplitude (ql_pair_force)
+            const double w = bias * (4.0 * M_PI / (2 * l + 1)) / (ng * ng) * a.ql_ref[l] * (m > 0 ? 4.0 : 2.0) * tab[QlTab<LMAX>::NRM + q];
             const int n = l * l + m;                                             // reference order: m = 0..l, then -1..-l
             re = w * qlm_full[2 * n];
             im = -w * qlm_full[2 * n + 1];
@@ -652,93 +893,190 @@ __global__ __launch_bounds__(QL_THREADS, (LMAX <= 6 ? 4 : 2)) void k_ql_forces(c
         s_qw[2 * q] = re;
         s_qw[2 * q + 1] = im;
         }
-    // chunk_setup's first barrier publishes s_qw
+    const unsigned int n_chunks = (a.N + PPB - 1) / PPB;
 
-    const unsigned int n_chunks = (a.N + QL_PPB - 1) / QL_PPB;
-    for (unsigned int chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x)
+    // ---- wave 3: the unit tables ----
+    FrcSetupRegs<S4> sr;
+    sr.pos = zero_s4<S4>();
+    sr.start = sr.cnt = 0;
+    auto request_setup = [&](const unsigned int chunk)
         {
-        chunk_setup<S4, LMAX>(a, postype, head_list, n_neigh, chunk, cs);
-        const unsigned int total = cs.off[QL_PPB];
-        double Fx = 0.0, Fy = 0.0, Fz = 0.0;                                     // thread p < QL_PPB: running force of particle p
-        for (unsigned int base = 0; base < total; base += QL_CAP)
+        const unsigned int i = chunk * PPB + lane;
+        sr.pos = zero_s4<S4>();
+        sr.start = sr.cnt = 0;
+        if (i < a.N)
             {
-            const unsigned int n = min(total - base, (unsigned int)QL_CAP);
-            if (base) __syncthreads();
-            chunk_gather<S4, LMAX>(a, postype, nlist, base, n, cs, HALF ? s_j : nullptr);
-            for (unsigned int t = threadIdx.x; t < n; t += QL_THREADS)
+            sr.pos = postype[i];
+            sr.start = head_list[i];
+            sr.cnt = n_neigh[i];
+            }
+        };
+    // first batch of a chunk, from the registers requested earlier; returns the chunk's number of list entries (wave-uniform)
+    auto publish_chunk = [&](Unit &u, const unsigned int chunk) -> unsigned int
+        {
+        const unsigned int i = chunk * PPB + lane;
+        const Particle pi = scalar4_traits<S4>::unpack(sr.pos);
+        const unsigned int cnt = (i < a.N && (unsigned int)pi.type == a.type) ? sr.cnt : 0u;       // :105
+        u.px[lane] = pi.x;
+        u.py[lane] = pi.y;
+        u.pz[lane] = pi.z;
+        u.start[lane] = sr.start;
+        unsigned int incl = cnt;
+#pragma unroll
+        for (int d = 1; d < MTD_WAVE; d <<= 1)
+            {
+            const unsigned int up = __shfl_up(incl, d, MTD_WAVE);
+            if (lane >= (unsigned int)d) incl += up;
+            }
+        u.off[lane + 1] = incl;
+        const unsigned int total = (unsigned int)wave_read((int)incl, 63);
+        if (lane == 0)
+            {
+            u.off[0] = 0;
+            u.chunk = chunk;
+            u.base = 0;
+            u.total = total;
+            u.valid = 1;
+            }
+        return total;
+        };
+    // what follows a unit (chunk, base, total): the next batch of the same chunk, the block's next chunk, or nothing
+    // kind: 0 nothing, 1 a new chunk (its setup registers are requested here), 2 the next batch of the same chunk
+    unsigned int pend_kind = 0, pend_chunk = 0;
+    auto plan_after = [&](const unsigned int chunk, const unsigned int base, const unsigned int total)
+        {
+        if (base + CAP < total)
+            {
+            pend_kind = 2;
+            return;
+            }
+        pend_chunk = chunk + gridDim.x;
+        pend_kind = pend_chunk < n_chunks ? 1 : 0;
+        if (pend_kind) request_setup(pend_chunk);
+        };
+    // publish the planned unit into `u` (`prev` is the unit before it) and plan the one after it
+    auto publish_planned = [&](Unit &u, const Unit &prev)
+        {
+        if (pend_kind == 1)
+            {
+            const unsigned int total = publish_chunk(u, pend_chunk);
+            plan_after(pend_chunk, 0, total);
+            }
+        else if (pend_kind == 2)
+            {
+            u.px[lane] = prev.px[lane];
+            u.py[lane] = prev.py[lane];
+            u.pz[lane] = prev.pz[lane];
+            u.start[lane] = prev.start[lane];
+            u.off[lane + 1] = prev.off[lane + 1];
+            const unsigned int chunk = prev.chunk, base = prev.base + CAP, total = prev.total;
+            if (lane == 0)
                 {
-                const double dx = cs.dx[t], dy = cs.dy[t], dz = cs.dz[t];
+                u.off[0] = 0;
+                u.chunk = chunk;
+                u.base = base;
+                u.total = total;
+                u.valid = 1;
+                }
+            plan_after(chunk, base, total);
+            }
+        else if (lane == 0)
+            u.valid = 0;
+        };
+
+    // ---- every thread: the list entries of a unit (owner search in the unit's prefix table) ----
+    auto request_entries = [&](const Unit &u, unsigned int (&j)[K], unsigned int &owners)
+        {
+        owners = 0;
+#pragma unroll
+        for (int k = 0; k < K; ++k) j[k] = 0;
+        if (!u.valid) return;
+        const unsigned int base = u.base, n = min(u.total - base, CAP);
+#pragma unroll
+        for (int k = 0; k < K; ++k)
+            {
+            const unsigned int t = k * QL_THREADS + tid;
+            if (t < n)
+                {
+                const unsigned int e = base + t;
+                unsigned int p = 0;
+#pragma unroll
+                for (unsigned int step = PPB / 2; step > 0; step >>= 1)
+                    if (u.off[p + step] <= e) p += step;
+                j[k] = nlist[u.start[p] + (e - u.off[p])];
+                owners |= p << (8 * k);
+                }
+            }
+        };
+
+    // ---- prologue: units 0 and 1 published, unit 2 planned; entries of units 0 and 1 and the first neighbour requested ----
+    if (setup_wave)
+        {
+        if (blockIdx.x < n_chunks)
+            {
+            request_setup(blockIdx.x);
+            const unsigned int total = publish_chunk(su[0], blockIdx.x);
+            plan_after(blockIdx.x, 0, total);
+            }
+        else if (lane == 0)
+            su[0].valid = 0;
+        publish_planned(su[1], su[0]);
+        }
+    lds_barrier();
+    unsigned int j_cur[K], j_next[K], own_cur, own_next;
+    request_entries(su[0], j_cur, own_cur);
+    request_entries(su[1], j_next, own_next);
+    S4 pos_raw = zero_s4<S4>();
+    if (su[0].valid && tid < min(su[0].total, CAP)) pos_raw = postype[j_cur[0]];
+    double Fx = 0.0, Fy = 0.0, Fz = 0.0;             // thread (p = tid / 4, q = tid % 4): every fourth pair force of particle p
+
+    for (unsigned int n = 0;; ++n)
+        {
+        const Unit &U = su[n % 3];
+        if (!U.valid) break;                                                      // published before the last barrier
+        const Unit &NU = su[(n + 1) % 3];
+        const unsigned int base = U.base, total = U.total, chunk = U.chunk;
+        const unsigned int n_cur = min(total - base, CAP);
+        const unsigned int n_next = NU.valid ? min(NU.total - NU.base, CAP) : 0u;
+        unsigned int j0 = j_cur[0], j1 = j_cur[1], j2 = j_cur[2], j3 = j_cur[3], owners = own_cur;
+#pragma unroll 1
+        for (int k = 0; k < K; ++k)
+            {
+            const unsigned int t = k * QL_THREADS + tid;
+            unsigned int tab_shift = 0;
+            asm volatile("" : "+s"(tab_shift));                 // a zero the compiler cannot see through: the table loads stay in the loop
+            const double *__restrict__ tab_k = tab + tab_shift;
+            // the next neighbour position is requested before this entry's arithmetic
+            const bool last = k == K - 1;
+            const unsigned int jx = last ? j_next[0] : j1;
+            const bool want = last ? tid < n_next : t + QL_THREADS < n_cur;
+            S4 pos_ahead = zero_s4<S4>();
+            if (want) pos_ahead = postype[jx];
+            if (t < n_cur)
+                {
+                const unsigned int p = owners & 255u;
+                const Particle pj = scalar4_traits<S4>::unpack(pos_raw);
+                double dx = U.px[p] - pj.x, dy = U.py[p] - pj.y, dz = U.pz[p] - pj.z;
+                min_image(a, dx, dy, dz);
                 const double rsq = dx * dx + dy * dy + dz * dz;
-                const unsigned int opaque0 = t >> 31;
                 double fpx = 0.0, fpy = 0.0, fpz = 0.0;
-                if (rsq <= a.rcutsq)
+                if ((unsigned int)pj.type == a.type && rsq <= a.rcutsq)        // :126, :141
                     {
-                    const PairGeom g = pair_geom(dx, dy, dz, rsq);
-                    double f, fprime_divr;
-                    smoothing(a, rsq, g.inv_r, f, fprime_divr);
-                    const double cot = g.dz * g.inv_rho;                         // m / tan(theta) (:305); theta = 0 -> inf like the reference
-                    double U = 0.0, V = 0.0, W = 0.0;
-                    // ascending m; the terms of order m need column m + 1 as well, so they run one step late
-                    double prev[LMAX + 1], cur[LMAX + 1];
-                    double sinpow = 0.3989422804014326779399460599343818684758586311649;         // 1 / sqrt(2 pi)
-                    cplx harm = {1.0, 0.0}, harm_prev = {1.0, 0.0};
-#pragma unroll
-                    for (int mm = 0; mm <= LMAX + 1; ++mm)
+                    ql_pair_force<LMAX>(a, tab_k, s_qw, active_l, t >> 31, dx, dy, dz, rsq, fpx, fpy, fpz);
+                    if (HALF)                                                    // :328-333
                         {
-                        if (mm <= LMAX)                                          // Condon-Shortley phase for odd m (:150, :303-304)
-                            amplitude_column<LMAX>(a, mm, g.ct, (mm % 2) ? -sinpow : sinpow, cur);
-                        if (mm >= 1)
-                            {
-                            const int m = mm - 1;
-#pragma unroll
-                            for (int l = m; l <= LMAX; ++l)
-                                {
-                                if (active_l & (1u << l))                        // degrees with Ql_ref[l] != 0 (and l <= lmax)
-                                    {
-                                    const int idx = l * (l + 1) / 2 + m;
-                                    // `opaque0` (always 0, but derived from the pair slot) keeps these reads inside the pair
-                                    // loop: hoisted, the loop-invariant table takes ~110 registers and costs a wave per SIMD
-                                    const double qr = s_qw[2 * idx + opaque0], qi = s_qw[2 * idx + 1 + opaque0];
-                                    const double zr = harm_prev.re * qr - harm_prev.im * qi;
-                                    const double zi = harm_prev.re * qi + harm_prev.im * qr;
-                                    const double A = prev[l];
-                                    // dA/dtheta: m cot A_lm + sqrt((l-m)(l+m+1)) A_l,m+1 (:305-309); column m+1 is `cur` (0 beyond lmax)
-                                    double B = (double)m * cot * A;
-                                    if (l > m && mm <= LMAX) B += sqrt((double)((l - m) * (l + m + 1))) * cur[l];
-                                    U += A * zr;
-                                    V += B * zr;
-                                    W -= (double)m * A * zi;                     // Re(i m Y z) (:312)
-                                    }
-                                }
-                            }
-#pragma unroll
-                        for (int l = 0; l <= LMAX; ++l) prev[l] = cur[l];
-                        harm_prev = harm;
-                        sinpow *= g.st;
-                        harm = cmul(harm, {g.cp, g.sp});
-                        __builtin_amdgcn_sched_barrier(0);           // keep the orders m in sequence: interleaved by the
-                        }                                            // scheduler they need ~250 VGPRs instead of ~140
-                    const double e_theta[3] = {g.ct * g.cp, g.ct * g.sp, -g.st};                 // :288
-                    const double e_phi[3] = {-g.sp, g.cp, 0.0};
-                    const double fa = fprime_divr * U, fb = f * g.inv_r * V, fc = f * g.inv_rho * W;   // 1/(r sin theta) = 1/rho
-                    fpx = -(fa * g.dx + fb * e_theta[0] + fc * e_phi[0]);
-                    fpy = -(fa * g.dy + fb * e_theta[1] + fc * e_phi[1]);
-                    fpz = -(fa * g.dz + fb * e_theta[2] + fc * e_phi[2]);
-                    if (HALF)                                                                    // :328-333
-                        {
-                        const unsigned int j = s_j[t];
-                        if (j < a.N)
+                        if (j0 < a.N)
                             {
                             if (EXACT)
                                 {
-                                unsigned long long *aj = exact_acc + (size_t)j * QL_ACC_WORDS;
+                                unsigned long long *aj = exact_acc + (size_t)j0 * QL_ACC_WORDS;
                                 ql_exact_add(aj, 0, -fpx);
                                 ql_exact_add(aj, 1, -fpy);
                                 ql_exact_add(aj, 2, -fpz);
                                 }
                             else
                                 {
-                                scalar *fj = (scalar *)&force[j];
+                                scalar *fj = (scalar *)&force[j0];
                                 atomicAdd(fj + 0, (scalar)(-fpx));
                                 atomicAdd(fj + 1, (scalar)(-fpy));
                                 atomicAdd(fj + 2, (scalar)(-fpz));
@@ -746,48 +1084,64 @@ __global__ __launch_bounds__(QL_THREADS, (LMAX <= 6 ? 4 : 2)) void k_ql_forces(c
                             }
                         }
                     }
-                // the pair force replaces the separation in its own slot
-                cs.dx[t] = fpx;
-                cs.dy[t] = fpy;
-                cs.dz[t] = fpz;
+                s_fx[t] = fpx;
+                s_fy[t] = fpy;
+                s_fz[t] = fpz;
                 }
-            __syncthreads();
-            // per-particle sums over this batch of pairs, in list order
-            if (threadIdx.x < QL_PPB)
-                {
-                const unsigned int lo = cs.off[threadIdx.x] > base ? cs.off[threadIdx.x] - base : 0u;
-                unsigned int hi = cs.off[threadIdx.x + 1] > base ? cs.off[threadIdx.x + 1] - base : 0u;
-                if (hi > n) hi = n;
-                for (unsigned int t = lo; t < hi; ++t)
-                    {
-                    Fx += cs.dx[t];
-                    Fy += cs.dy[t];
-                    Fz += cs.dz[t];
-                    }
-                }
+            pos_raw = pos_ahead;
+            j0 = j1; j1 = j2; j2 = j3;
+            owners >>= 8;
             }
-        if (threadIdx.x < QL_PPB)
+        if (setup_wave) publish_planned(su[(n + 2) % 3], NU);
+        lds_barrier();                             // the unit's pair forces and unit n + 2's table are in LDS
+        // per-particle sums of this unit's pair forces: thread q of particle p takes entries lo + q, lo + q + 4, ...
             {
-            const unsigned int i = chunk * QL_PPB + threadIdx.x;
-            if (i < a.N)
+            const unsigned int p = tid >> 2, q = tid & 3u;
+            const unsigned int lo = U.off[p] > base ? U.off[p] - base : 0u;
+            unsigned int hi = U.off[p + 1] > base ? U.off[p + 1] - base : 0u;
+            if (hi > n_cur) hi = n_cur;
+            for (unsigned int t = lo + q; t < hi; t += 4)
                 {
-                if (HALF && EXACT)
+                Fx += s_fx[t];
+                Fy += s_fy[t];
+                Fz += s_fz[t];
+                }
+            if (base + CAP >= total)               // the chunk's last batch: (q0 + q1) + (q2 + q3), every lane of the quad gets it
+                {
+                Fx += dpp_move<MTD_DPP_QUAD_XOR1>(Fx);
+                Fy += dpp_move<MTD_DPP_QUAD_XOR1>(Fy);
+                Fz += dpp_move<MTD_DPP_QUAD_XOR1>(Fz);
+                Fx += dpp_move<MTD_DPP_QUAD_XOR2>(Fx);
+                Fy += dpp_move<MTD_DPP_QUAD_XOR2>(Fy);
+                Fz += dpp_move<MTD_DPP_QUAD_XOR2>(Fz);
+                const unsigned int i = chunk * PPB + p;
+                if (q == 0 && i < a.N)
                     {
-                    own[3 * (size_t)i + 0] = Fx;
-                    own[3 * (size_t)i + 1] = Fy;
-                    own[3 * (size_t)i + 2] = Fz;
+                    if (HALF && EXACT)
+                        {
+                        own[3 * (size_t)i + 0] = Fx;
+                        own[3 * (size_t)i + 1] = Fy;
+                        own[3 * (size_t)i + 2] = Fz;
+                        }
+                    else if (HALF)
+                        {
+                        scalar *fi = (scalar *)&force[i];
+                        atomicAdd(fi + 0, (scalar)Fx);
+                        atomicAdd(fi + 1, (scalar)Fy);
+                        atomicAdd(fi + 2, (scalar)Fz);
+                        }
+                    else
+                        nt_store(scalar4_traits<S4>::make((scalar)Fx, (scalar)Fy, (scalar)Fz, (scalar)0), force + i);   // written once, not re-read here
                     }
-                else if (HALF)
-                    {
-                    scalar *fi = (scalar *)&force[i];
-                    atomicAdd(fi + 0, (scalar)Fx);
-                    atomicAdd(fi + 1, (scalar)Fy);
-                    atomicAdd(fi + 2, (scalar)Fz);
-                    }
-                else
-                    nt_store(scalar4_traits<S4>::make((scalar)Fx, (scalar)Fy, (scalar)Fz, (scalar)0), force + i);   // written once, not re-read here
+                Fx = Fy = Fz = 0.0;
                 }
             }
+        // rotate: unit n + 1's entries become the current ones, unit n + 2's are requested
+#pragma unroll
+        for (int k = 0; k < K; ++k) j_cur[k] = j_next[k];
+        own_cur = own_next;
+        request_entries(su[(n + 2) % 3], j_next, own_next);
+        lds_barrier();                             // the sums are done with s_f*: the next unit may write its pair forces
         }
     }
 
@@ -882,6 +1236,35 @@ int accumulate_impl(unsigned int N, const void *d_postype, int dtype, const mtd_
     return MTD_SUCCESS;
     }
 
+// the force pass on as many blocks as are resident at once (every block then walks its chunks in a pipeline: k_ql_forces)
+template<typename S4, int LMAX, bool HALF, bool EXACT>
+void launch_forces(const QlArgs<LMAX> &a, const S4 *postype, const unsigned int *d_head, const unsigned int *d_nneigh, const unsigned int *d_nlist,
+                   const double *d_qlm, S4 *force, const double *d_bias, const double bias_host, unsigned long long *acc, double *own, const double *tab,
+                   hipStream_t s)
+    {
+    static std::mutex mtx;
+    static std::map<int, unsigned int> resident;                       // per device, for this instantiation of the kernel
+    unsigned int cap = 0;
+        {
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        std::lock_guard<std::mutex> lock(mtx);
+        auto it = resident.find(dev);
+        if (it == resident.end())
+            {
+            int per_cu = 0, cus = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_ql_forces<S4, LMAX, HALF, EXACT>, QL_THREADS, 0) != hipSuccess || per_cu < 1)
+                per_cu = 2;
+            if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
+            (void)hipGetLastError();
+            it = resident.emplace(dev, (unsigned int)(per_cu * cus)).first;
+            }
+        cap = it->second;
+        }
+    const unsigned int blocks = ql_blocks(a.N, QL_FRC_PPB, cap);
+    k_ql_forces<S4, LMAX, HALF, EXACT><<<blocks, QL_THREADS, 0, s>>>(a, postype, d_head, d_nneigh, d_nlist, d_qlm, force, d_bias, bias_host, acc, own, tab);
+    }
+
 template<int LMAX>
 int forces_impl(unsigned int N, const void *d_postype, void *d_force, int dtype, const mtd_box *box, const unsigned int *d_head,
                 const unsigned int *d_nneigh, const unsigned int *d_nlist, int half, double rcut, double ron, unsigned int lmax,
@@ -892,7 +1275,8 @@ int forces_impl(unsigned int N, const void *d_postype, void *d_force, int dtype,
     QlArgs<LMAX> a;
     int rc = fill_args<LMAX>(a, N, box, rcut, ron, lmax, type, ql_ref, n_global, half);
     if (rc) return rc;
-    const unsigned int blocks = ql_blocks(N, QL_FRC_PPB, 1024);
+    const double *tab = ql_device_table<LMAX>(s, rc);
+    if (rc) return rc;
     // half lists: exact integer accumulators (memset of :236 = clearing them), stream-ordered scratch from the device's pool
     unsigned long long *acc = nullptr;
     double *own = nullptr;
@@ -951,20 +1335,20 @@ int forces_impl(unsigned int N, const void *d_postype, void *d_force, int dtype,
     if (dtype == MTD_F32)
         {
         if (exact)
-            k_ql_forces<float4, LMAX, true, true><<<blocks, QL_THREADS, 0, s>>>(a, (const float4 *)d_postype, d_head, d_nneigh, d_nlist, d_qlm, (float4 *)d_force, d_bias, bias_host, acc, own);
+            launch_forces<float4, LMAX, true, true>(a, (const float4 *)d_postype, d_head, d_nneigh, d_nlist, d_qlm, (float4 *)d_force, d_bias, bias_host, acc, own, tab, s);
         else if (half)
-            k_ql_forces<float4, LMAX, true, false><<<blocks, QL_THREADS, 0, s>>>(a, (const float4 *)d_postype, d_head, d_nneigh, d_nlist, d_qlm, (float4 *)d_force, d_bias, bias_host, nullptr, nullptr);
+            launch_forces<float4, LMAX, true, false>(a, (const float4 *)d_postype, d_head, d_nneigh, d_nlist, d_qlm, (float4 *)d_force, d_bias, bias_host, nullptr, nullptr, tab, s);
         else
-            k_ql_forces<float4, LMAX, false, false><<<blocks, QL_THREADS, 0, s>>>(a, (const float4 *)d_postype, d_head, d_nneigh, d_nlist, d_qlm, (float4 *)d_force, d_bias, bias_host, nullptr, nullptr);
+            launch_forces<float4, LMAX, false, false>(a, (const float4 *)d_postype, d_head, d_nneigh, d_nlist, d_qlm, (float4 *)d_force, d_bias, bias_host, nullptr, nullptr, tab, s);
         }
     else
         {
         if (exact)
-            k_ql_forces<double4, LMAX, true, true><<<blocks, QL_THREADS, 0, s>>>(a, (const double4 *)d_postype, d_head, d_nneigh, d_nlist, d_qlm, (double4 *)d_force, d_bias, bias_host, acc, own);
+            launch_forces<double4, LMAX, true, true>(a, (const double4 *)d_postype, d_head, d_nneigh, d_nlist, d_qlm, (double4 *)d_force, d_bias, bias_host, acc, own, tab, s);
         else if (half)
-            k_ql_forces<double4, LMAX, true, false><<<blocks, QL_THREADS, 0, s>>>(a, (const double4 *)d_postype, d_head, d_nneigh, d_nlist, d_qlm, (double4 *)d_force, d_bias, bias_host, nullptr, nullptr);
+            launch_forces<double4, LMAX, true, false>(a, (const double4 *)d_postype, d_head, d_nneigh, d_nlist, d_qlm, (double4 *)d_force, d_bias, bias_host, nullptr, nullptr, tab, s);
         else
-            k_ql_forces<double4, LMAX, false, false><<<blocks, QL_THREADS, 0, s>>>(a, (const double4 *)d_postype, d_head, d_nneigh, d_nlist, d_qlm, (double4 *)d_force, d_bias, bias_host, nullptr, nullptr);
+            launch_forces<double4, LMAX, false, false>(a, (const double4 *)d_postype, d_head, d_nneigh, d_nlist, d_qlm, (double4 *)d_force, d_bias, bias_host, nullptr, nullptr, tab, s);
         }
     hipError_t launch_err = hipGetLastError();
     if (exact && N)
