@@ -38,10 +38,6 @@ namespace
 using namespace mtd;
 
 constexpr int QL_THREADS = 256;
-// chunk geometry {central particles per chunk, pair slots staged in LDS per batch (3 doubles each = 24 KB)}: the CV pass
-// runs four blocks per CU, the force pass three (140 VGPRs)
-constexpr int QL_ACC_PPB = 64, QL_ACC_CAP = 1024;
-constexpr int QL_FRC_PPB = 64, QL_FRC_CAP = 1024;
 constexpr unsigned int QL_MAX_BLOCKS = 1024;
 
 template<int LMAX> struct QlArgs
@@ -275,301 +271,485 @@ __device__ __forceinline__ void smoothing_tab(const QlArgs<LMAX> &a, const doubl
         }
     }
 
-// pair geometry shared by both passes: unit-vector trigonometry straight from the separation (theta = acos(dz/r),
-// phi = atan2(dy, dx) of :138-139 without the inverse functions)
-struct PairGeom
+// ---- units of work of the two pair passes ----------------------------------------------------------------------------------
+// A block walks chunks of QL_PPB consecutive central particles; the neighbour-list segments of a chunk, flattened, are cut
+// into batches of <= QL_CAP entries: one UNIT, spread one entry per thread (QL_K per thread), so the waves stay full whatever
+// the per-particle neighbour counts are.  Every memory trip of a unit — (own particle, list head, count) -> list entries ->
+// neighbour positions — is requested one stage ahead and left in flight across the arithmetic of the units before it (the
+// block barriers are LDS-only: lds_barrier).  The last wave of the block prepares the unit tables in LDS (QlFeed): prefix of
+// the counts, own positions, and the owner of every entry slot (a byte per slot, filled by the owner's lane: one LDS read
+// per entry instead of a six-step search).  The tables rotate in a ring; what is in flight when is told at the two kernels.
+constexpr int QL_PPB = 64, QL_CAP = 1024, QL_K = QL_CAP / QL_THREADS;
+static_assert(QL_PPB == MTD_WAVE, "one wave scans the neighbour counts of a chunk");
+static_assert(QL_K == 4 && QL_PPB <= 256, "owner bytes of a thread's entries packed in one register");
+
+struct QlUnit
     {
-    double dx, dy, dz, rsq, inv_r, inv_rho, ct, st, cp, sp;
+    unsigned int start[QL_PPB];          // head_list of the particle
+    unsigned int off[QL_PPB + 1];        // exclusive prefix of the neighbour counts inside the chunk
+    double px[QL_PPB], py[QL_PPB], pz[QL_PPB];   // the central particles' own positions
+    unsigned char owner[QL_CAP];         // owner[t]: central particle (index in the chunk) of list entry base + t
+    unsigned int chunk, base, total, valid;
     };
 
-__device__ __forceinline__ PairGeom pair_geom(double dx, double dy, double dz, double rsq)
-    {
-    PairGeom g;
-    g.dx = dx; g.dy = dy; g.dz = dz; g.rsq = rsq;
-    g.inv_r = rsqrt(rsq);
-    const double rho2 = dx * dx + dy * dy;
-    const bool off_axis = rho2 > 0.0;
-    g.inv_rho = off_axis ? rsqrt(rho2) : INFINITY;      // on the z axis 1/(r sin theta) is inf like the reference
-    g.ct = dz * g.inv_r;
-    g.st = off_axis ? rho2 * g.inv_rho * g.inv_r : 0.0;
-    g.cp = off_axis ? dx * g.inv_rho : 1.0;                  // atan2(0, 0) = 0
-    g.sp = off_axis ? dy * g.inv_rho : 0.0;
-    return g;
-    }
+template<typename S4> __device__ __forceinline__ S4 zero_s4();
+template<> __device__ __forceinline__ float4 zero_s4<float4>() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+template<> __device__ __forceinline__ double4 zero_s4<double4>() { return make_double4(0.0, 0.0, 0.0, 0.0); }
 
-// column m of the raw amplitudes (no Condon-Shortley phase): col[l] = scale * jacobi[m][l-m], l = m..lmax, where the caller
-// passes scale = sin^m(theta) / sqrt(2 pi) (times f in the CV pass) (spherical_harmonics.hpp:78-93, 177-226); the
-// recurrence runs in the degree n = l - m (:203-211).  m is a compile-time constant in the unrolled callers.
-template<int LMAX>
-__device__ __forceinline__ void amplitude_column(const QlArgs<LMAX> &a, const int m, const double ct, const double scale,
-                                                 double (&col)[LMAX + 1])
+// registers and logic of the wave that prepares the units (all 64 lanes: lane p = central particle p of the chunk)
+template<typename S4, int LMAX> struct QlFeed
     {
-    double jm2 = 0.0, jm1 = jac_0(m);
-#pragma unroll
-    for (int n = 0; n <= LMAX; ++n)
+    const QlArgs<LMAX> &a;
+    const S4 *__restrict__ postype;
+    const unsigned int *__restrict__ head_list;
+    const unsigned int *__restrict__ n_neigh;
+    unsigned int n_chunks, lane;
+    S4 pos;                               // requested ahead: the next chunk's particle, list head and count
+    unsigned int start, cnt;
+    unsigned int pend_kind, pend_chunk;   // the next unit to publish: 0 none, 1 first batch of chunk pend_chunk, 2 next batch of the same chunk
+
+    __device__ __forceinline__ QlFeed(const QlArgs<LMAX> &a_, const S4 *p_, const unsigned int *h_, const unsigned int *n_)
+        : a(a_), postype(p_), head_list(h_), n_neigh(n_), n_chunks((a_.N + QL_PPB - 1) / QL_PPB), lane(threadIdx.x & 63u),
+          pos(zero_s4<S4>()), start(0), cnt(0), pend_kind(0), pend_chunk(0)
         {
-        if (n + m <= LMAX)                       // degrees above the run-time lmax are computed too and never read: no selects
-            {
-            double j;
-            if (n == 0)
-                j = jac_0(m);
-            else if (n == 1)
-                j = ct * jac_f0(m, 1) * jm1;
-            else
-                j = ct * jac_f0(m, n) * jm1 + jac_f1(m, n) * jm2;
-            col[n + m] = scale * j;
-            jm2 = jm1;
-            jm1 = j;
-            }
         }
-    }
-
-// chunk bookkeeping shared by both passes: the neighbour-list segments of QL_PPB consecutive central particles, flattened;
-// the separations of up to QL_CAP pairs are gathered into LDS first (phase 1: independent loads, many in flight per
-// thread), the fp64 arithmetic then runs on LDS operands only (phase 2)
-template<int PPB, int CAP> struct ChunkShared
-    {
-    static constexpr int ppb = PPB, cap = CAP;
-    unsigned int start[PPB];          // head_list of the particle
-    unsigned int off[PPB + 1];        // exclusive prefix of the neighbour counts inside the chunk
-    unsigned int wave_total[PPB / MTD_WAVE];
-    double px[PPB], py[PPB], pz[PPB];              // the central particles' own positions
-    double dx[CAP], dy[CAP], dz[CAP];              // min-imaged separations r_i - r_j; excluded pairs carry an infinite dx
-    unsigned int kept[QL_THREADS / MTD_WAVE];      // CV pass: pairs each wave kept of its share of the batch (compacted segments)
-    };
-
-template<typename S4, int LMAX, typename CS>
-__device__ __forceinline__ void chunk_setup(const QlArgs<LMAX> &a, const S4 *__restrict__ postype,
-                                            const unsigned int *__restrict__ head_list, const unsigned int *__restrict__ n_neigh,
-                                            const unsigned int chunk, CS &cs)
-    {
-    constexpr int QL_PPB = CS::ppb;
-    __syncthreads();                                                             // previous chunk fully consumed
-    unsigned int incl = 0;
-    if (threadIdx.x < QL_PPB)
+    __device__ __forceinline__ void request(const unsigned int chunk)
         {
-        const unsigned int i = chunk * QL_PPB + threadIdx.x;
-        unsigned int st = 0, cnt = 0;
+        const unsigned int i = chunk * QL_PPB + lane;
+        pos = zero_s4<S4>();
+        start = cnt = 0;
         if (i < a.N)
             {
-            const Particle pi = scalar4_traits<S4>::load(postype, i);
-            cs.px[threadIdx.x] = pi.x;
-            cs.py[threadIdx.x] = pi.y;
-            cs.pz[threadIdx.x] = pi.z;
-            if ((unsigned int)pi.type == a.type)                                 // :105
-                {
-                st = head_list[i];
-                cnt = n_neigh[i];
-                }
+            pos = postype[i];
+            start = head_list[i];
+            cnt = n_neigh[i];
             }
-        cs.start[threadIdx.x] = st;
-        // inclusive scan of the counts inside each wave
-        incl = cnt;
-        const int lane = threadIdx.x & 63;
+        }
+    // the owner bytes of the unit's slots that belong to this lane's particle (entries [lo, hi) of the chunk)
+    __device__ __forceinline__ void fill_owner(QlUnit &u, const unsigned int base, unsigned int lo, unsigned int hi)
+        {
+        if (lo < base) lo = base;
+        if (hi > base + QL_CAP) hi = base + QL_CAP;
+#pragma clang loop vectorize(disable) unroll(disable)
+        for (unsigned int e = lo; e < hi; ++e) u.owner[e - base] = (unsigned char)lane;
+        }
+    // first batch of a chunk from the registers requested earlier; returns the chunk's number of list entries (wave-uniform)
+    __device__ __forceinline__ unsigned int publish_chunk(QlUnit &u, const unsigned int chunk)
+        {
+        const unsigned int i = chunk * QL_PPB + lane;
+        const Particle pi = scalar4_traits<S4>::unpack(pos);
+        const unsigned int c = (i < a.N && (unsigned int)pi.type == a.type) ? cnt : 0u;             // :105
+        u.px[lane] = pi.x;
+        u.py[lane] = pi.y;
+        u.pz[lane] = pi.z;
+        u.start[lane] = start;
+        unsigned int incl = c;
 #pragma unroll
         for (int d = 1; d < MTD_WAVE; d <<= 1)
             {
             const unsigned int up = __shfl_up(incl, d, MTD_WAVE);
-            if (lane >= d) incl += up;
+            if (lane >= (unsigned int)d) incl += up;
             }
-        if (lane == 63) cs.wave_total[threadIdx.x >> 6] = incl;
+        u.off[lane + 1] = incl;
+        fill_owner(u, 0, incl - c, incl);
+        const unsigned int total = (unsigned int)wave_read((int)incl, 63);
+        if (lane == 0)
+            {
+            u.off[0] = 0;
+            u.chunk = chunk;
+            u.base = 0;
+            u.total = total;
+            u.valid = 1;
+            }
+        return total;
         }
-    __syncthreads();
-    if (threadIdx.x < QL_PPB)
+    // what follows the unit (chunk, base, total): the next batch of the same chunk, the block's next chunk (its registers are
+    // requested here), or nothing
+    __device__ __forceinline__ void plan_after(const unsigned int chunk, const unsigned int base, const unsigned int total)
         {
-        unsigned int base = 0;
-        for (unsigned int w = 0; w < (threadIdx.x >> 6); ++w) base += cs.wave_total[w];
-        cs.off[threadIdx.x + 1] = base + incl;
-        if (threadIdx.x == 0) cs.off[0] = 0;
+        if (base + QL_CAP < total)
+            {
+            pend_kind = 2;
+            return;
+            }
+        pend_chunk = chunk + gridDim.x;
+        pend_kind = pend_chunk < n_chunks ? 1 : 0;
+        if (pend_kind) request(pend_chunk);
         }
-    __syncthreads();
-    }
-
-template<typename CS> __device__ __forceinline__ unsigned int chunk_owner(const CS &cs, const unsigned int e)
-    {
-    constexpr int QL_PPB = CS::ppb;
-    unsigned int p = 0;
+    // publish the planned unit into `u` (`prev` is the unit before it) and plan the one after it
+    __device__ __forceinline__ void publish_planned(QlUnit &u, const QlUnit &prev)
+        {
+        if (pend_kind == 1)
+            {
+            const unsigned int total = publish_chunk(u, pend_chunk);
+            plan_after(pend_chunk, 0, total);
+            }
+        else if (pend_kind == 2)
+            {
+            const unsigned int lo = prev.off[lane], hi = prev.off[lane + 1];
+            u.px[lane] = prev.px[lane];
+            u.py[lane] = prev.py[lane];
+            u.pz[lane] = prev.pz[lane];
+            u.start[lane] = prev.start[lane];
+            u.off[lane + 1] = hi;
+            const unsigned int chunk = prev.chunk, base = prev.base + QL_CAP, total = prev.total;
+            fill_owner(u, base, lo, hi);
+            if (lane == 0)
+                {
+                u.off[0] = 0;
+                u.chunk = chunk;
+                u.base = base;
+                u.total = total;
+                u.valid = 1;
+                }
+            plan_after(chunk, base, total);
+            }
+        else if (lane == 0)
+            u.valid = 0;
+        }
+    // the block's first units, one after the other (each waits for its own loads); the unit after them is planned
+    template<int N_FIRST> __device__ __forceinline__ void begin(QlUnit *ring)
+        {
+        if (blockIdx.x < n_chunks)
+            {
+            request(blockIdx.x);
+            const unsigned int total = publish_chunk(ring[0], blockIdx.x);
+            plan_after(blockIdx.x, 0, total);
+            }
+        else if (lane == 0)
+            ring[0].valid = 0;
 #pragma unroll
-    for (unsigned int step = QL_PPB / 2; step > 0; step >>= 1)
-        if (cs.off[p + step] <= e) p += step;
-    return p;
-    }
+        for (int n = 1; n < N_FIRST; ++n) publish_planned(ring[n], ring[n - 1]);
+        }
+    };
 
-// CV pass: the separations of entries [base, base + QL_CAP) of the chunk are gathered into LDS, but only the pairs that take
-// part are stored, densely: every wave appends the pairs it keeps
-// of its share of the batch (entries w*64 + lane + k*256) to its own segment [w * CAP/4, ...) of the LDS arrays, in entry
-// order (ballot + popcount: deterministic), and publishes the count.  Pairs beyond the cut-off (a neighbour list is built
-// with a buffer) or of another type no longer idle a lane of the arithmetic phase.  SYM (symmetric full list without ghost
-// particles: (i, j) listed <=> (j, i) listed): the pair is visited once, from its lower index — Y_lm(-d) = (-1)^l Y_lm(d),
-// so the two visits of the reference add up to twice the even degrees and cancel in the odd ones, which is exactly the
-// scaling the finalize step applies to half lists (SteinhardtQl.cc:173-179).
-template<typename S4, int LMAX, bool SYM, typename CS>
-__device__ __forceinline__ void chunk_gather_compact(const QlArgs<LMAX> &a, const S4 *__restrict__ postype,
-                                                     const unsigned int *__restrict__ nlist, const unsigned int chunk,
-                                                     const unsigned int base, const unsigned int n, CS &cs)
+// every thread: the list entries t = k * QL_THREADS + tid of a unit are requested (owner bytes of the thread's entries packed)
+__device__ __forceinline__ void ql_request_entries(const QlUnit &u, const unsigned int *__restrict__ nlist, unsigned int (&j)[QL_K],
+                                                   unsigned int &owners)
     {
-    constexpr unsigned int SEG = CS::cap / (QL_THREADS / MTD_WAVE);
-    const unsigned int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    unsigned int cnt = 0;                                                        // wave-uniform
+    owners = 0;
 #pragma unroll
-    for (unsigned int k = 0; k < CS::cap / QL_THREADS; ++k)
+    for (int k = 0; k < QL_K; ++k) j[k] = 0;
+    if (!u.valid) return;
+    const unsigned int base = u.base, n = min(u.total - base, (unsigned int)QL_CAP);
+#pragma unroll
+    for (int k = 0; k < QL_K; ++k)
         {
         const unsigned int t = k * QL_THREADS + threadIdx.x;
-        bool keep = false;
-        double dx = 0.0, dy = 0.0, dz = 0.0;
         if (t < n)
             {
-            const unsigned int e = base + t;
-            const unsigned int p = chunk_owner(cs, e);
-            const unsigned int j = nlist[cs.start[p] + (e - cs.off[p])];
-            if (!(SYM && j < chunk * CS::ppb + p))
-                {
-                const Particle pj = scalar4_traits<S4>::load(postype, j);
-                dx = cs.px[p] - pj.x; dy = cs.py[p] - pj.y; dz = cs.pz[p] - pj.z;
-                min_image(a, dx, dy, dz);
-                keep = (unsigned int)pj.type == a.type && (dx * dx + dy * dy + dz * dz <= a.rcutsq);   // :126, :141
-                }
+            const unsigned int p = u.owner[t];
+            j[k] = nlist[u.start[p] + (base + t - u.off[p])];
+            owners |= p << (8 * k);
             }
+        }
+    }
+
+// ---- CV accumulation -------------------------------------------------------------------------------
+// Q'_lm = sum over pairs of f Y_lm, in the monic amplitudes of the table (QlTab): a thread keeps R_lm += f p_m,l-m(cos theta) h^m
+// (h = sin(theta) e^{i phi} = (dx + i dy) / r) for every (l, m >= 0) in registers — 7 real + 21 complex sums at lmax = 6 — and
+// the normalisation |nrm(l, m)| is applied once per block at the end (the Condon-Shortley phase in the finalize step).  One
+// role per wave up to lmax = 8 (every wave visits different pairs); above that the orders m are split between two roles
+// (even / odd waves visit the same pairs with half of the sums each), or the sums would not fit the register file.
+// The pipeline (ring of four unit tables), iteration n:
+//   compaction   the list entries of unit n + 1 (requested two iterations ago) are filtered — SYM: a symmetric full list
+//                without ghost particles ((i, j) listed <=> (j, i) listed) is visited from the lower index only:
+//                Y_lm(-d) = (-1)^l Y_lm(d), so the two visits of the reference add up to twice the even degrees and cancel
+//                in the odd ones, which is exactly the scaling the finalize step applies to half lists (SteinhardtQl.cc:173-179)
+//                — and the survivors written densely to LDS, every wave its own segment in entry order (ballot + popcount)
+//   arithmetic   of unit n on the dense pairs, one per thread and round: the next pair's neighbour position is requested first;
+//                the last round requests the first pair of unit n + 1.  Pairs beyond the cut-off (a list built with a
+//                buffer) or of another type are dropped here
+//   last wave    publishes unit n + 3 from registers requested an iteration ago, requests unit n + 4's
+//   every thread requests the list entries of unit n + 3
+__host__ __device__ constexpr bool ql_role_has(const int m, const int role, const int n_roles)
+    {
+    return n_roles == 1 || ((m % 4 == 0 || m % 4 == 3) ? 0 : 1) == role;
+    }
+
+struct QlDense                                     // the pairs of a unit that are visited, densely
+    {
+    unsigned int j[QL_CAP];
+    unsigned char p[QL_CAP];
+    unsigned int kept[QL_THREADS / MTD_WAVE];      // per gathering wave: its segment [w * QL_CAP / 4, ...) holds this many
+    };
+
+struct QlAccPipe
+    {
+    QlUnit su[4];
+    QlDense dense[2];
+    };
+
+constexpr int QL_RED = 16, QL_RED_STRIDE = 65;     // the final sums over the lanes, 16 values at a time, rows padded against bank conflicts
+constexpr size_t QL_ACC_LDS = sizeof(QlAccPipe) > (QL_THREADS / MTD_WAVE) * (QL_RED * QL_RED_STRIDE + 64) * sizeof(double)
+                                  ? sizeof(QlAccPipe)
+                                  : (QL_THREADS / MTD_WAVE) * (QL_RED * QL_RED_STRIDE + 64) * sizeof(double);
+
+__device__ __forceinline__ void ql_compact(const QlUnit &u, const unsigned int (&j)[QL_K], const unsigned int owners, const bool sym, QlDense &d)
+    {
+    constexpr unsigned int SEG = QL_CAP / (QL_THREADS / MTD_WAVE);
+    const unsigned int lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const unsigned int n = u.valid ? min(u.total - u.base, (unsigned int)QL_CAP) : 0u;
+    const unsigned int first = u.chunk * QL_PPB;
+    unsigned int cnt = 0;                                                        // wave-uniform
+#pragma unroll
+    for (int k = 0; k < QL_K; ++k)
+        {
+        const unsigned int t = k * QL_THREADS + threadIdx.x;
+        const unsigned int p = (owners >> (8 * k)) & 255u;
+        const bool keep = t < n && !(sym && j[k] < first + p);
         const unsigned long long mask = __ballot(keep);
         if (keep)
             {
             const unsigned int slot = wave * SEG + cnt + (unsigned int)__popcll(mask & ((1ull << lane) - 1ull));
-            cs.dx[slot] = dx;
-            cs.dy[slot] = dy;
-            cs.dz[slot] = dz;
+            d.j[slot] = j[k];
+            d.p[slot] = (unsigned char)p;
             }
         cnt += (unsigned int)__popcll(mask);
         }
-    if (lane == 0) cs.kept[wave] = cnt;
-    __syncthreads();
+    if (lane == 0) d.kept[wave] = cnt;
     }
 
-// ---- CV accumulation -------------------------------------------------------------------------------
-// The 28 complex accumulators (lmax = 6) alone are 112 VGPRs: with everything else that is two waves per SIMD, and the fp64
-// dependency chains of the recurrence are then exposed.  So the orders m are split between two ROLES (even / odd waves of
-// the block): every pair is visited once per role (the geometry twice — cheap next to the recurrence), each role keeps half
-// of the accumulators, and four waves per SIMD fit.
-__host__ __device__ constexpr bool ql_role_has(const int m, const int role) { return ((m % 4 == 0 || m % 4 == 3) ? 0 : 1) == role; }
-
-typedef ChunkShared<QL_ACC_PPB, QL_ACC_CAP> AccChunk;
-
-template<int LMAX, int ROLE>
-__device__ __forceinline__ void ql_accumulate_pairs(const QlArgs<LMAX> &a, const AccChunk &cs, const unsigned int n,
-                                                    const unsigned int first, cplx (&Q)[LMAX + 1][LMAX + 1])
+// flat index of a dense pair -> its slot (the segments of the four gathering waves one after the other)
+struct QlDenseMap
     {
-    // the kept pairs of the batch sit in one segment per gathering wave (chunk_gather_compact): flat index -> segment
-    constexpr unsigned int SEG = AccChunk::cap / (QL_THREADS / MTD_WAVE);
-    const unsigned int c0 = cs.kept[0], c1 = c0 + cs.kept[1], c2 = c1 + cs.kept[2], kept = c2 + cs.kept[3];
-    (void)n;
-    for (unsigned int fi = first; fi < kept; fi += QL_THREADS / 2)
+    unsigned int c0, c1, c2, total;
+    __device__ __forceinline__ explicit QlDenseMap(const QlDense &d)
         {
-        const unsigned int seg = (fi >= c0) + (fi >= c1) + (fi >= c2);
-        const unsigned int t = seg * SEG + fi - (seg == 0 ? 0u : (seg == 1 ? c0 : (seg == 2 ? c1 : c2)));
-        const double dx = cs.dx[t], dy = cs.dy[t], dz = cs.dz[t];
-        const double rsq = dx * dx + dy * dy + dz * dz;
-        const PairGeom g = pair_geom(dx, dy, dz, rsq);
-        double f, fprime_divr;
-        smoothing(a, rsq, g.inv_r, f, fprime_divr);
-        // Q'_lm += f * Y'_lm, column by column
-        double sinpow = f * 0.3989422804014326779399460599343818684758586311649;   // 1 / sqrt(2 pi)
-        cplx harm = {1.0, 0.0};                                                    // e^{i m phi}
-#pragma unroll
-        for (int m = 0; m <= LMAX; ++m)
-            {
-            if (ql_role_has(m, ROLE))
-                {
-                double col[LMAX + 1];
-                amplitude_column<LMAX>(a, m, g.ct, 1.0, col);
-                const double hr = sinpow * harm.re, hi = sinpow * harm.im;
-#pragma unroll
-                for (int l = m; l <= LMAX; ++l)
-                    {
-                    Q[m][l].re += col[l] * hr;
-                    Q[m][l].im += col[l] * hi;
-                    }
-                }
-            sinpow *= g.st;
-            harm = cmul(harm, {g.cp, g.sp});
-            }
+        c0 = d.kept[0];
+        c1 = c0 + d.kept[1];
+        c2 = c1 + d.kept[2];
+        total = c2 + d.kept[3];
         }
-    }
+    __device__ __forceinline__ unsigned int slot(const unsigned int fi) const
+        {
+        constexpr unsigned int SEG = QL_CAP / (QL_THREADS / MTD_WAVE);
+        // segment s starts at flat index c_{s-1} and at slot s * SEG: every segment boundary passed adds its unused tail
+        return fi + (fi >= c0 ? SEG - c0 : 0u) + (fi >= c1 ? SEG - (c1 - c0) : 0u) + (fi >= c2 ? SEG - (c2 - c1) : 0u);
+        }
+    };
 
-template<int LMAX, int ROLE>
-__device__ __forceinline__ void ql_wave_reduce(const cplx (&Q)[LMAX + 1][LMAX + 1], double *s_row)
-    {
-    const int lane = threadIdx.x & 63;
-#pragma unroll
-    for (int l = 0; l <= LMAX; ++l)
-#pragma unroll
-        for (int m = 0; m <= l; ++m)
-            if (ql_role_has(m, ROLE))
-                {
-                const int idx = l * (l + 1) / 2 + m;
-                const double re = wave_sum(Q[m][l].re), im = wave_sum(Q[m][l].im);
-                if (lane == 0)
-                    {
-                    s_row[2 * idx] = re;
-                    s_row[2 * idx + 1] = im;
-                    }
-                }
-    }
-
-// the whole chunk loop of one role, with its own accumulators: the two instantiations sit in the two arms of a wave-uniform
-// branch, so their registers overlap (one shared Q array would keep all 28 entries live in both)
-template<typename S4, int LMAX, int ROLE, bool SYM>
+// the whole loop of one role with its own sums: for two roles the instantiations sit in the two arms of a wave-uniform branch,
+// so their registers overlap (one shared array would keep every sum live in both); both arms run the same sequence of block barriers
+template<typename S4, int LMAX, int ROLE, int NROLES, bool SYM, bool EVEN>
 __device__ __forceinline__ void ql_accumulate_role(const QlArgs<LMAX> &a, const S4 *__restrict__ postype,
                                                    const unsigned int *__restrict__ head_list, const unsigned int *__restrict__ n_neigh,
-                                                   const unsigned int *__restrict__ nlist, AccChunk &cs, double *s_row)
+                                                   const unsigned int *__restrict__ nlist, const double *__restrict__ tab, QlAccPipe &pipe,
+                                                   double *red /* this wave's scratch, aliases the pipe */, double *s_row)
     {
-    constexpr int QL_PPB = QL_ACC_PPB, QL_CAP = QL_ACC_CAP;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const unsigned int first = (wave >> 1) * MTD_WAVE + lane;       // this thread's first pair slot within its role
-    cplx Q[LMAX + 1][LMAX + 1];
+    typedef QlTab<LMAX> T;
+    constexpr int NLM = (LMAX + 1) * (LMAX + 2) / 2;
+    constexpr unsigned int TPR = QL_THREADS / NROLES;                          // threads of a role
+    const unsigned int tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const unsigned int r_tid = (wave / NROLES) * MTD_WAVE + lane;              // this thread among those of its role
+    const bool setup_wave = wave == QL_THREADS / MTD_WAVE - 1;
+    QlFeed<S4, LMAX> feed(a, postype, head_list, n_neigh);
+    cplx Q[LMAX + 1][LMAX + 1];                                                // [m][l]
 #pragma unroll
     for (int m = 0; m <= LMAX; ++m)
 #pragma unroll
         for (int l = 0; l <= LMAX; ++l) Q[m][l] = {0.0, 0.0};
-    const unsigned int n_chunks = (a.N + QL_PPB - 1) / QL_PPB;
-    for (unsigned int chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x)
+
+    // prologue: units 0..2 published, unit 3 planned; entries of units 0..2 requested, unit 0 compacted, its first pair requested
+    if (setup_wave) feed.template begin<3>(pipe.su);
+    lds_barrier();
+    unsigned int j_a[QL_K], j_b[QL_K], own_a, own_b;
         {
-        chunk_setup<S4, LMAX>(a, postype, head_list, n_neigh, chunk, cs);
-        const unsigned int total = cs.off[QL_PPB];
-        for (unsigned int base = 0; base < total; base += QL_CAP)
+        unsigned int j_0[QL_K], own_0;
+        ql_request_entries(pipe.su[0], nlist, j_0, own_0);
+        ql_request_entries(pipe.su[1], nlist, j_a, own_a);
+        ql_request_entries(pipe.su[2], nlist, j_b, own_b);
+        ql_compact(pipe.su[0], j_0, own_0, SYM, pipe.dense[0]);
+        }
+    lds_barrier();
+    S4 pos_raw = zero_s4<S4>();
+    unsigned int p_cur = 0;
+        {
+        const QlDenseMap map(pipe.dense[0]);
+        if (r_tid < map.total)
             {
-            const unsigned int n = min(total - base, (unsigned int)QL_CAP);
-            if (base) __syncthreads();                                         // previous batch consumed
-            chunk_gather_compact<S4, LMAX, SYM>(a, postype, nlist, chunk, base, n, cs);
-            ql_accumulate_pairs<LMAX, ROLE>(a, cs, n, first, Q);
+            const unsigned int s = map.slot(r_tid);
+            p_cur = pipe.dense[0].p[s];
+            pos_raw = postype[pipe.dense[0].j[s]];
             }
         }
-    // every wave owns the (l, m) entries of its role; the other entries of its row stay zero (cleared at entry, published by
-    // the barriers of the chunk loop)
-    ql_wave_reduce<LMAX, ROLE>(Q, s_row);
+
+    for (unsigned int n = 0;; ++n)
+        {
+        const QlUnit &U = pipe.su[n % 4];
+        if (!U.valid) break;                                                      // published before the last barrier
+        const QlDense &D = pipe.dense[n & 1];
+        QlDense &DN = pipe.dense[(n + 1) & 1];
+        ql_compact(pipe.su[(n + 1) % 4], j_a, own_a, SYM, DN);                    // (an invalid unit compacts to nothing)
+        lds_barrier();
+        const QlDenseMap map(D), map_next(DN);
+        const unsigned int rounds = (map.total + TPR - 1) / TPR;
+        if (rounds == 0 && r_tid < map_next.total)                                // nothing to visit: only the hand-over to the next unit
+            {
+            const unsigned int s = map_next.slot(r_tid);
+            p_cur = DN.p[s];
+            pos_raw = postype[DN.j[s]];
+            }
+#pragma unroll 1
+        for (unsigned int it = 0; it < rounds; ++it)
+            {
+            const unsigned int fi = it * TPR + r_tid;
+            unsigned int tab_shift = 0;
+            asm volatile("" : "+s"(tab_shift));                 // a zero the compiler cannot see through: the table loads stay in the loop
+            const double *__restrict__ tab_k = tab + tab_shift;
+            // the next pair's neighbour position is requested before this pair's arithmetic
+            const bool last = it + 1 == rounds;
+            const unsigned int fn = last ? r_tid : fi + TPR;
+            const QlDense &DA = last ? DN : D;
+            const bool want = fn < (last ? map_next.total : map.total);
+            S4 pos_ahead = zero_s4<S4>();
+            unsigned int p_ahead = 0;
+            if (want)
+                {
+                const unsigned int s = last ? map_next.slot(fn) : map.slot(fn);
+                p_ahead = DA.p[s];
+                pos_ahead = postype[DA.j[s]];
+                }
+            // a slot beyond the unit's pairs, a neighbour of another type or beyond the cut-off takes part with weight zero (on a
+            // harmless separation): no divergent branch around the 49 running sums
+                {
+                const Particle pj = scalar4_traits<S4>::unpack(pos_raw);
+                double dx = U.px[p_cur] - pj.x, dy = U.py[p_cur] - pj.y, dz = U.pz[p_cur] - pj.z;
+                min_image(a, dx, dy, dz);
+                double rsq = dx * dx + dy * dy + dz * dz;
+                const bool visit = fi < map.total && (unsigned int)pj.type == a.type && rsq <= a.rcutsq;     // :126, :141
+                if (!visit)
+                    {
+                    dx = dy = 0.0;
+                    dz = rsq = 1.0;
+                    }
+                const double inv_r = rsqrt(rsq);
+                const double ct = dz * inv_r, ex = dx * inv_r, ey = dy * inv_r;
+                double f, fprime_divr;
+                smoothing_tab<LMAX>(a, tab_k, rsq, inv_r, f, fprime_divr);
+                if (!visit) f = 0.0;
+                cplx fh = {f, 0.0};                                              // f h^m
+#pragma unroll
+                for (int m = 0; m <= LMAX; ++m)
+                    {
+                    if (ql_role_has(m, ROLE, NROLES))
+                        {
+                        double pm2 = 1.0, pm1 = ct;                              // p_m,n-2 and p_m,n-1
+#pragma unroll
+                        for (int nn = 0; m + nn <= LMAX; ++nn)
+                            {
+                            const int l = m + nn;
+                            const bool wanted = !(EVEN && (l % 2));              // odd degrees of a half / symmetric list: never read
+                            if (nn == 0)
+                                {
+                                if (wanted) Q[m][l].re += fh.re;
+                                if (wanted && m > 0) Q[m][l].im += fh.im;
+                                }
+                            else
+                                {
+                                double pn = ct;
+                                if (nn >= 2)
+                                    {
+                                    pn = ct * pm1 - tab_k[T::beta(m, nn)] * pm2;
+                                    pm2 = pm1;
+                                    pm1 = pn;
+                                    }
+                                if (wanted) Q[m][l].re += pn * fh.re;
+                                if (wanted && m > 0) Q[m][l].im += pn * fh.im;
+                                }
+                            }
+                        }
+                    if (m < LMAX) fh = m == 0 ? cplx{f * ex, f * ey} : cmul(fh, {ex, ey});
+                    }
+                }
+            pos_raw = pos_ahead;
+            p_cur = p_ahead;
+            }
+        if (setup_wave) feed.publish_planned(pipe.su[(n + 3) % 4], pipe.su[(n + 2) % 4]);
+        lds_barrier();                             // unit n + 3's table is in LDS; dense[n & 1] and unit n's table are free
+#pragma unroll
+        for (int k = 0; k < QL_K; ++k) j_a[k] = j_b[k];
+        own_a = own_b;
+        ql_request_entries(pipe.su[(n + 3) % 4], nlist, j_b, own_b);
+        }
+
+    // the sums over the lanes of this wave, QL_RED values at a time through LDS (the pipe's memory: every wave has left the
+    // loop): lane-major rows, 16 lanes add a row's quarter each in a fixed order, lanes 0..15 the four quarters.  A wave owns
+    // the (l, m) of its role; the other entries of its row stay zero.
+    lds_barrier();
+    double *part = red + QL_RED * QL_RED_STRIDE;
+#pragma unroll
+    for (int r = 0; r * QL_RED < 2 * NLM; ++r)
+        {
+#pragma unroll
+        for (int v = 0; v < QL_RED; ++v)
+            {
+            const int q = r * QL_RED + v;                        // slot in the row: 2 * (l (l + 1) / 2 + m) + (0: re, 1: im)
+            if (q < 2 * NLM)
+                {
+                int l = 0;
+                while ((l + 1) * (l + 2) / 2 <= q / 2) ++l;
+                const int m = q / 2 - l * (l + 1) / 2;
+                double val = 0.0;
+                if (ql_role_has(m, ROLE, NROLES) && !(EVEN && (l % 2))) val = (q & 1) ? (m > 0 ? Q[m][l].im : 0.0) : Q[m][l].re;
+                red[v * QL_RED_STRIDE + lane] = val;
+                }
+            }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const unsigned int v = lane & (QL_RED - 1), quarter = lane / QL_RED;
+        double sum = 0.0;
+        if (r * QL_RED + (int)v < 2 * NLM)
+            {
+#pragma unroll
+            for (int i = 0; i < MTD_WAVE / 4; ++i) sum += red[v * QL_RED_STRIDE + quarter * (MTD_WAVE / 4) + i];
+            }
+        part[quarter * QL_RED + v] = sum;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (lane < QL_RED && r * QL_RED + (int)lane < 2 * NLM)
+            s_row[r * QL_RED + lane] = (part[lane] + part[QL_RED + lane]) + (part[2 * QL_RED + lane] + part[3 * QL_RED + lane]);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
     }
 
-template<typename S4, int LMAX, bool SYM>
-__global__ __launch_bounds__(QL_THREADS, (LMAX <= 6 ? 4 : 2)) void k_ql_accumulate(const QlArgs<LMAX> a, const S4 *__restrict__ postype,
+template<int LMAX> constexpr int ql_acc_roles() { return LMAX <= 8 ? 1 : 2; }
+
+// EVEN: the list is a half list or a symmetric full one — the finalize step sets the odd degrees to zero (:173-179), so their
+// sums are not formed (16 of the 28 (l, m) at lmax = 6: half the registers, and room for a third or fourth wave per SIMD)
+template<int LMAX, bool EVEN> constexpr int ql_acc_blocks_per_cu() { return LMAX <= 6 ? (EVEN ? 3 : 2) : (LMAX <= 8 && EVEN ? 2 : 1); }
+
+template<typename S4, int LMAX, bool SYM, bool EVEN>
+__global__ __launch_bounds__(QL_THREADS, (ql_acc_blocks_per_cu<LMAX, EVEN>())) void k_ql_accumulate(const QlArgs<LMAX> a, const S4 *__restrict__ postype,
                                                                  const unsigned int *__restrict__ head_list,
                                                                  const unsigned int *__restrict__ n_neigh,
-                                                                 const unsigned int *__restrict__ nlist, double *__restrict__ partials)
+                                                                 const unsigned int *__restrict__ nlist, double *__restrict__ partials,
+                                                                 const double *__restrict__ tab)
     {
     constexpr int NLM = (LMAX + 1) * (LMAX + 2) / 2;
+    constexpr int NROLES = ql_acc_roles<LMAX>();
     __shared__ double s_wave[QL_THREADS / MTD_WAVE][2 * NLM];
-    __shared__ AccChunk cs;
+    __shared__ __attribute__((aligned(16))) unsigned char s_raw[QL_ACC_LDS];
+    QlAccPipe &pipe = *reinterpret_cast<QlAccPipe *>(s_raw);
     const int wave = threadIdx.x >> 6;
-    for (unsigned int q = threadIdx.x; q < (QL_THREADS / MTD_WAVE) * 2 * NLM; q += QL_THREADS) (&s_wave[0][0])[q] = 0.0;
-    // both arms run the same sequence of block barriers (the chunk loop depends on blockIdx and N only)
-    if (wave & 1)
-        ql_accumulate_role<S4, LMAX, 1, SYM>(a, postype, head_list, n_neigh, nlist, cs, s_wave[wave]);
+    double *red = reinterpret_cast<double *>(s_raw) + (size_t)wave * (QL_RED * QL_RED_STRIDE + 64);
+    if (NROLES == 1)
+        ql_accumulate_role<S4, LMAX, 0, 1, SYM, EVEN>(a, postype, head_list, n_neigh, nlist, tab, pipe, red, s_wave[wave]);
+    else if (wave & 1)
+        ql_accumulate_role<S4, LMAX, 1, 2, SYM, EVEN>(a, postype, head_list, n_neigh, nlist, tab, pipe, red, s_wave[wave]);
     else
-        ql_accumulate_role<S4, LMAX, 0, SYM>(a, postype, head_list, n_neigh, nlist, cs, s_wave[wave]);
+        ql_accumulate_role<S4, LMAX, 0, 2, SYM, EVEN>(a, postype, head_list, n_neigh, nlist, tab, pipe, red, s_wave[wave]);
     __syncthreads();
     const unsigned int n_out = (a.lmax + 1) * (a.lmax + 2);     // 2 * n_lm of the RUNTIME lmax (same (l,m) order)
     for (unsigned int q = threadIdx.x; q < n_out; q += blockDim.x)
         {
         double v = 0.0;
         for (int w = 0; w < QL_THREADS / MTD_WAVE; ++w) v += s_wave[w][q];
-        partials[(size_t)blockIdx.x * n_out + q] = v;
+        partials[(size_t)blockIdx.x * n_out + q] = v * fabs(tab[QlTab<LMAX>::NRM + q / 2]);     // the monic amplitudes' normalisation
         }
     }
 
@@ -730,7 +910,7 @@ __global__ __launch_bounds__(256) void k_ql_exact_to_force(const unsigned long l
 // the SAME list entries in both roles (it fetches the neighbour of entry t and computes the pair of entry t), so the
 // separations no longer pass through LDS, and every trip is requested one stage ahead and left in flight across the
 // arithmetic (the block barriers are LDS-only: lds_barrier):
-//   unit n      = one batch of <= QL_FRC_CAP list entries of one chunk of QL_FRC_PPB central particles
+//   unit n      = one batch of <= QL_CAP list entries of one chunk of QL_PPB central particles
 //   arithmetic  of unit n, entry k of the thread: the neighbour position of entry k + 1 is requested first; the last entry
 //               requests the first neighbour of unit n + 1 (its list entries are in registers since the end of unit n - 1)
 //   wave 3      (the wave with the fewest entries in a partly filled batch) publishes unit n + 2's prefix table and own
@@ -740,24 +920,6 @@ __global__ __launch_bounds__(256) void k_ql_exact_to_force(const unsigned long l
 // Three unit tables rotate in LDS (unit n in use, n + 1 referenced by the requests, n + 2 being written).
 // EXACT (half lists): reaction forces into the exact accumulators, the particle's own sum into own[i] — the conversion pass
 // adds it; !EXACT: the floating-point atomics of round 1 (mtd_ql_set_half_list_exact(0): 2.5 x faster, sums in arrival order).
-template<int PPB> struct FrcUnit
-    {
-    unsigned int start[PPB];          // head_list of the particle
-    unsigned int off[PPB + 1];        // exclusive prefix of the neighbour counts inside the chunk
-    double px[PPB], py[PPB], pz[PPB]; // the central particles' own positions
-    unsigned int chunk, base, total, valid;
-    };
-
-template<typename S4> struct FrcSetupRegs
-    {
-    S4 pos;
-    unsigned int start, cnt;
-    };
-
-template<typename S4> __device__ __forceinline__ S4 zero_s4();
-template<> __device__ __forceinline__ float4 zero_s4<float4>() { return make_float4(0.f, 0.f, 0.f, 0.f); }
-template<> __device__ __forceinline__ double4 zero_s4<double4>() { return make_double4(0.0, 0.0, 0.0, 0.0); }
-
 // the pair force of one list entry (SteinhardtQl.cc:287-333 contracted as the header describes), in the monic amplitudes:
 // with h = sin(theta) e^{i phi} = (dx + i dy) / r, P = p_m,l-m(cos theta) and Z_lm = h^m q_lm (q_lm = nrm(l, m) w_l conj(Q_lm)
 // from LDS),
@@ -857,14 +1019,12 @@ __global__ __launch_bounds__(QL_THREADS, (LMAX <= 6 ? 3 : 2)) void k_ql_forces(c
                                                              const double *__restrict__ tab)
     {
     typedef typename scalar4_traits<S4>::scalar scalar;
-    typedef FrcUnit<QL_FRC_PPB> Unit;
     constexpr int NLM = (LMAX + 1) * (LMAX + 2) / 2;
-    constexpr unsigned int PPB = QL_FRC_PPB, CAP = QL_FRC_CAP;
-    constexpr int K = QL_FRC_CAP / QL_THREADS;                 // list entries per thread and unit
-    static_assert(QL_FRC_PPB == MTD_WAVE, "one wave scans the neighbour counts of a chunk");
-    static_assert(K == 4 && QL_THREADS == 4 * QL_FRC_PPB, "owner bytes packed in one register; four summing threads per particle");
+    constexpr unsigned int PPB = QL_PPB, CAP = QL_CAP;
+    constexpr int K = QL_K;                                    // list entries per thread and unit
+    static_assert(QL_THREADS == 4 * QL_PPB, "four summing threads per particle");
     __shared__ double s_qw[2 * NLM];                 // w_l (2 or 4) conj(Q_lm), m >= 0, index l(l+1)/2 + m
-    __shared__ Unit su[3];
+    __shared__ QlUnit su[3];
     __shared__ double s_fx[CAP], s_fy[CAP], s_fz[CAP];          // pair forces of the unit, by list entry
     const unsigned int tid = threadIdx.x, lane = tid & 63u;
     const bool setup_wave = (tid >> 6) == QL_THREADS / MTD_WAVE - 1;
@@ -893,148 +1053,22 @@ __global__ __launch_bounds__(QL_THREADS, (LMAX <= 6 ? 3 : 2)) void k_ql_forces(c
         s_qw[2 * q] = re;
         s_qw[2 * q + 1] = im;
         }
-    const unsigned int n_chunks = (a.N + PPB - 1) / PPB;
-
-    // ---- wave 3: the unit tables ----
-    FrcSetupRegs<S4> sr;
-    sr.pos = zero_s4<S4>();
-    sr.start = sr.cnt = 0;
-    auto request_setup = [&](const unsigned int chunk)
-        {
-        const unsigned int i = chunk * PPB + lane;
-        sr.pos = zero_s4<S4>();
-        sr.start = sr.cnt = 0;
-        if (i < a.N)
-            {
-            sr.pos = postype[i];
-            sr.start = head_list[i];
-            sr.cnt = n_neigh[i];
-            }
-        };
-    // first batch of a chunk, from the registers requested earlier; returns the chunk's number of list entries (wave-uniform)
-    auto publish_chunk = [&](Unit &u, const unsigned int chunk) -> unsigned int
-        {
-        const unsigned int i = chunk * PPB + lane;
-        const Particle pi = scalar4_traits<S4>::unpack(sr.pos);
-        const unsigned int cnt = (i < a.N && (unsigned int)pi.type == a.type) ? sr.cnt : 0u;       // :105
-        u.px[lane] = pi.x;
-        u.py[lane] = pi.y;
-        u.pz[lane] = pi.z;
-        u.start[lane] = sr.start;
-        unsigned int incl = cnt;
-#pragma unroll
-        for (int d = 1; d < MTD_WAVE; d <<= 1)
-            {
-            const unsigned int up = __shfl_up(incl, d, MTD_WAVE);
-            if (lane >= (unsigned int)d) incl += up;
-            }
-        u.off[lane + 1] = incl;
-        const unsigned int total = (unsigned int)wave_read((int)incl, 63);
-        if (lane == 0)
-            {
-            u.off[0] = 0;
-            u.chunk = chunk;
-            u.base = 0;
-            u.total = total;
-            u.valid = 1;
-            }
-        return total;
-        };
-    // what follows a unit (chunk, base, total): the next batch of the same chunk, the block's next chunk, or nothing
-    // kind: 0 nothing, 1 a new chunk (its setup registers are requested here), 2 the next batch of the same chunk
-    unsigned int pend_kind = 0, pend_chunk = 0;
-    auto plan_after = [&](const unsigned int chunk, const unsigned int base, const unsigned int total)
-        {
-        if (base + CAP < total)
-            {
-            pend_kind = 2;
-            return;
-            }
-        pend_chunk = chunk + gridDim.x;
-        pend_kind = pend_chunk < n_chunks ? 1 : 0;
-        if (pend_kind) request_setup(pend_chunk);
-        };
-    // publish the planned unit into `u` (`prev` is the unit before it) and plan the one after it
-    auto publish_planned = [&](Unit &u, const Unit &prev)
-        {
-        if (pend_kind == 1)
-            {
-            const unsigned int total = publish_chunk(u, pend_chunk);
-            plan_after(pend_chunk, 0, total);
-            }
-        else if (pend_kind == 2)
-            {
-            u.px[lane] = prev.px[lane];
-            u.py[lane] = prev.py[lane];
-            u.pz[lane] = prev.pz[lane];
-            u.start[lane] = prev.start[lane];
-            u.off[lane + 1] = prev.off[lane + 1];
-            const unsigned int chunk = prev.chunk, base = prev.base + CAP, total = prev.total;
-            if (lane == 0)
-                {
-                u.off[0] = 0;
-                u.chunk = chunk;
-                u.base = base;
-                u.total = total;
-                u.valid = 1;
-                }
-            plan_after(chunk, base, total);
-            }
-        else if (lane == 0)
-            u.valid = 0;
-        };
-
-    // ---- every thread: the list entries of a unit (owner search in the unit's prefix table) ----
-    auto request_entries = [&](const Unit &u, unsigned int (&j)[K], unsigned int &owners)
-        {
-        owners = 0;
-#pragma unroll
-        for (int k = 0; k < K; ++k) j[k] = 0;
-        if (!u.valid) return;
-        const unsigned int base = u.base, n = min(u.total - base, CAP);
-#pragma unroll
-        for (int k = 0; k < K; ++k)
-            {
-            const unsigned int t = k * QL_THREADS + tid;
-            if (t < n)
-                {
-                const unsigned int e = base + t;
-                unsigned int p = 0;
-#pragma unroll
-                for (unsigned int step = PPB / 2; step > 0; step >>= 1)
-                    if (u.off[p + step] <= e) p += step;
-                j[k] = nlist[u.start[p] + (e - u.off[p])];
-                owners |= p << (8 * k);
-                }
-            }
-        };
-
     // ---- prologue: units 0 and 1 published, unit 2 planned; entries of units 0 and 1 and the first neighbour requested ----
-    if (setup_wave)
-        {
-        if (blockIdx.x < n_chunks)
-            {
-            request_setup(blockIdx.x);
-            const unsigned int total = publish_chunk(su[0], blockIdx.x);
-            plan_after(blockIdx.x, 0, total);
-            }
-        else if (lane == 0)
-            su[0].valid = 0;
-        publish_planned(su[1], su[0]);
-        }
+    QlFeed<S4, LMAX> feed(a, postype, head_list, n_neigh);
+    if (setup_wave) feed.template begin<2>(su);
     lds_barrier();
     unsigned int j_cur[K], j_next[K], own_cur, own_next;
-    request_entries(su[0], j_cur, own_cur);
-    request_entries(su[1], j_next, own_next);
+    ql_request_entries(su[0], nlist, j_cur, own_cur);
+    ql_request_entries(su[1], nlist, j_next, own_next);
     S4 pos_raw = zero_s4<S4>();
     if (su[0].valid && tid < min(su[0].total, CAP)) pos_raw = postype[j_cur[0]];
     double Fx = 0.0, Fy = 0.0, Fz = 0.0;             // thread (p = tid / 4, q = tid % 4): every fourth pair force of particle p
 
     for (unsigned int n = 0;; ++n)
         {
-        const Unit &U = su[n % 3];
+        const QlUnit &U = su[n % 3];
         if (!U.valid) break;                                                      // published before the last barrier
-        const Unit &NU = su[(n + 1) % 3];
+        const QlUnit &NU = su[(n + 1) % 3];
         const unsigned int base = U.base, total = U.total, chunk = U.chunk;
         const unsigned int n_cur = min(total - base, CAP);
         const unsigned int n_next = NU.valid ? min(NU.total - NU.base, CAP) : 0u;
@@ -1092,7 +1126,7 @@ __global__ __launch_bounds__(QL_THREADS, (LMAX <= 6 ? 3 : 2)) void k_ql_forces(c
             j0 = j1; j1 = j2; j2 = j3;
             owners >>= 8;
             }
-        if (setup_wave) publish_planned(su[(n + 2) % 3], NU);
+        if (setup_wave) feed.publish_planned(su[(n + 2) % 3], NU);
         lds_barrier();                             // the unit's pair forces and unit n + 2's table are in LDS
         // per-particle sums of this unit's pair forces: thread q of particle p takes entries lo + q, lo + q + 4, ...
             {
@@ -1140,7 +1174,7 @@ __global__ __launch_bounds__(QL_THREADS, (LMAX <= 6 ? 3 : 2)) void k_ql_forces(c
 #pragma unroll
         for (int k = 0; k < K; ++k) j_cur[k] = j_next[k];
         own_cur = own_next;
-        request_entries(su[(n + 2) % 3], j_next, own_next);
+        ql_request_entries(su[(n + 2) % 3], nlist, j_next, own_next);
         lds_barrier();                             // the sums are done with s_f*: the next unit may write its pair forces
         }
     }
@@ -1193,6 +1227,39 @@ void launch_finalize(const QlArgs<LMAX> &a, const double *d_qprime, double *d_ql
         k_ql_finalize<LMAX><<<1, 256, 0, s>>>(a, d_qprime, d_qlm, d_ql, d_value);
     }
 
+// blocks of `kernel` that are resident at once on the current device (both pair passes launch exactly that many, or fewer if the
+// system is small: every block then walks its chunks in a pipeline); cached per (kernel, device)
+template<typename Kernel> unsigned int ql_resident_blocks(Kernel kernel)
+    {
+    static std::mutex mtx;
+    static std::map<std::pair<const void *, int>, unsigned int> resident;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> lock(mtx);
+    const std::pair<const void *, int> key((const void *)kernel, dev);
+    auto it = resident.find(key);
+    if (it == resident.end())
+        {
+        int per_cu = 0, cus = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, QL_THREADS, 0) != hipSuccess || per_cu < 1) per_cu = 1;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
+        (void)hipGetLastError();
+        unsigned int n = (unsigned int)(per_cu * cus);
+        if (n > QL_MAX_BLOCKS) n = QL_MAX_BLOCKS;                      // the scratch holds this many rows of partial sums
+        it = resident.emplace(key, n).first;
+        }
+    return it->second;
+    }
+
+template<typename S4, int LMAX, bool SYM, bool EVEN>
+unsigned int launch_accumulate(const QlArgs<LMAX> &a, const S4 *postype, const unsigned int *d_head, const unsigned int *d_nneigh,
+                               const unsigned int *d_nlist, double *d_partials, const double *tab, hipStream_t s)
+    {
+    const unsigned int blocks = ql_blocks(a.N, QL_PPB, ql_resident_blocks(k_ql_accumulate<S4, LMAX, SYM, EVEN>));
+    k_ql_accumulate<S4, LMAX, SYM, EVEN><<<blocks, QL_THREADS, 0, s>>>(a, postype, d_head, d_nneigh, d_nlist, d_partials, tab);
+    return blocks;
+    }
+
 template<int LMAX>
 int accumulate_impl(unsigned int N, const void *d_postype, int dtype, const mtd_box *box, const unsigned int *d_head,
                     const unsigned int *d_nneigh, const unsigned int *d_nlist, int half, double rcut, double ron, unsigned int lmax,
@@ -1200,7 +1267,7 @@ int accumulate_impl(unsigned int N, const void *d_postype, int dtype, const mtd_
                     double *d_qprime, double *d_qlm, double *d_ql, double *d_value, bool accumulate, bool finalize, hipStream_t s)
     {
     // half: 0 full list, 1 half list, 2 full list that is symmetric and indexes no ghost particle — the CV pass then visits
-    // every pair once and the finalize step scales like for a half list (chunk_gather_compact)
+    // every pair once and the finalize step scales like for a half list (ql_compact)
     QlArgs<LMAX> a;
     int rc = fill_args<LMAX>(a, N, box, rcut, ron, lmax, type, ql_ref, n_global, half != 0);
     if (rc) return rc;
@@ -1210,22 +1277,18 @@ int accumulate_impl(unsigned int N, const void *d_postype, int dtype, const mtd_
         MTD_LAUNCH_CHECK();
         return MTD_SUCCESS;
         }
-    const unsigned int blocks = ql_blocks(N, QL_ACC_PPB, 1024);
+    const double *tab = ql_device_table<LMAX>(s, rc);
+    if (rc) return rc;
     const unsigned int n_out = (lmax + 1) * (lmax + 2);
+    unsigned int blocks = 0;
     if (dtype == MTD_F32)
-        {
-        if (half == 2)
-            k_ql_accumulate<float4, LMAX, true><<<blocks, QL_THREADS, 0, s>>>(a, (const float4 *)d_postype, d_head, d_nneigh, d_nlist, d_partials);
-        else
-            k_ql_accumulate<float4, LMAX, false><<<blocks, QL_THREADS, 0, s>>>(a, (const float4 *)d_postype, d_head, d_nneigh, d_nlist, d_partials);
-        }
+        blocks = half == 2   ? launch_accumulate<float4, LMAX, true, true>(a, (const float4 *)d_postype, d_head, d_nneigh, d_nlist, d_partials, tab, s)
+                 : half == 1 ? launch_accumulate<float4, LMAX, false, true>(a, (const float4 *)d_postype, d_head, d_nneigh, d_nlist, d_partials, tab, s)
+                             : launch_accumulate<float4, LMAX, false, false>(a, (const float4 *)d_postype, d_head, d_nneigh, d_nlist, d_partials, tab, s);
     else
-        {
-        if (half == 2)
-            k_ql_accumulate<double4, LMAX, true><<<blocks, QL_THREADS, 0, s>>>(a, (const double4 *)d_postype, d_head, d_nneigh, d_nlist, d_partials);
-        else
-            k_ql_accumulate<double4, LMAX, false><<<blocks, QL_THREADS, 0, s>>>(a, (const double4 *)d_postype, d_head, d_nneigh, d_nlist, d_partials);
-        }
+        blocks = half == 2   ? launch_accumulate<double4, LMAX, true, true>(a, (const double4 *)d_postype, d_head, d_nneigh, d_nlist, d_partials, tab, s)
+                 : half == 1 ? launch_accumulate<double4, LMAX, false, true>(a, (const double4 *)d_postype, d_head, d_nneigh, d_nlist, d_partials, tab, s)
+                             : launch_accumulate<double4, LMAX, false, false>(a, (const double4 *)d_postype, d_head, d_nneigh, d_nlist, d_partials, tab, s);
     MTD_LAUNCH_CHECK();
     *n_partials = blocks;
     rc = mtd_reduce_partials(d_partials, blocks, n_out, n_out, 1.0, 0.0, d_qprime, (mtd_stream_t)s);
@@ -1236,32 +1299,13 @@ int accumulate_impl(unsigned int N, const void *d_postype, int dtype, const mtd_
     return MTD_SUCCESS;
     }
 
-// the force pass on as many blocks as are resident at once (every block then walks its chunks in a pipeline: k_ql_forces)
 template<typename S4, int LMAX, bool HALF, bool EXACT>
 void launch_forces(const QlArgs<LMAX> &a, const S4 *postype, const unsigned int *d_head, const unsigned int *d_nneigh, const unsigned int *d_nlist,
                    const double *d_qlm, S4 *force, const double *d_bias, const double bias_host, unsigned long long *acc, double *own, const double *tab,
                    hipStream_t s)
     {
-    static std::mutex mtx;
-    static std::map<int, unsigned int> resident;                       // per device, for this instantiation of the kernel
-    unsigned int cap = 0;
-        {
-        int dev = 0;
-        (void)hipGetDevice(&dev);
-        std::lock_guard<std::mutex> lock(mtx);
-        auto it = resident.find(dev);
-        if (it == resident.end())
-            {
-            int per_cu = 0, cus = 0;
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_ql_forces<S4, LMAX, HALF, EXACT>, QL_THREADS, 0) != hipSuccess || per_cu < 1)
-                per_cu = 2;
-            if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
-            (void)hipGetLastError();
-            it = resident.emplace(dev, (unsigned int)(per_cu * cus)).first;
-            }
-        cap = it->second;
-        }
-    const unsigned int blocks = ql_blocks(a.N, QL_FRC_PPB, cap);
+    const unsigned int cap = ql_resident_blocks(k_ql_forces<S4, LMAX, HALF, EXACT>);
+    const unsigned int blocks = ql_blocks(a.N, QL_PPB, cap);
     k_ql_forces<S4, LMAX, HALF, EXACT><<<blocks, QL_THREADS, 0, s>>>(a, postype, d_head, d_nneigh, d_nlist, d_qlm, force, d_bias, bias_host, acc, own, tab);
     }
 
@@ -1471,34 +1515,42 @@ __global__ void k_sym_sort(const unsigned int n, const unsigned int *__restrict_
 
 namespace
 {
-// Diagnostic: the spherical harmonics exactly as the pair kernels evaluate them — pair_geom's unit-vector trigonometry from a
-// separation, amplitude_column's Jacobi recurrence with the prefactors folded to literals, e^{i m phi} by repeated
-// multiplication, sin^m(theta) / sqrt(2 pi) by repeated multiplication (ql_accumulate_pairs with f = 1) — one thread per
-// direction, written in fsph's order (spherical_harmonics.hpp:229-246, full_m: per degree l the orders 0..l, then -1..-l as
-// plain conjugates).  tests/test_gpu_golden.py holds it against the vectors the reference's own header produced.
+// Diagnostic: the spherical harmonics exactly as the pair kernels evaluate them — h = (dx + i dy) / r and cos(theta) = dz / r
+// straight from the separation, the monic recurrence with its constants from the device table, h^m by repeated multiplication,
+// |nrm(l, m)| at the end (ql_accumulate_role with f = 1) — one thread per direction, written in fsph's order
+// (spherical_harmonics.hpp:229-246, full_m: per degree l the orders 0..l, then -1..-l as plain conjugates).
+// tests/test_gpu_golden.py holds it against the vectors the reference's own header produced.
 template<int LMAX>
-__global__ void k_debug_sph(const unsigned int n, const unsigned int lmax, const double *__restrict__ sep, double *__restrict__ out)
+__global__ void k_debug_sph(const unsigned int n, const unsigned int lmax, const double *__restrict__ sep, double *__restrict__ out,
+                            const double *__restrict__ tab)
     {
+    typedef QlTab<LMAX> T;
     const unsigned int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n) return;
-    QlArgs<LMAX> a;
-    a.lmax = lmax;
     const double dx = sep[3 * t], dy = sep[3 * t + 1], dz = sep[3 * t + 2];
-    const PairGeom g = pair_geom(dx, dy, dz, dx * dx + dy * dy + dz * dz);
+    const double inv_r = rsqrt(dx * dx + dy * dy + dz * dz);
+    const double ct = dz * inv_r, ex = dx * inv_r, ey = dy * inv_r;
     double *o = out + (size_t)t * 2 * (lmax + 1) * (lmax + 1);
-    double sinpow = 0.3989422804014326779399460599343818684758586311649;   // 1 / sqrt(2 pi)
-    cplx harm = {1.0, 0.0};
+    cplx h = {1.0, 0.0};
 #pragma unroll
     for (int m = 0; m <= LMAX; ++m)
         {
-        double col[LMAX + 1];
-        amplitude_column<LMAX>(a, m, g.ct, 1.0, col);
-        const double hr = sinpow * harm.re, hi = sinpow * harm.im;
+        double pm2 = 1.0, pm1 = ct;
 #pragma unroll
-        for (int l = m; l <= LMAX; ++l)
+        for (int nn = 0; m + nn <= LMAX; ++nn)
+            {
+            const int l = m + nn;
+            double pn = nn == 0 ? 1.0 : ct;
+            if (nn >= 2)
+                {
+                pn = ct * pm1 - tab[T::beta(m, nn)] * pm2;
+                pm2 = pm1;
+                pm1 = pn;
+                }
             if (l <= (int)lmax)
                 {
-                const double re = col[l] * hr, im = col[l] * hi;
+                const double nrm = fabs(tab[T::nrm(l, m)]);
+                const double re = nrm * (pn * h.re), im = nrm * (pn * h.im);
                 o[2 * (l * l + m)] = re;
                 o[2 * (l * l + m) + 1] = im;
                 if (m > 0)
@@ -1507,8 +1559,8 @@ __global__ void k_debug_sph(const unsigned int n, const unsigned int lmax, const
                     o[2 * (l * l + l + m) + 1] = -im;
                     }
                 }
-        sinpow *= g.st;
-        harm = cmul(harm, {g.cp, g.sp});
+            }
+        h = cmul(h, {ex, ey});
         }
     }
 } // namespace
@@ -1583,11 +1635,28 @@ int mtd_debug_sph_harmonics(unsigned int lmax, unsigned int n, const double *h_s
     if (e == hipSuccess)
         {
         const unsigned int blocks = (n + 63) / 64;
-        if (lmax <= 4) k_debug_sph<4><<<blocks, 64>>>(n, lmax, d_sep, d_out);
-        else if (lmax <= 6) k_debug_sph<6><<<blocks, 64>>>(n, lmax, d_sep, d_out);
-        else if (lmax <= 8) k_debug_sph<8><<<blocks, 64>>>(n, lmax, d_sep, d_out);
-        else k_debug_sph<12><<<blocks, 64>>>(n, lmax, d_sep, d_out);
-        e = hipGetLastError();
+        int rc = MTD_SUCCESS;
+        if (lmax <= 4)
+            {
+            const double *tab = ql_device_table<4>(nullptr, rc);
+            if (!rc) k_debug_sph<4><<<blocks, 64>>>(n, lmax, d_sep, d_out, tab);
+            }
+        else if (lmax <= 6)
+            {
+            const double *tab = ql_device_table<6>(nullptr, rc);
+            if (!rc) k_debug_sph<6><<<blocks, 64>>>(n, lmax, d_sep, d_out, tab);
+            }
+        else if (lmax <= 8)
+            {
+            const double *tab = ql_device_table<8>(nullptr, rc);
+            if (!rc) k_debug_sph<8><<<blocks, 64>>>(n, lmax, d_sep, d_out, tab);
+            }
+        else
+            {
+            const double *tab = ql_device_table<12>(nullptr, rc);
+            if (!rc) k_debug_sph<12><<<blocks, 64>>>(n, lmax, d_sep, d_out, tab);
+            }
+        e = rc ? (hipError_t)rc : hipGetLastError();
         }
     if (e == hipSuccess) e = hipMemcpy(h_out, d_out, n_out * sizeof(double), hipMemcpyDeviceToHost);
     (void)hipFree(d_sep);
