@@ -554,7 +554,7 @@ int mtd_fused_cv_pass(mtd_metad *m, const mtd_lamellar_set *set, unsigned int n_
     const unsigned int blocks = lam_cv_blocks(n_particles);
     *n_partials = blocks;
     const unsigned int n_apply = m->pending_apply ? (m->cfg.len + FCV_THREADS - 1) / FCV_THREADS : 0;
-    const bool fast = lam_fast_trig() != 0;
+    const bool fast = lam_fast_trig(k) != 0;
     CommK ckv;
     const CommK *ck = nullptr;
     if (m->comm)
@@ -622,7 +622,7 @@ int mtd_fused_force_pass_slots(mtd_metad *m, const mtd_lamellar_set *set, const 
     const int dep = (m->add_bias && (timestep % m->stride == 0)) ? 1 : 0;   // .cc:368
     const unsigned int n_grid = dep ? m->cfg.n_gblocks : 0;
     const double two_over_n = 2.0 / (double)n_global;
-    const bool fast = lam_fast_trig() != 0;
+    const bool fast = lam_fast_trig(k) != 0;
     static const bool force_general = std::getenv("MTD_FUSED_GENERAL") != nullptr;
     CommK ck;
     std::memset(&ck, 0, sizeof(ck));

@@ -680,7 +680,7 @@ int mtd_fused_step(mtd_metad *m, const mtd_lamellar_set *set, unsigned int n_par
     // measured faster at the headline size (21.9 against 23.9 us per step)
     static const int env_mode = [] { const char *e = std::getenv("MTD_FUSED_STEP"); return !e ? -1 : (e[0] == '1' ? 1 : 0); }();
     const bool off = m->step_mode >= 0 ? m->step_mode == 0 : env_mode != 1;
-    const bool fast = lam_fast_trig() != 0;
+    const bool fast = lam_fast_trig(k) != 0;
     const bool comm = m->comm != nullptr;
 
     unsigned int nb = (n_particles + FS_CHUNK - 1) / FS_CHUNK;

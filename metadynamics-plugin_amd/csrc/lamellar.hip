@@ -307,7 +307,16 @@ int fill_kargs(LamKArgs &k, const mtd_lamellar_set *set, const mtd_box *box)
 
 unsigned int lam_cv_blocks(unsigned int N) { return cv_blocks(N); }
 unsigned int lam_force_blocks(unsigned int N) { return force_blocks(N); }
-int lam_fast_trig() { return g_fast_trig; }
+// the hardware sine / cosine for this mode set?  Their argument (in turns) must stay inside [-256, 256]: with positions inside
+// the box |b_i' . r| <= 1/2, so |phase| <= (|h| + |k| + |l|) / 2 — sets with larger indices than any lamellar study uses take
+// the accurate path, whatever mtd_lamellar_set_fast_trig says (the bound leaves room for particles five box lengths outside)
+int lam_fast_trig(const LamKArgs &k)
+    {
+    if (!g_fast_trig) return 0;
+    for (unsigned int m = 0; m < k.n_modes; ++m)
+        if (std::fabs(k.h[m].x) + std::fabs(k.h[m].y) + std::fabs(k.h[m].z) > 100.0f) return 0;
+    return 1;
+    }
 } // namespace mtd
 
 extern "C" {
@@ -339,9 +348,9 @@ int mtd_lamellar_cv_partials(const mtd_lamellar_set *set, unsigned int n_particl
     const unsigned int blocks = cv_blocks(n_particles);
     *n_partials = blocks;
     if (dtype == MTD_F32)
-        return g_fast_trig ? launch_cv<float4, true>(k, n_particles, d_postype, d_partials, blocks, s)
+        return lam_fast_trig(k) ? launch_cv<float4, true>(k, n_particles, d_postype, d_partials, blocks, s)
                            : launch_cv<float4, false>(k, n_particles, d_postype, d_partials, blocks, s);
-    return g_fast_trig ? launch_cv<double4, true>(k, n_particles, d_postype, d_partials, blocks, s)
+    return lam_fast_trig(k) ? launch_cv<double4, true>(k, n_particles, d_postype, d_partials, blocks, s)
                        : launch_cv<double4, false>(k, n_particles, d_postype, d_partials, blocks, s);
     }
 
@@ -379,14 +388,14 @@ int mtd_calculate_fourier_modes(unsigned int n_wave, const int *lattice_vectors,
     const unsigned int blocks = cv_blocks(n_particles);
     if (dtype == MTD_F32)
         {
-        if (g_fast_trig)
+        if (lam_fast_trig(k))
             k_lamellar_mode_partials<float4, true><<<blocks, CV_THREADS, 0, s>>>(k, (const float4 *)d_postype, n_particles, d_scratch);
         else
             k_lamellar_mode_partials<float4, false><<<blocks, CV_THREADS, 0, s>>>(k, (const float4 *)d_postype, n_particles, d_scratch);
         }
     else
         {
-        if (g_fast_trig)
+        if (lam_fast_trig(k))
             k_lamellar_mode_partials<double4, true><<<blocks, CV_THREADS, 0, s>>>(k, (const double4 *)d_postype, n_particles, d_scratch);
         else
             k_lamellar_mode_partials<double4, false><<<blocks, CV_THREADS, 0, s>>>(k, (const double4 *)d_postype, n_particles, d_scratch);
@@ -417,14 +426,14 @@ static int lamellar_forces_impl(const mtd_lamellar_set *set, unsigned int n_part
     const double two_over_n = 2.0 / (double)n_global;
     if (dtype == MTD_F32)
         {
-        if (g_fast_trig)
+        if (lam_fast_trig(k))
             k_lamellar_forces<float4, true><<<blocks, FORCE_THREADS, 0, s>>>(k, (const float4 *)d_postype, out, n_particles, d_bias, bias_host, two_over_n);
         else
             k_lamellar_forces<float4, false><<<blocks, FORCE_THREADS, 0, s>>>(k, (const float4 *)d_postype, out, n_particles, d_bias, bias_host, two_over_n);
         }
     else
         {
-        if (g_fast_trig)
+        if (lam_fast_trig(k))
             k_lamellar_forces<double4, true><<<blocks, FORCE_THREADS, 0, s>>>(k, (const double4 *)d_postype, out, n_particles, d_bias, bias_host, two_over_n);
         else
             k_lamellar_forces<double4, false><<<blocks, FORCE_THREADS, 0, s>>>(k, (const double4 *)d_postype, out, n_particles, d_bias, bias_host, two_over_n);

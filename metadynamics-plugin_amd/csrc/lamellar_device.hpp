@@ -34,12 +34,15 @@ struct ForcePtrs
     void *f[MTD_MAX_CV];
     };
 
-// cos / sin of 2*pi*t.  FAST: hardware v_cos_f32 / v_sin_f32 take the angle in turns (domain
-// [-256, 256]); v_fract first so the full fp32 mantissa is spent on the fractional phase.
+// cos / sin of 2*pi*t.  FAST: hardware v_cos_f32 / v_sin_f32 take the angle in turns, domain [-256, 256] (outside it they
+// return 1 / 0: the host only selects FAST for mode sets whose phases stay far inside, lam_fast_trig).  No v_fract in front:
+// the hardware reduces the range itself and is MORE accurate on the raw phase (tools/probe_fract.hip: max error 1.25e-7
+// against 2.65e-7 with an explicit fract) — and the pair kernels sit on the instruction-issue limit (profiles/r3), where one
+// instruction per particle and mode is 6 % of the step.
 template<bool FAST> __device__ __forceinline__ float cos2pi(float t)
     {
     if (FAST)
-        return __builtin_amdgcn_cosf(__builtin_amdgcn_fractf(t));
+        return __builtin_amdgcn_cosf(t);
     else
         return cospif(2.0f * t);
     }
@@ -47,7 +50,7 @@ template<bool FAST> __device__ __forceinline__ float cos2pi(float t)
 template<bool FAST> __device__ __forceinline__ float sin2pi(float t)
     {
     if (FAST)
-        return __builtin_amdgcn_sinf(__builtin_amdgcn_fractf(t));
+        return __builtin_amdgcn_sinf(t);
     else
         return sinpif(2.0f * t);
     }

@@ -11,5 +11,6 @@ constexpr unsigned int LAM_MAX_BLOCKS = 1024;
 int fill_kargs(LamKArgs &k, const mtd_lamellar_set *set, const mtd_box *box);
 unsigned int lam_cv_blocks(unsigned int N);
 unsigned int lam_force_blocks(unsigned int N);
-int lam_fast_trig();
+// hardware sine / cosine for this mode set? (the library setting AND phases inside the instructions' domain)
+int lam_fast_trig(const LamKArgs &k);
 }

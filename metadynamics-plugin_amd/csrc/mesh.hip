@@ -2244,6 +2244,7 @@ struct mtd_mesh
     CountRider *d_rider;
     CountRider *h_rider;       // what d_rider holds (copied again only when something changed: a box, a grid, a mode set)
     int rider_armed;
+    int rider_fast;                 // hardware trigonometry for the rider's mode set (lam_fast_trig)
     unsigned int rider_n_apply;
     struct mtd_metad *rider_engine;
     };
@@ -2581,6 +2582,7 @@ int mtd_mesh_set_lamellar_rider(mtd_mesh *mesh, mtd_metad *engine, const mtd_lam
         MTD_HIP_TRY(hipMemcpyAsync(mesh->d_rider, mesh->h_rider, sizeof(CountRider), hipMemcpyHostToDevice, (hipStream_t)stream));
         }
     mesh->rider_armed = 1;
+    mesh->rider_fast = mtd::lam_fast_trig(r.k);
     mesh->rider_n_apply = r.n_apply;
     mesh->rider_engine = engine;
     *n_partials = nb;
@@ -2666,7 +2668,7 @@ static int mesh_assign_local(mtd_mesh *m, unsigned int n_particles, const void *
             {
             // (the rider's arguments were copied to the device on this stream by mtd_mesh_set_lamellar_rider)
             const unsigned int grid = nb;
-            const bool fast = mtd::lam_fast_trig() != 0;
+            const bool fast = m->rider_fast != 0;
             n_apply_blocks = m->rider_n_apply;
             if (dtype == MTD_F32) { if (fast) MTD_TILE_COUNT(float4, true, true, grid); else MTD_TILE_COUNT(float4, true, false, grid); }
             else { if (fast) MTD_TILE_COUNT(double4, true, true, grid); else MTD_TILE_COUNT(double4, true, false, grid); }
