@@ -993,50 +993,57 @@ __global__ __launch_bounds__(TF_THREADS) void k_tile_forces(const MeshGeom g, co
     unsigned int q = q0 + threadIdx.x;
     const unsigned int q_last = q1 - 1;
     double4 pk = packed[min(q, q_last)];
-    // Re(inv) of the tile + halo, row by row (32 lanes per row of <= 18 entries: no divisions in the loop)
+    // Re(inv) of the tile + halo.  The counters of round 3 (profiles/r3) put this kernel on the instruction-issue limit with
+    // two thirds of its vector instructions in THIS staging (23 rows per thread with wraps and compares, 14 of 32 lanes idle
+    // in every row: ~1100 instructions per wave against ~170 per particle and 3.8 particles per thread).  Now a table per
+    // block: row r = ly + wyn lz of the image -> its global row offset and its LDS row offset (one thread per row, once), and
+    // the image is walked flat, idx = tid + 256 k -> (row, lx) by a multiply-shift: a dozen instructions per element, every
+    // lane busy, all loads of a thread issued before its first LDS store.
     const unsigned int wxn = min(tg.tx, g.nx - x0) + 2, wyn = min(tg.ty, g.ny - y0) + 2, wzn = min(tg.tz, g.nz - z0) + 2;
-    const unsigned int lx = threadIdx.x & 31;
-    int gx = x0 + (int)lx - 1;
-    gx = gx < 0 ? gx + (int)g.nx : (gx >= (int)g.nx ? gx - (int)g.nx : gx);
-    // all loads of a thread are issued before the first LDS store (a load -> store loop pays one memory round trip per row).
-    // Row r of a thread is row (tid / 32) + 8 r of the image: (ly, lz) advance by 8 rows with compares instead of a division
-    // per row (the unrolled divisions were more vector instructions than the whole particle loop), the LDS row offset is
-    // computed once and kept.
-    constexpr int TF_ROWS = ((TP_Y + 2) * (TP_Z + 2) + TF_THREADS / 32 - 1) / (TF_THREADS / 32);
-    constexpr unsigned int TF_STEP = TF_THREADS / 32;
-    double v[TF_ROWS];
-    unsigned int srow[TF_ROWS];                                        // LDS offset of the row, ~0u: nothing to stage
+    constexpr int TF_MAXROWS = (TP_Y + 2) * (TP_Z + 2);
+    constexpr int TF_ELEMS = (TP_HMAX + TF_THREADS - 1) / TF_THREADS;
+    __shared__ unsigned int s_grow[TF_MAXROWS];                        // global offset of the row's x = 0 cell
+    __shared__ unsigned short s_lrow[TF_MAXROWS];                      // LDS offset of the row's lx = 0 entry
+    __shared__ unsigned short s_gx[TP_X + 2];                          // wrapped global x of image column lx
     const unsigned int n_rows = wyn * wzn;
-    {
-    unsigned int row = threadIdx.x >> 5;
-    unsigned int lz = row / wyn, ly = row - lz * wyn;
-#pragma unroll
-    for (int r = 0; r < TF_ROWS; ++r)
+    if (threadIdx.x < n_rows)
         {
-        v[r] = 0.0;
-        srow[r] = ~0u;
-        if (row < n_rows && lx < wxn)
-            {
-            int gy = y0 + (int)ly - 1, gz = z0 + (int)lz - 1;
-            gy = gy < 0 ? gy + (int)g.ny : (gy >= (int)g.ny ? gy - (int)g.ny : gy);
-            gz = gz < 0 ? gz + (int)g.nz : (gz >= (int)g.nz ? gz - (int)g.nz : gz);
-            v[r] = inv[gx + g.nx * (gy + g.ny * gz)];
-            srow[r] = lx + tg.hx * (ly + tg.hy * lz);
-            }
-        row += TF_STEP;
-        ly += TF_STEP;
-#pragma unroll
-        for (int turn = 0; turn < 3; ++turn)                           // wyn >= 3 and 8 rows further: at most three wraps
-            if (ly >= wyn)
-                {
-                ly -= wyn;
-                ++lz;
-                }
+        const unsigned int lz = threadIdx.x / wyn, ly = threadIdx.x - lz * wyn;
+        int gy = y0 + (int)ly - 1, gz = z0 + (int)lz - 1;
+        gy = gy < 0 ? gy + (int)g.ny : (gy >= (int)g.ny ? gy - (int)g.ny : gy);
+        gz = gz < 0 ? gz + (int)g.nz : (gz >= (int)g.nz ? gz - (int)g.nz : gz);
+        s_grow[threadIdx.x] = g.nx * ((unsigned int)gy + g.ny * (unsigned int)gz);
+        s_lrow[threadIdx.x] = (unsigned short)(tg.hx * (ly + tg.hy * lz));
         }
-    }
+    if (threadIdx.x < wxn)
+        {
+        int gx = x0 + (int)threadIdx.x - 1;
+        gx = gx < 0 ? gx + (int)g.nx : (gx >= (int)g.nx ? gx - (int)g.nx : gx);
+        s_gx[threadIdx.x] = (unsigned short)gx;
+        }
+    __syncthreads();
+    {
+    const unsigned int n_img = n_rows * wxn;
+    const unsigned int inv_w = (65536u + wxn - 1) / wxn;               // idx / wxn = (idx * inv_w) >> 16 for idx < 4096, wxn <= 18
+    double v[TF_ELEMS];
+    unsigned int dst[TF_ELEMS];                                        // ~0u: nothing to stage
 #pragma unroll
-    for (int r = 0; r < TF_ROWS; ++r)
-        if (srow[r] != ~0u) s_inv[srow[r]] = v[r];
+    for (int e = 0; e < TF_ELEMS; ++e)
+        {
+        const unsigned int idx = threadIdx.x + e * TF_THREADS;
+        v[e] = 0.0;
+        dst[e] = ~0u;
+        if (idx < n_img)
+            {
+            const unsigned int row = (idx * inv_w) >> 16, lx = idx - row * wxn;
+            v[e] = inv[s_grow[row] + s_gx[lx]];
+            dst[e] = s_lrow[row] + lx;
+            }
+        }
+#pragma unroll
+    for (int e = 0; e < TF_ELEMS; ++e)
+        if (dst[e] != ~0u) s_inv[dst[e]] = v[e];
+    }
     __syncthreads();
     TILE_STAMP(1, 1);
     const double bias = d_bias ? *d_bias : bias_host;
