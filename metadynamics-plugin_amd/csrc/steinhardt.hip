@@ -4,25 +4,29 @@
 // spherical harmonics of spherical_harmonics.hpp:32-246 (fsph).  The reference has NO GPU implementation of this
 // CV (SURVEY §2.4 "new"): it runs a host loop that constructs a PointSPHEvaluator (five heap arrays) per pair.
 //
-// MI355X design (vector-ALU bound in fp64, not HBM bound):
-//   pair-parallel mapping: a block walks chunks of 16 consecutive central particles; the ~230 neighbour-list entries of a
-//                     chunk are spread one per thread (owner found by a 4-step search over the chunk's prefix counts in
-//                     LDS), so the waves stay ~90 % full whatever the per-particle neighbour counts are, and enough
-//                     waves exist to hide the fp64 dependency chains (one thread per particle ran at occupancy 1)
-//   k_ql_accumulate   per pair the real amplitudes A_lm(theta) (m >= 0) come from fsph's Jacobi recurrence in registers
-//                     (cos/sin of the angles from dx/r — no acos/atan2, no heap); Q'_lm += f A_lm e^{i m phi} is kept in
-//                     registers (28 complex at lmax = 6) and reduced wave -> block in a fixed order; negative m are
-//                     conjugates, the Condon-Shortley phase is applied at the end
+// MI355X design.  Neither pass is HBM bound (40 B per pair against ~0.3 kflop of fp64); both are bound by instruction ISSUE — a
+// SIMD issues one instruction per four cycles of whatever kind, so scalar moves and branches cost what fp64 FMAs cost
+// (profiles/r3: 97 % of the issue slots of the force pass in use before it was rewritten for the slot count):
+//   units             a block walks chunks of 64 consecutive central particles; the neighbour-list entries of a chunk, flattened,
+//                     are cut into units of <= 1024 entries, one per thread and round, so the waves stay full whatever the
+//                     per-particle neighbour counts are; every memory trip of a unit — (own particle, list head, count) -> list
+//                     entries -> neighbour positions — is requested a stage ahead and stays in flight across the arithmetic
+//                     of the units before it (QlUnit / QlFeed, LDS-only barriers)
+//   monic amplitudes  Y_lm = nrm(l, m) p_m,l-m(cos theta) h^m with h = sin(theta) e^{i phi} = (dx + i dy) / r and the monic form of
+//                     fsph's Jacobi recurrence (one constant and two instructions per entry); no acos / atan2, no heap;
+//                     constants from a table in device memory through the scalar cache (QlTab)
+//   k_ql_accumulate   Q'_lm = sum f Y_lm: every (l, m >= 0) in the registers of ONE wave up to lmax = 8 (49 doubles at lmax = 6;
+//                     28 for half / symmetric lists, whose odd degrees the finalize step zeroes); entries filtered and compacted
+//                     before the neighbour is fetched; lane sums through LDS in a fixed order; negative m are conjugates, the
+//                     normalisation is applied once per block, the Condon-Shortley phase in the finalize step
 //   k_reduce_partials (lamellar.hip) -> Q'_lm ; [multi-GPU: all-reduce of (lmax+1)(lmax+2) doubles here]
 //   k_ql_finalize     full Q_lm table in the reference's order, third-law scaling, Q_l, CV value
-//   k_ql_forces       the spherical-basis gradient of :287-321 contracted BEFORE it is expanded: with
-//                     Y_lm = A_lm e^{i m phi}, dY/dtheta = (m cot A_lm + c_lm A_l,m+1) e^{i m phi}, dY/dphi = i m Y_lm and
-//                     z = e^{i m phi} conj(Q_lm) w_l, the pair force is -(alpha U + beta V + gamma W) with three scalars
-//                     U = sum A Re z, V = sum (dA/dtheta) Re z, W = -sum m A Im z and three real vectors
-//                     alpha = d f'/r, beta = (f/r) e_theta, gamma = (f/rho) e_phi; m < 0 terms equal their m > 0 partners
-//                     (Y_l,-m = (-1)^m conj Y_lm), so only m >= 0 is visited (weight 2), and degrees with Ql_ref[l] = 0
-//                     are skipped.  ~0.4 kflop per pair instead of ~4.5.  Per-particle sums over the pairs of a chunk in
-//                     a fixed order through LDS (deterministic, no atomics for full lists).
+//   k_ql_forces       the spherical-basis gradient of :287-321 contracted BEFORE it is expanded: with Z_lm = h^m q_lm
+//                     (q_lm = nrm w_l conj(Q_lm) in LDS) the pair force is -(alpha U + beta V + gamma W) with three scalars
+//                     U = sum P Re Z, V = cot sum m P Re Z + sin sum d_lm p_m+1,l-m-1 Re Z, W = -sum m P Im Z and three real
+//                     vectors alpha = d f'/r, beta = (f/r) e_theta, gamma = (f/rho) e_phi; m < 0 terms equal their m > 0
+//                     partners (weight 2), degrees with Ql_ref[l] = 0 are skipped as a whole.  Per-particle sums over the
+//                     pairs of a unit in a fixed order through LDS (deterministic, no atomics for full lists).
 // Double precision throughout.
 #include "mtd_device.hpp"
 #include "metad_host.hpp"
@@ -89,61 +93,14 @@ __device__ __forceinline__ void min_image(const QlArgs<LMAX> &a, double &x, doub
     x -= a.L[0] * rint(x * a.Linv[0]);
     }
 
-// cos(pi x) and sin(pi x) for x in [0, 1] (the smoothing window): with y = x - 1/2, cos(pi x) = -sin(pi y) and
-// sin(pi x) = cos(pi y), |pi y| <= pi/2, Taylor series in z^2 to z^21 / z^20 (truncation < 3e-16); ~25 FMAs instead of
-// the ~80 instructions of the general-range library routine
-__device__ __forceinline__ void sincospi_unit(const double x, double &sn, double &cs)
-    {
-    const double z = M_PI * (x - 0.5), z2 = z * z;
-    double s = -1.0 / 51090942171709440000.0;          // -1/21!
-    s = s * z2 + 1.0 / 121645100408832000.0;           //  1/19!
-    s = s * z2 - 1.0 / 355687428096000.0;              // -1/17!
-    s = s * z2 + 1.0 / 1307674368000.0;                //  1/15!
-    s = s * z2 - 1.0 / 6227020800.0;                   // -1/13!
-    s = s * z2 + 1.0 / 39916800.0;                     //  1/11!
-    s = s * z2 - 1.0 / 362880.0;                       // -1/9!
-    s = s * z2 + 1.0 / 5040.0;                         //  1/7!
-    s = s * z2 - 1.0 / 120.0;                          // -1/5!
-    s = s * z2 + 1.0 / 6.0;                            //  1/3!
-    const double sin_z = z - z * z2 * s;
-    double c = 1.0 / 2432902008176640000.0;            //  1/20!
-    c = c * z2 - 1.0 / 6402373705728000.0;             // -1/18!
-    c = c * z2 + 1.0 / 20922789888000.0;               //  1/16!
-    c = c * z2 - 1.0 / 87178291200.0;                  // -1/14!
-    c = c * z2 + 1.0 / 479001600.0;                    //  1/12!
-    c = c * z2 - 1.0 / 3628800.0;                      // -1/10!
-    c = c * z2 + 1.0 / 40320.0;                        //  1/8!
-    c = c * z2 - 1.0 / 720.0;                          // -1/6!
-    c = c * z2 + 1.0 / 24.0;                           //  1/4!
-    c = c * z2 - 0.5;                                  // -1/2!
-    const double cos_z = 1.0 + z2 * c;
-    cs = -sin_z;
-    sn = cos_z;
-    }
-
-// smoothing function f (:36-48) and f'/r (:50-60); r = rsq * inv_r
-template<int LMAX>
-__device__ __forceinline__ void smoothing(const QlArgs<LMAX> &a, const double rsq, const double inv_r, double &f, double &fprime_divr)
-    {
-    f = 1.0;
-    fprime_divr = 0.0;
-    if (rsq > a.ronsq)
-        {
-        double sn, cs;
-        sincospi_unit((rsq * inv_r - a.r_on) * a.inv_width, sn, cs);
-        f = 0.5 * (cs + 1.0);
-        fprime_divr = -(0.5 * M_PI) * inv_r * a.inv_width * sn;
-        }
-    }
-
-// ---- constants of the force pass, read through the scalar cache -------------------------------------------------------------
+// ---- constants of the pair passes, read through the scalar cache -------------------------------------------------------------
 // Counters of round 3 (profiles/r3): the pair kernels are bound by instruction ISSUE — vector + scalar + LDS + branch
 // instructions times four cycles add up to the launch time.  A 64-bit literal is two s_mov_b32, and the ~100 literals of a pair
 // (recurrence prefactors, derivative factors, the smoothing polynomial) were a quarter of all issue slots (or, where the
 // compiler kept them in VGPRs, a v_mov per use and 44 registers).  They now sit in a small table in device memory that the
 // kernel reads with s_load_dwordx8/x16 (eight constants per issue slot) right where they are used; the table pointer carries an
 // offset the compiler cannot see through (always zero), or it would hoist ~90 loads out of the pair loop and spill them.
-//   [SM_SIN, +10)  [SM_COS, +10)   Taylor coefficients of sincospi_unit, highest order first
+//   [SM_SIN, +10)  [SM_COS, +10)   Taylor coefficients of sincospi_unit_tab, highest order first
 //   beta(m, n)     monic form of the Jacobi recurrence of spherical_harmonics.hpp:203-211 in the degree n = l - m:
 //                  J_m(n) = kappa(m, n) p_mn(x), p_m0 = 1, p_m1 = x, p_mn = x p_m,n-1 - beta(m, n) p_m,n-2
 //                  (kappa(m, 0) = jacobi[m][0], kappa(m, n) = f0(m, n) kappa(m, n - 1), beta = -f1(m, n) / (f0(m, n) f0(m, n - 1)))
@@ -169,7 +126,7 @@ template<int LMAX> void ql_build_table(double *t)
     {
     typedef QlTab<LMAX> T;
     for (int i = 0; i < T::SIZE; ++i) t[i] = 0.0;
-    // sin: -1/21!, 1/19!, ..., 1/3! ; cos: 1/20!, -1/18!, ..., -1/2!   (sincospi_unit)
+    // sin: -1/21!, 1/19!, ..., 1/3! ; cos: 1/20!, -1/18!, ..., -1/2!   (sincospi_unit_tab)
     double fact = 1.0;                                       // k!
     double inv[22];
     inv[0] = 1.0;
@@ -240,7 +197,9 @@ __device__ __forceinline__ double fma_uniform_addend(const double a, const doubl
     return r;
     }
 
-// sincospi_unit with its coefficients from the table (c = table + SM_SIN; same operations, same results)
+// cos(pi x) and sin(pi x) for x in [0, 1] (the smoothing window): with y = x - 1/2, cos(pi x) = -sin(pi y) and
+// sin(pi x) = cos(pi y), |pi y| <= pi/2, Taylor series in z^2 to z^21 / z^20 (truncation < 3e-16); ~25 FMAs instead of
+// the ~80 instructions of the general-range library routine.  Coefficients from the table (c = table + SM_SIN).
 __device__ __forceinline__ void sincospi_unit_tab(const double *__restrict__ c, const double x, double &sn, double &cs)
     {
     const double z = M_PI * (x - 0.5), z2 = z * z;
@@ -1026,7 +985,7 @@ __global__ __launch_bounds__(QL_THREADS, (LMAX <= 6 ? 3 : 2)) void k_ql_forces(c
     __shared__ double s_qw[2 * NLM];                 // w_l (2 or 4) conj(Q_lm), m >= 0, index l(l+1)/2 + m
     __shared__ QlUnit su[3];
     __shared__ double s_fx[CAP], s_fy[CAP], s_fz[CAP];          // pair forces of the unit, by list entry
-    const unsigned int tid = threadIdx.x, lane = tid & 63u;
+    const unsigned int tid = threadIdx.x;
     const bool setup_wave = (tid >> 6) == QL_THREADS / MTD_WAVE - 1;
     const double bias = d_bias ? *d_bias : bias_host;
     const double ng = (double)a.n_global;
