@@ -121,8 +121,10 @@ int mtd_lamellar_forces(const mtd_lamellar_set *set, unsigned int n_particles, c
                         void *const *d_force, int dtype, unsigned int n_global, const double *d_bias,
                         const mtd_box *global_box, mtd_stream_t stream);
 
-/* 1 (default): hardware v_sin_f32 / v_cos_f32 on the fractional phase in turns — what the reference's GPU kernels do
- * (fast::sin / fast::cos, LamellarOrderParameterGPU.cu:36-37, 180); 0: ocml sinpi / cospi.  Process-wide switch. */
+/* 1 (default): hardware v_sin_f32 / v_cos_f32 on the phase in turns — what the reference's GPU kernels do
+ * (fast::sin / fast::cos, LamellarOrderParameterGPU.cu:36-37, 180); 0: ocml sinpi / cospi.  Process-wide switch.  The hardware
+ * path is only taken for mode sets with |h| + |k| + |l| <= 100 per mode (phases inside the instructions' domain of +-256 turns
+ * for positions within five box lengths of the box); others run the accurate path whatever this switch says. */
 int mtd_lamellar_set_fast_trig(int enable);
 int mtd_lamellar_get_fast_trig(void);
 
