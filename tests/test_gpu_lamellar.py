@@ -213,3 +213,24 @@ def test_full_size_config2(abi, ref):
     F2 = gpu_forces(abi, cvs, packed, box, [-2.0, 0.0])
     assert np.allclose(F2[0][:, :3], -2.0 * F[0][:, :3], rtol=2e-6, atol=1e-12)
     assert np.all(F2[1] == 0.0)
+
+
+def test_fast_trig_only_inside_the_instructions_domain(abi, ref):
+    """the hardware sine / cosine take the phase in turns and are only defined on [-256, 256] (beyond it they return 1 / 0):
+    a mode set whose phases can leave that range runs the accurate path even with fast trigonometry switched on
+    (lamellar.hip::lam_fast_trig: |h| + |k| + |l| <= 100 per mode)"""
+    N, L = 20000, 20.0
+    pos, types = util.snapshot_random(N, L, seed=77, modulated=True, dtype=np.float32)
+    box, rbox = _box(abi, ref, L)
+    cvs = [([(600, 0, 0), (0, 599, 1)], util.MODE_AB)]                 # phases up to 300 turns
+    pt = util.pack_postype(pos, types, np.float32)
+    opt = util.oracle_postype(pos, types)
+    s_ref = ref.lamellar_cv(cvs[0][0], opt, cvs[0][1], rbox)
+    s_fast = gpu_cv(abi, cvs, pt, box, fast=True)[0]
+    s_acc = gpu_cv(abi, cvs, pt, box, fast=False)[0]
+    assert s_fast == s_acc                                             # the same kernels ran
+    # (the phase itself is a float: 300 turns carry 2e-5 turns of rounding, whatever evaluates the cosine)
+    assert abs(s_fast - s_ref) <= 2e-3 * 2 / np.sqrt(N)
+    F_fast = gpu_forces(abi, cvs, pt, box, [0.7], fast=True)[0]
+    F_acc = gpu_forces(abi, cvs, pt, box, [0.7], fast=False)[0]
+    assert np.array_equal(F_fast, F_acc)
