@@ -8,7 +8,7 @@
 // final-reduce launches (:510-541, :771-885), texture-bound force gather (:566-754).
 //
 // MI355X design: single rank, no ghost cells (the multi-GPU plan replicates the mesh).
-// Assignment and force pass run by TILES (steps 1b-5b, 9b further down: particles grouped by 16x16x8 tile, weights summed
+// Assignment and force pass run by TILES (steps 1b-5b, 9b further down: particles grouped by tile of 64x8x8 cells, weights summed
 // in LDS as 64-bit fixed point, Re(inv) read from an LDS image); the cell-level steps 1-5 and 9 listed here remain for
 // meshes with more than 8192 tiles and behind MTD_MESH_ASSIGN=cells.
 //   1 k_mesh_bin        cell of every particle and its arrival slot in that cell (ONE returning atomic per particle),
@@ -518,7 +518,7 @@ __global__ __launch_bounds__(GT_THREADS) void k_mesh_gather(const MeshGeom g, co
 // ---- 1b-5b. tile path of the assignment and of the force pass ------------------------------------------------------
 // The cell-level pipeline above pays for a sort down to single cells: one returning global atomic, two scattered record
 // stores and a per-cell gather loop per particle (bin 42 + scan 15 + place 40 + sortfix 18 + gather 78 us at 10^6 particles
-// on 128^3).  Here the particles are only grouped by TILE of 16x16x8 cells and the TSC weights are summed in LDS:
+// on 128^3).  Here the particles are only grouped by TILE of 64x8x8 cells (16x16x8 until round 3) and the TSC weights are summed in LDS:
 //   1b k_tile_count    a block owns a contiguous chunk of particles: tile of every particle, its arrival slot in the
 //                      block's LDS histogram (LDS atomic), the histogram written as one row per block, [block][tile]; sum of mode^2
 //   2b scan            exclusive scan over the blocks of every tile's counts = where each block's particles of each tile go
@@ -532,10 +532,31 @@ __global__ __launch_bounds__(GT_THREADS) void k_mesh_gather(const MeshGeom g, co
 //   9b k_tile_forces   a block owns a tile: Re(inv) of the tile + halo staged in LDS, 27 LDS reads per particle
 // Fixed point: an entry is sum(a * W W W) * 2^k in int64 with 2^k * N * max|a| < 2^62 (k = 42 at 10^6 particles, |a| = 1:
 // resolution 2e-13, against 1e-6 asked of the CV).  Meshes with more than TP_MAX_TILES tiles (> 256^3) keep the cell path.
-constexpr int TP_X = 16, TP_Y = 16, TP_Z = 8;
+// Tile shape and block sizes (overridable at build time for experiments, csrc/Makefile EXTRA_HIPFLAGS, tools/exp_mesh.sh).
+// Round 3: 512 tiles of 64x8x8 cells at 128^3 instead of 1024 of 16x16x8, 512 threads in the force pass: config 3 161 -> 154 us per
+// step (force pass 27.8 -> 22.9 us: rows of 66 doubles straddle fewer 128-byte lines per payload byte than rows of 18, and two
+// blocks of eight waves per CU stage and sum as well as four of four; place 14.3 -> 13.3: runs of 8 ids per count block and tile).
+// Measured beside it (profiles/r3/tile_shape_ab.log): 32x16x8 and 16x16x16 (512 tiles) 154-156, 256 tiles with 1024-thread
+// blocks 167, 128x8x4 156, 32x8x8 (1024 tiles) 159.
+#ifndef MTD_TP_X
+#define MTD_TP_X 64
+#endif
+#ifndef MTD_TP_Y
+#define MTD_TP_Y 8
+#endif
+#ifndef MTD_TP_Z
+#define MTD_TP_Z 8
+#endif
+#ifndef MTD_TP_THREADS
+#define MTD_TP_THREADS 256
+#endif
+#ifndef MTD_TF_THREADS
+#define MTD_TF_THREADS 512
+#endif
+constexpr int TP_X = MTD_TP_X, TP_Y = MTD_TP_Y, TP_Z = MTD_TP_Z;
 constexpr unsigned int TP_MAX_TILES = 8192;                         // LDS histogram of k_tile_count: 32 KB
-constexpr int TP_HMAX = (TP_X + 2) * (TP_Y + 2) * (TP_Z + 2);       // 3240 entries, 25.9 KB
-constexpr int TP_THREADS = 256;      // six blocks per CU (26 KB of LDS each): every tile of a 128^3 mesh resident at once
+constexpr int TP_HMAX = (TP_X + 2) * (TP_Y + 2) * (TP_Z + 2);       // 6600 entries, 52.8 KB
+constexpr int TP_THREADS = MTD_TP_THREADS;      // three blocks per CU (53 KB of LDS each): every tile of a 128^3 mesh resident at once
 
 struct TileGeom
     {
@@ -752,16 +773,13 @@ __global__ __launch_bounds__(256) void k_tile_rowscan(const unsigned int *__rest
     }
 
 // 3b. place: particle id -> its tile's segment.  A block keeps the prefix over the tile totals in LDS.
-// POSCOPY: the particle's raw position record travels with its id into tile order — into the first bytes of the 32-byte slot the
-// scatter pass will overwrite with the record for the force pass (no buffer of its own).  The scatter pass then reads ids and
-// positions side by side, coalesced, in ONE memory round trip; gathered by id the 16-byte records arrived in 128-byte requests
-// (96 MB fetched for 20 MB of payload, profiles/r3/pmc_mesh_ql_summary.txt) behind a dependent id -> position chain.
-template<typename S4, bool POSCOPY>
+// (This form — one scattered 4-byte store per particle, the scatter pass gathering the positions through the ids — is the fallback
+// of k_tile_place_sorted below: chunks of more than 4096 particles or tables that do not fit the LDS.)
+template<typename S4>
 __global__ __launch_bounds__(256) void k_tile_place(const TileGeom tg, const unsigned int N, const unsigned int *__restrict__ tile_of,
                                                     const unsigned int *__restrict__ slot_of, const unsigned int *__restrict__ rowscan,
                                                     const unsigned int *__restrict__ tile_total, unsigned int *__restrict__ ids,
-                                                    unsigned int *__restrict__ tile_first, const S4 *__restrict__ postype,
-                                                    double4 *__restrict__ packed)
+                                                    unsigned int *__restrict__ tile_first)
     {
     extern __shared__ unsigned int s_first[];                    // [n_tiles]: first slot of every tile
     __shared__ unsigned int s_wsum[4];
@@ -804,7 +822,129 @@ __global__ __launch_bounds__(256) void k_tile_place(const TileGeom tg, const uns
         const unsigned int t = tile_of[i];
         const unsigned int slot = s_first[t] + rowscan[(size_t)t * tg.n_blocks + i / tg.chunk] + slot_of[i];
         ids[slot] = i;
-        if (POSCOPY) *(S4 *)(packed + slot) = postype[i];
+        }
+    }
+
+// 3c. place, SORTED (the default): a block owns the chunk of one counting block, sorts it by tile in LDS — local offset = prefix
+// over the chunk's own histogram row + arrival slot — and walks the sorted image, so that consecutive lanes store to consecutive
+// slots: the particles of a (chunk, tile) pair leave as one run (8 of them on average at 4096 particles per chunk and 512 tiles).
+// What travels is the RAW POSITION RECORD next to the id: the scatter pass then reads ids and positions side by side, coalesced,
+// in one memory round trip.  (Gathered by id, the 16-byte records arrived in 128-byte requests — 96 MB fetched for 20 MB of payload,
+// profiles/r3/pmc_mesh_ql_summary.txt — behind a dependent id -> position chain; copying them WITHOUT the local sort, one
+// scattered 16-byte store per particle, cost the place kernel more than the gather cost the scatter pass: 167 against 160 us.)
+// LDS: prefix and destination per tile, (tile, local index) and the raw record per particle of the chunk.
+constexpr int TPS_THREADS = 1024;
+constexpr unsigned int TPS_CHUNK_MAX = 4096;                       // local index and arrival slot in 16 bits with room to spare
+constexpr int TPS_PER = TPS_CHUNK_MAX / TPS_THREADS;
+constexpr size_t PS_LDS_MAX = 160 * 1024 - 256;                    // dynamic LDS the kernel may be given (the static part is 128 bytes)
+
+template<typename S4> size_t place_sorted_lds_bytes(const unsigned int n_tiles, const unsigned int chunk)
+    {
+    return sizeof(unsigned int) * (2 * (size_t)n_tiles + chunk) + sizeof(S4) * (size_t)chunk;
+    }
+
+template<typename S4>
+__global__ __launch_bounds__(TPS_THREADS) void k_tile_place_sorted(const TileGeom tg, const unsigned int N, const S4 *__restrict__ postype,
+                                                                   const unsigned int *__restrict__ tile_of,
+                                                                   const unsigned int *__restrict__ slot_of,
+                                                                   const unsigned int *__restrict__ hist,
+                                                                   const unsigned int *__restrict__ rowscan,
+                                                                   const unsigned int *__restrict__ tile_total, unsigned int *__restrict__ ids,
+                                                                   S4 *__restrict__ possorted, unsigned int *__restrict__ tile_first)
+    {
+    extern __shared__ __align__(16) unsigned char s_raw[];
+    S4 *s_pos = (S4 *)s_raw;                                                   // [chunk]
+    unsigned int *s_meta = (unsigned int *)(s_pos + tg.chunk);                 // [chunk]: tile << 16 | index in the chunk
+    unsigned int *s_lpre = s_meta + tg.chunk;                                  // [n_tiles]: prefix over this chunk's histogram row
+    unsigned int *s_dest = s_lpre + tg.n_tiles;                                // [n_tiles]: first global slot of the (chunk, tile) run
+    __shared__ unsigned int s_w[2][TPS_THREADS / 64];
+    const unsigned int b = blockIdx.x;
+    const unsigned int i0 = min(N, b * tg.chunk), i1 = min(N, i0 + tg.chunk);
+    const unsigned int i_last = i1 ? i1 - 1 : 0u;
+    // everything this thread will read of the chunk is requested first (clamped indices, no branch): one memory round trip
+    unsigned int tl[TPS_PER], sl[TPS_PER];
+    S4 raw[TPS_PER];
+#pragma unroll
+    for (int k = 0; k < TPS_PER; ++k)
+        {
+        const unsigned int i = min(i0 + threadIdx.x + k * TPS_THREADS, i_last);
+        tl[k] = 0; sl[k] = 0;
+        raw[k] = scalar4_traits<S4>::make(0, 0, 0, 0);
+        if (i0 < i1)                                                             // (uniform over the block)
+            {
+            tl[k] = tile_of[i];
+            sl[k] = slot_of[i];
+            raw[k] = postype[i];
+            }
+        }
+    // the two prefixes over the tiles: tile totals (first slot of every tile) and this chunk's histogram row
+    const unsigned int per = (tg.n_tiles + TPS_THREADS - 1) / TPS_THREADS;
+    unsigned int tot = 0, loc = 0;
+    for (unsigned int j = 0; j < per; ++j)
+        {
+        const unsigned int t = threadIdx.x * per + j;
+        if (t < tg.n_tiles)
+            {
+            tot += tile_total[t];
+            loc += hist[(size_t)b * tg.n_tiles + t];
+            }
+        }
+    unsigned int itot = tot, iloc = loc;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1)
+        {
+        const unsigned int o0 = __shfl_up(itot, off, 64), o1 = __shfl_up(iloc, off, 64);
+        if (lane >= off)
+            {
+            itot += o0;
+            iloc += o1;
+            }
+        }
+    if (lane == 63)
+        {
+        s_w[0][wave] = itot;
+        s_w[1][wave] = iloc;
+        }
+    __syncthreads();
+    unsigned int run = itot - tot, lrun = iloc - loc;
+    for (int w = 0; w < wave; ++w)
+        {
+        run += s_w[0][w];
+        lrun += s_w[1][w];
+        }
+    for (unsigned int j = 0; j < per; ++j)
+        {
+        const unsigned int t = threadIdx.x * per + j;
+        if (t < tg.n_tiles)
+            {
+            s_lpre[t] = lrun;
+            s_dest[t] = run + rowscan[(size_t)t * tg.n_blocks + b];
+            if (b == 0) tile_first[t] = run;                         // for the scatter and force kernels: one load instead of a prefix
+            run += tile_total[t];
+            lrun += hist[(size_t)b * tg.n_tiles + t];
+            }
+        }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < TPS_PER; ++k)
+        {
+        const unsigned int li = threadIdx.x + k * TPS_THREADS;
+        if (i0 + li < i1)
+            {
+            const unsigned int lofs = s_lpre[tl[k]] + sl[k];
+            s_pos[lofs] = raw[k];
+            s_meta[lofs] = (tl[k] << 16) | li;
+            }
+        }
+    __syncthreads();
+    const unsigned int n = i1 - i0;
+    for (unsigned int j = threadIdx.x; j < n; j += TPS_THREADS)
+        {
+        const unsigned int meta = s_meta[j], t = meta >> 16;
+        const unsigned int dst = s_dest[t] + (j - s_lpre[t]);
+        possorted[dst] = s_pos[j];
+        ids[dst] = i0 + (meta & 0xffffu);
         }
     }
 
@@ -813,7 +953,8 @@ __global__ __launch_bounds__(TP_THREADS) void k_tile_scatter(const MeshGeom g, c
                                                              const double *__restrict__ mode, const unsigned int *__restrict__ tile_total,
                                                              const unsigned int *__restrict__ tile_first,
                                                              const unsigned int *__restrict__ ids, long long *__restrict__ tilebuf,
-                                                             double4 *__restrict__ packed, const unsigned int n_types, const int poscopy)
+                                                             double4 *__restrict__ packed, const unsigned int n_types,
+                                                             const S4 *__restrict__ possorted)
     {
     __shared__ unsigned long long s_t[TP_HMAX];
     __shared__ double s_mode[TP_MODE_LDS];
@@ -831,13 +972,13 @@ __global__ __launch_bounds__(TP_THREADS) void k_tile_scatter(const MeshGeom g, c
     const unsigned int q_last = q1 ? q1 - 1 : 0u;
     unsigned int id = 0, id_next = 0;
     S4 raw = scalar4_traits<S4>::make(0, 0, 0, 0);
-    // poscopy: k_tile_place left the raw position in the particle's slot of `packed` (this kernel overwrites the slot with the
-    // record once the position is in registers): ids and positions come side by side, no id -> position chain
+    // possorted (k_tile_place_sorted): the raw position records in tile order — ids and positions come side by side, coalesced, no
+    // id -> position chain; without it (fallback place kernel) the positions are gathered through the ids
     if (q0 < q1)                                                     // (uniform over the block; an empty tile — or no particles at
         {                                                            // all, and then no position array either — loads nothing)
         id = ids[min(q, q_last)];
         id_next = ids[min(q + TP_THREADS, q_last)];
-        raw = poscopy ? *(const S4 *)(packed + min(q, q_last)) : postype[id];
+        raw = possorted ? possorted[min(q, q_last)] : postype[id];
         }
     stage_modes(s_mode, mode, n_types);
     for (unsigned int e = threadIdx.x; e < tg.hcells; e += TP_THREADS) s_t[e] = 0ull;
@@ -848,7 +989,7 @@ __global__ __launch_bounds__(TP_THREADS) void k_tile_scatter(const MeshGeom g, c
         const Particle cur = scalar4_traits<S4>::unpack(raw);
         const unsigned int cur_id = id;
         const unsigned int qn = q + TP_THREADS;
-        raw = poscopy ? *(const S4 *)(packed + min(qn, q_last)) : postype[id_next];
+        raw = possorted ? possorted[min(qn, q_last)] : postype[id_next];
         id = id_next;
         id_next = ids[min(qn + TP_THREADS, q_last)];
         int ix, iy, iz;
@@ -968,7 +1109,7 @@ __global__ __launch_bounds__(256) void k_tile_combine_rows(const MeshGeom g, con
         }
     }
 
-constexpr int TF_THREADS = 256;        // four blocks per CU (128 VGPRs): one stages its tile while the others sum
+constexpr int TF_THREADS = MTD_TF_THREADS;        // two blocks of eight waves per CU (128 VGPRs): one stages its tile while the other sums
 
 template<typename S4>
 __global__ __launch_bounds__(TF_THREADS) void k_tile_forces(const MeshGeom g, const TileGeom tg, const unsigned int *__restrict__ tile_total,
@@ -1006,14 +1147,14 @@ __global__ __launch_bounds__(TF_THREADS) void k_tile_forces(const MeshGeom g, co
     __shared__ unsigned short s_lrow[TF_MAXROWS];                      // LDS offset of the row's lx = 0 entry
     __shared__ unsigned short s_gx[TP_X + 2];                          // wrapped global x of image column lx
     const unsigned int n_rows = wyn * wzn;
-    if (threadIdx.x < n_rows)
+    for (unsigned int r = threadIdx.x; r < n_rows; r += TF_THREADS)   // (one trip at the default tile shape)
         {
-        const unsigned int lz = threadIdx.x / wyn, ly = threadIdx.x - lz * wyn;
+        const unsigned int lz = r / wyn, ly = r - lz * wyn;
         int gy = y0 + (int)ly - 1, gz = z0 + (int)lz - 1;
         gy = gy < 0 ? gy + (int)g.ny : (gy >= (int)g.ny ? gy - (int)g.ny : gy);
         gz = gz < 0 ? gz + (int)g.nz : (gz >= (int)g.nz ? gz - (int)g.nz : gz);
-        s_grow[threadIdx.x] = g.nx * ((unsigned int)gy + g.ny * (unsigned int)gz);
-        s_lrow[threadIdx.x] = (unsigned short)(tg.hx * (ly + tg.hy * lz));
+        s_grow[r] = g.nx * ((unsigned int)gy + g.ny * (unsigned int)gz);
+        s_lrow[r] = (unsigned short)(tg.hx * (ly + tg.hy * lz));
         }
     if (threadIdx.x < wxn)
         {
@@ -1024,7 +1165,8 @@ __global__ __launch_bounds__(TF_THREADS) void k_tile_forces(const MeshGeom g, co
     __syncthreads();
     {
     const unsigned int n_img = n_rows * wxn;
-    const unsigned int inv_w = (65536u + wxn - 1) / wxn;               // idx / wxn = (idx * inv_w) >> 16 for idx < 4096, wxn <= 18
+    static_assert(TP_HMAX < 12288 && TP_HMAX * (TP_X + 2) <= (1 << 20), "multiply-shift division of the flat image index");
+    const unsigned int inv_w = ((1u << 20) + wxn - 1) / wxn;           // idx / wxn = (idx * inv_w) >> 20: exact while idx * wxn < 2^20 (wxn >= 3: no overflow)
     double v[TF_ELEMS];
     unsigned int dst[TF_ELEMS];                                        // ~0u: nothing to stage
 #pragma unroll
@@ -1035,7 +1177,7 @@ __global__ __launch_bounds__(TF_THREADS) void k_tile_forces(const MeshGeom g, co
         dst[e] = ~0u;
         if (idx < n_img)
             {
-            const unsigned int row = (idx * inv_w) >> 16, lx = idx - row * wxn;
+            const unsigned int row = (idx * inv_w) >> 20, lx = idx - row * wxn;
             v[e] = inv[s_grow[row] + s_gx[lx]];
             dst[e] = s_lrow[row] + lx;
             }
@@ -2240,6 +2382,7 @@ struct mtd_mesh
     bool combine_two;          // no mesh coordinate has three sources: k_tile_combine_rows
     uint4 *d_tsrc;             // per-axis table of the tile-buffer offsets that stand for a mesh coordinate (k_tile_combine)
     unsigned int *d_ids;
+    void *d_possorted;             // raw position records in tile order (k_tile_place_sorted): 32 bytes per particle hold either precision
     double amax;               // max |mode coefficient| (fixed-point scale)
     // slab decomposition over the ranks of a mailbox (mtd_mesh_slab_attach): exported buffers of every rank as mapped here
     struct mtd_comm *slab_comm;
@@ -2414,11 +2557,11 @@ int mtd_mesh_create(mtd_mesh **out, unsigned int nx, unsigned int ny, unsigned i
     const size_t MH = (size_t)m->hxp * ny * nz;
     m->n_cv_partials = fft_z_pass(m).n_blocks;                 // one partial sum per block of the fused z pass (an upper bound: the
                                                                // whole-mesh path puts several tiles into a block, fft_z_tpb)
-    // tile path (k_tile_*): tiles of 16x16x8 cells clamped to the mesh; MTD_MESH_ASSIGN=cells keeps the cell-level pipeline
+    // tile path (k_tile_*): tiles of 64x8x8 cells clamped to the mesh; MTD_MESH_ASSIGN=cells keeps the cell-level pipeline
     {
     TileGeom &tg = m->tg;
     tg.tx = nx < (unsigned int)TP_X ? nx : TP_X; tg.ty = ny < (unsigned int)TP_Y ? ny : TP_Y; tg.tz = nz < (unsigned int)TP_Z ? nz : TP_Z;
-    // a block per tile: a small mesh in 16x16x8 tiles gives the scatter and force passes fewer blocks than there are compute
+    // a block per tile: a small mesh in 64x8x8 tiles gives the scatter and force passes fewer blocks than there are compute
     // units (64^3: 128); halve the longest tile edge (not below 8) until there are at least two blocks per CU or 8^3 is reached
     auto count_tiles = [&](const TileGeom &t) { return (unsigned long long)((nx + t.tx - 1) / t.tx) * ((ny + t.ty - 1) / t.ty) * ((nz + t.tz - 1) / t.tz); };
     // (more, smaller tiles than that cost more than they bring: 128^3 in 2048 / 4096 tiles 191.7 / 208.6 us per step against 171.9)
@@ -2454,7 +2597,8 @@ int mtd_mesh_create(mtd_mesh **out, unsigned int nx, unsigned int ny, unsigned i
                  o_inv = take(sizeof(double) * M), o_slot = take(sizeof(unsigned int) * N),
                  o_itab = take(sizeof(double) * (nx + ny + nz)),
                  o_tilebuf = take(sizeof(long long) * (size_t)m->tg.n_tiles * m->tg.hcells), o_ids2 = take(sizeof(unsigned int) * N),
-                 o_tsrc = take(sizeof(uint4) * (nx + ny + nz)), o_ttot = take(sizeof(unsigned int) * 2 * ((size_t)m->tg.n_tiles + 1));
+                 o_tsrc = take(sizeof(uint4) * (nx + ny + nz)), o_ttot = take(sizeof(unsigned int) * 2 * ((size_t)m->tg.n_tiles + 1)),
+                 o_psort = take(m->tile_path ? sizeof(double4) * N : 0);
     hipError_t e = hipMalloc(&m->slab, off);
     if (e != hipSuccess)
         {
@@ -2475,6 +2619,7 @@ int mtd_mesh_create(mtd_mesh **out, unsigned int nx, unsigned int ny, unsigned i
     m->d_itab = (double *)(p + o_itab);
     m->d_tilebuf = (long long *)(p + o_tilebuf);
     m->d_ids = (unsigned int *)(p + o_ids2);
+    m->d_possorted = m->tile_path ? (void *)(p + o_psort) : nullptr;
     m->d_tsrc = (uint4 *)(p + o_tsrc);
     m->d_tile_total = (unsigned int *)(p + o_ttot);
     m->d_tile_first = m->d_tile_total + m->tg.n_tiles + 1;
@@ -2692,28 +2837,35 @@ static int mesh_assign_local(mtd_mesh *m, unsigned int n_particles, const void *
         MTD_LAUNCH_CHECK();
         unsigned int pb = (N + 1023) / 1024;                        // >= four particles per thread: the LDS prefix of the tile totals is formed once per block
         pb = pb < 1 ? 1 : (pb > 512 ? 512 : pb);
-        // MEASURED SLOWER and therefore opt-in (MTD_MESH_POSCOPY=1): 167.3 against 160.0 us per step of config 3 — the 10^6
-        // scattered 16-byte stores of the place kernel cost more than the gather they save the scatter pass
-        static const bool poscopy = std::getenv("MTD_MESH_POSCOPY") != nullptr;
-        if (dtype == MTD_F32)
+        // sorted place (the default): raw position records and ids leave in tile order, in runs; MTD_MESH_PLACE=ids keeps the
+        // one-store-per-particle form, which is also the fallback when a chunk or the tables do not fit
+        const bool f32 = dtype == MTD_F32;
+        const size_t ps_lds = f32 ? place_sorted_lds_bytes<float4>(tg.n_tiles, tg.chunk) : place_sorted_lds_bytes<double4>(tg.n_tiles, tg.chunk);
+        const char *ps_env = std::getenv("MTD_MESH_PLACE");           // (read per call: a test runs both forms in one process)
+        const bool ps_off = ps_env && std::strcmp(ps_env, "ids") == 0;
+        static const bool ps_lds_ok = [] {
+            hipError_t e = hipFuncSetAttribute((const void *)k_tile_place_sorted<float4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PS_LDS_MAX);
+            if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_tile_place_sorted<double4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PS_LDS_MAX);
+            if (e != hipSuccess) (void)hipGetLastError();
+            return e == hipSuccess;
+        }();
+        const bool sorted = !ps_off && ps_lds_ok && m->d_possorted && tg.chunk <= TPS_CHUNK_MAX && ps_lds <= PS_LDS_MAX;
+        if (sorted)
             {
-            if (poscopy)
-                k_tile_place<float4, true><<<pb, 256, sizeof(unsigned int) * tg.n_tiles, s>>>(tg, N, m->d_cell_of, m->d_slot_of, m->d_start, m->d_tile_total, m->d_ids, m->d_tile_first, (const float4 *)d_postype, m->d_packed);
+            if (f32)
+                k_tile_place_sorted<float4><<<nb, TPS_THREADS, ps_lds, s>>>(tg, N, (const float4 *)d_postype, m->d_cell_of, m->d_slot_of, m->d_count, m->d_start, m->d_tile_total, m->d_ids, (float4 *)m->d_possorted, m->d_tile_first);
             else
-                k_tile_place<float4, false><<<pb, 256, sizeof(unsigned int) * tg.n_tiles, s>>>(tg, N, m->d_cell_of, m->d_slot_of, m->d_start, m->d_tile_total, m->d_ids, m->d_tile_first, (const float4 *)d_postype, m->d_packed);
+                k_tile_place_sorted<double4><<<nb, TPS_THREADS, ps_lds, s>>>(tg, N, (const double4 *)d_postype, m->d_cell_of, m->d_slot_of, m->d_count, m->d_start, m->d_tile_total, m->d_ids, (double4 *)m->d_possorted, m->d_tile_first);
             }
+        else if (f32)
+            k_tile_place<float4><<<pb, 256, sizeof(unsigned int) * tg.n_tiles, s>>>(tg, N, m->d_cell_of, m->d_slot_of, m->d_start, m->d_tile_total, m->d_ids, m->d_tile_first);
         else
-            {
-            if (poscopy)
-                k_tile_place<double4, true><<<pb, 256, sizeof(unsigned int) * tg.n_tiles, s>>>(tg, N, m->d_cell_of, m->d_slot_of, m->d_start, m->d_tile_total, m->d_ids, m->d_tile_first, (const double4 *)d_postype, m->d_packed);
-            else
-                k_tile_place<double4, false><<<pb, 256, sizeof(unsigned int) * tg.n_tiles, s>>>(tg, N, m->d_cell_of, m->d_slot_of, m->d_start, m->d_tile_total, m->d_ids, m->d_tile_first, (const double4 *)d_postype, m->d_packed);
-            }
+            k_tile_place<double4><<<pb, 256, sizeof(unsigned int) * tg.n_tiles, s>>>(tg, N, m->d_cell_of, m->d_slot_of, m->d_start, m->d_tile_total, m->d_ids, m->d_tile_first);
         MTD_LAUNCH_CHECK();
-        if (dtype == MTD_F32)
-            k_tile_scatter<float4><<<tg.n_tiles, TP_THREADS, 0, s>>>(g, tg, (const float4 *)d_postype, m->d_mode, m->d_tile_total, m->d_tile_first, m->d_ids, m->d_tilebuf, m->d_packed, m->n_types, poscopy ? 1 : 0);
+        if (f32)
+            k_tile_scatter<float4><<<tg.n_tiles, TP_THREADS, 0, s>>>(g, tg, (const float4 *)d_postype, m->d_mode, m->d_tile_total, m->d_tile_first, m->d_ids, m->d_tilebuf, m->d_packed, m->n_types, sorted ? (const float4 *)m->d_possorted : nullptr);
         else
-            k_tile_scatter<double4><<<tg.n_tiles, TP_THREADS, 0, s>>>(g, tg, (const double4 *)d_postype, m->d_mode, m->d_tile_total, m->d_tile_first, m->d_ids, m->d_tilebuf, m->d_packed, m->n_types, poscopy ? 1 : 0);
+            k_tile_scatter<double4><<<tg.n_tiles, TP_THREADS, 0, s>>>(g, tg, (const double4 *)d_postype, m->d_mode, m->d_tile_total, m->d_tile_first, m->d_ids, m->d_tilebuf, m->d_packed, m->n_types, sorted ? (const double4 *)m->d_possorted : nullptr);
         MTD_LAUNCH_CHECK();
         {
         const unsigned int cthreads = m->nx >= 256 ? 256 : (m->nx > 64 ? 128 : 64);

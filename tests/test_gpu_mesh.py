@@ -59,11 +59,43 @@ class GpuMesh:
         return (out[0::2] + 1j * out[1::2]).reshape(nz, ny, nx)
 
 
-@pytest.fixture(params=["tiles", "cells"])
+@pytest.fixture(params=["tiles", "tiles-ids", "cells"])
 def assign_path(request, monkeypatch):
-    """both assignment / force pipelines of mesh.hip: by tiles (default) and the cell-level one (meshes > 256^3)"""
-    monkeypatch.setenv("MTD_MESH_ASSIGN", request.param)
+    """the assignment / force pipelines of mesh.hip: by tiles with the sorted place kernel (default: position records travel into
+    tile order in runs), by tiles with the one-store-per-particle place kernel (its fallback: the scatter pass gathers by id), and
+    the cell-level one (meshes > 256^3)"""
+    monkeypatch.setenv("MTD_MESH_ASSIGN", request.param.split("-")[0])
+    monkeypatch.setenv("MTD_MESH_PLACE", "ids" if request.param.endswith("-ids") else "sorted")
     return request.param
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("N,dims", [(0, (16, 16, 16)), (1, (16, 16, 16)), (4097, (32, 16, 24)), (70001, (64, 32, 16)), (12289, (128, 8, 8))])
+def test_sorted_place_against_place_by_id(abi, monkeypatch, dtype, N, dims):
+    """k_tile_place_sorted against k_tile_place: the same particles in every tile (in another order inside a tile, which the
+    fixed-point sums do not see), so the mesh, the CV and every particle's force are the same bits.  Chunk boundaries: empty
+    system, one particle, one particle beyond a chunk, many chunks."""
+    L = 14.0
+    pos, types = util.snapshot_random(max(N, 1), L, seed=5 + N, modulated=True, dtype=dtype)
+    pos, types = pos[:N], types[:N]
+    box = abi.Box.make(L)
+    dt = abi.MTD_F32 if dtype == np.float32 else abi.MTD_F64
+    d_pos = torch.from_numpy(util.pack_postype(pos, types, dtype)).cuda() if N else torch.zeros((0, 4), dtype=torch.float32 if dtype == np.float32 else torch.float64, device="cuda")
+    out = {}
+    for place in ("sorted", "ids"):
+        monkeypatch.setenv("MTD_MESH_PLACE", place)
+        g = GpuMesh(abi, dims, [1.0, -0.7], max(N, 1))
+        try:
+            s = g.cv(d_pos, dt, box, max(N, 1))
+            F = g.forces(d_pos, dt, box, max(N, 1), 0.8) if N else np.zeros((0, 4))
+            out[place] = (s, g.array(0).copy(), F)
+        finally:
+            g.close()
+    assert out["sorted"][0] == out["ids"][0]
+    assert np.array_equal(out["sorted"][1], out["ids"][1])
+    assert np.array_equal(out["sorted"][2], out["ids"][2])
+    if N > 1:
+        assert np.abs(out["sorted"][1]).max() > 0 and np.abs(out["sorted"][2]).max() > 0
 
 
 def test_mesh_bitwise_independent_of_particle_order(abi):
