@@ -548,7 +548,7 @@ __global__ __launch_bounds__(GT_THREADS) void k_mesh_gather(const MeshGeom g, co
 #define MTD_TP_Z 8
 #endif
 #ifndef MTD_TP_THREADS
-#define MTD_TP_THREADS 256
+#define MTD_TP_THREADS 512
 #endif
 #ifndef MTD_TF_THREADS
 #define MTD_TF_THREADS 512
