@@ -948,21 +948,275 @@ __global__ __launch_bounds__(TPS_THREADS) void k_tile_place_sorted(const TileGeo
         }
     }
 
+// ---- 1c-3c in ONE launch: the BIN pipeline (steady state of a run; k_tile_count -> k_tile_rowscan -> k_tile_place_sorted remain
+// for the first assignment of a mesh, for riders and for chunks / tables that do not fit) ------------------------------------------
+// Counting first and placing afterwards exists only because a tile's segment must be known before the first particle is stored.
+// In a simulation the tiles' populations change by a few particles per step: every tile owns a segment with SLACK, planned from the
+// exact counts of the previous snapshot (cap = count + max(count / 8, 32), rounded to 8), and a block reserves the run of each of
+// its (chunk, tile) pairs with ONE returning atomic add on the tile's cursor.  Whatever does not fit its tile's segment goes to
+// an overflow list (tile and slot appended with an atomic counter) that the scatter and force passes scan when it is not empty:
+// any snapshot is handled, a badly planned one only slowly, and the cursors — exact counts whatever overflowed — plan the
+// next one.  Which slot of its tile a particle gets depends on the order the atomics are served in; nothing that is computed does:
+// the mesh is a sum of integers, forces are per particle.  One launch instead of three, the positions read once, no tile / slot /
+// histogram / row-scan arrays (config 3: count 8.2 + row scan 4.9 + sorted place 11.6 us -> one launch).
+struct TileLists                    // where the scatter and force passes find a tile's particles
+    {
+    const unsigned int *first;      // first slot of the tile's segment
+    const unsigned int *count;      // particles of the tile: entry t * cstride
+    const unsigned int *cap;        // bin pipeline: slots of the segment (particles beyond it are in the overflow list); else null
+    const unsigned int *ovf_count;  // bin pipeline: entries of the overflow list; else null
+    const unsigned int *ovf_tile;   // tile of overflow entry k; its slot is ovf_base + k
+    unsigned int cstride, ovf_base;
+    };
+
+struct TilePlan                     // what the planning block reads and writes
+    {
+    const unsigned int *count;      // exact particles per tile of this snapshot (entry t * cstride)
+    unsigned int cstride, n_tiles;
+    unsigned int *first_next, *cap_next;       // the next snapshot's segments
+    unsigned int *cursor_next, *ovf_count_next;   // zeroed for the next snapshot (entry t * cstride_next)
+    unsigned int cstride_next;
+    const double *modesq_partials;  // sum of mode^2 (:622): block sums of the bin kernel -> mode_sq (null: somebody else adds them up)
+    unsigned int n_partials;
+    double *mode_sq;
+    };
+
+constexpr unsigned int TB_CSTRIDE = 32;                            // one cursor per 128-byte line: 245 blocks add to every one of them
+__host__ __device__ __forceinline__ unsigned int tile_capacity(const unsigned int count)
+    {
+    const unsigned int slack = count >> 3;
+    return (count + (slack > 32u ? slack : 32u) + 7u) & ~7u;
+    }
+// slots all segments together can take (the overflow list lives behind them)
+static size_t tile_capacity_total_max(const size_t n_particles, const size_t n_tiles) { return n_particles + n_particles / 8 + 40 * n_tiles + 8; }
+
+// one block (any size that is a multiple of 64, up to 1024 threads)
+__device__ __forceinline__ void tile_plan_block(const TilePlan &P, unsigned int *s_w, double *s_red)
+    {
+    const unsigned int B = blockDim.x;
+    const unsigned int per = (P.n_tiles + B - 1) / B;
+    unsigned int mine = 0;
+    for (unsigned int j = 0; j < per; ++j)
+        {
+        const unsigned int t = threadIdx.x * per + j;
+        if (t < P.n_tiles) mine += tile_capacity(P.count[(size_t)t * P.cstride]);
+        }
+    unsigned int incl = mine;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1)
+        {
+        const unsigned int o = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += o;
+        }
+    if (lane == 63) s_w[wave] = incl;
+    __syncthreads();
+    unsigned int run = incl - mine;
+    for (int w = 0; w < wave; ++w) run += s_w[w];
+    for (unsigned int j = 0; j < per; ++j)
+        {
+        const unsigned int t = threadIdx.x * per + j;
+        if (t < P.n_tiles)
+            {
+            const unsigned int cap = tile_capacity(P.count[(size_t)t * P.cstride]);
+            P.first_next[t] = run;
+            P.cap_next[t] = cap;
+            P.cursor_next[(size_t)t * P.cstride_next] = 0u;
+            run += cap;
+            }
+        }
+    if (threadIdx.x == 0) *P.ovf_count_next = 0u;
+    if (P.modesq_partials)
+        {
+        // (the order of k_tile_rowscan's extra block: 256 strided partial sums, then the waves in sequence — the same bits)
+        double v = 0.0;
+        if (threadIdx.x < 256)
+            for (unsigned int b = threadIdx.x; b < P.n_partials; b += 256) v += P.modesq_partials[b];
+        v = block_sum(v, s_red);
+        if (threadIdx.x == 0) *P.mode_sq = v;
+        }
+    }
+
+__global__ __launch_bounds__(1024) void k_tile_plan(const TilePlan P)
+    {
+    __shared__ unsigned int s_w[16];
+    __shared__ double s_red[16];
+    tile_plan_block(P, s_w, s_red);
+    }
+
+constexpr int TB_THREADS = 1024;
+constexpr int TB_PER = TPS_CHUNK_MAX / TB_THREADS;                 // particles per thread
+constexpr int TB_TILES_PER_MAX = 8;                                // tiles per thread in the prefix: n_tiles <= 8192
+constexpr size_t TB_LDS_MAX = 160 * 1024 - 1024;                   // dynamic LDS (the static part is < 1 KB)
+
+template<typename S4> size_t tile_bin_lds_bytes(const unsigned int n_tiles, const unsigned int chunk)
+    {
+    return sizeof(unsigned int) * (3 * (size_t)n_tiles + chunk) + sizeof(S4) * (size_t)chunk;
+    }
+
+template<typename S4>
+__global__ __launch_bounds__(TB_THREADS) void k_tile_bin(const MeshGeom g, const TileGeom tg, const S4 *__restrict__ postype, const unsigned int N,
+                                                         const double *__restrict__ mode, const unsigned int n_types,
+                                                         const unsigned int *__restrict__ plan_first, const unsigned int *__restrict__ plan_cap,
+                                                         unsigned int *__restrict__ cursor, unsigned int *__restrict__ ovf_count,
+                                                         unsigned int *__restrict__ ovf_tile, const unsigned int ovf_base,
+                                                         unsigned int *__restrict__ ids, S4 *__restrict__ possorted,
+                                                         double *__restrict__ modesq_partials)
+    {
+    extern __shared__ __align__(16) unsigned char s_raw[];
+    S4 *s_pos = (S4 *)s_raw;                                                   // [chunk]
+    unsigned int *s_meta = (unsigned int *)(s_pos + tg.chunk);                 // [chunk]: tile << 16 | index in the chunk
+    unsigned int *s_lpre = s_meta + tg.chunk;                                  // [n_tiles]: histogram of the chunk, then its prefix
+    unsigned int *s_dest = s_lpre + tg.n_tiles;                                // [n_tiles]: first slot of the (chunk, tile) run
+    unsigned int *s_room = s_dest + tg.n_tiles;                                // [n_tiles]: slots of the run inside the tile's segment
+    __shared__ double s_red[16];
+    __shared__ double s_mode[TP_MODE_LDS];
+    __shared__ unsigned int s_w[TB_THREADS / 64];
+    const unsigned int b = blockIdx.x;
+    const unsigned int i0 = min(N, b * tg.chunk), i1 = min(N, i0 + tg.chunk);
+    const unsigned int i_last = i1 ? i1 - 1 : 0u;
+    S4 raw[TB_PER];
+    unsigned int tl[TB_PER], sl[TB_PER];
+#pragma unroll
+    for (int k = 0; k < TB_PER; ++k) raw[k] = scalar4_traits<S4>::make(0, 0, 0, 0);
+    if (i0 < i1) raw[0] = postype[min(i0 + threadIdx.x, i_last)];              // (uniform over the block)
+    stage_modes(s_mode, mode, n_types);
+    for (unsigned int t = threadIdx.x; t < tg.n_tiles; t += TB_THREADS) s_lpre[t] = 0;
+    __syncthreads();
+    // 1. as k_tile_count: tile of every particle, arrival slot from the LDS histogram; the next position in flight meanwhile
+    double msq = 0.0;
+#pragma unroll
+    for (int k = 0; k < TB_PER; ++k)
+        {
+        const unsigned int i = i0 + threadIdx.x + k * TB_THREADS;
+        if (k + 1 < TB_PER && i0 < i1) raw[k + 1 < TB_PER ? k + 1 : k] = postype[min(i + TB_THREADS, i_last)];
+        tl[k] = 0;
+        sl[k] = 0;
+        if (i < i1)
+            {
+            const Particle p = scalar4_traits<S4>::unpack(raw[k]);
+            int ix, iy, iz;
+            double sx, sy, sz;
+            locate(g, p, ix, iy, iz, sx, sy, sz);
+            const unsigned int t = (unsigned int)ix / tg.tx + tg.ntx * ((unsigned int)iy / tg.ty + tg.nty * ((unsigned int)iz / tg.tz));
+            tl[k] = t;
+            sl[k] = atomicAdd(&s_lpre[t], 1u);
+            const double a = mode_of(s_mode, mode, (unsigned int)p.type);
+            msq += a * a;
+            }
+        }
+    lds_barrier();
+    // 2. the runs of this chunk: one returning atomic per (chunk, tile) pair that has particles — requested first, consumed last —
+    //    and the prefix over the chunk's histogram meanwhile
+    const unsigned int per = (tg.n_tiles + TB_THREADS - 1) / TB_THREADS;       // <= TB_TILES_PER_MAX (host)
+    unsigned int cnt[TB_TILES_PER_MAX], base[TB_TILES_PER_MAX], pfirst[TB_TILES_PER_MAX], pcap[TB_TILES_PER_MAX];
+    unsigned int loc = 0;
+#pragma unroll
+    for (int j = 0; j < TB_TILES_PER_MAX; ++j)
+        {
+        cnt[j] = 0; base[j] = 0; pfirst[j] = 0; pcap[j] = 0;
+        const unsigned int t = threadIdx.x * per + j;
+        if ((unsigned int)j < per && t < tg.n_tiles)
+            {
+            cnt[j] = s_lpre[t];
+            pfirst[j] = plan_first[t];
+            pcap[j] = plan_cap[t];
+            if (cnt[j]) base[j] = atomicAdd(&cursor[(size_t)t * TB_CSTRIDE], cnt[j]);
+            loc += cnt[j];
+            }
+        }
+    unsigned int iloc = loc;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1)
+        {
+        const unsigned int o = __shfl_up(iloc, off, 64);
+        if (lane >= off) iloc += o;
+        }
+    if (lane == 63) s_w[wave] = iloc;
+    lds_barrier();
+    unsigned int lrun = iloc - loc;
+    for (int w = 0; w < wave; ++w) lrun += s_w[w];
+#pragma unroll
+    for (int j = 0; j < TB_TILES_PER_MAX; ++j)
+        {
+        const unsigned int t = threadIdx.x * per + j;
+        if ((unsigned int)j < per && t < tg.n_tiles)
+            {
+            s_lpre[t] = lrun;
+            lrun += cnt[j];
+            }
+        }
+    lds_barrier();
+    // 3. the chunk sorted by tile in LDS
+#pragma unroll
+    for (int k = 0; k < TB_PER; ++k)
+        {
+        const unsigned int li = threadIdx.x + k * TB_THREADS;
+        if (i0 + li < i1)
+            {
+            const unsigned int lofs = s_lpre[tl[k]] + sl[k];
+            s_pos[lofs] = raw[k];
+            s_meta[lofs] = (tl[k] << 16) | li;
+            }
+        }
+#pragma unroll
+    for (int j = 0; j < TB_TILES_PER_MAX; ++j)
+        {
+        const unsigned int t = threadIdx.x * per + j;
+        if ((unsigned int)j < per && t < tg.n_tiles)
+            {
+            s_dest[t] = pfirst[j] + base[j];
+            s_room[t] = pcap[j] > base[j] ? pcap[j] - base[j] : 0u;
+            }
+        }
+    __syncthreads();
+    // 4. out, in runs; what does not fit its tile's segment goes to the overflow list
+    const unsigned int n = i1 - i0;
+    for (unsigned int j = threadIdx.x; j < n; j += TB_THREADS)
+        {
+        const unsigned int meta = s_meta[j], t = meta >> 16;
+        const unsigned int r = j - s_lpre[t];
+        unsigned int dst;
+        if (r < s_room[t])
+            dst = s_dest[t] + r;
+        else
+            {
+            const unsigned int k = atomicAdd(ovf_count, 1u);
+            ovf_tile[k] = t;
+            dst = ovf_base + k;
+            }
+        possorted[dst] = s_pos[j];
+        ids[dst] = i0 + (meta & 0xffffu);
+        }
+    msq = block_sum_lds(msq, s_red);
+    if (threadIdx.x == 0) modesq_partials[b] = msq;
+    }
+
 template<typename S4>
 __global__ __launch_bounds__(TP_THREADS) void k_tile_scatter(const MeshGeom g, const TileGeom tg, const S4 *__restrict__ postype,
-                                                             const double *__restrict__ mode, const unsigned int *__restrict__ tile_total,
-                                                             const unsigned int *__restrict__ tile_first,
+                                                             const double *__restrict__ mode, const TileLists L,
                                                              const unsigned int *__restrict__ ids, long long *__restrict__ tilebuf,
                                                              double4 *__restrict__ packed, const unsigned int n_types,
-                                                             const S4 *__restrict__ possorted)
+                                                             const S4 *__restrict__ possorted, const TilePlan plan)
     {
     __shared__ unsigned long long s_t[TP_HMAX];
     __shared__ double s_mode[TP_MODE_LDS];
+    if (blockIdx.x == tg.n_tiles)
+        {
+        // bin pipeline: the extra block plans the NEXT snapshot's segments from this one's exact counts (and adds up sum mode^2)
+        __shared__ unsigned int s_w[16];
+        __shared__ double s_red[16];
+        tile_plan_block(plan, s_w, s_red);
+        return;
+        }
     const unsigned int t = blockIdx.x;
     const unsigned int tix = t % tg.ntx, tiy = (t / tg.ntx) % tg.nty, tiz = t / (tg.ntx * tg.nty);
     const int x0 = tix * tg.tx, y0 = tiy * tg.ty, z0 = tiz * tg.tz;
     TILE_STAMP(0, 0);
-    const unsigned int q0 = tile_first[t], q1 = q0 + tile_total[t];  // (k_tile_place, k_tile_rowscan)
+    const unsigned int n_all = L.count[(size_t)t * L.cstride];       // (k_tile_place*, k_tile_rowscan; bin pipeline: the tile's cursor)
+    const unsigned int q0 = L.first[t], q1 = q0 + (L.cap ? min(n_all, L.cap[t]) : n_all);
+    const unsigned int n_ovf = L.ovf_count ? *L.ovf_count : 0u;      // (uniform; zero in a well-planned step)
     // Software pipeline over the thread's particles: ids run two particles ahead, positions one, and the position travels RAW
     // (as loaded) to the iteration that uses it.  Carried as a converted Particle it was waited for right behind its load — the
     // conversion to double sat there — and every trip paid the id -> position chain of two memory round trips in full.
@@ -972,8 +1226,8 @@ __global__ __launch_bounds__(TP_THREADS) void k_tile_scatter(const MeshGeom g, c
     const unsigned int q_last = q1 ? q1 - 1 : 0u;
     unsigned int id = 0, id_next = 0;
     S4 raw = scalar4_traits<S4>::make(0, 0, 0, 0);
-    // possorted (k_tile_place_sorted): the raw position records in tile order — ids and positions come side by side, coalesced, no
-    // id -> position chain; without it (fallback place kernel) the positions are gathered through the ids
+    // possorted (k_tile_place_sorted, k_tile_bin): the raw position records in tile order — ids and positions come side by side,
+    // coalesced, no id -> position chain; without it (fallback place kernel) the positions are gathered through the ids
     if (q0 < q1)                                                     // (uniform over the block; an empty tile — or no particles at
         {                                                            // all, and then no position array either — loads nothing)
         id = ids[min(q, q_last)];
@@ -984,14 +1238,10 @@ __global__ __launch_bounds__(TP_THREADS) void k_tile_scatter(const MeshGeom g, c
     for (unsigned int e = threadIdx.x; e < tg.hcells; e += TP_THREADS) s_t[e] = 0ull;
     __syncthreads();
     TILE_STAMP(0, 1);
-    while (q < q1)
+    // one particle: its record for the force pass at `slot`, its 27 weights into the LDS image
+    auto deposit = [&](const S4 &rawv, const unsigned int cur_id, const unsigned int slot)
         {
-        const Particle cur = scalar4_traits<S4>::unpack(raw);
-        const unsigned int cur_id = id;
-        const unsigned int qn = q + TP_THREADS;
-        raw = possorted ? possorted[min(qn, q_last)] : postype[id_next];
-        id = id_next;
-        id_next = ids[min(qn + TP_THREADS, q_last)];
+        const Particle cur = scalar4_traits<S4>::unpack(rawv);
         int ix, iy, iz;
         double sx, sy, sz;
         locate(g, cur, ix, iy, iz, sx, sy, sz);
@@ -1007,7 +1257,7 @@ __global__ __launch_bounds__(TP_THREADS) void k_tile_scatter(const MeshGeom g, c
         // the force pass of this snapshot walks the same tile order: in-cell shift, mode, id and the stencil's corner in
         // the tile image, stored in place (coalesced) so that it neither gathers nor locates again
         // (32 bytes: the fourth word carries id, type and corner as integers; 40-byte records cost the two passes ~3 us)
-        packed[q] = make_double4(sx, sy, sz, __hiloint2double((int)(base | ((unsigned int)cur.type << 16)), (int)cur_id));
+        packed[slot] = make_double4(sx, sy, sz, __hiloint2double((int)(base | ((unsigned int)cur.type << 16)), (int)cur_id));
 #pragma unroll
         for (int k = 0; k < 3; ++k)
 #pragma unroll
@@ -1024,9 +1274,26 @@ __global__ __launch_bounds__(TP_THREADS) void k_tile_scatter(const MeshGeom g, c
                     atomicAdd(&s_t[row + i], (unsigned long long)(__double_as_longlong(shifted) - 0x4338000000000000ll));
                     }
                 }
+        };
+    while (q < q1)
+        {
+        const S4 cur_raw = raw;
+        const unsigned int cur_id = id;
+        const unsigned int qn = q + TP_THREADS;
+        raw = possorted ? possorted[min(qn, q_last)] : postype[id_next];
+        id = id_next;
+        id_next = ids[min(qn + TP_THREADS, q_last)];
+        deposit(cur_raw, cur_id, q);
         if (q == q0 + threadIdx.x) TILE_STAMP(0, 2);                   // first particle of thread 0 done
         q = qn;
         }
+    // bin pipeline, a snapshot the plan did not fit: this tile's particles in the overflow list (every block scans the list)
+    for (unsigned int k = threadIdx.x; k < n_ovf; k += TP_THREADS)
+        if (L.ovf_tile[k] == t)
+            {
+            const unsigned int slot = L.ovf_base + k;
+            deposit(possorted[slot], ids[slot], slot);
+            }
     TILE_STAMP(0, 3);
     lds_barrier();                                                   // (the record stores of the loop drain behind it)
     TILE_STAMP(0, 4);
@@ -1112,8 +1379,7 @@ __global__ __launch_bounds__(256) void k_tile_combine_rows(const MeshGeom g, con
 constexpr int TF_THREADS = MTD_TF_THREADS;        // two blocks of eight waves per CU (128 VGPRs): one stages its tile while the other sums
 
 template<typename S4>
-__global__ __launch_bounds__(TF_THREADS) void k_tile_forces(const MeshGeom g, const TileGeom tg, const unsigned int *__restrict__ tile_total,
-                                                            const unsigned int *__restrict__ tile_first,
+__global__ __launch_bounds__(TF_THREADS) void k_tile_forces(const MeshGeom g, const TileGeom tg, const TileLists L,
                                                             const double *__restrict__ mode, const double4 *__restrict__ packed,
                                                             const double *__restrict__ inv, S4 *__restrict__ force,
                                                             const double *__restrict__ d_bias, const double bias_host,
@@ -1127,12 +1393,14 @@ __global__ __launch_bounds__(TF_THREADS) void k_tile_forces(const MeshGeom g, co
     const unsigned int tix = t % tg.ntx, tiy = (t / tg.ntx) % tg.nty, tiz = t / (tg.ntx * tg.nty);
     const int x0 = tix * tg.tx, y0 = tiy * tg.ty, z0 = tiz * tg.tz;
     TILE_STAMP(1, 0);
-    const unsigned int q0 = tile_first[t], q1 = q0 + tile_total[t];
-    if (q0 == q1) return;
+    const unsigned int n_all = L.count[(size_t)t * L.cstride];
+    const unsigned int q0 = L.first[t], q1 = q0 + (L.cap ? min(n_all, L.cap[t]) : n_all);
+    const unsigned int n_ovf = L.ovf_count ? *L.ovf_count : 0u;      // (uniform; zero in a well-planned step)
+    if (n_all == 0) return;                                          // (nothing of this tile in the overflow list either)
     // (records are loaded unconditionally from clamped slots: behind a branch the compiler cannot count the load and waits
     // for everything in flight — the previous particle's force store included — at the first use of the record)
     unsigned int q = q0 + threadIdx.x;
-    const unsigned int q_last = q1 - 1;
+    const unsigned int q_last = q1 > q0 ? q1 - 1 : q0;               // (q1 == q0: every particle of the tile overflowed; slot q0 is allocated)
     double4 pk = packed[min(q, q_last)];
     // Re(inv) of the tile + halo.  The counters of round 3 (profiles/r3) put this kernel on the instruction-issue limit with
     // two thirds of its vector instructions in THIS staging (23 rows per thread with wraps and compares, 14 of 32 lanes idle
@@ -1190,11 +1458,8 @@ __global__ __launch_bounds__(TF_THREADS) void k_tile_forces(const MeshGeom g, co
     TILE_STAMP(1, 1);
     const double bias = d_bias ? *d_bias : bias_host;
     const double s = two_over_n * bias;                                // :861
-    while (q < q1)
+    auto force_of = [&](const double4 &cur)
         {
-        const double4 cur = pk;
-        const unsigned int qn = q + TF_THREADS;
-        pk = packed[min(qn, q_last)];
         const unsigned int bt = (unsigned int)__double2hiint(cur.w);          // the record of k_tile_scatter
         const uint2 cib = make_uint2((unsigned int)__double2loint(cur.w), bt & 0xffffu);
         const double a = mode_of(s_mode, mode, bt >> 16), sx = cur.x, sy = cur.y, sz = cur.z;
@@ -1229,9 +1494,19 @@ __global__ __launch_bounds__(TF_THREADS) void k_tile_forces(const MeshGeom g, co
         const double fy = (c1 * g.binv[0][1] + c2 * g.binv[1][1] + c3 * g.binv[2][1]) * s;
         const double fz = (c1 * g.binv[0][2] + c2 * g.binv[1][2] + c3 * g.binv[2][2]) * s;
         force[cib.x] = scalar4_traits<S4>::make((scalar)fx, (scalar)fy, (scalar)fz, (scalar)0);
+        };
+    while (q < q1)
+        {
+        const double4 cur = pk;
+        const unsigned int qn = q + TF_THREADS;
+        pk = packed[min(qn, q_last)];
+        force_of(cur);
         if (q == q0 + threadIdx.x) TILE_STAMP(1, 2);
         q = qn;
         }
+    // bin pipeline: this tile's particles in the overflow list (their records sit at the list's slots)
+    for (unsigned int k = threadIdx.x; k < n_ovf; k += TF_THREADS)
+        if (L.ovf_tile[k] == t) force_of(packed[L.ovf_base + k]);
     TILE_STAMP(1, 3);
     }
 
@@ -2383,6 +2658,13 @@ struct mtd_mesh
     uint4 *d_tsrc;             // per-axis table of the tile-buffer offsets that stand for a mesh coordinate (k_tile_combine)
     unsigned int *d_ids;
     void *d_possorted;             // raw position records in tile order (k_tile_place_sorted): 32 bytes per particle hold either precision
+    // bin pipeline (k_tile_bin): segments with slack planned from the previous snapshot's exact counts, two sets (the force pass of a
+    // snapshot reads the set its assignment used while the next one is being planned)
+    unsigned int *d_plan_first[2], *d_plan_cap[2], *d_cursor[2], *d_ovf_count[2], *d_ovf_tile;
+    unsigned int ovf_base;          // first slot of the overflow list in ids / possorted / packed (= all segments' slots at the most)
+    int plan_valid, bin_parity;     // set `bin_parity` is planned (for plan_n particles) and its cursors are zero
+    unsigned int plan_n;
+    TileLists lists;                // where the last assignment left the tiles' particles (the force pass walks the same lists)
     double amax;               // max |mode coefficient| (fixed-point scale)
     // slab decomposition over the ranks of a mailbox (mtd_mesh_slab_attach): exported buffers of every rank as mapped here
     struct mtd_comm *slab_comm;
@@ -2587,18 +2869,22 @@ int mtd_mesh_create(mtd_mesh **out, unsigned int nx, unsigned int ny, unsigned i
     const size_t n_scan = std::max<size_t>(m->M, (size_t)m->tg.n_tiles * m->tile_blocks_max);   // entries the scan kernels may see
     const unsigned int n_tiles = (unsigned int)((n_scan + SCAN_TILE - 1) / SCAN_TILE);
     auto al = [](size_t b) { return (b + 255) / 256 * 256; };
+    // tile-ordered arrays (ids, position records, force records): all segments' slots of the bin pipeline + an overflow list of N
+    const size_t n_slots_extra = m->tile_path ? tile_capacity_total_max(N, m->tg.n_tiles) : 0;
     size_t off = 0;
     auto take = [&](size_t b) { size_t o = off; off += al(b); return o; };
     const size_t o_mode = take(sizeof(double) * n_types), o_rho = take(sizeof(double) * (M + 1)), o_msqp = take(sizeof(double) * m->n_count_blocks), o_cvp = take(sizeof(double) * m->n_cv_partials), o_f = take(sizeof(double2) * MH),
                  o_g = take(sizeof(double2) * MH), o_tw0 = take(sizeof(double2) * nx), o_tw1 = take(sizeof(double2) * ny),
-                 o_tw2 = take(sizeof(double2) * nz), o_packed = take(sizeof(double4) * N), o_cell = take(sizeof(unsigned int) * N),
+                 o_tw2 = take(sizeof(double2) * nz), o_packed = take(sizeof(double4) * (N + n_slots_extra)), o_cell = take(sizeof(unsigned int) * N),
                  o_count = take(sizeof(unsigned int) * (n_scan + 1)), o_start = take(sizeof(unsigned int) * (n_scan + 1)),
                  o_ids = take(sizeof(uint2) * N), o_tiles = take(sizeof(unsigned int) * n_tiles),
                  o_inv = take(sizeof(double) * M), o_slot = take(sizeof(unsigned int) * N),
                  o_itab = take(sizeof(double) * (nx + ny + nz)),
-                 o_tilebuf = take(sizeof(long long) * (size_t)m->tg.n_tiles * m->tg.hcells), o_ids2 = take(sizeof(unsigned int) * N),
+                 o_tilebuf = take(sizeof(long long) * (size_t)m->tg.n_tiles * m->tg.hcells), o_ids2 = take(sizeof(unsigned int) * (N + n_slots_extra)),
                  o_tsrc = take(sizeof(uint4) * (nx + ny + nz)), o_ttot = take(sizeof(unsigned int) * 2 * ((size_t)m->tg.n_tiles + 1)),
-                 o_psort = take(m->tile_path ? sizeof(double4) * N : 0);
+                 o_psort = take(m->tile_path ? sizeof(double4) * (N + n_slots_extra) : 0),
+                 o_plan = take(m->tile_path ? sizeof(unsigned int) * (4 * (size_t)m->tg.n_tiles + 2 * (size_t)m->tg.n_tiles * TB_CSTRIDE + 2 * TB_CSTRIDE) : 0),
+                 o_ovft = take(m->tile_path ? sizeof(unsigned int) * N : 0);
     hipError_t e = hipMalloc(&m->slab, off);
     if (e != hipSuccess)
         {
@@ -2620,6 +2906,18 @@ int mtd_mesh_create(mtd_mesh **out, unsigned int nx, unsigned int ny, unsigned i
     m->d_tilebuf = (long long *)(p + o_tilebuf);
     m->d_ids = (unsigned int *)(p + o_ids2);
     m->d_possorted = m->tile_path ? (void *)(p + o_psort) : nullptr;
+    if (m->tile_path)
+        {
+        const size_t T = m->tg.n_tiles;
+        unsigned int *q = (unsigned int *)(p + o_plan);
+        for (int i = 0; i < 2; ++i) { m->d_plan_first[i] = q; q += T; m->d_plan_cap[i] = q; q += T; }
+        for (int i = 0; i < 2; ++i) { m->d_cursor[i] = q; q += T * TB_CSTRIDE; }
+        for (int i = 0; i < 2; ++i) { m->d_ovf_count[i] = q; q += TB_CSTRIDE; }
+        m->d_ovf_tile = (unsigned int *)(p + o_ovft);
+        m->ovf_base = (unsigned int)n_slots_extra;
+        }
+    m->plan_valid = 0; m->bin_parity = 0; m->plan_n = 0;
+    std::memset(&m->lists, 0, sizeof(m->lists));
     m->d_tsrc = (uint4 *)(p + o_tsrc);
     m->d_tile_total = (unsigned int *)(p + o_ttot);
     m->d_tile_first = m->d_tile_total + m->tg.n_tiles + 1;
@@ -2811,6 +3109,47 @@ static int mesh_assign_local(mtd_mesh *m, unsigned int n_particles, const void *
             }
         tg.scale = std::ldexp(1.0, k);
         tg.inv_scale = std::ldexp(1.0, -k);
+        const bool f32 = dtype == MTD_F32;
+        // ---- bin pipeline (steady state): one launch bins, sorts and stores the chunk; the scatter launch's extra block plans the next
+        // snapshot.  Needs a plan for this particle number (the first assignment of a mesh goes through the counting pipeline and
+        // plans from its exact counts), no riders (they travel in the counting / row-scan kernels), a chunk and tables that fit the LDS.
+        const char *bin_env = std::getenv("MTD_MESH_BIN");               // (read per call: tests run both pipelines in one process)
+        const bool bin_off = bin_env && bin_env[0] == '0';
+        const size_t tb_lds = f32 ? tile_bin_lds_bytes<float4>(tg.n_tiles, tg.chunk) : tile_bin_lds_bytes<double4>(tg.n_tiles, tg.chunk);
+        static const bool tb_lds_ok = [] {
+            hipError_t e = hipFuncSetAttribute((const void *)k_tile_bin<float4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TB_LDS_MAX);
+            if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_tile_bin<double4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TB_LDS_MAX);
+            if (e != hipSuccess) (void)hipGetLastError();
+            return e == hipSuccess;
+        }();
+        const bool bin_fits = !bin_off && tb_lds_ok && m->d_possorted && tg.chunk <= TPS_CHUNK_MAX && tb_lds <= TB_LDS_MAX &&
+                              tg.n_tiles <= (unsigned int)(TB_TILES_PER_MAX * TB_THREADS);
+        TilePlan plan;
+        std::memset(&plan, 0, sizeof(plan));
+        if (bin_fits && m->plan_valid && m->plan_n == N && !m->rider_armed)
+            {
+            const int p = m->bin_parity;
+            if (f32)
+                k_tile_bin<float4><<<nb, TB_THREADS, tb_lds, s>>>(g, tg, (const float4 *)d_postype, N, m->d_mode, m->n_types, m->d_plan_first[p], m->d_plan_cap[p], m->d_cursor[p], m->d_ovf_count[p], m->d_ovf_tile, m->ovf_base, m->d_ids, (float4 *)m->d_possorted, m->d_modesq_partials);
+            else
+                k_tile_bin<double4><<<nb, TB_THREADS, tb_lds, s>>>(g, tg, (const double4 *)d_postype, N, m->d_mode, m->n_types, m->d_plan_first[p], m->d_plan_cap[p], m->d_cursor[p], m->d_ovf_count[p], m->d_ovf_tile, m->ovf_base, m->d_ids, (double4 *)m->d_possorted, m->d_modesq_partials);
+            MTD_LAUNCH_CHECK();
+            TileLists L;
+            L.first = m->d_plan_first[p]; L.count = m->d_cursor[p]; L.cap = m->d_plan_cap[p]; L.ovf_count = m->d_ovf_count[p];
+            L.ovf_tile = m->d_ovf_tile; L.cstride = TB_CSTRIDE; L.ovf_base = m->ovf_base;
+            plan.count = m->d_cursor[p]; plan.cstride = TB_CSTRIDE; plan.n_tiles = tg.n_tiles;
+            plan.first_next = m->d_plan_first[1 - p]; plan.cap_next = m->d_plan_cap[1 - p];
+            plan.cursor_next = m->d_cursor[1 - p]; plan.ovf_count_next = m->d_ovf_count[1 - p]; plan.cstride_next = TB_CSTRIDE;
+            plan.modesq_partials = m->d_modesq_partials; plan.n_partials = nb; plan.mode_sq = m->d_mode_sq;
+            if (f32)
+                k_tile_scatter<float4><<<tg.n_tiles + 1, TP_THREADS, 0, s>>>(g, tg, (const float4 *)d_postype, m->d_mode, L, m->d_ids, m->d_tilebuf, m->d_packed, m->n_types, (const float4 *)m->d_possorted, plan);
+            else
+                k_tile_scatter<double4><<<tg.n_tiles + 1, TP_THREADS, 0, s>>>(g, tg, (const double4 *)d_postype, m->d_mode, L, m->d_ids, m->d_tilebuf, m->d_packed, m->n_types, (const double4 *)m->d_possorted, plan);
+            m->lists = L;
+            m->bin_parity = 1 - p;                                       // (planned and zeroed by the extra block)
+            }
+        else
+            {
         const size_t lds = sizeof(unsigned int) * tg.n_tiles;
         unsigned int n_apply_blocks = 0;
 #define MTD_TILE_COUNT(S4, RIDER, FAST, GRID) \
@@ -2839,7 +3178,6 @@ static int mesh_assign_local(mtd_mesh *m, unsigned int n_particles, const void *
         pb = pb < 1 ? 1 : (pb > 512 ? 512 : pb);
         // sorted place (the default): raw position records and ids leave in tile order, in runs; MTD_MESH_PLACE=ids keeps the
         // one-store-per-particle form, which is also the fallback when a chunk or the tables do not fit
-        const bool f32 = dtype == MTD_F32;
         const size_t ps_lds = f32 ? place_sorted_lds_bytes<float4>(tg.n_tiles, tg.chunk) : place_sorted_lds_bytes<double4>(tg.n_tiles, tg.chunk);
         const char *ps_env = std::getenv("MTD_MESH_PLACE");           // (read per call: a test runs both forms in one process)
         const bool ps_off = ps_env && std::strcmp(ps_env, "ids") == 0;
@@ -2862,10 +3200,27 @@ static int mesh_assign_local(mtd_mesh *m, unsigned int n_particles, const void *
         else
             k_tile_place<double4><<<pb, 256, sizeof(unsigned int) * tg.n_tiles, s>>>(tg, N, m->d_cell_of, m->d_slot_of, m->d_start, m->d_tile_total, m->d_ids, m->d_tile_first);
         MTD_LAUNCH_CHECK();
+        TileLists L;
+        std::memset(&L, 0, sizeof(L));
+        L.first = m->d_tile_first; L.count = m->d_tile_total; L.cstride = 1;
         if (f32)
-            k_tile_scatter<float4><<<tg.n_tiles, TP_THREADS, 0, s>>>(g, tg, (const float4 *)d_postype, m->d_mode, m->d_tile_total, m->d_tile_first, m->d_ids, m->d_tilebuf, m->d_packed, m->n_types, sorted ? (const float4 *)m->d_possorted : nullptr);
+            k_tile_scatter<float4><<<tg.n_tiles, TP_THREADS, 0, s>>>(g, tg, (const float4 *)d_postype, m->d_mode, L, m->d_ids, m->d_tilebuf, m->d_packed, m->n_types, sorted ? (const float4 *)m->d_possorted : nullptr, plan);
         else
-            k_tile_scatter<double4><<<tg.n_tiles, TP_THREADS, 0, s>>>(g, tg, (const double4 *)d_postype, m->d_mode, m->d_tile_total, m->d_tile_first, m->d_ids, m->d_tilebuf, m->d_packed, m->n_types, sorted ? (const double4 *)m->d_possorted : nullptr);
+            k_tile_scatter<double4><<<tg.n_tiles, TP_THREADS, 0, s>>>(g, tg, (const double4 *)d_postype, m->d_mode, L, m->d_ids, m->d_tilebuf, m->d_packed, m->n_types, sorted ? (const double4 *)m->d_possorted : nullptr, plan);
+        m->lists = L;
+        if (bin_fits && !(m->plan_valid && m->plan_n == N))
+            {
+            // the exact counts of this snapshot plan the segments of the next one
+            MTD_LAUNCH_CHECK();
+            const int p = m->bin_parity;
+            plan.count = m->d_tile_total; plan.cstride = 1; plan.n_tiles = tg.n_tiles;
+            plan.first_next = m->d_plan_first[p]; plan.cap_next = m->d_plan_cap[p];
+            plan.cursor_next = m->d_cursor[p]; plan.ovf_count_next = m->d_ovf_count[p]; plan.cstride_next = TB_CSTRIDE;
+            k_tile_plan<<<1, 1024, 0, s>>>(plan);
+            m->plan_valid = 1;
+            m->plan_n = N;
+            }
+            }
         MTD_LAUNCH_CHECK();
         {
         const unsigned int cthreads = m->nx >= 256 ? 256 : (m->nx > 64 ? 128 : 64);
@@ -3017,9 +3372,9 @@ int mtd_mesh_forces(mtd_mesh *m, unsigned int n_particles, const void *d_postype
     if (m->tile_path)
         {
         if (dtype == MTD_F32)
-            k_tile_forces<float4><<<m->tg.n_tiles, TF_THREADS, 0, s>>>(g, m->tg, m->d_tile_total, m->d_tile_first, m->d_mode, m->d_packed, m->d_inv, (float4 *)d_force, d_bias, bias_host, two_over_n, m->n_types);
+            k_tile_forces<float4><<<m->tg.n_tiles, TF_THREADS, 0, s>>>(g, m->tg, m->lists, m->d_mode, m->d_packed, m->d_inv, (float4 *)d_force, d_bias, bias_host, two_over_n, m->n_types);
         else
-            k_tile_forces<double4><<<m->tg.n_tiles, TF_THREADS, 0, s>>>(g, m->tg, m->d_tile_total, m->d_tile_first, m->d_mode, m->d_packed, m->d_inv, (double4 *)d_force, d_bias, bias_host, two_over_n, m->n_types);
+            k_tile_forces<double4><<<m->tg.n_tiles, TF_THREADS, 0, s>>>(g, m->tg, m->lists, m->d_mode, m->d_packed, m->d_inv, (double4 *)d_force, d_bias, bias_host, two_over_n, m->n_types);
         MTD_LAUNCH_CHECK();
         return MTD_SUCCESS;
         }

@@ -98,6 +98,45 @@ def test_sorted_place_against_place_by_id(abi, monkeypatch, dtype, N, dims):
         assert np.abs(out["sorted"][1]).max() > 0 and np.abs(out["sorted"][2]).max() > 0
 
 
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("N,dims", [(1, (16, 16, 16)), (5000, (32, 16, 24)), (70001, (128, 32, 16)), (200003, (128, 128, 128))])
+def test_bin_pipeline_against_counting_pipeline(abi, monkeypatch, dtype, N, dims):
+    """k_tile_bin (one launch: segments with slack planned from the previous snapshot's exact counts, runs reserved with atomics,
+    overflow list) against count -> row scan -> sorted place on a SEQUENCE of snapshots through one mesh: the first assignment
+    (counting pipeline, plans), the same snapshot again (bin, everything fits), a snapshot with every particle in a corner of the
+    box (most of it overflows the old plan), that one again (re-planned), a uniform one again (the corner's segments overflow the
+    other way), an empty... no: a shuffled one.  The same particles end up in every tile, so mesh, sum of mode^2, CV and every
+    particle's force are the same bits as with MTD_MESH_BIN=0."""
+    L = 14.0
+    rng = np.random.default_rng(100 + N)
+    pos_u, types = util.snapshot_random(N, L, seed=9 + N, modulated=True, dtype=dtype)
+    pos_c = (pos_u.astype(np.float64) * 0.12 - 0.3 * L).astype(dtype)              # every particle in one corner
+    perm = rng.permutation(N)
+    seq = [(pos_u, types), (pos_u, types), (pos_c, types), (pos_c, types), (pos_u, types), (pos_u[perm], types[perm])]
+    box = abi.Box.make(L)
+    dt = abi.MTD_F32 if dtype == np.float32 else abi.MTD_F64
+    out = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("MTD_MESH_BIN", mode)
+        g = GpuMesh(abi, dims, [1.0, -0.7], N)
+        res = []
+        try:
+            for pos, ty in seq:
+                d_pos = torch.from_numpy(util.pack_postype(pos, ty, dtype)).cuda()
+                s = g.cv(d_pos, dt, box, N)
+                F = g.forces(d_pos, dt, box, N, 0.8)
+                res.append((s, g.array(0).copy(), g.array(7), F))
+        finally:
+            g.close()
+        out[mode] = res
+    for a, b in zip(out["1"], out["0"]):
+        assert a[0] == b[0] and a[2] == b[2]
+        assert np.array_equal(a[1], b[1])
+        assert np.array_equal(a[3], b[3])
+    if N > 1:
+        assert np.abs(out["1"][2][1]).max() > 0 and np.abs(out["1"][2][3]).max() > 0
+
+
 def test_mesh_bitwise_independent_of_particle_order(abi):
     """tile path: the weights are summed as 64-bit fixed point, so the mesh does not depend on the order of the adds"""
     N, L = 40011, 12.0
