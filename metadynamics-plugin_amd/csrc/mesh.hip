@@ -981,7 +981,7 @@ struct TilePlan                     // what the planning block reads and writes
     double *mode_sq;
     };
 
-constexpr unsigned int TB_CSTRIDE = 32;                            // one cursor per 128-byte line: 245 blocks add to every one of them
+constexpr unsigned int TB_CSTRIDE = 1;                             // cursors side by side: the 64 atomics of a wave travel as four 64-byte requests (one per 128-byte line each: 64 requests, 11 us per launch)
 __host__ __device__ __forceinline__ unsigned int tile_capacity(const unsigned int count)
     {
     const unsigned int slack = count >> 3;
@@ -1054,7 +1054,10 @@ template<typename S4> size_t tile_bin_lds_bytes(const unsigned int n_tiles, cons
     return sizeof(unsigned int) * (3 * (size_t)n_tiles + chunk) + sizeof(S4) * (size_t)chunk;
     }
 
-template<typename S4>
+// PER: tiles per thread in the prefix over the chunk's histogram (a compile-time constant: 1, 2, 4 or 8 — every lane runs every trip
+// with a clamped tile, so that the atomics and the loads beside them are unconditional and STAY IN FLIGHT: behind a branch the
+// compiler waited for each atomic right where it was issued, 6 us per block)
+template<typename S4, int PER>
 __global__ __launch_bounds__(TB_THREADS) void k_tile_bin(const MeshGeom g, const TileGeom tg, const S4 *__restrict__ postype, const unsigned int N,
                                                          const double *__restrict__ mode, const unsigned int n_types,
                                                          const unsigned int *__restrict__ plan_first, const unsigned int *__restrict__ plan_cap,
@@ -1074,22 +1077,28 @@ __global__ __launch_bounds__(TB_THREADS) void k_tile_bin(const MeshGeom g, const
     __shared__ unsigned int s_w[TB_THREADS / 64];
     const unsigned int b = blockIdx.x;
     const unsigned int i0 = min(N, b * tg.chunk), i1 = min(N, i0 + tg.chunk);
-    const unsigned int i_last = i1 ? i1 - 1 : 0u;
+    CNT_STAMP(0);
+    if (i0 >= i1)                                                              // (uniform over the block: nothing to bin, nothing to read)
+        {
+        if (threadIdx.x == 0) modesq_partials[b] = 0.0;
+        return;
+        }
+    const unsigned int i_last = i1 - 1;
     S4 raw[TB_PER];
     unsigned int tl[TB_PER], sl[TB_PER];
-#pragma unroll
-    for (int k = 0; k < TB_PER; ++k) raw[k] = scalar4_traits<S4>::make(0, 0, 0, 0);
-    if (i0 < i1) raw[0] = postype[min(i0 + threadIdx.x, i_last)];              // (uniform over the block)
+    raw[0] = postype[min(i0 + threadIdx.x, i_last)];
     stage_modes(s_mode, mode, n_types);
     for (unsigned int t = threadIdx.x; t < tg.n_tiles; t += TB_THREADS) s_lpre[t] = 0;
     __syncthreads();
+    CNT_STAMP(1);
     // 1. as k_tile_count: tile of every particle, arrival slot from the LDS histogram; the next position in flight meanwhile
+    //    (unconditional loads from clamped indices)
     double msq = 0.0;
 #pragma unroll
     for (int k = 0; k < TB_PER; ++k)
         {
         const unsigned int i = i0 + threadIdx.x + k * TB_THREADS;
-        if (k + 1 < TB_PER && i0 < i1) raw[k + 1 < TB_PER ? k + 1 : k] = postype[min(i + TB_THREADS, i_last)];
+        if (k + 1 < TB_PER) raw[k + 1 < TB_PER ? k + 1 : k] = postype[min(i + TB_THREADS, i_last)];
         tl[k] = 0;
         sl[k] = 0;
         if (i < i1)
@@ -1105,26 +1114,28 @@ __global__ __launch_bounds__(TB_THREADS) void k_tile_bin(const MeshGeom g, const
             msq += a * a;
             }
         }
+    CNT_STAMP(2);
     lds_barrier();
-    // 2. the runs of this chunk: one returning atomic per (chunk, tile) pair that has particles — requested first, consumed last —
-    //    and the prefix over the chunk's histogram meanwhile
-    const unsigned int per = (tg.n_tiles + TB_THREADS - 1) / TB_THREADS;       // <= TB_TILES_PER_MAX (host)
-    unsigned int cnt[TB_TILES_PER_MAX], base[TB_TILES_PER_MAX], pfirst[TB_TILES_PER_MAX], pcap[TB_TILES_PER_MAX];
+    CNT_STAMP(3);
+    // 2. the runs of this chunk: one returning atomic per (chunk, tile) pair — requested first, consumed last — and the prefix over
+    //    the chunk's histogram meanwhile.  Lanes beyond the last tile add zero to cursors of their own behind the tiles' (the
+    //    cursor arrays have TB_TILES_PER_MAX * TB_THREADS entries; all of them on ONE word would serialise: 1.4 ms per launch).
+    unsigned int cnt[PER], base[PER], pfirst[PER], pcap[PER];
     unsigned int loc = 0;
+    const unsigned int t_last = tg.n_tiles - 1;
 #pragma unroll
-    for (int j = 0; j < TB_TILES_PER_MAX; ++j)
+    for (int j = 0; j < PER; ++j)
         {
-        cnt[j] = 0; base[j] = 0; pfirst[j] = 0; pcap[j] = 0;
-        const unsigned int t = threadIdx.x * per + j;
-        if ((unsigned int)j < per && t < tg.n_tiles)
-            {
-            cnt[j] = s_lpre[t];
-            pfirst[j] = plan_first[t];
-            pcap[j] = plan_cap[t];
-            if (cnt[j]) base[j] = atomicAdd(&cursor[(size_t)t * TB_CSTRIDE], cnt[j]);
-            loc += cnt[j];
-            }
+        const unsigned int t = threadIdx.x * PER + j, tc = min(t, t_last);
+        const unsigned int c = s_lpre[tc];
+        cnt[j] = t <= t_last ? c : 0u;
+        pfirst[j] = plan_first[tc];
+        pcap[j] = plan_cap[tc];
+        loc += cnt[j];
         }
+#pragma unroll
+    for (int j = 0; j < PER; ++j)
+        base[j] = atomicAdd(&cursor[(size_t)(threadIdx.x * PER + j) * TB_CSTRIDE], cnt[j]);
     unsigned int iloc = loc;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
@@ -1138,16 +1149,14 @@ __global__ __launch_bounds__(TB_THREADS) void k_tile_bin(const MeshGeom g, const
     unsigned int lrun = iloc - loc;
     for (int w = 0; w < wave; ++w) lrun += s_w[w];
 #pragma unroll
-    for (int j = 0; j < TB_TILES_PER_MAX; ++j)
+    for (int j = 0; j < PER; ++j)
         {
-        const unsigned int t = threadIdx.x * per + j;
-        if ((unsigned int)j < per && t < tg.n_tiles)
-            {
-            s_lpre[t] = lrun;
-            lrun += cnt[j];
-            }
+        const unsigned int t = threadIdx.x * PER + j;
+        if (t <= t_last) s_lpre[t] = lrun;
+        lrun += cnt[j];
         }
     lds_barrier();
+    CNT_STAMP(4);
     // 3. the chunk sorted by tile in LDS
 #pragma unroll
     for (int k = 0; k < TB_PER; ++k)
@@ -1161,16 +1170,17 @@ __global__ __launch_bounds__(TB_THREADS) void k_tile_bin(const MeshGeom g, const
             }
         }
 #pragma unroll
-    for (int j = 0; j < TB_TILES_PER_MAX; ++j)
+    for (int j = 0; j < PER; ++j)
         {
-        const unsigned int t = threadIdx.x * per + j;
-        if ((unsigned int)j < per && t < tg.n_tiles)
+        const unsigned int t = threadIdx.x * PER + j;
+        if (t <= t_last)
             {
             s_dest[t] = pfirst[j] + base[j];
             s_room[t] = pcap[j] > base[j] ? pcap[j] - base[j] : 0u;
             }
         }
     __syncthreads();
+    CNT_STAMP(5);
     // 4. out, in runs; what does not fit its tile's segment goes to the overflow list
     const unsigned int n = i1 - i0;
     for (unsigned int j = threadIdx.x; j < n; j += TB_THREADS)
@@ -1189,8 +1199,10 @@ __global__ __launch_bounds__(TB_THREADS) void k_tile_bin(const MeshGeom g, const
         possorted[dst] = s_pos[j];
         ids[dst] = i0 + (meta & 0xffffu);
         }
+    CNT_STAMP(6);
     msq = block_sum_lds(msq, s_red);
     if (threadIdx.x == 0) modesq_partials[b] = msq;
+    CNT_STAMP(7);
     }
 
 template<typename S4>
@@ -2883,7 +2895,7 @@ int mtd_mesh_create(mtd_mesh **out, unsigned int nx, unsigned int ny, unsigned i
                  o_tilebuf = take(sizeof(long long) * (size_t)m->tg.n_tiles * m->tg.hcells), o_ids2 = take(sizeof(unsigned int) * (N + n_slots_extra)),
                  o_tsrc = take(sizeof(uint4) * (nx + ny + nz)), o_ttot = take(sizeof(unsigned int) * 2 * ((size_t)m->tg.n_tiles + 1)),
                  o_psort = take(m->tile_path ? sizeof(double4) * (N + n_slots_extra) : 0),
-                 o_plan = take(m->tile_path ? sizeof(unsigned int) * (4 * (size_t)m->tg.n_tiles + 2 * (size_t)m->tg.n_tiles * TB_CSTRIDE + 2 * TB_CSTRIDE) : 0),
+                 o_plan = take(m->tile_path ? sizeof(unsigned int) * (4 * (size_t)m->tg.n_tiles + 2 * (size_t)TB_TILES_PER_MAX * TB_THREADS * TB_CSTRIDE + 2 * TB_CSTRIDE) : 0),
                  o_ovft = take(m->tile_path ? sizeof(unsigned int) * N : 0);
     hipError_t e = hipMalloc(&m->slab, off);
     if (e != hipSuccess)
@@ -2911,7 +2923,7 @@ int mtd_mesh_create(mtd_mesh **out, unsigned int nx, unsigned int ny, unsigned i
         const size_t T = m->tg.n_tiles;
         unsigned int *q = (unsigned int *)(p + o_plan);
         for (int i = 0; i < 2; ++i) { m->d_plan_first[i] = q; q += T; m->d_plan_cap[i] = q; q += T; }
-        for (int i = 0; i < 2; ++i) { m->d_cursor[i] = q; q += T * TB_CSTRIDE; }
+        for (int i = 0; i < 2; ++i) { m->d_cursor[i] = q; q += (size_t)TB_TILES_PER_MAX * TB_THREADS * TB_CSTRIDE; }   // (with the idle lanes' cursors)
         for (int i = 0; i < 2; ++i) { m->d_ovf_count[i] = q; q += TB_CSTRIDE; }
         m->d_ovf_tile = (unsigned int *)(p + o_ovft);
         m->ovf_base = (unsigned int)n_slots_extra;
@@ -3117,8 +3129,10 @@ static int mesh_assign_local(mtd_mesh *m, unsigned int n_particles, const void *
         const bool bin_off = bin_env && bin_env[0] == '0';
         const size_t tb_lds = f32 ? tile_bin_lds_bytes<float4>(tg.n_tiles, tg.chunk) : tile_bin_lds_bytes<double4>(tg.n_tiles, tg.chunk);
         static const bool tb_lds_ok = [] {
-            hipError_t e = hipFuncSetAttribute((const void *)k_tile_bin<float4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TB_LDS_MAX);
-            if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_tile_bin<double4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TB_LDS_MAX);
+            hipError_t e = hipSuccess;
+            const void *fns[8] = { (const void *)k_tile_bin<float4, 1>, (const void *)k_tile_bin<float4, 2>, (const void *)k_tile_bin<float4, 4>, (const void *)k_tile_bin<float4, 8>,
+                                   (const void *)k_tile_bin<double4, 1>, (const void *)k_tile_bin<double4, 2>, (const void *)k_tile_bin<double4, 4>, (const void *)k_tile_bin<double4, 8> };
+            for (int i = 0; i < 8 && e == hipSuccess; ++i) e = hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, (int)TB_LDS_MAX);
             if (e != hipSuccess) (void)hipGetLastError();
             return e == hipSuccess;
         }();
@@ -3129,10 +3143,21 @@ static int mesh_assign_local(mtd_mesh *m, unsigned int n_particles, const void *
         if (bin_fits && m->plan_valid && m->plan_n == N && !m->rider_armed)
             {
             const int p = m->bin_parity;
+            const unsigned int tiles_per = (tg.n_tiles + TB_THREADS - 1) / TB_THREADS;
+#define MTD_TILE_BIN(S4, PER) \
+            k_tile_bin<S4, PER><<<nb, TB_THREADS, tb_lds, s>>>(g, tg, (const S4 *)d_postype, N, m->d_mode, m->n_types, m->d_plan_first[p], m->d_plan_cap[p], \
+                                                               m->d_cursor[p], m->d_ovf_count[p], m->d_ovf_tile, m->ovf_base, m->d_ids, (S4 *)m->d_possorted, m->d_modesq_partials)
             if (f32)
-                k_tile_bin<float4><<<nb, TB_THREADS, tb_lds, s>>>(g, tg, (const float4 *)d_postype, N, m->d_mode, m->n_types, m->d_plan_first[p], m->d_plan_cap[p], m->d_cursor[p], m->d_ovf_count[p], m->d_ovf_tile, m->ovf_base, m->d_ids, (float4 *)m->d_possorted, m->d_modesq_partials);
+                {
+                if (tiles_per <= 1) MTD_TILE_BIN(float4, 1); else if (tiles_per <= 2) MTD_TILE_BIN(float4, 2);
+                else if (tiles_per <= 4) MTD_TILE_BIN(float4, 4); else MTD_TILE_BIN(float4, 8);
+                }
             else
-                k_tile_bin<double4><<<nb, TB_THREADS, tb_lds, s>>>(g, tg, (const double4 *)d_postype, N, m->d_mode, m->n_types, m->d_plan_first[p], m->d_plan_cap[p], m->d_cursor[p], m->d_ovf_count[p], m->d_ovf_tile, m->ovf_base, m->d_ids, (double4 *)m->d_possorted, m->d_modesq_partials);
+                {
+                if (tiles_per <= 1) MTD_TILE_BIN(double4, 1); else if (tiles_per <= 2) MTD_TILE_BIN(double4, 2);
+                else if (tiles_per <= 4) MTD_TILE_BIN(double4, 4); else MTD_TILE_BIN(double4, 8);
+                }
+#undef MTD_TILE_BIN
             MTD_LAUNCH_CHECK();
             TileLists L;
             L.first = m->d_plan_first[p]; L.count = m->d_cursor[p]; L.cap = m->d_plan_cap[p]; L.ovf_count = m->d_ovf_count[p];

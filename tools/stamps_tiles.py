@@ -42,7 +42,10 @@ lib.mtd_debug_read_count_stamps(cb)
 c = np.array(cb[:], dtype=np.float64).reshape(8, 1024) * 0.01
 used = c[0] > 0
 t0 = c[0][used].min()
-print("k_tile_count (%d blocks; us after the first block's entry: min / median / max)" % used.sum())
-for row, name in enumerate(["entry", "histogram cleared, first position in", "out of the particle loop (thread 0)", "block out of the loop", "histogram row and block sum written"]):
+print("k_tile_count / k_tile_bin (%d blocks; us after the first block's entry: min / median / max)" % used.sum())
+rows_count = ["entry", "histogram cleared, first position in", "out of the particle loop (thread 0)", "block out of the loop", "histogram row and block sum written"]
+rows_bin = ["entry", "histogram cleared, first position in", "out of the particle loop (thread 0)", "block out of the loop", "atomics requested, prefix written",
+            "chunk sorted in LDS, atomics back", "thread 0 out of the store loop", "block sum written"]
+for row, name in enumerate(rows_bin if c[7][used].max() > 0 else rows_count):
     x = c[row][used] - t0
     print("  %-42s %6.2f %6.2f %6.2f" % (name, x.min(), np.median(x), x.max()))
