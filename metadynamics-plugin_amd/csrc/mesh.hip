@@ -1133,9 +1133,19 @@ __global__ __launch_bounds__(TB_THREADS) void k_tile_bin(const MeshGeom g, const
         pcap[j] = plan_cap[tc];
         loc += cnt[j];
         }
+    // (waves whose lanes all lie beyond the last tile request nothing: a branch on a wave-uniform SCALAR condition leaves the
+    // atomics of the other waves unconditional)
+    if (__builtin_amdgcn_readfirstlane((int)((threadIdx.x & ~63u) * PER)) <= (int)t_last)
+        {
 #pragma unroll
-    for (int j = 0; j < PER; ++j)
-        base[j] = atomicAdd(&cursor[(size_t)(threadIdx.x * PER + j) * TB_CSTRIDE], cnt[j]);
+        for (int j = 0; j < PER; ++j)
+            base[j] = atomicAdd(&cursor[(size_t)(threadIdx.x * PER + j) * TB_CSTRIDE], cnt[j]);
+        }
+    else
+        {
+#pragma unroll
+        for (int j = 0; j < PER; ++j) base[j] = 0;
+        }
     unsigned int iloc = loc;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
