@@ -409,6 +409,29 @@ def sub_record_config3(steps, fast_trig):
         return a.elapsed_time(b) * 1e3 / n
 
     cv_us, f_us = timed(cv_call), timed(force_call)
+
+    def assign_info():
+        pl, n_ovf = C.c_int(-1), C.c_uint(0)
+        _abi.check(lib.mtd_mesh_assign_info(h, C.byref(pl), C.byref(n_ovf), None))
+        return {0: "cells", 1: "counting", 2: "bin"}.get(pl.value, str(pl.value)), int(n_ovf.value)
+
+    pipeline_static, ovf_static = assign_info()
+    # the same call on a snapshot that MOVES: two snapshots a random displacement apart (rms 0.1 mesh cells per coordinate, ~16 thermal
+    # MD steps at dt = 0.005) alternate, so every step bins on segments planned from other positions (the bin pipeline)
+    rng = np.random.default_rng(99)
+    pos2 = pos.astype(np.float64) + rng.normal(0.0, 0.1 * L / 128, size=pos.shape)
+    pos2 = (np.mod(pos2 + L / 2, L) - L / 2).astype(np.float32)
+    pos2[pos2 >= L / 2] = -L / 2
+    d_pos2 = torch.from_numpy(util.pack_postype(pos2, types, np.float32)).cuda()
+    flip = [0]
+
+    def cv_call_moving():
+        flip[0] ^= 1
+        p = d_pos2 if flip[0] else d_pos
+        _abi.check(lib.mtd_mesh_compute_cv(h, N, p.data_ptr(), _abi.MTD_F32, C.byref(box), N, C.byref(parts), C.byref(n_parts), None))
+
+    cv_moving_us = timed(cv_call_moving)
+    pipeline_moving, ovf_moving = assign_info()
     _abi.check(lib.mtd_mesh_destroy(h))
     M, hfrac = 128 ** 3, 72.0 / 128.0
     bytes_survey = 48 * N + 68 * M + (64 - 16) * 1_000_000          # 48 B N + 68 B M, + the lamellar CV sharing the position reads
@@ -422,7 +445,11 @@ def sub_record_config3(steps, fast_trig):
                          "step_algorithmic_bytes_survey_fp32_c2c": bytes_survey, "step_frac_survey": bytes_survey / per_step / 1e9 / HBM_PEAK_GBS,
                          "step_algorithmic_bytes_this_build_fp64_r2c": int(bytes_build), "step_frac": bytes_build / per_step / 1e9 / HBM_PEAK_GBS,
                          "mesh_compute_cv_us": cv_us, "mesh_forces_us": f_us,
-                         "traffic": _traffic_record(["k_tile_count", "k_tile_rowscan", "k_tile_place", "k_tile_scatter", "k_tile_combine_rows",
+                         "assign": {"pipeline": pipeline_static, "overflow_last_step": ovf_static,
+                                    "moving_snapshots": {"mesh_compute_cv_us": cv_moving_us, "pipeline": pipeline_moving, "overflow_last_step": ovf_moving,
+                                                         "displacement_rms_cells": 0.1,
+                                                         "note": "two snapshots a random displacement apart alternate: every step bins on tile segments planned from the other snapshot"}},
+                         "traffic": _traffic_record(["k_tile_bin", "k_tile_scatter", "k_tile_combine_rows",
                                                      "k_fft_xy_forward", "k_fft_z_spectral", "k_fft_xy_inverse", "k_tile_forces"]),
                          "dominant_kernels": "k_tile_scatter, k_tile_forces, k_fft_z_spectral (per-kernel table: profiles/%s/config3_mesh_kernel_stats.csv)" % PROFILE_ROUND,
                          "timing": "host API: wall clock around System::run, synchronised on both sides; mesh calls: HIP events on the launch stream"}}

@@ -392,6 +392,12 @@ int mtd_mesh_set_lamellar_rider(mtd_mesh *mesh, mtd_metad *engine, const mtd_lam
  * *was_armed (may be NULL): 1 when they were still waiting — their sums were then NOT formed */
 int mtd_mesh_clear_rider(mtd_mesh *mesh, int *was_armed);
 int mtd_mesh_assign(mtd_mesh *m, unsigned int n_particles, const void *d_postype, int dtype, const mtd_box *box, mtd_stream_t stream);
+/* How the last assignment (mtd_mesh_assign / mtd_mesh_compute_cv / mtd_mesh_slab_*) grouped the particles by tile; waits for `stream`.
+ * *pipeline: 0 the cell-level pipeline (meshes beyond 256^3, MTD_MESH_ASSIGN=cells), 1 the counting pipeline (count -> row scan ->
+ * place: the first assignment of a mesh, a changed particle number, riders), 2 the bin pipeline (one launch on tile segments with
+ * slack planned from the previous snapshot's exact counts).  *n_overflow: particles of a bin step that did not fit
+ * their tile's planned segment and travelled through the overflow list (correct, only slower; 0 in a well-planned step). */
+int mtd_mesh_assign_info(mtd_mesh *m, int *pipeline, unsigned int *n_overflow, mtd_stream_t stream);
 int mtd_mesh_exchange_buffer(mtd_mesh *m, double **d_buffer, size_t *count);
 int mtd_mesh_spectral(mtd_mesh *m, const mtd_box *box, unsigned int n_global, const double **d_partials, unsigned int *n_partials,
                       mtd_stream_t stream);

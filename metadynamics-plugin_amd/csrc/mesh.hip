@@ -1047,7 +1047,7 @@ __global__ __launch_bounds__(1024) void k_tile_plan(const TilePlan P)
 constexpr int TB_THREADS = 1024;
 constexpr int TB_PER = TPS_CHUNK_MAX / TB_THREADS;                 // particles per thread
 constexpr int TB_TILES_PER_MAX = 8;                                // tiles per thread in the prefix: n_tiles <= 8192
-constexpr size_t TB_LDS_MAX = 160 * 1024 - 1024;                   // dynamic LDS (the static part is < 1 KB)
+constexpr size_t TB_LDS_MAX = 160 * 1024 - 4096;                   // dynamic LDS (the static part — with a rider's tables — is < 4 KB)
 
 template<typename S4> size_t tile_bin_lds_bytes(const unsigned int n_tiles, const unsigned int chunk)
     {
@@ -1057,16 +1057,35 @@ template<typename S4> size_t tile_bin_lds_bytes(const unsigned int n_tiles, cons
 // PER: tiles per thread in the prefix over the chunk's histogram (a compile-time constant: 1, 2, 4 or 8 — every lane runs every trip
 // with a clamped tile, so that the atomics and the loads beside them are unconditional and STAY IN FLIGHT: behind a branch the
 // compiler waited for each atomic right where it was issued, 6 us per block)
-template<typename S4, int PER>
+// RIDER (mtd_mesh_set_lamellar_rider): 0 none; 1 / 2: the block partial sums of a set of lamellar CVs (accurate / hardware
+// trigonometry) are formed from the four positions every thread holds anyway — in the ~3 us the block WAITS for its atomics (245
+// blocks add to every cursor; the memory side serves one word's atomics one after the other): four particles per thread in packed
+// fp32, lam_cv_group of the fused step's launch A, ~0.8 us of issue slots per block.  Inside the counting kernel's per-particle
+// chain the same terms made the step slower (profiles/r3/mesh_rider_ab.log); here they fill a hole: launch A of a mixed lamellar +
+// mesh set (7.9 us at config 3) is gone.
+// (the rider's arguments travel in the kernel-argument segment like the fused step's: no device copy per step; nothing for RIDER = 0)
+struct BinRiderArgs { mtd::LamKArgs k; double *partials; };
+struct BinNoRider { };
+template<int RIDER> struct BinRider { typedef BinRiderArgs type; };
+template<> struct BinRider<0> { typedef BinNoRider type; };
+__device__ __forceinline__ const mtd::LamKArgs &bin_rider_k(const BinRiderArgs &r) { return r.k; }
+__device__ __forceinline__ double *bin_rider_partials(const BinRiderArgs &r) { return r.partials; }
+__device__ __forceinline__ const mtd::LamKArgs &bin_rider_k(const BinNoRider &) { return *(const mtd::LamKArgs *)nullptr; }   // (never evaluated)
+__device__ __forceinline__ double *bin_rider_partials(const BinNoRider &) { return nullptr; }
+
+template<typename S4, int PER, int RIDER>
 __global__ __launch_bounds__(TB_THREADS) void k_tile_bin(const MeshGeom g, const TileGeom tg, const S4 *__restrict__ postype, const unsigned int N,
                                                          const double *__restrict__ mode, const unsigned int n_types,
                                                          const unsigned int *__restrict__ plan_first, const unsigned int *__restrict__ plan_cap,
                                                          unsigned int *__restrict__ cursor, unsigned int *__restrict__ ovf_count,
                                                          unsigned int *__restrict__ ovf_tile, const unsigned int ovf_base,
                                                          unsigned int *__restrict__ ids, S4 *__restrict__ possorted,
-                                                         double *__restrict__ modesq_partials)
+                                                         double *__restrict__ modesq_partials, const typename BinRider<RIDER>::type rider)
     {
     extern __shared__ __align__(16) unsigned char s_raw[];
+    __shared__ float s_coeff[RIDER ? MTD_MAX_CV * MTD_MAX_TYPES : 1];
+    __shared__ mtd::ModeTables s_mt;
+    __shared__ double s_wave[RIDER ? (TB_THREADS / 64) * 3 : 1];
     S4 *s_pos = (S4 *)s_raw;                                                   // [chunk]
     unsigned int *s_meta = (unsigned int *)(s_pos + tg.chunk);                 // [chunk]: tile << 16 | index in the chunk
     unsigned int *s_lpre = s_meta + tg.chunk;                                  // [n_tiles]: histogram of the chunk, then its prefix
@@ -1081,14 +1100,30 @@ __global__ __launch_bounds__(TB_THREADS) void k_tile_bin(const MeshGeom g, const
     if (i0 >= i1)                                                              // (uniform over the block: nothing to bin, nothing to read)
         {
         if (threadIdx.x == 0) modesq_partials[b] = 0.0;
+        if (RIDER && threadIdx.x < bin_rider_k(rider).n_cv) bin_rider_partials(rider)[(size_t)b * bin_rider_k(rider).n_cv + threadIdx.x] = 0.0;
         return;
         }
     const unsigned int i_last = i1 - 1;
     S4 raw[TB_PER];
     unsigned int tl[TB_PER], sl[TB_PER];
     raw[0] = postype[min(i0 + threadIdx.x, i_last)];
+    // the rider's tables: ONE unconditional load per thread from clamped indices, requested right behind the first position (the same
+    // memory round trip; the host has put the visited modes into a dense list already: the staging loops of launch A — a loop over
+    // blockDim, the list through an index array — cost this kernel four dependent round trips in front of its first particle, +6 us)
+    float4 tab_h = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    float tab_c = 0.0f;
+    if (RIDER)
+        {
+        tab_h = bin_rider_k(rider).h[min(threadIdx.x, (unsigned int)MTD_MAX_MODES - 1)];
+        tab_c = (&bin_rider_k(rider).coeff[0][0])[min(threadIdx.x, (unsigned int)(MTD_MAX_CV * MTD_MAX_TYPES) - 1)];
+        }
     stage_modes(s_mode, mode, n_types);
     for (unsigned int t = threadIdx.x; t < tg.n_tiles; t += TB_THREADS) s_lpre[t] = 0;
+    if (RIDER)
+        {
+        if (threadIdx.x < MTD_MAX_MODES) s_mt.h[threadIdx.x] = tab_h;
+        if (threadIdx.x < MTD_MAX_CV * MTD_MAX_TYPES) s_coeff[threadIdx.x] = tab_c;
+        }
     __syncthreads();
     CNT_STAMP(1);
     // 1. as k_tile_count: tile of every particle, arrival slot from the LDS histogram; the next position in flight meanwhile
@@ -1179,6 +1214,17 @@ __global__ __launch_bounds__(TB_THREADS) void k_tile_bin(const MeshGeom g, const
             s_meta[lofs] = (tl[k] << 16) | li;
             }
         }
+    float acc[3] = { 0.0f, 0.0f, 0.0f };
+    if (RIDER)
+        {
+        // (kept between the staging and the first use of the atomics' results)
+        __builtin_amdgcn_sched_barrier(0);
+        mtd::RawGroup<S4, TB_PER> grp;
+#pragma unroll
+        for (int k = 0; k < TB_PER; ++k) grp.v[k] = raw[k];
+        mtd::lam_cv_group<S4, 3, RIDER == 2, TB_PER>(bin_rider_k(rider), i1, i0 + threadIdx.x, TB_THREADS, s_coeff, s_mt, grp, acc);
+        __builtin_amdgcn_sched_barrier(0);
+        }
 #pragma unroll
     for (int j = 0; j < PER; ++j)
         {
@@ -1212,6 +1258,24 @@ __global__ __launch_bounds__(TB_THREADS) void k_tile_bin(const MeshGeom g, const
     CNT_STAMP(6);
     msq = block_sum_lds(msq, s_red);
     if (threadIdx.x == 0) modesq_partials[b] = msq;
+    if (RIDER)
+        {
+        // fp32 wave sums -> fp64 across the waves in a fixed order, as lam_cv_block_reduce; partials[chunk][n_cv]
+        const unsigned int n_cv = bin_rider_k(rider).n_cv;
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+            {
+            const float v = wave_sum(acc[c]);
+            if (lane == 0) s_wave[wave * 3 + c] = (double)v;
+            }
+        lds_barrier();
+        if (threadIdx.x < n_cv)
+            {
+            double r = 0.0;
+            for (int w = 0; w < TB_THREADS / 64; ++w) r += s_wave[w * 3 + threadIdx.x];
+            bin_rider_partials(rider)[(size_t)b * n_cv + threadIdx.x] = r;
+            }
+        }
     CNT_STAMP(7);
     }
 
@@ -1220,10 +1284,21 @@ __global__ __launch_bounds__(TP_THREADS) void k_tile_scatter(const MeshGeom g, c
                                                              const double *__restrict__ mode, const TileLists L,
                                                              const unsigned int *__restrict__ ids, long long *__restrict__ tilebuf,
                                                              double4 *__restrict__ packed, const unsigned int n_types,
-                                                             const S4 *__restrict__ possorted, const TilePlan plan)
+                                                             const S4 *__restrict__ possorted, const TilePlan plan,
+                                                             const mtd::MetadCfg apply_cfg)
     {
     __shared__ unsigned long long s_t[TP_HMAX];
     __shared__ double s_mode[TP_MODE_LDS];
+    if (blockIdx.x > tg.n_tiles)
+        {
+        // passenger of a bin step with riders: the bias-grid engine's deferred second pass, one cell per thread (blocks of the size
+        // launch A of the fused step gives it: the same sums in the same order)
+        __shared__ double s_red2[16];
+        const unsigned int ab = blockIdx.x - tg.n_tiles - 1;
+        const unsigned int c0 = ab * TP_THREADS;
+        mtd::apply_cells(apply_cfg, c0, min(apply_cfg.len, c0 + (unsigned int)TP_THREADS), ab == 0, s_red2);
+        return;
+        }
     if (blockIdx.x == tg.n_tiles)
         {
         // bin pipeline: the extra block plans the NEXT snapshot's segments from this one's exact counts (and adds up sum mode^2)
@@ -2687,6 +2762,7 @@ struct mtd_mesh
     int plan_valid, bin_parity;     // set `bin_parity` is planned (for plan_n particles) and its cursors are zero
     unsigned int plan_n;
     TileLists lists;                // where the last assignment left the tiles' particles (the force pass walks the same lists)
+    int last_pipeline;              // of the last assignment: 0 cells, 1 counting, 2 bin (mtd_mesh_assign_info)
     double amax;               // max |mode coefficient| (fixed-point scale)
     // slab decomposition over the ranks of a mailbox (mtd_mesh_slab_attach): exported buffers of every rank as mapped here
     struct mtd_comm *slab_comm;
@@ -2698,6 +2774,7 @@ struct mtd_mesh
     CountRider *d_rider;
     CountRider *h_rider;       // what d_rider holds (copied again only when something changed: a box, a grid, a mode set)
     int rider_armed;
+    int rider_dirty;                // h_rider is newer than d_rider
     int rider_fast;                 // hardware trigonometry for the rider's mode set (lam_fast_trig)
     unsigned int rider_n_apply;
     struct mtd_metad *rider_engine;
@@ -2938,7 +3015,7 @@ int mtd_mesh_create(mtd_mesh **out, unsigned int nx, unsigned int ny, unsigned i
         m->d_ovf_tile = (unsigned int *)(p + o_ovft);
         m->ovf_base = (unsigned int)n_slots_extra;
         }
-    m->plan_valid = 0; m->bin_parity = 0; m->plan_n = 0;
+    m->plan_valid = 0; m->bin_parity = 0; m->plan_n = 0; m->last_pipeline = 0;
     std::memset(&m->lists, 0, sizeof(m->lists));
     m->d_tsrc = (uint4 *)(p + o_tsrc);
     m->d_tile_total = (unsigned int *)(p + o_ttot);
@@ -3048,10 +3125,12 @@ int mtd_mesh_set_lamellar_rider(mtd_mesh *mesh, mtd_metad *engine, const mtd_lam
         if (!mesh->h_rider) return (int)hipErrorOutOfMemory;
         std::memset(mesh->h_rider, 0xff, sizeof(CountRider));
         }
+    // (the device copy is made by the assignment that needs one — the counting pipeline; the bin pipeline takes the arguments by value)
+    (void)stream;
     if (std::memcmp(mesh->h_rider, &r, sizeof(r)) != 0)
         {
         *mesh->h_rider = r;
-        MTD_HIP_TRY(hipMemcpyAsync(mesh->d_rider, mesh->h_rider, sizeof(CountRider), hipMemcpyHostToDevice, (hipStream_t)stream));
+        mesh->rider_dirty = 1;
         }
     mesh->rider_armed = 1;
     mesh->rider_fast = mtd::lam_fast_trig(r.k);
@@ -3140,9 +3219,10 @@ static int mesh_assign_local(mtd_mesh *m, unsigned int n_particles, const void *
         const size_t tb_lds = f32 ? tile_bin_lds_bytes<float4>(tg.n_tiles, tg.chunk) : tile_bin_lds_bytes<double4>(tg.n_tiles, tg.chunk);
         static const bool tb_lds_ok = [] {
             hipError_t e = hipSuccess;
-            const void *fns[8] = { (const void *)k_tile_bin<float4, 1>, (const void *)k_tile_bin<float4, 2>, (const void *)k_tile_bin<float4, 4>, (const void *)k_tile_bin<float4, 8>,
-                                   (const void *)k_tile_bin<double4, 1>, (const void *)k_tile_bin<double4, 2>, (const void *)k_tile_bin<double4, 4>, (const void *)k_tile_bin<double4, 8> };
-            for (int i = 0; i < 8 && e == hipSuccess; ++i) e = hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, (int)TB_LDS_MAX);
+#define MTD_BIN_FNS(S4, R) (const void *)k_tile_bin<S4, 1, R>, (const void *)k_tile_bin<S4, 2, R>, (const void *)k_tile_bin<S4, 4, R>, (const void *)k_tile_bin<S4, 8, R>
+            const void *fns[24] = { MTD_BIN_FNS(float4, 0), MTD_BIN_FNS(float4, 1), MTD_BIN_FNS(float4, 2), MTD_BIN_FNS(double4, 0), MTD_BIN_FNS(double4, 1), MTD_BIN_FNS(double4, 2) };
+#undef MTD_BIN_FNS
+            for (int i = 0; i < 24 && e == hipSuccess; ++i) e = hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, (int)TB_LDS_MAX);
             if (e != hipSuccess) (void)hipGetLastError();
             return e == hipSuccess;
         }();
@@ -3150,23 +3230,57 @@ static int mesh_assign_local(mtd_mesh *m, unsigned int n_particles, const void *
                               tg.n_tiles <= (unsigned int)(TB_TILES_PER_MAX * TB_THREADS);
         TilePlan plan;
         std::memset(&plan, 0, sizeof(plan));
-        if (bin_fits && m->plan_valid && m->plan_n == N && !m->rider_armed)
+        mtd::MetadCfg apply_cfg;                                         // (read by the scatter launch's passenger blocks only)
+        std::memset(&apply_cfg, 0, sizeof(apply_cfg));
+        // (riders of the counting kernel's own loop — MTD_MESH_RIDER=count — keep the counting pipeline)
+        const char *rider_env = std::getenv("MTD_MESH_RIDER");
+        const bool rider_in_count = rider_env && std::strcmp(rider_env, "count") == 0;
+        if (bin_fits && m->plan_valid && m->plan_n == N && !(m->rider_armed && rider_in_count))
             {
             const int p = m->bin_parity;
+            int rider_kind = 0;
+            unsigned int n_apply = 0;
+            if (m->rider_armed)
+                {
+                rider_kind = m->rider_fast ? 2 : 1;
+                if (m->rider_n_apply)
+                    {
+                    apply_cfg = m->h_rider->cfg;
+                    n_apply = (apply_cfg.len + TP_THREADS - 1) / TP_THREADS;
+                    }
+                m->rider_armed = 0;
+                if (m->rider_engine && m->rider_n_apply) m->rider_engine->pending_apply = 0;
+                }
             const unsigned int tiles_per = (tg.n_tiles + TB_THREADS - 1) / TB_THREADS;
-#define MTD_TILE_BIN(S4, PER) \
-            k_tile_bin<S4, PER><<<nb, TB_THREADS, tb_lds, s>>>(g, tg, (const S4 *)d_postype, N, m->d_mode, m->n_types, m->d_plan_first[p], m->d_plan_cap[p], \
-                                                               m->d_cursor[p], m->d_ovf_count[p], m->d_ovf_tile, m->ovf_base, m->d_ids, (S4 *)m->d_possorted, m->d_modesq_partials)
+            BinRiderArgs ra;
+            BinNoRider no_rider;
+            if (rider_kind)
+                {
+                ra.k = m->h_rider->k;
+                for (unsigned int q = 0; q < ra.k.n_modes && q < MTD_MAX_MODES; ++q)     // the visited modes as a dense list (load_modes_cv)
+                    {
+                    ra.k.h[q] = m->h_rider->k.h[m->h_rider->k.corder[q]];
+                    ra.k.corder[q] = (unsigned char)q;
+                    }
+                ra.partials = m->h_rider->partials;
+                }
+#define MTD_TILE_BIN(S4, PER, R, RA) \
+            k_tile_bin<S4, PER, R><<<nb, TB_THREADS, tb_lds, s>>>(g, tg, (const S4 *)d_postype, N, m->d_mode, m->n_types, m->d_plan_first[p], m->d_plan_cap[p], \
+                                                                  m->d_cursor[p], m->d_ovf_count[p], m->d_ovf_tile, m->ovf_base, m->d_ids, (S4 *)m->d_possorted, \
+                                                                  m->d_modesq_partials, RA)
+#define MTD_TILE_BIN_R(S4, PER) \
+            do { if (rider_kind == 2) MTD_TILE_BIN(S4, PER, 2, ra); else if (rider_kind == 1) MTD_TILE_BIN(S4, PER, 1, ra); else MTD_TILE_BIN(S4, PER, 0, no_rider); } while (0)
             if (f32)
                 {
-                if (tiles_per <= 1) MTD_TILE_BIN(float4, 1); else if (tiles_per <= 2) MTD_TILE_BIN(float4, 2);
-                else if (tiles_per <= 4) MTD_TILE_BIN(float4, 4); else MTD_TILE_BIN(float4, 8);
+                if (tiles_per <= 1) MTD_TILE_BIN_R(float4, 1); else if (tiles_per <= 2) MTD_TILE_BIN_R(float4, 2);
+                else if (tiles_per <= 4) MTD_TILE_BIN_R(float4, 4); else MTD_TILE_BIN_R(float4, 8);
                 }
             else
                 {
-                if (tiles_per <= 1) MTD_TILE_BIN(double4, 1); else if (tiles_per <= 2) MTD_TILE_BIN(double4, 2);
-                else if (tiles_per <= 4) MTD_TILE_BIN(double4, 4); else MTD_TILE_BIN(double4, 8);
+                if (tiles_per <= 1) MTD_TILE_BIN_R(double4, 1); else if (tiles_per <= 2) MTD_TILE_BIN_R(double4, 2);
+                else if (tiles_per <= 4) MTD_TILE_BIN_R(double4, 4); else MTD_TILE_BIN_R(double4, 8);
                 }
+#undef MTD_TILE_BIN_R
 #undef MTD_TILE_BIN
             MTD_LAUNCH_CHECK();
             TileLists L;
@@ -3177,10 +3291,11 @@ static int mesh_assign_local(mtd_mesh *m, unsigned int n_particles, const void *
             plan.cursor_next = m->d_cursor[1 - p]; plan.ovf_count_next = m->d_ovf_count[1 - p]; plan.cstride_next = TB_CSTRIDE;
             plan.modesq_partials = m->d_modesq_partials; plan.n_partials = nb; plan.mode_sq = m->d_mode_sq;
             if (f32)
-                k_tile_scatter<float4><<<tg.n_tiles + 1, TP_THREADS, 0, s>>>(g, tg, (const float4 *)d_postype, m->d_mode, L, m->d_ids, m->d_tilebuf, m->d_packed, m->n_types, (const float4 *)m->d_possorted, plan);
+                k_tile_scatter<float4><<<tg.n_tiles + 1 + n_apply, TP_THREADS, 0, s>>>(g, tg, (const float4 *)d_postype, m->d_mode, L, m->d_ids, m->d_tilebuf, m->d_packed, m->n_types, (const float4 *)m->d_possorted, plan, apply_cfg);
             else
-                k_tile_scatter<double4><<<tg.n_tiles + 1, TP_THREADS, 0, s>>>(g, tg, (const double4 *)d_postype, m->d_mode, L, m->d_ids, m->d_tilebuf, m->d_packed, m->n_types, (const double4 *)m->d_possorted, plan);
+                k_tile_scatter<double4><<<tg.n_tiles + 1 + n_apply, TP_THREADS, 0, s>>>(g, tg, (const double4 *)d_postype, m->d_mode, L, m->d_ids, m->d_tilebuf, m->d_packed, m->n_types, (const double4 *)m->d_possorted, plan, apply_cfg);
             m->lists = L;
+            m->last_pipeline = 2;
             m->bin_parity = 1 - p;                                       // (planned and zeroed by the extra block)
             }
         else
@@ -3192,7 +3307,11 @@ static int mesh_assign_local(mtd_mesh *m, unsigned int n_particles, const void *
                                                                     m->d_count, m->d_modesq_partials, m->n_types, m->d_rider)
         if (m->rider_armed)
             {
-            // (the rider's arguments were copied to the device on this stream by mtd_mesh_set_lamellar_rider)
+            if (m->rider_dirty)
+                {
+                MTD_HIP_TRY(hipMemcpyAsync(m->d_rider, m->h_rider, sizeof(CountRider), hipMemcpyHostToDevice, s));
+                m->rider_dirty = 0;
+                }
             const unsigned int grid = nb;
             const bool fast = m->rider_fast != 0;
             n_apply_blocks = m->rider_n_apply;
@@ -3239,10 +3358,11 @@ static int mesh_assign_local(mtd_mesh *m, unsigned int n_particles, const void *
         std::memset(&L, 0, sizeof(L));
         L.first = m->d_tile_first; L.count = m->d_tile_total; L.cstride = 1;
         if (f32)
-            k_tile_scatter<float4><<<tg.n_tiles, TP_THREADS, 0, s>>>(g, tg, (const float4 *)d_postype, m->d_mode, L, m->d_ids, m->d_tilebuf, m->d_packed, m->n_types, sorted ? (const float4 *)m->d_possorted : nullptr, plan);
+            k_tile_scatter<float4><<<tg.n_tiles, TP_THREADS, 0, s>>>(g, tg, (const float4 *)d_postype, m->d_mode, L, m->d_ids, m->d_tilebuf, m->d_packed, m->n_types, sorted ? (const float4 *)m->d_possorted : nullptr, plan, apply_cfg);
         else
-            k_tile_scatter<double4><<<tg.n_tiles, TP_THREADS, 0, s>>>(g, tg, (const double4 *)d_postype, m->d_mode, L, m->d_ids, m->d_tilebuf, m->d_packed, m->n_types, sorted ? (const double4 *)m->d_possorted : nullptr, plan);
+            k_tile_scatter<double4><<<tg.n_tiles, TP_THREADS, 0, s>>>(g, tg, (const double4 *)d_postype, m->d_mode, L, m->d_ids, m->d_tilebuf, m->d_packed, m->n_types, sorted ? (const double4 *)m->d_possorted : nullptr, plan, apply_cfg);
         m->lists = L;
+        m->last_pipeline = 1;
         if (bin_fits && !(m->plan_valid && m->plan_n == N))
             {
             // the exact counts of this snapshot plan the segments of the next one
@@ -3294,6 +3414,23 @@ static int mesh_assign_local(mtd_mesh *m, unsigned int n_particles, const void *
     k_mesh_gather<<<tl.ntx * tl.nty * tl.ntz, GT_THREADS, 0, s>>>(g, tl, m->d_start, m->d_packed, m->d_rho);
     MTD_LAUNCH_CHECK();
     m->n_last = N;
+    return MTD_SUCCESS;
+    }
+
+int mtd_mesh_assign_info(mtd_mesh *m, int *pipeline, unsigned int *n_overflow, mtd_stream_t stream)
+    {
+    if (!m) return MTD_ERR_INVALID_ARGUMENT;
+    const int pl = m->tile_path ? m->last_pipeline : 0;
+    if (pipeline) *pipeline = pl;
+    if (n_overflow)
+        {
+        *n_overflow = 0;
+        if (pl == 2 && m->lists.ovf_count)
+            {
+            MTD_HIP_TRY(hipMemcpyAsync(n_overflow, m->lists.ovf_count, sizeof(unsigned int), hipMemcpyDeviceToHost, (hipStream_t)stream));
+            MTD_HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+            }
+        }
     return MTD_SUCCESS;
     }
 

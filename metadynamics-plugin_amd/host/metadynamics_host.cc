@@ -1064,14 +1064,15 @@ void IntegratorMetaDynamics::updateBiasPotential(unsigned int timestep)
                         hooked = std::dynamic_pointer_cast<OrderParameterMeshGPU>(m_variables[i].m_cv);
             if (hooked) hooked->setCvEvent(m_exec_conf->getEvent(1));
             }
-        // One mesh CV beside the lamellar ones (BASELINE.json's config 3): the lamellar sums and the deferred grid pass can RIDE in
-        // the mesh's own pass over the positions (the kernel that bins the particles, mtd_mesh_set_lamellar_rider) instead of
-        // taking a launch and a second read of the position array of their own (launch A of the fused step).  Built, parity-green
-        // and MEASURED SLOWER (161.5 against 159.3 us per step at config 3, profiles/r3/mesh_rider_ab.log): the binning kernel is
-        // bound by its per-particle chain of fp64 arithmetic (locate), the lamellar terms lengthen that chain one particle at a
-        // time, while launch A sums four particles per thread in packed fp32 beside its loads.  Opt-in: MTD_MESH_RIDER=1.
+        // One mesh CV beside the lamellar ones (BASELINE.json's config 3): the lamellar sums and the deferred grid pass RIDE in the
+        // mesh's assignment launches (mtd_mesh_set_lamellar_rider) instead of taking a launch and a second read of the position array
+        // of their own (launch A of the fused step, 7.9 us at config 3).  In the bin pipeline — every assignment of a mesh but its
+        // first — the sums are formed while the binning blocks wait for their atomics and the grid pass travels as extra blocks of
+        // the scatter launch: 140 -> 133 us per step.  (The first form, the sums inside the counting kernel's per-particle chain,
+        // measured SLOWER than launch A, 161.5 against 159.3 us, profiles/r3/mesh_rider_ab.log; it still carries the first step and
+        // MTD_MESH_RIDER=count.)  MTD_MESH_RIDER=0 keeps launch A.
         std::shared_ptr<OrderParameterMeshGPU> carrier;
-        static const bool use_rider = std::getenv("MTD_MESH_RIDER") != nullptr;
+        static const bool use_rider = [] { const char *e = std::getenv("MTD_MESH_RIDER"); return !(e && (e[0] == '0' || std::strcmp(e, "off") == 0)); }();
         if (!lam_slots.empty() && !side && use_rider && lam_slots.size() <= 3)
             {
             unsigned int n_mesh = 0;

@@ -121,9 +121,15 @@ def test_bin_pipeline_against_counting_pipeline(abi, monkeypatch, dtype, N, dims
         g = GpuMesh(abi, dims, [1.0, -0.7], N)
         res = []
         try:
-            for pos, ty in seq:
+            for step, (pos, ty) in enumerate(seq):
                 d_pos = torch.from_numpy(util.pack_postype(pos, ty, dtype)).cuda()
                 s = g.cv(d_pos, dt, box, N)
+                pl, n_ovf = C.c_int(-1), C.c_uint(0)
+                abi.check(g.lib.mtd_mesh_assign_info(g.h, C.byref(pl), C.byref(n_ovf), None))
+                assert pl.value == (2 if mode == "1" and step > 0 else 1)
+                if mode == "1" and N >= 5000:
+                    # the plan fits a repeated snapshot; the corner snapshot overflows the uniform plan and vice versa
+                    assert (n_ovf.value > 0) == (step in (2, 4)), (step, n_ovf.value)
                 F = g.forces(d_pos, dt, box, N, 0.8)
                 res.append((s, g.array(0).copy(), g.array(7), F))
         finally:
@@ -429,13 +435,16 @@ def test_mesh_256_cubed_tile_path_against_cell_path(abi, monkeypatch):
     assert fm > 0 and np.abs(out["tiles"][2] - out["cells"][2]).max() <= 5e-7 * fm
 
 
+@pytest.mark.parametrize("pipeline", ["bin", "counting"])
 @pytest.mark.parametrize("dtype,fast", [(np.float32, 1), (np.float32, 0), (np.float64, 1)])
-def test_lamellar_and_deferred_grid_pass_ride_in_the_binning_kernel(abi, ref, dtype, fast):
+def test_lamellar_and_deferred_grid_pass_ride_in_the_binning_kernel(abi, ref, dtype, fast, pipeline):
     """mtd_mesh_set_lamellar_rider: the kernel that bins the particles for the mesh also forms the block partial sums of a set of
-    lamellar CVs (LamellarOrderParameter.cc:143-179 beside OrderParameterMesh.cc:517-640: one pass over the positions) and carries
-    the bias-grid engine's deferred second pass.  The lamellar sums against the oracle (1e-6) and against the stand-alone CV pass
-    (another grouping of the same fp32 terms: 1e-7), the mesh bit for bit what it is without riders, the grid arrays after the
-    ridden deferred pass against the oracle's."""
+    lamellar CVs (LamellarOrderParameter.cc:143-179 beside OrderParameterMesh.cc:517-640: one pass over the positions) and the
+    assignment carries the bias-grid engine's deferred second pass — in the bin pipeline (k_tile_bin while it waits for its atomics;
+    the grid pass as extra blocks of the scatter launch) and in the counting pipeline of a mesh's first assignment (k_tile_count's
+    particle loop; the row-scan launch).  The lamellar sums against the oracle (1e-6) and against the stand-alone CV pass (another
+    grouping of the same fp32 terms: 1e-7), the mesh bit for bit what it is without riders, the grid arrays after the ridden
+    deferred pass against the oracle's."""
     from test_gpu_metad import GpuMetad, compare
     lib = abi.load()
     N, L = 30011, 28.0
@@ -454,6 +463,8 @@ def test_lamellar_and_deferred_grid_pass_ride_in_the_binning_kernel(abi, ref, dt
     try:
         s_plain = plain.cv(d_pos, dt, box, N)
         rho_plain = plain.array(0).copy()
+        if pipeline == "bin":
+            assert ridden.cv(d_pos, dt, box, N) == s_plain       # the first assignment of a mesh counts and plans; the ridden one bins
         # a deposit through the generic entry point leaves its second grid pass pending ...
         g.step(0, [0.3])
         b_ref = r.update_bias(0, [0.3])
@@ -466,6 +477,9 @@ def test_lamellar_and_deferred_grid_pass_ride_in_the_binning_kernel(abi, ref, dt
         abi.check(lib.mtd_mesh_clear_rider(ridden.h, C.byref(was)))
         assert was.value == 0                                        # consumed by the assignment
         assert s_ridden == s_plain and np.array_equal(ridden.array(0), rho_plain)
+        pl = C.c_int(-1)
+        abi.check(lib.mtd_mesh_assign_info(ridden.h, C.byref(pl), None, None))
+        assert pl.value == (2 if pipeline == "bin" else 1)
         sums = partials[: n_part.value * 2].cpu().numpy().reshape(n_part.value, 2).sum(axis=0) / N
         opt = util.oracle_postype(pos.astype(np.float64) if dtype == np.float64 else pos, types)
         s_ref = [ref.lamellar_cv(v, opt, m, rbox) for v, m in cvs]

@@ -43,7 +43,18 @@ while time.time() - t0 < budget:
     for path in ("tiles", "cells"):
         os.environ["MTD_MESH_ASSIGN"] = path
         g = GpuMesh(_abi, dims, mode, max(N, 1))
-        s = g.cv(d_pos, dt, box, n_global)
+        if path == "tiles" and N and it % 2 == 0:
+            # the bin pipeline with a plan made for ANOTHER snapshot (overflow lists), then re-planned: the first assignment of a
+            # mesh counts and plans, the second bins on that plan, the third on the second's
+            other = (-0.5 * np.array(Ls) + (rng.random((N, 1)) ** 3) * a1 + rng.random((N, 1)) * a2 + rng.random((N, 1)) * a3).astype(dtype)
+            d_other = torch.from_numpy(util.pack_postype(other, types, dtype)).cuda()
+            g.cv(d_other, dt, box, n_global)
+            s_stale = g.cv(d_pos, dt, box, n_global)
+            rho_stale = g.array(0).copy()
+            s = g.cv(d_pos, dt, box, n_global)
+            assert s == s_stale and np.array_equal(rho_stale, g.array(0)), ("bin pipeline: stale plan against fresh plan", dims, N)
+        else:
+            s = g.cv(d_pos, dt, box, n_global)
         rho = g.array(0).copy()
         F = g.forces(d_pos, dt, box, n_global, 0.8) if N else np.zeros((0, 4))
         res[path] = (s, rho, F)
