@@ -522,11 +522,15 @@ __global__ __launch_bounds__(GT_THREADS) void k_mesh_gather(const MeshGeom g, co
 //   1b k_tile_count    a block owns a contiguous chunk of particles: tile of every particle, its arrival slot in the
 //                      block's LDS histogram (LDS atomic), the histogram written as one row per block, [block][tile]; sum of mode^2
 //   2b scan            exclusive scan over the blocks of every tile's counts = where each block's particles of each tile go
-//   3b k_tile_place    particle id -> start[tile][block] + slot (4-byte scattered store; no record is built)
+//   3b k_tile_place_sorted  a block sorts its chunk by tile in LDS and stores raw position records + ids into tile order in runs
+//                      (k_tile_place: one scattered 4-byte id per particle, the fallback when chunk or tables do not fit the LDS)
+//   1c k_tile_bin      STEADY STATE (every assignment of a mesh but its first): 1b-3b in one launch on tile segments with slack
+//                      planned from the previous snapshot's exact counts, runs reserved with one returning atomic per (chunk, tile),
+//                      overflow list for what does not fit; a mixed set's lamellar sums ride in its wait for the atomics
 //   4b k_tile_scatter  a block owns a tile: the tile + one halo layer live in LDS as 64-bit FIXED-POINT sums, every particle
-//                      of the tile (position gathered through its id) adds its 27 weights with LDS atomics; integer sums
-//                      do not depend on the order of the adds, so the mesh is bitwise reproducible without any sorting;
-//                      the LDS tile is written to a per-tile buffer
+//                      of the tile (tile-ordered position records, read coalesced) adds its 27 weights with LDS atomics; integer
+//                      sums do not depend on the order of the adds, so the mesh is bitwise reproducible without any sorting;
+//                      the LDS tile is written to a per-tile buffer; an extra block plans the next snapshot's segments
 //   5b k_tile_combine  every mesh cell adds the entries that stand for it in its own tile's buffer and in the halo layers
 //                      of the neighbouring tiles (integers, then one conversion to double)
 //   9b k_tile_forces   a block owns a tile: Re(inv) of the tile + halo staged in LDS, 27 LDS reads per particle
@@ -536,7 +540,7 @@ __global__ __launch_bounds__(GT_THREADS) void k_mesh_gather(const MeshGeom g, co
 // Round 3: 512 tiles of 64x8x8 cells at 128^3 instead of 1024 of 16x16x8, 512 threads in the force pass: config 3 161 -> 154 us per
 // step (force pass 27.8 -> 22.9 us: rows of 66 doubles straddle fewer 128-byte lines per payload byte than rows of 18, and two
 // blocks of eight waves per CU stage and sum as well as four of four; place 14.3 -> 13.3: runs of 8 ids per count block and tile).
-// Measured beside it (profiles/r3/tile_shape_ab.log): 32x16x8 and 16x16x16 (512 tiles) 154-156, 256 tiles with 1024-thread
+// Measured beside it (profiles/r3/tile_pipeline_ab.log): 32x16x8 and 16x16x16 (512 tiles) 154-156, 256 tiles with 1024-thread
 // blocks 167, 128x8x4 156, 32x8x8 (1024 tiles) 159.
 #ifndef MTD_TP_X
 #define MTD_TP_X 64
