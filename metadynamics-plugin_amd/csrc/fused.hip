@@ -99,8 +99,9 @@ __global__ __launch_bounds__(FCV_THREADS) void k_fused_cv(const LamKArgs a, cons
     // launch A 7.4 against 6.9 us: the table loads below queue behind twice the requests in the CU's in-order vector L1)
     RawGroup<S4, U> first;
     lam_load_group<S4, U>(postype, N, block_id * FCV_THREADS + threadIdx.x, n_blocks * FCV_THREADS, first);
-    load_coeff(a, s_coeff);
-    load_modes_cv(a, s_mt);
+    // (the tables: one unconditional load per thread behind the particles' — `a` is the dense form, launch_fused_cv)
+    const CvTableRegs tab = stage_cv_tables_request(a);
+    stage_cv_tables_store(tab, s_coeff, s_mt);
     __syncthreads();
     MTD_STAMP(4, block_id == 0 && threadIdx.x == 0);
     float acc[NCV];
@@ -500,11 +501,12 @@ const void *fused_cv_comm_kernel(int dtype, unsigned int n_cv, bool fast)
     }
 
 template<typename S4, bool FAST>
-int launch_fused_cv(const LamKArgs &k, unsigned int N, const void *d_postype, double *d_partials, unsigned int cv_blocks,
+int launch_fused_cv(const LamKArgs &k_in, unsigned int N, const void *d_postype, double *d_partials, unsigned int cv_blocks,
                     const MetadCfg &cfg, unsigned int n_apply, const CommK *ck, hipStream_t s)
     {
     const S4 *p = (const S4 *)d_postype;
     const unsigned int grid = cv_blocks + n_apply;
+    const LamKArgs k = dense_cv_args(k_in);                          // (the kernel stages its tables with flat loads)
     if (ck)
         {
         if (grid > resident_capacity(fused_cv_comm_kernel_of<S4, FAST>(k.n_cv), FCV_THREADS)) return MTD_ERR_UNSUPPORTED;

@@ -93,6 +93,40 @@ __device__ __forceinline__ void load_modes_cv(const LamKArgs &a, ModeTables &t)
     for (unsigned int k = threadIdx.x; k < a.n_modes; k += blockDim.x) t.h[k] = a.h[a.corder[k]];
     }
 
+// The same two tables for a launch whose LamKArgs the host has made DENSE (dense_cv_args: h[k] is already the k-th visited mode,
+// corder the identity): ONE unconditional load per thread from a clamped index, to be requested right behind the first particles —
+// stage_cv_tables_request — and stored just in front of the barrier — stage_cv_tables_store.  The loops above compile to three
+// dependent memory round trips in front of a kernel's first particle (a batched loop over blockDim for the coefficients, the index
+// array, the modes through it): ~1.5 us of launch A's 7, +6 us for a kernel that had a barrier of its own in front (mesh.hip).
+struct CvTableRegs
+    {
+    float4 h;
+    float c;
+    };
+__device__ __forceinline__ CvTableRegs stage_cv_tables_request(const LamKArgs &a)
+    {
+    CvTableRegs r;
+    r.h = a.h[min(threadIdx.x, (unsigned int)MTD_MAX_MODES - 1)];
+    r.c = (&a.coeff[0][0])[min(threadIdx.x, (unsigned int)(MTD_MAX_CV * MTD_MAX_TYPES) - 1)];
+    return r;
+    }
+__device__ __forceinline__ void stage_cv_tables_store(const CvTableRegs &r, float *s_coeff, ModeTables &t)   // blockDim >= 128
+    {
+    if (threadIdx.x < MTD_MAX_MODES) t.h[threadIdx.x] = r.h;
+    if (threadIdx.x < MTD_MAX_CV * MTD_MAX_TYPES) s_coeff[threadIdx.x] = r.c;
+    }
+// host: the argument block with the visited modes of the CV pass as a dense list (what load_modes_cv gathers on the device)
+inline LamKArgs dense_cv_args(const LamKArgs &k)
+    {
+    LamKArgs d = k;
+    for (unsigned int q = 0; q < k.n_modes && q < MTD_MAX_MODES; ++q)
+        {
+        d.h[q] = k.h[k.corder[q]];
+        d.corder[q] = (unsigned char)q;
+        }
+    return d;
+    }
+
 // acc[c] += sum over this thread's particles of a_c(type_j) sum_k cos(q_k . r_j)
 // thread `tid` of `n_threads` walks particles tid, tid + n_threads, ... in groups of U (even).
 // Two things keep this pass off the instruction-issue limit it otherwise sits on (M = 16 modes: 36 issue cycles per

@@ -1114,20 +1114,11 @@ __global__ __launch_bounds__(TB_THREADS) void k_tile_bin(const MeshGeom g, const
     // the rider's tables: ONE unconditional load per thread from clamped indices, requested right behind the first position (the same
     // memory round trip; the host has put the visited modes into a dense list already: the staging loops of launch A — a loop over
     // blockDim, the list through an index array — cost this kernel four dependent round trips in front of its first particle, +6 us)
-    float4 tab_h = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    float tab_c = 0.0f;
-    if (RIDER)
-        {
-        tab_h = bin_rider_k(rider).h[min(threadIdx.x, (unsigned int)MTD_MAX_MODES - 1)];
-        tab_c = (&bin_rider_k(rider).coeff[0][0])[min(threadIdx.x, (unsigned int)(MTD_MAX_CV * MTD_MAX_TYPES) - 1)];
-        }
+    mtd::CvTableRegs tab;
+    if (RIDER) tab = mtd::stage_cv_tables_request(bin_rider_k(rider));
     stage_modes(s_mode, mode, n_types);
     for (unsigned int t = threadIdx.x; t < tg.n_tiles; t += TB_THREADS) s_lpre[t] = 0;
-    if (RIDER)
-        {
-        if (threadIdx.x < MTD_MAX_MODES) s_mt.h[threadIdx.x] = tab_h;
-        if (threadIdx.x < MTD_MAX_CV * MTD_MAX_TYPES) s_coeff[threadIdx.x] = tab_c;
-        }
+    if (RIDER) mtd::stage_cv_tables_store(tab, s_coeff, s_mt);
     __syncthreads();
     CNT_STAMP(1);
     // 1. as k_tile_count: tile of every particle, arrival slot from the LDS histogram; the next position in flight meanwhile
@@ -3260,12 +3251,7 @@ static int mesh_assign_local(mtd_mesh *m, unsigned int n_particles, const void *
             BinNoRider no_rider;
             if (rider_kind)
                 {
-                ra.k = m->h_rider->k;
-                for (unsigned int q = 0; q < ra.k.n_modes && q < MTD_MAX_MODES; ++q)     // the visited modes as a dense list (load_modes_cv)
-                    {
-                    ra.k.h[q] = m->h_rider->k.h[m->h_rider->k.corder[q]];
-                    ra.k.corder[q] = (unsigned char)q;
-                    }
+                ra.k = mtd::dense_cv_args(m->h_rider->k);                // (the visited modes as a dense list: flat table loads)
                 ra.partials = m->h_rider->partials;
                 }
 #define MTD_TILE_BIN(S4, PER, R, RA) \
