@@ -98,7 +98,10 @@ __global__ __launch_bounds__(FCV_THREADS) void k_fused_cv(const LamKArgs a, cons
     // (both groups of a thread requested here — the whole position array in the launch's first microsecond — measured SLOWER,
     // launch A 7.4 against 6.9 us: the table loads below queue behind twice the requests in the CU's in-order vector L1)
     RawGroup<S4, U> first;
-    lam_load_group<S4, U>(postype, N, block_id * FCV_THREADS + threadIdx.x, n_blocks * FCV_THREADS, first);
+    // (an empty system — postype may be NULL — reads the head of the partial-sum buffer instead, at least 1024 doubles by the ABI's
+    // contract: unconditional loads, see lam_load_group_nc; nothing of it is used, the loop below does not run)
+    const S4 *src = N ? postype : (const S4 *)partials;
+    lam_load_group_nc<S4, U>(src, N ? N : 1u, block_id * FCV_THREADS + threadIdx.x, n_blocks * FCV_THREADS, first);
     // (the tables: one unconditional load per thread behind the particles' — `a` is the dense form, launch_fused_cv)
     const CvTableRegs tab = stage_cv_tables_request(a);
     stage_cv_tables_store(tab, s_coeff, s_mt);

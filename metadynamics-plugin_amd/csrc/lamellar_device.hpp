@@ -157,6 +157,21 @@ __device__ __forceinline__ void lam_load_group(const S4 *__restrict__ postype, c
         }
     }
 
+// The same without the look at N (N >= 1: the caller knows there is a particle, or hands in any readable address with N = 1):
+// the loads sit in the caller's basic block, so the scheduler is free to keep them in flight — behind lam_load_group's
+// `if (N == 0) return` the compiler packed the loaded values into pairs INSIDE the branch and waited for every load right there.
+template<typename S4, int U>
+__device__ __forceinline__ void lam_load_group_nc(const S4 *__restrict__ postype, const unsigned int N, const unsigned int base,
+                                                  const unsigned int n_threads, RawGroup<S4, U> &g)
+    {
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+        {
+        const unsigned int i = base + u * n_threads;
+        g.v[u] = postype[i < N ? i : N - 1];
+        }
+    }
+
 // `first` holds the group at base = tid (lam_load_group, issued by the caller before it staged the tables); every further
 // group is requested before the current one is summed, so only the very first memory round trip of the launch is exposed
 // (measured: 2.6 us per exposed round trip, more than summing a group)
@@ -229,8 +244,11 @@ __device__ __forceinline__ void lam_cv_accumulate(const LamKArgs &a, const S4 *_
     for (unsigned int base = tid; base < N; base += U * n_threads)
         {
         const unsigned int next = base + U * n_threads;
-        RawGroup<S4, U> nxt = cur;
-        if (next < N) lam_load_group<S4, U>(postype, N, next, n_threads, nxt);
+        // UNCONDITIONAL (lam_load_group clamps every index to the last particle; the loop runs only if there is one): behind
+        // `if (next < N)` the compiler could not count the loads and put an s_waitcnt vmcnt(0) into the projection of the CURRENT
+        // group — the next group's round trip was paid in full before the first cosine (gfx950 ISA), not overlapped
+        RawGroup<S4, U> nxt;
+        lam_load_group_nc<S4, U>(postype, N, next < N ? next : N - 1, n_threads, nxt);
         lam_cv_group<S4, NCV, FAST, U>(a, N, base, n_threads, s_coeff, mt, cur, acc);
         cur = nxt;
         }
