@@ -379,12 +379,14 @@ int mtd_mesh_compute_cv(mtd_mesh *m, unsigned int n_particles, const void *d_pos
  * _assign spreads this rank's particles, the ranks all-reduce (sum) the *count doubles at *d_buffer — the real mesh
  * followed by the sum of mode^2 — and _spectral runs FFT -> updateMeshes -> iFFT -> computeCV on the reduced mesh. */
 /* Riders on the NEXT mtd_mesh_compute_cv / mtd_mesh_assign of this mesh (one-shot, tile pipeline only — MTD_ERR_UNSUPPORTED
- * otherwise, then call mtd_fused_cv_pass): the kernel that bins the particles also forms, from the particle it is looking at
- * anyway, the block partial sums of the lamellar CVs of `set` (at most 3; what mtd_fused_cv_pass leaves in d_partials: feed them
- * to mtd_metad_set_cv_source with n_partials = *n_partials, stride = set->n_cv, offset = c, scale 1 / N_global), and blocks
- * behind the counting ones run the deferred second grid pass of `engine`'s previous deposit (may be NULL).  A mixed set
- * (cv.lamellar + cv.mesh: LamellarOrderParameter.cc:143-179 and OrderParameterMesh.cc:517-640 both stream the positions) then
- * reads the positions once for both and spends one launch less per step.  n_particles, the stream and the position array of
+ * otherwise, then call mtd_fused_cv_pass): the kernel that bins the particles also forms, from the positions it holds anyway, the
+ * block partial sums of the lamellar CVs of `set` (at most 3; what mtd_fused_cv_pass leaves in d_partials: feed them to
+ * mtd_metad_set_cv_source with n_partials = *n_partials, stride = set->n_cv, offset = c, scale 1 / N_global), and the assignment's
+ * launches carry the deferred second grid pass of `engine`'s previous deposit (may be NULL).  In the bin pipeline (every assignment
+ * of a mesh but its first) the sums are formed while the binning blocks wait for their atomics and the grid pass travels as extra
+ * blocks of the scatter launch; the counting pipeline forms them in its particle loop / carries the pass in its row-scan launch.  A
+ * mixed set (cv.lamellar + cv.mesh: LamellarOrderParameter.cc:143-179 and OrderParameterMesh.cc:517-640 both stream the positions)
+ * then reads the positions once for both and spends one launch less per step.  n_particles, the stream and the position array of
  * that next call must be the ones the CVs share; d_partials: mtd_lamellar_scratch_doubles(n_particles) doubles. */
 int mtd_mesh_set_lamellar_rider(mtd_mesh *mesh, mtd_metad *engine, const mtd_lamellar_set *set, const mtd_box *global_box,
                                 unsigned int n_particles, double *d_partials, unsigned int *n_partials, mtd_stream_t stream);
