@@ -45,7 +45,10 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
+#include <mutex>
 #include <new>
+#include <utility>
 #include <vector>
 
 namespace
@@ -3167,6 +3170,25 @@ int mtd_mesh_set_bug_compat(mtd_mesh *m, int on)
     return MTD_SUCCESS;
     }
 
+// Raise the dynamic-LDS limit of a group of kernels once per DEVICE (a function attribute belongs to the device that is current when
+// it is set; a process that drives several GPUs sets it on each).  A runtime that refuses leaves the caller its fallback path.
+static bool dyn_lds_ok(const int group, const void *const *fns, const int n, const size_t bytes)
+    {
+    static std::mutex mu;
+    static std::map<std::pair<int, int>, bool> done;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return false;
+    std::lock_guard<std::mutex> lock(mu);
+    const auto key = std::make_pair(dev, group);
+    auto it = done.find(key);
+    if (it != done.end()) return it->second;
+    hipError_t e = hipSuccess;
+    for (int i = 0; i < n && e == hipSuccess; ++i) e = hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e != hipSuccess) (void)hipGetLastError();
+    done[key] = e == hipSuccess;
+    return e == hipSuccess;
+    }
+
 static int mesh_assign_local(mtd_mesh *m, unsigned int n_particles, const void *d_postype, int dtype, const mtd_box *box, mtd_stream_t stream);
 
 int mtd_mesh_assign(mtd_mesh *m, unsigned int n_particles, const void *d_postype, int dtype, const mtd_box *box, mtd_stream_t stream)
@@ -3212,15 +3234,10 @@ static int mesh_assign_local(mtd_mesh *m, unsigned int n_particles, const void *
         const char *bin_env = std::getenv("MTD_MESH_BIN");               // (read per call: tests run both pipelines in one process)
         const bool bin_off = bin_env && bin_env[0] == '0';
         const size_t tb_lds = f32 ? tile_bin_lds_bytes<float4>(tg.n_tiles, tg.chunk) : tile_bin_lds_bytes<double4>(tg.n_tiles, tg.chunk);
-        static const bool tb_lds_ok = [] {
-            hipError_t e = hipSuccess;
 #define MTD_BIN_FNS(S4, R) (const void *)k_tile_bin<S4, 1, R>, (const void *)k_tile_bin<S4, 2, R>, (const void *)k_tile_bin<S4, 4, R>, (const void *)k_tile_bin<S4, 8, R>
-            const void *fns[24] = { MTD_BIN_FNS(float4, 0), MTD_BIN_FNS(float4, 1), MTD_BIN_FNS(float4, 2), MTD_BIN_FNS(double4, 0), MTD_BIN_FNS(double4, 1), MTD_BIN_FNS(double4, 2) };
+        static const void *const bin_fns[24] = { MTD_BIN_FNS(float4, 0), MTD_BIN_FNS(float4, 1), MTD_BIN_FNS(float4, 2), MTD_BIN_FNS(double4, 0), MTD_BIN_FNS(double4, 1), MTD_BIN_FNS(double4, 2) };
 #undef MTD_BIN_FNS
-            for (int i = 0; i < 24 && e == hipSuccess; ++i) e = hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, (int)TB_LDS_MAX);
-            if (e != hipSuccess) (void)hipGetLastError();
-            return e == hipSuccess;
-        }();
+        const bool tb_lds_ok = dyn_lds_ok(0, bin_fns, 24, TB_LDS_MAX);
         const bool bin_fits = !bin_off && tb_lds_ok && m->d_possorted && tg.chunk <= TPS_CHUNK_MAX && tb_lds <= TB_LDS_MAX &&
                               tg.n_tiles <= (unsigned int)(TB_TILES_PER_MAX * TB_THREADS);
         TilePlan plan;
@@ -3230,7 +3247,10 @@ static int mesh_assign_local(mtd_mesh *m, unsigned int n_particles, const void *
         // (riders of the counting kernel's own loop — MTD_MESH_RIDER=count — keep the counting pipeline)
         const char *rider_env = std::getenv("MTD_MESH_RIDER");
         const bool rider_in_count = rider_env && std::strcmp(rider_env, "count") == 0;
-        if (bin_fits && m->plan_valid && m->plan_n == N && !(m->rider_armed && rider_in_count))
+        // a plan made for another particle number still is a plan (a domain-decomposed run's local count changes every step: what does
+        // not fit overflows); only a count that differs by a factor of two or more is counted and planned afresh
+        const bool plan_usable = m->plan_valid && N >= m->plan_n / 2 && N / 2 <= m->plan_n;
+        if (bin_fits && plan_usable && !(m->rider_armed && rider_in_count))
             {
             const int p = m->bin_parity;
             int rider_kind = 0;
@@ -3285,6 +3305,7 @@ static int mesh_assign_local(mtd_mesh *m, unsigned int n_particles, const void *
             else
                 k_tile_scatter<double4><<<tg.n_tiles + 1 + n_apply, TP_THREADS, 0, s>>>(g, tg, (const double4 *)d_postype, m->d_mode, L, m->d_ids, m->d_tilebuf, m->d_packed, m->n_types, (const double4 *)m->d_possorted, plan, apply_cfg);
             m->lists = L;
+            m->plan_n = N;
             m->last_pipeline = 2;
             m->bin_parity = 1 - p;                                       // (planned and zeroed by the extra block)
             }
@@ -3325,12 +3346,8 @@ static int mesh_assign_local(mtd_mesh *m, unsigned int n_particles, const void *
         const size_t ps_lds = f32 ? place_sorted_lds_bytes<float4>(tg.n_tiles, tg.chunk) : place_sorted_lds_bytes<double4>(tg.n_tiles, tg.chunk);
         const char *ps_env = std::getenv("MTD_MESH_PLACE");           // (read per call: a test runs both forms in one process)
         const bool ps_off = ps_env && std::strcmp(ps_env, "ids") == 0;
-        static const bool ps_lds_ok = [] {
-            hipError_t e = hipFuncSetAttribute((const void *)k_tile_place_sorted<float4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PS_LDS_MAX);
-            if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_tile_place_sorted<double4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PS_LDS_MAX);
-            if (e != hipSuccess) (void)hipGetLastError();
-            return e == hipSuccess;
-        }();
+        static const void *const ps_fns[2] = { (const void *)k_tile_place_sorted<float4>, (const void *)k_tile_place_sorted<double4> };
+        const bool ps_lds_ok = dyn_lds_ok(1, ps_fns, 2, PS_LDS_MAX);
         const bool sorted = !ps_off && ps_lds_ok && m->d_possorted && tg.chunk <= TPS_CHUNK_MAX && ps_lds <= PS_LDS_MAX;
         if (sorted)
             {
@@ -3353,7 +3370,7 @@ static int mesh_assign_local(mtd_mesh *m, unsigned int n_particles, const void *
             k_tile_scatter<double4><<<tg.n_tiles, TP_THREADS, 0, s>>>(g, tg, (const double4 *)d_postype, m->d_mode, L, m->d_ids, m->d_tilebuf, m->d_packed, m->n_types, sorted ? (const double4 *)m->d_possorted : nullptr, plan, apply_cfg);
         m->lists = L;
         m->last_pipeline = 1;
-        if (bin_fits && !(m->plan_valid && m->plan_n == N))
+        if (bin_fits && !plan_usable)
             {
             // the exact counts of this snapshot plan the segments of the next one
             MTD_LAUNCH_CHECK();
@@ -3454,12 +3471,8 @@ int mtd_mesh_spectral(mtd_mesh *m, const mtd_box *box, unsigned int n_global, co
     size_t xy_lds_f = 0, xy_lds_i = 0;
     static const bool xy_off = [] { const char *e = std::getenv("MTD_FFT_XY"); return e && e[0] == '0'; }();
     // (a runtime that refuses the 160 KB of dynamic LDS leaves the separate passes, it does not fail the step)
-    static const bool xy_lds_ok = [] {
-        hipError_t e = hipFuncSetAttribute((const void *)k_fft_xy_forward, hipFuncAttributeMaxDynamicSharedMemorySize, (int)XY_LDS_MAX);
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_fft_xy_inverse, hipFuncAttributeMaxDynamicSharedMemorySize, (int)XY_LDS_MAX);
-        if (e != hipSuccess) (void)hipGetLastError();
-        return e == hipSuccess;
-    }();
+    static const void *const xy_fns[2] = { (const void *)k_fft_xy_forward, (const void *)k_fft_xy_inverse };
+    const bool xy_lds_ok = dyn_lds_ok(2, xy_fns, 2, XY_LDS_MAX);
     const bool xy = !xy_off && xy_lds_ok && xy_plan(m, 0, xy_f, xy_lds_f) && xy_plan(m, 1, xy_i, xy_lds_i);
     if (xy)
         {

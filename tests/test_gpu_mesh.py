@@ -143,6 +143,36 @@ def test_bin_pipeline_against_counting_pipeline(abi, monkeypatch, dtype, N, dims
         assert np.abs(out["1"][2][1]).max() > 0 and np.abs(out["1"][2][3]).max() > 0
 
 
+def test_bin_pipeline_with_a_changing_particle_number(abi, monkeypatch):
+    """a domain-decomposed run's local particle number changes from step to step: the plan of the previous snapshot still serves (what
+    does not fit overflows), only a count that differs by a factor of two or more is counted and planned afresh.  Mesh, CV and
+    forces are the same bits as with the counting pipeline for every N of the sequence."""
+    L, dims, n_max = 11.0, (32, 32, 16), 30000
+    pos, types = util.snapshot_random(n_max, L, seed=41, modulated=True, dtype=np.float32)
+    box = abi.Box.make(L)
+    seq = [5000, 5200, 4000, 7500, 30000, 29000, 0, 1, 17]
+    expect = [1, 2, 2, 2, 1, 2, 1, 2, 1]          # 1 counting, 2 bin: 30000 > 2 x 7500; 0 < 29000 / 2; 1 / 2 <= 0 (a plan of empty tiles: all overflow); 17 / 2 > 1
+    out = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("MTD_MESH_BIN", mode)
+        g = GpuMesh(abi, dims, [1.0, -0.7], n_max)
+        res = []
+        try:
+            for n, want in zip(seq, expect):
+                d_pos = torch.from_numpy(util.pack_postype(pos[:n], types[:n], np.float32)).cuda() if n else torch.zeros((0, 4), dtype=torch.float32, device="cuda")
+                s = g.cv(d_pos, abi.MTD_F32, box, max(n, 1))
+                pl = C.c_int(-1)
+                abi.check(g.lib.mtd_mesh_assign_info(g.h, C.byref(pl), None, None))
+                assert pl.value == (want if mode == "1" else 1), (n, pl.value)
+                F = g.forces(d_pos, abi.MTD_F32, box, max(n, 1), 0.8) if n else np.zeros((0, 4))
+                res.append((s, g.array(0).copy(), F))
+        finally:
+            g.close()
+        out[mode] = res
+    for a, b in zip(out["1"], out["0"]):
+        assert a[0] == b[0] and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+
+
 def test_mesh_bitwise_independent_of_particle_order(abi):
     """tile path: the weights are summed as 64-bit fixed point, so the mesh does not depend on the order of the adds"""
     N, L = 40011, 12.0
