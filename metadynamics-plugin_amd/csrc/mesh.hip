@@ -2219,12 +2219,20 @@ __device__ __forceinline__ void xy_fetch_columns(double2 (&pre)[XY_PREFETCH], co
         }
     }
 
+// cvp_*: the CV's partial sums of the fused z pass (one per block of that launch: 1152 at 128^3) folded to one per block of THIS
+// launch, which runs between the z pass and whoever reads the CV — the bias-grid engine's chain reads 256 partial sums per variable in
+// the memory round trip it starts from and needs another dependent trip for every 512 beyond them, in every block of its launch.
+// Wave 0 requests its entries (block + lane * gridDim) in front of everything else, unconditionally (cvp_n = 0: nothing counts, the
+// clamped index reads entry 0), and adds them up when the kernel is done: no wait of its own.
 __global__ __launch_bounds__(XY_THREADS) void k_fft_xy_inverse(const double2 *__restrict__ half_in, double *__restrict__ real_out,
                                                                const double2 *__restrict__ tw_x, const double2 *__restrict__ tw_y,
-                                                               const XYPlan pl)
+                                                               const XYPlan pl, const double *__restrict__ cvp_in, const unsigned int cvp_n,
+                                                               double *__restrict__ cvp_out)
     {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double2 *X = (double2 *)smem, *Y = X + (size_t)pl.nx * pl.xs, *TX = Y + (size_t)pl.ny * pl.ys, *TY = TX + pl.nx / 2;
+    const unsigned int cvp_k = blockIdx.x + (threadIdx.x & 63u) * gridDim.x;
+    double cvp = cvp_in[min(cvp_k, cvp_n ? cvp_n - 1 : 0u)];
     unsigned int plane, part;
     xy_block(pl, plane, part);
     const unsigned int nx = pl.nx, ny = pl.ny, pairs = pl.pb, xs = pl.xs, ys = pl.ys;
@@ -2277,6 +2285,12 @@ __global__ __launch_bounds__(XY_THREADS) void k_fft_xy_inverse(const double2 *__
         const size_t la = line_base + y_base + 2 * u;
         __builtin_nontemporal_store(z.x, real_out + la * nx + p);
         __builtin_nontemporal_store(z.y, real_out + (la + 1) * nx + p);
+        }
+    if (threadIdx.x < 64)                                        // (wave 0, uniform over the wave)
+        {
+        cvp = cvp_k < cvp_n ? cvp : 0.0;
+        const double tot = wave_sum(cvp);
+        if (threadIdx.x == 0 && cvp_n) cvp_out[blockIdx.x] = tot;
         }
     XY_STAMP(1, 8);
     }
@@ -2730,7 +2744,7 @@ struct mtd_mesh
     int fourier_valid;         // d_f holds the Fourier mesh of the last spectral step
     hipEvent_t cv_event;       // recorded after the pass that completes the CV partial sums (mtd_mesh_set_cv_event), or null
     void *slab;
-    double *d_mode, *d_rho, *d_inv, *d_modesq_partials, *d_mode_sq, *d_cv_partials;
+    double *d_mode, *d_rho, *d_inv, *d_modesq_partials, *d_mode_sq, *d_cv_partials, *d_cv_folded;
     double2 *d_f, *d_g, *d_tw[3];
     double4 *d_packed;
     unsigned int *d_cell_of, *d_slot_of, *d_count, *d_start, *d_tile_sums;
@@ -2970,7 +2984,7 @@ int mtd_mesh_create(mtd_mesh **out, unsigned int nx, unsigned int ny, unsigned i
     const size_t n_slots_extra = m->tile_path ? tile_capacity_total_max(N, m->tg.n_tiles) : 0;
     size_t off = 0;
     auto take = [&](size_t b) { size_t o = off; off += al(b); return o; };
-    const size_t o_mode = take(sizeof(double) * n_types), o_rho = take(sizeof(double) * (M + 1)), o_msqp = take(sizeof(double) * m->n_count_blocks), o_cvp = take(sizeof(double) * m->n_cv_partials), o_f = take(sizeof(double2) * MH),
+    const size_t o_mode = take(sizeof(double) * n_types), o_rho = take(sizeof(double) * (M + 1)), o_msqp = take(sizeof(double) * m->n_count_blocks), o_cvp = take(sizeof(double) * m->n_cv_partials), o_cvf = take(sizeof(double) * ((size_t)nz * XY_PARTS + 1)), o_f = take(sizeof(double2) * MH),
                  o_g = take(sizeof(double2) * MH), o_tw0 = take(sizeof(double2) * nx), o_tw1 = take(sizeof(double2) * ny),
                  o_tw2 = take(sizeof(double2) * nz), o_packed = take(sizeof(double4) * (N + n_slots_extra)), o_cell = take(sizeof(unsigned int) * N),
                  o_count = take(sizeof(unsigned int) * (n_scan + 1)), o_start = take(sizeof(unsigned int) * (n_scan + 1)),
@@ -2992,7 +3006,7 @@ int mtd_mesh_create(mtd_mesh **out, unsigned int nx, unsigned int ny, unsigned i
     char *p = (char *)m->slab;
     m->d_mode = (double *)(p + o_mode); m->d_rho = (double *)(p + o_rho); m->d_modesq_partials = (double *)(p + o_msqp);
     m->d_mode_sq = m->d_rho + M;   // directly behind the real mesh: one exchange buffer of M + 1 doubles
-    m->d_cv_partials = (double *)(p + o_cvp); m->d_f = (double2 *)(p + o_f);
+    m->d_cv_partials = (double *)(p + o_cvp); m->d_cv_folded = (double *)(p + o_cvf); m->d_f = (double2 *)(p + o_f);
     m->d_g = (double2 *)(p + o_g); m->d_tw[0] = (double2 *)(p + o_tw0); m->d_tw[1] = (double2 *)(p + o_tw1);
     m->d_tw[2] = (double2 *)(p + o_tw2); m->d_packed = (double4 *)(p + o_packed); m->d_cell_of = (unsigned int *)(p + o_cell);
     m->d_count = (unsigned int *)(p + o_count); m->d_start = (unsigned int *)(p + o_start); m->d_idcell = (uint2 *)(p + o_ids);
@@ -3501,12 +3515,20 @@ int mtd_mesh_spectral(mtd_mesh *m, const mtd_box *box, unsigned int n_global, co
         k_fft_z_spectral<false, 1><<<z_blocks_whole, FFT_THREADS, fft_lds_bytes(pz.n, pz.tile), s>>>(
             g, m->d_f, m->d_g, pz.tw, ilog2(pz.n), pz.tile, pz.tiles_per_row, m->d_mode_sq, (double)n_global, m->d_itab, m->d_cv_partials, none, m->keep_fourier);
     m->fourier_valid = m->keep_fourier;
+    bool fold_cv = false;
+    unsigned int n_folded = 0;
     if (m->cv_event) MTD_HIP_TRY(hipEventRecord(m->cv_event, s));          // the CV partial sums are complete from here on
     MTD_LAUNCH_CHECK();
     if (xy)
         {
-        k_fft_xy_inverse<<<m->nz * XY_PARTS, XY_THREADS, xy_lds_i, s>>>(m->d_g, m->d_inv, m->d_tw[0], m->d_tw[1], xy_i);   // Re(inv)
+        // (the CV's partial sums folded to one per block of this launch when that is fewer — and nobody was promised them earlier:
+        // mtd_mesh_set_cv_event marks the z pass as the point where the sums are complete)
+        const unsigned int xy_blocks = m->nz * XY_PARTS;
+        fold_cv = !m->cv_event && z_blocks_whole > xy_blocks && z_blocks_whole <= 64 * xy_blocks;
+        k_fft_xy_inverse<<<xy_blocks, XY_THREADS, xy_lds_i, s>>>(m->d_g, m->d_inv, m->d_tw[0], m->d_tw[1], xy_i, m->d_cv_partials,
+                                                                 fold_cv ? z_blocks_whole : 0u, m->d_cv_folded);   // Re(inv)
         MTD_LAUNCH_CHECK();
+        if (fold_cv) n_folded = xy_blocks;
         }
     else
         {
@@ -3515,8 +3537,8 @@ int mtd_mesh_spectral(mtd_mesh *m, const mtd_box *box, unsigned int n_global, co
         k_fft_x_c2r<<<x_blocks, FFT_THREADS, x_lds, s>>>(m->d_g, m->d_inv, m->d_tw[0], m->nx, ilog2(m->nx), x_tile, m->hxp, n_lines);   // Re(inv)
         MTD_LAUNCH_CHECK();
         }
-    *d_partials = m->d_cv_partials;
-    *n_partials = z_blocks_whole;
+    *d_partials = fold_cv ? m->d_cv_folded : m->d_cv_partials;
+    *n_partials = fold_cv ? n_folded : z_blocks_whole;
     return MTD_SUCCESS;
     }
 
