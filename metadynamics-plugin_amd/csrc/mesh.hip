@@ -1484,7 +1484,14 @@ __global__ __launch_bounds__(TF_THREADS) void k_tile_forces(const MeshGeom g, co
     __shared__ double s_inv[TP_HMAX];
     __shared__ double s_mode[TP_MODE_LDS];
     stage_modes(s_mode, mode, n_types);                              // (published by the barrier behind the staging of Re(inv))
-    const unsigned int t = blockIdx.x;
+    // Blocks go to the eight XCDs round robin (block b -> XCD b mod 8) and every XCD has an L2 of its own: the blocks of one XCD take
+    // a CONTIGUOUS range of tiles — two z layers of tiles at 128^3 — so that the halo rows neighbouring tiles share are fetched once
+    // per XCD instead of once per tile (the launch has 8 * ceil(n_tiles / 8) blocks; the surplus ones leave): config 3 133.6 -> 132.4 us.
+    // (Giving the combine pass and the x/y transforms the same slabs, so that a pass would find the mesh the previous one wrote in
+    // its XCD's L2, changed nothing beyond that: 132.8.)
+    const unsigned int per_xcd = (tg.n_tiles + 7) / 8;
+    const unsigned int t = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
+    if ((blockIdx.x >> 3) >= per_xcd || t >= tg.n_tiles) return;
     const unsigned int tix = t % tg.ntx, tiy = (t / tg.ntx) % tg.nty, tiz = t / (tg.ntx * tg.nty);
     const int x0 = tix * tg.tx, y0 = tiy * tg.ty, z0 = tiz * tg.tz;
     TILE_STAMP(1, 0);
@@ -3569,9 +3576,9 @@ int mtd_mesh_forces(mtd_mesh *m, unsigned int n_particles, const void *d_postype
     if (m->tile_path)
         {
         if (dtype == MTD_F32)
-            k_tile_forces<float4><<<m->tg.n_tiles, TF_THREADS, 0, s>>>(g, m->tg, m->lists, m->d_mode, m->d_packed, m->d_inv, (float4 *)d_force, d_bias, bias_host, two_over_n, m->n_types);
+            k_tile_forces<float4><<<8 * ((m->tg.n_tiles + 7) / 8), TF_THREADS, 0, s>>>(g, m->tg, m->lists, m->d_mode, m->d_packed, m->d_inv, (float4 *)d_force, d_bias, bias_host, two_over_n, m->n_types);
         else
-            k_tile_forces<double4><<<m->tg.n_tiles, TF_THREADS, 0, s>>>(g, m->tg, m->lists, m->d_mode, m->d_packed, m->d_inv, (double4 *)d_force, d_bias, bias_host, two_over_n, m->n_types);
+            k_tile_forces<double4><<<8 * ((m->tg.n_tiles + 7) / 8), TF_THREADS, 0, s>>>(g, m->tg, m->lists, m->d_mode, m->d_packed, m->d_inv, (double4 *)d_force, d_bias, bias_host, two_over_n, m->n_types);
         MTD_LAUNCH_CHECK();
         return MTD_SUCCESS;
         }
