@@ -1077,8 +1077,6 @@ template<int RIDER> struct BinRider { typedef BinRiderArgs type; };
 template<> struct BinRider<0> { typedef BinNoRider type; };
 __device__ __forceinline__ const mtd::LamKArgs &bin_rider_k(const BinRiderArgs &r) { return r.k; }
 __device__ __forceinline__ double *bin_rider_partials(const BinRiderArgs &r) { return r.partials; }
-__device__ __forceinline__ const mtd::LamKArgs &bin_rider_k(const BinNoRider &) { return *(const mtd::LamKArgs *)nullptr; }   // (never evaluated)
-__device__ __forceinline__ double *bin_rider_partials(const BinNoRider &) { return nullptr; }
 
 template<typename S4, int PER, int RIDER>
 __global__ __launch_bounds__(TB_THREADS) void k_tile_bin(const MeshGeom g, const TileGeom tg, const S4 *__restrict__ postype, const unsigned int N,
@@ -1107,7 +1105,8 @@ __global__ __launch_bounds__(TB_THREADS) void k_tile_bin(const MeshGeom g, const
     if (i0 >= i1)                                                              // (uniform over the block: nothing to bin, nothing to read)
         {
         if (threadIdx.x == 0) modesq_partials[b] = 0.0;
-        if (RIDER && threadIdx.x < bin_rider_k(rider).n_cv) bin_rider_partials(rider)[(size_t)b * bin_rider_k(rider).n_cv + threadIdx.x] = 0.0;
+        if constexpr (RIDER != 0)
+            if (threadIdx.x < bin_rider_k(rider).n_cv) bin_rider_partials(rider)[(size_t)b * bin_rider_k(rider).n_cv + threadIdx.x] = 0.0;
         return;
         }
     const unsigned int i_last = i1 - 1;
@@ -1118,10 +1117,10 @@ __global__ __launch_bounds__(TB_THREADS) void k_tile_bin(const MeshGeom g, const
     // memory round trip; the host has put the visited modes into a dense list already: the staging loops of launch A — a loop over
     // blockDim, the list through an index array — cost this kernel four dependent round trips in front of its first particle, +6 us)
     mtd::CvTableRegs tab;
-    if (RIDER) tab = mtd::stage_cv_tables_request(bin_rider_k(rider));
+    if constexpr (RIDER != 0) tab = mtd::stage_cv_tables_request(bin_rider_k(rider));
     stage_modes(s_mode, mode, n_types);
     for (unsigned int t = threadIdx.x; t < tg.n_tiles; t += TB_THREADS) s_lpre[t] = 0;
-    if (RIDER) mtd::stage_cv_tables_store(tab, s_coeff, s_mt);
+    if constexpr (RIDER != 0) mtd::stage_cv_tables_store(tab, s_coeff, s_mt);
     __syncthreads();
     CNT_STAMP(1);
     // 1. as k_tile_count: tile of every particle, arrival slot from the LDS histogram; the next position in flight meanwhile
@@ -1213,7 +1212,7 @@ __global__ __launch_bounds__(TB_THREADS) void k_tile_bin(const MeshGeom g, const
             }
         }
     float acc[3] = { 0.0f, 0.0f, 0.0f };
-    if (RIDER)
+    if constexpr (RIDER != 0)
         {
         // (kept between the staging and the first use of the atomics' results)
         __builtin_amdgcn_sched_barrier(0);
@@ -1256,7 +1255,7 @@ __global__ __launch_bounds__(TB_THREADS) void k_tile_bin(const MeshGeom g, const
     CNT_STAMP(6);
     msq = block_sum_lds(msq, s_red);
     if (threadIdx.x == 0) modesq_partials[b] = msq;
-    if (RIDER)
+    if constexpr (RIDER != 0)
         {
         // fp32 wave sums -> fp64 across the waves in a fixed order, as lam_cv_block_reduce; partials[chunk][n_cv]
         const unsigned int n_cv = bin_rider_k(rider).n_cv;

@@ -17,8 +17,8 @@ for round in 1 2; do
     touch metadynamics-plugin_amd/csrc/mesh.hip
     make -C metadynamics-plugin_amd/csrc -s -j8 EXTRA_HIPFLAGS="$V" >> $LOG 2>&1 || { echo "build failed" | tee -a $LOG; continue; }
     if [ $round = 1 ]; then timeout -k 10 600 python3 -m pytest tests/test_gpu_mesh.py -x -q 2>&1 | tail -2 | tee -a $LOG; fi
-    run "[$V]" MTD_MESH_RIDER=0
-    run "[$V]" MTD_MESH_RIDER=0
+    run "[$V]" MTD_EXP=1
+    run "[$V]" MTD_EXP=1
     [ -n "$EXP_RIDER" ] && run "[$V] riders $EXP_RIDER" MTD_MESH_RIDER=$EXP_RIDER
   done
 done
