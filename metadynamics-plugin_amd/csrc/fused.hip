@@ -145,13 +145,17 @@ __global__ __launch_bounds__(FCV_THREADS) void k_fused_cv(const LamKArgs a, cons
 constexpr int FF_STREAM_WAVES = FF_THREADS / MTD_WAVE - 1;
 constexpr int FF_STREAM_THREADS = FF_STREAM_WAVES * MTD_WAVE;
 constexpr int FF_U = 4;        // particles per register group
-// register groups per streaming thread: 2 (= 8 particles, every block of a 10^6-particle launch resident at
-// once) where that fits 128 VGPRs without spilling (fp32 particle data, <= 2 CVs), else 1
-template<typename S4, int NCV> struct ff_groups { static constexpr int value = 1; };
-template<> struct ff_groups<float4, 1> { static constexpr int value = 2; };
-template<> struct ff_groups<float4, 2> { static constexpr int value = 2; };
-template<> struct ff_groups<double4, 1> { static constexpr int value = 2; };
-template<> struct ff_groups<double4, 2> { static constexpr int value = 2; };
+// register groups per streaming thread: 2 (= 8 particles, every block of a 10^6-particle launch resident at once) where that fits
+// 128 VGPRs WITHOUT SPILLING, else 1.  Checked against the compiler's resource report (-Rpass-analysis=kernel-resource-usage), not
+// assumed: until the end of round 3 the double-precision 2-CV instantiation and the accurate-trigonometry fp32 one ran two groups
+// with 36 bytes of scratch per lane — reloads from scratch have the latency of memory — and one group in two generations of blocks is
+// faster (f64: launch B 33.3 -> 26.4 us, step 41.5 -> 35.1 us).
+template<typename S4, int NCV, bool FAST> struct ff_groups { static constexpr int value = 1; };
+template<> struct ff_groups<float4, 1, true> { static constexpr int value = 2; };
+template<> struct ff_groups<float4, 2, true> { static constexpr int value = 2; };
+template<> struct ff_groups<float4, 1, false> { static constexpr int value = 2; };
+template<> struct ff_groups<double4, 1, true> { static constexpr int value = 2; };
+template<> struct ff_groups<double4, 1, false> { static constexpr int value = 2; };
 
 template<typename S4, int NCV, bool FAST, int GROUPS, bool COMM>
 __global__ __launch_bounds__(FF_THREADS, 4) void k_fused_force(const LamKArgs a, const S4 *__restrict__ postype, const ForcePtrs out,
@@ -639,10 +643,9 @@ int mtd_fused_force_pass_slots(mtd_metad *m, const mtd_lamellar_set *set, const 
         }
     if (m->cfg.n_cv <= (unsigned int)CHAIN_MAX_CV && !force_general)
         {
-        const unsigned int groups = (set->n_cv <= 2) ? 2 : 1;
-        unsigned int fblocks = (n_particles + FF_STREAM_THREADS * FF_U * groups - 1) / (FF_STREAM_THREADS * FF_U * groups);
-        if (fblocks == 0 && n_grid == 0) fblocks = 1;               // still one block to publish the scalars
-        const unsigned int grid = n_grid + fblocks;
+        // (the force blocks of the launch: every streaming thread takes ff_groups<S4, NCV, FASTV>::value groups of FF_U particles — the
+        // count is formed where the instantiation is chosen, so that the two cannot disagree)
+        unsigned int grid = 0;
         // measurement aid (mtd_profile_force_begin): the launch records its own begin and end through the start / stop events of
         // hipExtLaunchKernelGGL — the dispatch's time stamps, what a kernel trace reports for it
         hipEvent_t ev_start = nullptr, ev_stop = nullptr;
@@ -652,8 +655,12 @@ int mtd_fused_force_pass_slots(mtd_metad *m, const mtd_lamellar_set *set, const 
              else KERNEL<<<grid, FF_THREADS, 0, s>>>(k, (const S4T *)d_postype, out, n_particles, two_over_n, m->cfg, dep, n_grid, ck); } while (0)
 #define MTD_LAUNCH_FF(S4, NCV, FASTV) \
         do { typedef S4 S4T; \
-             if (m->comm) MTD_LAUNCH_FF_K((k_fused_force<S4, NCV, FASTV, ff_groups<S4, NCV>::value, true>)); \
-             else MTD_LAUNCH_FF_K((k_fused_force<S4, NCV, FASTV, ff_groups<S4, NCV>::value, false>)); } while (0)
+             const unsigned int per_block = FF_STREAM_THREADS * FF_U * ff_groups<S4, NCV, FASTV>::value; \
+             unsigned int fblocks = (n_particles + per_block - 1) / per_block; \
+             if (fblocks == 0 && n_grid == 0) fblocks = 1;               /* still one block to publish the scalars */ \
+             grid = n_grid + fblocks; \
+             if (m->comm) MTD_LAUNCH_FF_K((k_fused_force<S4, NCV, FASTV, ff_groups<S4, NCV, FASTV>::value, true>)); \
+             else MTD_LAUNCH_FF_K((k_fused_force<S4, NCV, FASTV, ff_groups<S4, NCV, FASTV>::value, false>)); } while (0)
 #define MTD_LAUNCH_FF_NCV(S4, FASTV) \
         switch (set->n_cv) { case 1: MTD_LAUNCH_FF(S4, 1, FASTV); break; case 2: MTD_LAUNCH_FF(S4, 2, FASTV); break; default: MTD_LAUNCH_FF(S4, 3, FASTV); break; }
         if (dtype == MTD_F32)
