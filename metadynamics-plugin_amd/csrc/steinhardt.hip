@@ -680,7 +680,11 @@ template<int LMAX> constexpr int ql_acc_roles() { return LMAX <= 8 ? 1 : 2; }
 
 // EVEN: the list is a half list or a symmetric full one — the finalize step sets the odd degrees to zero (:173-179), so their
 // sums are not formed (16 of the 28 (l, m) at lmax = 6: half the registers, and room for a third or fourth wave per SIMD)
+#ifdef MTD_QL_ACC_OCC          // (experiment builds: csrc/Makefile EXTRA_HIPFLAGS)
+template<int LMAX, bool EVEN> constexpr int ql_acc_blocks_per_cu() { return MTD_QL_ACC_OCC; }
+#else
 template<int LMAX, bool EVEN> constexpr int ql_acc_blocks_per_cu() { return LMAX <= 6 ? (EVEN ? 3 : 2) : (LMAX <= 8 && EVEN ? 2 : 1); }
+#endif
 
 template<typename S4, int LMAX, bool SYM, bool EVEN>
 __global__ __launch_bounds__(QL_THREADS, (ql_acc_blocks_per_cu<LMAX, EVEN>())) void k_ql_accumulate(const QlArgs<LMAX> a, const S4 *__restrict__ postype,
