@@ -77,7 +77,10 @@ while time.time() - t0 < budget:
                 amax = max(abs(x) for x in m)
                 # cancellation floor of the parity tests (1e-6 n_wave / sqrt(N)), times the largest Miller index: the phases are
                 # rounded to fp32 turns once, and h g_1 + k g_2 + l g_3 carries that rounding |h| + |k| + |l| times
-                floor = len(v) * amax * max(1, max(max(abs(x) for x in hkl) for hkl in v)) / np.sqrt(N)
+                # (the index SUM, as the line above says: until the end of round 3 this used the largest single index, which is the same
+                # for axis-aligned modes and three times too strict for (-3, 3, -3) — one case in 2.5e4 at 1.1 of that tolerance,
+                # bit for bit the same value from the library of the round's first half)
+                floor = len(v) * amax * max(1, max(sum(abs(x) for x in hkl) for hkl in v)) / np.sqrt(N)
                 tol = (1e-6 if not fast else 3e-6) * max(abs(s_ref), floor)
                 worst["cv"] = max(worst["cv"], abs(st["cv"][c] - s_ref) / max(abs(s_ref), floor, 1e-300))
                 assert abs(st["cv"][c] - s_ref) <= tol, ("cv", c, st["cv"][c], s_ref, N, n_cv, dtype, fast, cvs[c])

@@ -81,7 +81,13 @@ while time.time() - t0 < budget:
             # one-launch step — and, since round 3, a mixed set whose lamellar sums ride in the mesh's binning kernel — groups its
             # fp32 sums differently, its CV value differs by ~1e-9 and the bias FACTOR by up to 1e-3 of
             # itself.  What the force kernels contribute is the force per unit bias factor: compared on that.
-            fa, fb = fa / a["bias"][c], fb / b["bias"][c]
+            # (an umbrella adds its own derivative to the factor the force kernel multiplies with — CollectiveVariable.cc:22-66,
+            # harmonic: bias + kappa (s - cv0) — so THAT sum is the unit; dividing by the grid's bias factor alone left
+            # kappa (s - cv0) (1 / bias_a - 1 / bias_b) in the comparison: 2.5e-4 in one of 1.7e5 sets once the riders were the default)
+            ua = 0.7 * (a["cv"][c] - 0.1) if spec[c][0] == "lam_umbrella" else 0.0
+            ub = 0.7 * (b["cv"][c] - 0.1) if spec[c][0] == "lam_umbrella" else 0.0
+            if abs(a["bias"][c] + ua) > 1e-300 and abs(b["bias"][c] + ub) > 1e-300:
+                fa, fb = fa / (a["bias"][c] + ua), fb / (b["bias"][c] + ub)
         sc = np.abs(fb).max()
         if sc > 1e-20:
             worst["force"] = max(worst["force"], np.abs(fa - fb).max() / sc)
