@@ -19,7 +19,16 @@ box = _abi.Box.make(L)
 h = C.c_void_p()
 _abi.check(lib.mtd_mesh_create(C.byref(h), n, n, n, (C.c_double * 2)(1.0, -1.0), 2, N))
 part, npart = C.c_void_p(), C.c_uint()
+# usage: stamps_tiles.py [rider]   rider: a lamellar CV's partial sums ride in the binning kernel (as in a mixed set of the host classes)
+rider = len(sys.argv) > 1 and sys.argv[1] == "rider"
+if rider:
+    _abi.check(lib.mtd_lamellar_set_fast_trig(1))
+    lset = _abi.LamellarSet.make([(util.CV1_VECTORS, util.MODE_AB)])
+    partials = torch.zeros(lib.mtd_lamellar_scratch_doubles(N), dtype=torch.float64, device="cuda")
+    n_part = C.c_uint()
 for t in range(60):
+    if rider:
+        _abi.check(lib.mtd_mesh_set_lamellar_rider(h, None, C.byref(lset), C.byref(box), N, partials.data_ptr(), C.byref(n_part), None))
     _abi.check(lib.mtd_mesh_compute_cv(h, N, d_pos.data_ptr(), _abi.MTD_F32, C.byref(box), N, C.byref(part), C.byref(npart), None))
     _abi.check(lib.mtd_mesh_forces(h, N, d_pos.data_ptr(), d_f.data_ptr(), _abi.MTD_F32, C.byref(box), N, None, C.c_double(-2.5), None))
 torch.cuda.synchronize()
