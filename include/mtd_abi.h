@@ -79,7 +79,11 @@ typedef struct mtd_lamellar_set
     unsigned int first[MTD_MAX_CV + 1];
     int hkl[MTD_MAX_MODES][3];                  /* Miller indices (cv.py:251-256, std_vector_int3) */
     double coeff[MTD_MAX_CV][MTD_MAX_TYPES];    /* per-type mode coefficients (cv.py:242-249) */
+    int trig_mode;                              /* MTD_TRIG_DEFAULT (0: the process default, mtd_lamellar_set_fast_trig), MTD_TRIG_HARDWARE
+                                                   or MTD_TRIG_ACCURATE for THIS set's kernels — see below */
     } mtd_lamellar_set;
+
+enum mtd_trig_mode { MTD_TRIG_DEFAULT = 0, MTD_TRIG_HARDWARE = 1, MTD_TRIG_ACCURATE = 2 };
 
 /* workspace (device doubles) needed for n_particles: block partial sums */
 size_t mtd_lamellar_scratch_doubles(unsigned int n_particles);
@@ -121,10 +125,16 @@ int mtd_lamellar_forces(const mtd_lamellar_set *set, unsigned int n_particles, c
                         void *const *d_force, int dtype, unsigned int n_global, const double *d_bias,
                         const mtd_box *global_box, mtd_stream_t stream);
 
-/* 1 (default): hardware v_sin_f32 / v_cos_f32 on the phase in turns — what the reference's GPU kernels do
- * (fast::sin / fast::cos, LamellarOrderParameterGPU.cu:36-37, 180); 0: ocml sinpi / cospi.  Process-wide switch.  The hardware
- * path is only taken for mode sets with |h| + |k| + |l| <= 100 per mode (phases inside the instructions' domain of +-256 turns
- * for positions within five box lengths of the box); others run the accurate path whatever this switch says. */
+/* Trigonometry of the lamellar kernels.  MTD_TRIG_HARDWARE: v_sin_f32 / v_cos_f32 on the phase in turns — what the reference's
+ * GPU kernels do (fast::sin / fast::cos, LamellarOrderParameterGPU.cu:36-37, 180); MTD_TRIG_ACCURATE: ocml sinpi / cospi.  The
+ * mode is a property of the CV SET (mtd_lamellar_set::trig_mode); sets that leave it at MTD_TRIG_DEFAULT take the process default,
+ * which this call sets (1, the initial value: hardware; 0: accurate) — two sets with different modes can run in one process.
+ * PRECONDITION of the hardware mode: the instructions' domain is +-256 turns, outside it they return cos = 1 / sin = 0 without
+ * any error.  A phase is sum_i hkl_i * g_i with g_i = b_i . r the fractional coordinate: positions inside the box give
+ * |phase| <= (|h| + |k| + |l|) / 2.  The library therefore takes the hardware path only for mode sets with |h| + |k| + |l| <= 100
+ * per mode (others run the accurate path whatever the mode says), which leaves room for particles up to FIVE box lengths outside
+ * the box; a caller that hands over UNWRAPPED coordinates further out than that must select MTD_TRIG_ACCURATE (correct for any
+ * range) — HOOMD keeps its particles wrapped, the reference's kernels rely on the same. */
 int mtd_lamellar_set_fast_trig(int enable);
 int mtd_lamellar_get_fast_trig(void);
 
@@ -207,7 +217,13 @@ unsigned int mtd_metad_num_elements(const mtd_metad *m);
 int mtd_metad_get_array(mtd_metad *m, int which, void *host_out, mtd_stream_t stream);
 int mtd_metad_set_array(mtd_metad *m, int which, const void *host_in, mtd_stream_t stream);
 int mtd_metad_set_num_gaussians(mtd_metad *m, unsigned int n, mtd_stream_t stream);
+/* The device address of one of the arrays above (NULL for a bad index).  A caller that WRITES the bias grid (which = 0) through
+ * the pointer must say so after every such write, on the stream the write ran on, with mtd_metad_grid_touched: the engine keeps
+ * a small patch of grid values around the last CV values (the scalar chain's preload) which is then rewritten from the grid
+ * before its next use.  Fetching the pointer for which = 0 invalidates the patch once, on the NULL stream (kept for callers
+ * that write before their next update on that stream); returns NULL when that fails. */
 void *mtd_metad_device_array(mtd_metad *m, int which);
+int mtd_metad_grid_touched(mtd_metad *m, mtd_stream_t stream);
 
 /* ================================================================================================
  * Fused bias step for lamellar CVs — the headline path (no reference counterpart: it replaces the
@@ -561,6 +577,12 @@ int mtd_debug_sph_harmonics(unsigned int lmax, unsigned int n, const double *h_s
 /* IndexGrid::getCoordinates (IndexGrid.cc:46-58) and getIndex (:20-44) as the grid kernels compute them */
 int mtd_debug_index_decode(unsigned int n_cv, const unsigned int *lengths, unsigned int n, const unsigned int *h_indices,
                            unsigned int *h_coords, unsigned int *h_index_back);
+/* The agreement check of mtd_metad_update_bias_walkers as two pure-host functions (no device needed; tests/test_abi_exports.py):
+ * _pack writes the 12 doubles a walker contributes for (stride, add_bias, timestep) — each quantity split into 16-bit halves,
+ * every half followed by its square, so that sums over <= 2^16 walkers stay exact integers below 2^53 whatever the order of
+ * the reduction; _verify returns 1 when `sums` (the all-reduced 12 doubles) say that all `world` walkers sent what `mine` holds. */
+void mtd_debug_walker_check_pack(unsigned int stride, int add_bias, unsigned int timestep, double *out12);
+int mtd_debug_walker_check_verify(const double *sums12, const double *mine12, unsigned int world);
 
 #ifdef __cplusplus
 }

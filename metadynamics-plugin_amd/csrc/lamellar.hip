@@ -258,6 +258,9 @@ int fill_kargs(LamKArgs &k, const mtd_lamellar_set *set, const mtd_box *box)
     k.n_cv = set->n_cv;
     k.n_modes = set->n_modes;
     k.n_types = set->n_types;
+    if (set->trig_mode != MTD_TRIG_DEFAULT && set->trig_mode != MTD_TRIG_HARDWARE && set->trig_mode != MTD_TRIG_ACCURATE)
+        return MTD_ERR_INVALID_ARGUMENT;
+    k.trig = (unsigned int)set->trig_mode;
     for (unsigned int c = 0; c <= set->n_cv; ++c) k.first[c] = set->first[c];
     for (unsigned int c = 0; c < MTD_MAX_CV; ++c) k.slot[c] = (unsigned char)c;
     const double two_pi = 2.0 * M_PI;
@@ -307,12 +310,15 @@ int fill_kargs(LamKArgs &k, const mtd_lamellar_set *set, const mtd_box *box)
 
 unsigned int lam_cv_blocks(unsigned int N) { return cv_blocks(N); }
 unsigned int lam_force_blocks(unsigned int N) { return force_blocks(N); }
-// the hardware sine / cosine for this mode set?  Their argument (in turns) must stay inside [-256, 256]: with positions inside
-// the box |b_i' . r| <= 1/2, so |phase| <= (|h| + |k| + |l|) / 2 — sets with larger indices than any lamellar study uses take
-// the accurate path, whatever mtd_lamellar_set_fast_trig says (the bound leaves room for particles five box lengths outside)
+// the hardware sine / cosine for this mode set?  The set's own mode decides (mtd_lamellar_set::trig_mode), the process default
+// (mtd_lamellar_set_fast_trig) only where the set leaves it open.  Their argument (in turns) must stay inside [-256, 256]: with
+// positions inside the box |b_i' . r| <= 1/2, so |phase| <= (|h| + |k| + |l|) / 2 — sets with larger indices than any lamellar
+// study uses take the accurate path whatever the mode says (the bound leaves room for particles five box lengths outside:
+// the precondition stated in mtd_abi.h)
 int lam_fast_trig(const LamKArgs &k)
     {
-    if (!g_fast_trig) return 0;
+    if (k.trig == MTD_TRIG_ACCURATE) return 0;
+    if (k.trig == MTD_TRIG_DEFAULT && !g_fast_trig) return 0;
     for (unsigned int m = 0; m < k.n_modes; ++m)
         if (std::fabs(k.h[m].x) + std::fabs(k.h[m].y) + std::fabs(k.h[m].z) > 100.0f) return 0;
     return 1;

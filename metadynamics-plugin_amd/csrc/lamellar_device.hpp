@@ -17,7 +17,8 @@ namespace mtd
 struct LamKArgs
     {
     double B[3][3];                           // reciprocal rows without 2*pi
-    unsigned int n_cv, n_modes, n_types, _pad;
+    unsigned int n_cv, n_modes, n_types;
+    unsigned int trig;                        // mtd_lamellar_set::trig_mode (host side only: selects the instantiation, lam_fast_trig)
     unsigned int first[MTD_MAX_CV + 1];
     unsigned char slot[MTD_MAX_CV];           // CV c of the set is collective variable slot[c] of the bias grid (fused force pass)
     unsigned int _pad2;

@@ -235,13 +235,27 @@ namespace
 std::mutex g_deferred_mutex;
 mtd_metad *g_deferred_engine = nullptr;
 hipStream_t g_deferred_stream = nullptr;
+int g_deferred_device = -1;             // the NULL stream of two devices compares equal: the slot is keyed by (device, stream)
+
+int current_device()
+    {
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess)
+        {
+        (void)hipGetLastError();
+        return -1;
+        }
+    return dev;
+    }
 }
 
 void announce_pending_apply(mtd_metad *m, hipStream_t s)
     {
+    const int dev = current_device();
     std::lock_guard<std::mutex> lock(g_deferred_mutex);
     g_deferred_engine = m;
     g_deferred_stream = s;
+    g_deferred_device = dev;
     }
 
 void withdraw_pending_apply(mtd_metad *m)
@@ -250,18 +264,26 @@ void withdraw_pending_apply(mtd_metad *m)
     if (g_deferred_engine == m) g_deferred_engine = nullptr;
     }
 
-bool take_pending_apply(hipStream_t s, MetadCfg &cfg)
+// the engine whose deferred pass a launch on (current device, s) may carry, and its configuration; nullptr when there is none.
+// The pass stays pending until the carrier's launch is known to have succeeded: commit_pending_apply.
+mtd_metad *take_pending_apply(hipStream_t s, MetadCfg &cfg)
     {
     static const bool off = std::getenv("MTD_NO_APPLY_PASSENGER") != nullptr;      // diagnostic: every deferred pass as its own launch
-    if (off) return false;
+    if (off) return nullptr;
+    const int dev = current_device();
     std::lock_guard<std::mutex> lock(g_deferred_mutex);
     mtd_metad *m = g_deferred_engine;
-    if (!m || g_deferred_stream != s) return false;
+    if (!m || g_deferred_stream != s || g_deferred_device != dev || dev < 0) return nullptr;
     g_deferred_engine = nullptr;
-    if (!m->pending_apply || m->comm) return false;
+    if (!m->pending_apply || m->comm) return nullptr;
     cfg = m->cfg;
+    return m;
+    }
+
+void commit_pending_apply(mtd_metad *m)
+    {
+    std::lock_guard<std::mutex> lock(g_deferred_mutex);
     m->pending_apply = 0;
-    return true;
     }
 }
 
@@ -587,6 +609,27 @@ int mtd_metad_update_phase_b(mtd_metad *m, int deposited, mtd_stream_t stream)
     return MTD_SUCCESS;
     }
 
+void mtd_debug_walker_check_pack(unsigned int stride, int add_bias, unsigned int timestep, double *out12)
+    {
+    const unsigned int q[3] = { stride, (unsigned int)(add_bias != 0), timestep };
+    for (int i = 0; i < 3; ++i)
+        {
+        const double lo = (double)(q[i] & 0xffffu), hi = (double)(q[i] >> 16);
+        out12[4 * i] = lo;
+        out12[4 * i + 1] = lo * lo;
+        out12[4 * i + 2] = hi;
+        out12[4 * i + 3] = hi * hi;
+        }
+    }
+
+int mtd_debug_walker_check_verify(const double *sums12, const double *mine12, unsigned int world)
+    {
+    const double W = (double)world;                                  // every product below is an exact integer < 2^53
+    for (int i = 0; i < 12; ++i)
+        if (sums12[i] != W * mine12[i]) return 0;
+    return 1;
+    }
+
 int mtd_metad_update_bias_walkers(mtd_metad *m, mtd_rccl *walkers, unsigned int timestep, mtd_stream_t stream)
     {
     if (!m) return MTD_ERR_INVALID_ARGUMENT;
@@ -596,13 +639,16 @@ int mtd_metad_update_bias_walkers(mtd_metad *m, mtd_rccl *walkers, unsigned int 
         // Whether a step deposits — and with it whether this walker enters the two all-reduces below — follows from stride,
         // add_hills and the time step.  Walkers that disagree would wait in different collectives for ever (RCCL has no bound,
         // unlike the mailbox).  Checked once per (communicator, stride, add_hills): sum and sum of squares of each quantity over
-        // the walkers equal W x and W x^2 only when all are equal.  One small all-reduce and a synchronisation, at set-up.
+        // the walkers equal W x and W x^2 only when all are equal (Cauchy-Schwarz).  The quantities travel as 16-bit halves, so every
+        // square stays below 2^32 and every sum is an exact integer in a double whatever order the reduction takes (a time
+        // step of 3e9 squared does not fit 53 bits: fl(fl(x^2 + x^2) + x^2) != fl(3 x * x) gave false alarms).  One small
+        // all-reduce and a synchronisation, at set-up.
         double *d_chk = nullptr;
-        MTD_HIP_TRY(hipMalloc(&d_chk, 6 * sizeof(double)));
-        const double mine[3] = { (double)m->stride, (double)m->add_bias, (double)timestep };
-        double h[6] = { mine[0], mine[0] * mine[0], mine[1], mine[1] * mine[1], mine[2], mine[2] * mine[2] };
-        hipError_t e = hipMemcpyAsync(d_chk, h, sizeof(h), hipMemcpyHostToDevice, (hipStream_t)stream);
-        rc = e == hipSuccess ? mtd_comm_allreduce_large(walkers, d_chk, 6, MTD_ELEM_F64, stream) : (int)e;
+        MTD_HIP_TRY(hipMalloc(&d_chk, 12 * sizeof(double)));
+        double mine[12], h[12];
+        mtd_debug_walker_check_pack(m->stride, m->add_bias, timestep, mine);
+        hipError_t e = hipMemcpyAsync(d_chk, mine, sizeof(mine), hipMemcpyHostToDevice, (hipStream_t)stream);
+        rc = e == hipSuccess ? mtd_comm_allreduce_large(walkers, d_chk, 12, MTD_ELEM_F64, stream) : (int)e;
         if (!rc)
             {
             e = hipMemcpyAsync(h, d_chk, sizeof(h), hipMemcpyDeviceToHost, (hipStream_t)stream);
@@ -611,9 +657,7 @@ int mtd_metad_update_bias_walkers(mtd_metad *m, mtd_rccl *walkers, unsigned int 
             }
         (void)hipFree(d_chk);
         if (rc) return rc;
-        const double W = (double)mtd_rccl_world(walkers);
-        for (int q = 0; q < 3; ++q)
-            if (h[2 * q] != W * mine[q] || h[2 * q + 1] != W * mine[q] * mine[q]) return MTD_ERR_COLLECTIVE;
+        if (!mtd_debug_walker_check_verify(h, mine, mtd_rccl_world(walkers))) return MTD_ERR_COLLECTIVE;
         m->walkers_checked = (const void *)walkers;
         m->walkers_stride = m->stride;
         m->walkers_add_bias = m->add_bias;
@@ -722,9 +766,20 @@ void *mtd_metad_device_array(mtd_metad *m, int which)
         {
         // the caller may write the grid through the pointer: the patch around the last CV values (MetadState::patch_v) is
         // no longer known to be the grid's until the next deferred pass has rewritten it
-        (void)hipMemset(&m->cfg.st->patch_valid, 0, sizeof(int));
+        if (hipMemset(&m->cfg.st->patch_valid, 0, sizeof(int)) != hipSuccess)
+            {
+            (void)hipGetLastError();
+            return nullptr;
+            }
         }
     return m ? array_ptr(m, which, &e) : nullptr;
+    }
+
+int mtd_metad_grid_touched(mtd_metad *m, mtd_stream_t stream)
+    {
+    if (!m) return MTD_ERR_INVALID_ARGUMENT;
+    MTD_HIP_TRY(hipMemsetAsync(&m->cfg.st->patch_valid, 0, sizeof(int), (hipStream_t)stream));
+    return MTD_SUCCESS;
     }
 
 int mtd_metad_get_array(mtd_metad *m, int which, void *host_out, mtd_stream_t stream)

@@ -42,7 +42,8 @@ int fused_grid_step(mtd_metad *m, unsigned int timestep, hipStream_t s);
 // pending pass, a kernel with room takes it (cfg copied out, pending flag cleared) and runs apply_cells in extra blocks
 void announce_pending_apply(mtd_metad *m, hipStream_t s);
 void withdraw_pending_apply(mtd_metad *m);
-bool take_pending_apply(hipStream_t s, MetadCfg &cfg);
+mtd_metad *take_pending_apply(hipStream_t s, MetadCfg &cfg);
+void commit_pending_apply(mtd_metad *m);
 // fused_step.hip: release the one-launch step's buffers (mtd_metad_destroy)
 void fused_step_release(mtd_metad *m);
 }

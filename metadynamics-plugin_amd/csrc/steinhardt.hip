@@ -1184,8 +1184,11 @@ template<int LMAX>
 void launch_finalize(const QlArgs<LMAX> &a, const double *d_qprime, double *d_qlm, double *d_ql, double *d_value, hipStream_t s)
     {
     mtd::MetadCfg cfg;
-    if (mtd::take_pending_apply(s, cfg))
+    if (mtd_metad *engine = mtd::take_pending_apply(s, cfg))
+        {
         k_ql_finalize_carrier<LMAX><<<1 + (cfg.len + 255) / 256, 256, 0, s>>>(a, d_qprime, d_qlm, d_ql, d_value, cfg);
+        if (hipPeekAtLastError() == hipSuccess) mtd::commit_pending_apply(engine);      // a failed launch leaves the pass pending
+        }
     else
         k_ql_finalize<LMAX><<<1, 256, 0, s>>>(a, d_qprime, d_qlm, d_ql, d_value);
     }

@@ -923,6 +923,7 @@ void IntegratorMetaDynamics::fusedLamellarStep(unsigned int timestep)
             }
         for (unsigned int t = 0; t < m_fused_set.n_types; ++t) m_fused_set.coeff[c][t] = lam->getMode()[t];
         m_fused_force_ptrs[c] = lam->getForceArray().data();
+        m_fused_set.trig_mode = std::max(m_fused_set.trig_mode, lam->getTrigMode());     // accurate (2) wins over hardware (1) over default
         }
     m_fused_set.first[n_cv] = k;
     m_fused_set.n_modes = k;
@@ -983,6 +984,7 @@ void IntegratorMetaDynamics::buildMixedLamellarSet(const std::vector<unsigned in
             }
         for (unsigned int t = 0; t < m_fused_set.n_types; ++t) m_fused_set.coeff[c][t] = lam->getMode()[t];
         m_fused_force_ptrs[c] = lam->getForceArray().data();
+        m_fused_set.trig_mode = std::max(m_fused_set.trig_mode, lam->getTrigMode());
         }
     m_fused_set.first[slots.size()] = k;
     m_fused_set.n_modes = k;

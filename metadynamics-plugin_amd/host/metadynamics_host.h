@@ -121,6 +121,15 @@ class LamellarOrderParameterGPU : public CollectiveVariable
             }
         const std::vector<double> &getMode() const { return m_mode; }
         const std::vector<int3> &getLatticeVectors() const { return m_lattice_vectors; }
+        //! this build: trigonometry of THIS variable's kernels (MTD_TRIG_DEFAULT / _HARDWARE / _ACCURATE, mtd_abi.h); variables
+        //! that share a fused launch take the accurate functions as soon as one of them asks for them
+        void setTrigMode(int mode)
+            {
+            if (mode != MTD_TRIG_DEFAULT && mode != MTD_TRIG_HARDWARE && mode != MTD_TRIG_ACCURATE)
+                throw std::runtime_error("cv.lamellar: trig mode must be 0 (default), 1 (hardware) or 2 (accurate)");
+            m_set.trig_mode = mode;
+            }
+        int getTrigMode() const { return m_set.trig_mode; }
 
     protected:
         void enqueuePartials();

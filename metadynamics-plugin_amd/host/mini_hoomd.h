@@ -124,6 +124,9 @@ class ExecutionConfiguration
         ExecutionConfiguration &operator=(const ExecutionConfiguration &) = delete;
         bool isCUDAEnabled() const { return true; }   // name kept from the reference (cv.py:260)
         hipStream_t getStream() const { return m_stream; }
+        //! every launch of the host classes goes to this stream from now on (default: the null stream, like the reference's
+        //! drivers).  A caller that captures steps into a hipGraph needs a stream of its own: the null stream cannot be captured.
+        void setStream(uintptr_t stream) { m_stream = reinterpret_cast<hipStream_t>(stream); }
         //! A second stream for launches that depend on little of what the main stream is doing (mixed CV sets: the lamellar
         //! CV pass beside the mesh assignment, the grid-engine launch beside the mesh's inverse transforms), ordered against
         //! the main stream by the three events below.  OFF unless MTD_SIDE_STREAM=1: measured at config 3 (10^6 particles,

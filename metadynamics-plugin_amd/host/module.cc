@@ -148,6 +148,7 @@ PYBIND11_MODULE(_metadynamics, m)
         .def(py::init<>())
         .def("isCUDAEnabled", &ExecutionConfiguration::isCUDAEnabled)
         .def("setMailbox", &ExecutionConfiguration::setMailbox)
+        .def("setStream", &ExecutionConfiguration::setStream)
         .def("setWalkerCommunicator", &ExecutionConfiguration::setWalkerCommunicator)
         .def("getNRanks", &ExecutionConfiguration::getNRanks)
         .def("getRank", &ExecutionConfiguration::getRank)
@@ -222,7 +223,9 @@ PYBIND11_MODULE(_metadynamics, m)
     // LamellarOrderParameterGPU.cc:134-141 (the reference's CPU class LamellarOrderParameter has no
     // counterpart here: this build has no CPU path, cv.lamellar always creates the GPU class)
     py::class_<LamellarOrderParameterGPU, CollectiveVariable, std::shared_ptr<LamellarOrderParameterGPU>>(m, "LamellarOrderParameterGPU")
-        .def(py::init<std::shared_ptr<SystemDefinition>, const std::vector<double> &, const std::vector<int3> &, const std::string &>());
+        .def(py::init<std::shared_ptr<SystemDefinition>, const std::vector<double> &, const std::vector<int3> &, const std::string &>())
+        .def("setTrigMode", &LamellarOrderParameterGPU::setTrigMode)
+        .def("getTrigMode", &LamellarOrderParameterGPU::getTrigMode);
 
     // OrderParameterMesh.cc:1181-1193 / OrderParameterMeshGPU.cc:571-584
     py::class_<OrderParameterMeshGPU, CollectiveVariable, std::shared_ptr<OrderParameterMeshGPU>>(m, "OrderParameterMeshGPU")

@@ -51,12 +51,15 @@ class LamellarSet(C.Structure):
     _fields_ = [("n_cv", C.c_uint), ("n_types", C.c_uint), ("n_modes", C.c_uint),
                 ("first", C.c_uint * (MTD_MAX_CV + 1)),
                 ("hkl", (C.c_int * 3) * MTD_MAX_MODES),
-                ("coeff", (C.c_double * MTD_MAX_TYPES) * MTD_MAX_CV)]
+                ("coeff", (C.c_double * MTD_MAX_TYPES) * MTD_MAX_CV),
+                ("trig_mode", C.c_int)]
 
     @classmethod
-    def make(cls, cvs):
-        """cvs: list of (lattice_vectors [(h,k,l)...], mode coefficients per type [a_0, a_1, ...])."""
+    def make(cls, cvs, trig_mode=0):
+        """cvs: list of (lattice_vectors [(h,k,l)...], mode coefficients per type [a_0, a_1, ...]);
+        trig_mode: 0 the process default, 1 hardware sine / cosine, 2 ocml sinpi / cospi (mtd_abi.h)."""
         s = cls()
+        s.trig_mode = int(trig_mode)
         if not 1 <= len(cvs) <= MTD_MAX_CV:
             raise MtdError("between 1 and %d lamellar CVs can be fused" % MTD_MAX_CV)
         n_types = len(cvs[0][1])

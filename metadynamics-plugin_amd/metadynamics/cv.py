@@ -105,6 +105,15 @@ class lamellar(_collective_variable):
         self.cpp_force = _metadynamics.LamellarOrderParameterGPU(context.current.system_definition, cpp_mode,
                                                                  cpp_lattice_vectors, suffix)
 
+    def set_trig_mode(self, mode):
+        """this build: the trigonometry of this variable's kernels — "hardware" (v_sin_f32 / v_cos_f32, like the reference's
+        fast::sin / fast::cos), "accurate" (sinpi / cospi; also the mode for unwrapped coordinates far outside the box) or
+        "default" (the process-wide default).  Variables evaluated in one fused launch run accurately if any of them asks to."""
+        codes = {"default": 0, "hardware": 1, "accurate": 2}
+        if mode not in codes:
+            raise RuntimeError("Error setting parameters of collective variable.")
+        self.cpp_force.setTrigMode(codes[mode])
+
 
 class aspect_ratio(_collective_variable):
     """cv.py:275-305"""

@@ -1,6 +1,7 @@
 /* oracle/mtd_ref_lamellar.c — TEST INFRASTRUCTURE ONLY (see mtd_ref.h).
  * Restatement of LamellarOrderParameter.cc (CPU path, Scalar = double).  Parity unpinned: the
- * reference holds no vectors for this path; pinned by analytic KATs in tests/test_oracle_lamellar.py.
+ * reference holds no vectors for this path; pinned by analytic KATs in tests/test_oracle_kat.py
+ * (single particle, perfect lamellae, numerical gradients incl. the reference's factor 2).
  */
 #include "mtd_ref.h"
 #include <math.h>

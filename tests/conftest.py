@@ -69,8 +69,10 @@ def ref():
 
 @pytest.fixture(autouse=True)
 def _accurate_trig_by_default(request):
-    """The trig mode of the lamellar kernels is a process-wide switch (mtd_lamellar_set_fast_trig): every GPU test starts
-    from the library default (accurate) so that results do not depend on the order the tests run in."""
+    """The process-wide DEFAULT of the lamellar kernels' trigonometry (mtd_lamellar_set_fast_trig; the library starts with 1,
+    the hardware sine / cosine) applies to every CV set that does not choose a mode of its own: every GPU test starts from
+    the accurate functions (0) so that results do not depend on the order the tests run in; tests of the hardware mode
+    switch it on themselves or set mtd_lamellar_set::trig_mode."""
     if "gpu" in request.keywords:
         try:
             from metadynamics import _abi

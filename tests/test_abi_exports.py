@@ -27,7 +27,8 @@ def test_abi_version_and_status_strings(abi):
 def test_struct_layouts_match_header(abi):
     """ctypes mirrors of the PODs must have the C layout (sizes computed from the header's field list)"""
     assert C.sizeof(abi.Box) == 9 * 8 + 8
-    assert C.sizeof(abi.LamellarSet) == 4 * 3 + 4 * 9 + 12 * 64 + 8 * 8 * 16
+    assert C.sizeof(abi.LamellarSet) == 4 * 3 + 4 * 9 + 12 * 64 + 8 * 8 * 16 + 8       # (trig_mode + tail padding)
+    assert abi.LamellarSet.trig_mode.offset == 4 * 3 + 4 * 9 + 12 * 64 + 8 * 8 * 16
     s = abi.LamellarSet.make([(util.CV1_VECTORS, [1.0, -1.0]), (util.CV2_VECTORS, [1.0, -1.0])])
     assert (s.n_cv, s.n_types, s.n_modes) == (2, 2, 16)
     assert list(s.first[:3]) == [0, 8, 16]
@@ -56,6 +57,45 @@ def test_argument_validation_without_gpu(abi):
     assert bad == -1                                              # cv_min >= cv_max (IntegratorMetaDynamics.cc:800-805)
     assert lib.mtd_metad_create(C.byref(h), 7, util.dbl_array([0.1] * 7), util.dbl_array([0.0] * 7),
                                 util.dbl_array([1.0] * 7), util.uint_array([2] * 7), 1.0, 1.0, 1.0, 1, 0, 1) == -2
+
+
+def test_walker_agreement_check_is_exact_at_large_timesteps(abi):
+    """mtd_metad_update_bias_walkers checks once that all walkers agree on stride / add_hills / time step through sums and sums of
+    squares (metad.hip).  With plain doubles a time step of ~3e9 squared no longer fits 53 bits and a ring-ordered sum gave false
+    alarms (round 3 advisor finding); the quantities travel as 16-bit halves now: exact for any reduction order."""
+    import numpy as np
+    lib = abi.load()
+    pack, verify = lib.mtd_debug_walker_check_pack, lib.mtd_debug_walker_check_verify
+    pack.restype, verify.restype = None, C.c_int
+    pack.argtypes = [C.c_uint, C.c_int, C.c_uint, C.POINTER(C.c_double)]
+    verify.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_uint]
+    rng = np.random.default_rng(3)
+
+    def packed(stride, add, t):
+        out = (C.c_double * 12)()
+        pack(int(stride), int(add), int(t), out)
+        return np.array(out[:])
+
+    def reduce_in_order(parts, order):
+        acc = parts[order[0]].copy()
+        for i in order[1:]:
+            acc = acc + parts[i]                                   # one rounding per addition, like a ring all-reduce
+        return acc
+
+    for W in (2, 3, 5, 8):
+        for _ in range(400):
+            t = int(rng.integers(95_000_000, 4_294_967_295))
+            stride = int(rng.integers(1, 4_000_000_000))
+            mine = packed(stride, 1, t)
+            parts = [mine.copy() for _ in range(W)]
+            for order in (list(range(W)), list(range(W))[::-1], list(rng.permutation(W))):
+                s = reduce_in_order(parts, order)
+                assert verify(s.ctypes.data_as(C.POINTER(C.c_double)), mine.ctypes.data_as(C.POINTER(C.c_double)), W) == 1
+            # one walker a step ahead / another stride / hills switched off: refused
+            for bad in (packed(stride, 1, t - 1), packed(stride + 65536, 1, t), packed(stride, 0, t)):
+                parts2 = [mine.copy() for _ in range(W - 1)] + [bad]
+                s = reduce_in_order(parts2, list(range(W)))
+                assert verify(s.ctypes.data_as(C.POINTER(C.c_double)), mine.ctypes.data_as(C.POINTER(C.c_double)), W) == 0
 
 
 def test_hoomd_adapter_calls_only_declared_entry_points():
