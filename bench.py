@@ -46,7 +46,7 @@ GRID = dict(sigma=[1e-3, 1e-3], cv_min=[-0.02, -0.02], cv_max=[0.02, 0.02], num_
 W, DELTA_T, T = 1.0, 7.0, 1.0
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP64_VECTOR_PEAK_TFLOPS = 78.6   # MI355X_MICROARCH.md: fp64 vector (non-matrix) peak
-PROFILE_ROUND = "r3"
+PROFILE_ROUND = "r4"
 
 
 def parse(argv=None):
@@ -73,6 +73,12 @@ def parse(argv=None):
     ap.add_argument("--no-sub-records", action="store_true", help="skip the config 3 / config 5 sub-records (N = 1)")
     ap.add_argument("--no-variants", action="store_true", help="skip extra.steady_state / stride100 / f64 / accurate_trig (N = 1)")
     ap.add_argument("--sub-steps", type=int, default=200, help="steps timed for each sub-record")
+    ap.add_argument("--config", type=int, choices=[2, 3, 5], default=2,
+                    help="2 (default, the headline): two lamellar CVs; 3: cv.mesh on 128^3 + one lamellar CV; 5: cv.steinhardt on a noisy "
+                         "fcc crystal (BASELINE.json configs[2] / configs[4]) — any N through the C++ host classes, System::run")
+    ap.add_argument("--mesh", choices=["replicated", "slab"], default="replicated",
+                    help="--config 3 at N > 1: every rank keeps the whole mesh and the ranks sum their assignments (default), or the mesh "
+                         "itself is decomposed into slabs over the ranks")
     return ap.parse_args(argv)
 
 
@@ -334,15 +340,18 @@ def _timed_host_steps(context, steps, repeats=3):
     return float(np.median(out))
 
 
-def _traffic_record(kernels):
-    """HBM bytes per launch of the named kernels from the PMC passes committed under profiles/ (None when absent)"""
+def _traffic_record(kernels, family):
+    """(per-kernel counter records of the PMC passes committed under profiles/, stale) — the records only while the kernels' sources
+    (`family`: "mesh" / "ql") are the ones the counters were collected on: otherwise (None, True); (None, None) when no file exists"""
     path = os.path.join(ROOT, "profiles", PROFILE_ROUND, "pmc_mesh_ql_summary.json")
     if not os.path.exists(path):
-        return None
+        return None, None
     rec = json.load(open(path))
+    if (rec.get("kernel_source_sha256") or {}).get(family) != kernel_source_sha(family):
+        return None, True
     out = {k: rec[k] for k in kernels if k in rec}
     out["_source"] = "profiles/%s/pmc_mesh_ql_summary.json" % PROFILE_ROUND
-    return out
+    return out, False
 
 
 def sub_record_config3(steps, fast_trig):
@@ -433,6 +442,8 @@ def sub_record_config3(steps, fast_trig):
     cv_moving_us = timed(cv_call_moving)
     pipeline_moving, ovf_moving = assign_info()
     _abi.check(lib.mtd_mesh_destroy(h))
+    mesh_traffic, mesh_stale = _traffic_record(["k_tile_bin", "k_tile_scatter", "k_tile_combine_rows", "k_fft_xy_forward", "k_fft_z_spectral",
+                                                "k_fft_xy_inverse", "k_tile_forces"], "mesh")
     M, hfrac = 128 ** 3, 72.0 / 128.0
     bytes_survey = 48 * N + 68 * M + (64 - 16) * 1_000_000          # 48 B N + 68 B M, + the lamellar CV sharing the position reads
     bytes_build = 48 * N + 8 * M + (8 + 16 * hfrac) * M + 32 * hfrac * M + 48 * hfrac * M + 32 * hfrac * M + (16 * hfrac + 8) * M + 48 * N
@@ -449,8 +460,7 @@ def sub_record_config3(steps, fast_trig):
                                     "moving_snapshots": {"mesh_compute_cv_us": cv_moving_us, "pipeline": pipeline_moving, "overflow_last_step": ovf_moving,
                                                          "displacement_rms_cells": 0.1,
                                                          "note": "two snapshots a random displacement apart alternate: every step bins on tile segments planned from the other snapshot"}},
-                         "traffic": _traffic_record(["k_tile_bin", "k_tile_scatter", "k_tile_combine_rows",
-                                                     "k_fft_xy_forward", "k_fft_z_spectral", "k_fft_xy_inverse", "k_tile_forces"]),
+                         "traffic": mesh_traffic, "traffic_stale": mesh_stale,
                          "dominant_kernels": "k_tile_scatter, k_tile_forces, k_fft_z_spectral (per-kernel table: profiles/%s/config3_mesh_kernel_stats.csv)" % PROFILE_ROUND,
                          "timing": "host API: wall clock around System::run, synchronised on both sides; mesh calls: HIP events on the launch stream"}}
 
@@ -489,24 +499,37 @@ def sub_record_config5(steps):
     hills, bias_f, V_now = integ.getNumGaussians(), list(integ.getBiasFactors()), integ.getLogValue("bias", t_now)
     context.current = None
     pairs = len(lists[2])
-    flops = pairs * (500.0 / 2 + 400.0)       # symmetric full list: the CV pass visits a pair once, the force pass every entry
+    # flops per step as ISSUED: (2 FMA_F64 + MUL_F64 + ADD_F64) wave instructions x 64 lanes, summed over the launches of a step, from
+    # the instruction counters committed under profiles/ (an upper bound: every lane counted as active) — only while the sources are
+    # the ones the counters were collected on; without them the line carries round 3's per-entry model and says so
+    ql_counters, ql_stale = _traffic_record(["k_ql_accumulate", "k_ql_forces", "k_ql_finalize_chain", "k_ql_forces_half"], "ql")
+    flops_c = sum(v.get("fp64_flops_per_launch", 0.0) for k, v in (ql_counters or {}).items() if isinstance(v, dict))
+    if flops_c > 0:
+        flops, flops_source = flops_c, "counters"
+    else:
+        flops, flops_source = pairs * (500.0 / 2 + 400.0), "model (no counters for these kernel sources; reads ~1.37 x high against round 3's counters)"
     return {"workload": "1xMI355X: 2.56x10^5 particles (noisy fcc), SteinhardtQl l<=6 CV with full neighbour list (%.1f neighbours), 1D 512-bin bias grid" % (pairs / N),
             "ms_per_step": 1e3 * per_step, "ms_per_step_runs": [1e3 * x for x in _timed_host_steps.last], "value": N / per_step,
             "unit": "particle-CV-evals/s", "steps": steps, "dtype": "f64",
             "pair_entries": pairs, "pair_visits_per_s": 1.5 * pairs / per_step, "steinhardt_cv": s,
             "grid": [0.0, hi, 512], "sigma": 0.01 * hi, "on_grid": bool(0.0 <= s < hi), "hills": hills, "bias_factors": bias_f, "V": V_now,
             "roofline": {"bound": "valu_fp64", "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s", "achieved": flops / per_step / 1e12,
-                         "frac": flops / per_step / 1e12 / FP64_VECTOR_PEAK_TFLOPS, "flops_per_step_model": flops,
-                         "counters": _traffic_record(["k_ql_accumulate", "k_ql_forces"]),
+                         "frac": flops / per_step / 1e12 / FP64_VECTOR_PEAK_TFLOPS, "flops_per_step": flops, "flops_source": flops_source,
+                         "counters": ql_counters, "counters_stale": ql_stale,
                          "dominant_kernels": "k_ql_forces, k_ql_accumulate (per-kernel table: profiles/%s/config5_steinhardt_kernel_stats.csv)" % PROFILE_ROUND,
                          "timing": "host API: wall clock around System::run, synchronised on both sides"}}
 
 
-def kernel_source_sha():
-    """fingerprint of the sources the fused kernels are built from (the PMC traffic figures under profiles/ carry the same)"""
+KERNEL_SOURCES = {"fused": ("fused.hip", "lamellar_device.hpp", "metad_device.hpp", "comm_device.hpp", "mtd_device.hpp"),
+                  "mesh": ("mesh.hip", "lamellar_device.hpp", "metad_device.hpp", "comm_device.hpp", "mtd_device.hpp", "exact_div.hpp"),
+                  "ql": ("steinhardt.hip", "metad_device.hpp", "mtd_device.hpp")}
+
+
+def kernel_source_sha(family="fused"):
+    """fingerprint of the sources a family of kernels is built from (the PMC figures under profiles/ carry the same)"""
     import hashlib
     h = hashlib.sha256()
-    for f in ("fused.hip", "lamellar_device.hpp", "metad_device.hpp", "comm_device.hpp", "mtd_device.hpp"):
+    for f in KERNEL_SOURCES[family]:
         h.update(open(os.path.join(ROOT, "metadynamics-plugin_amd", "csrc", f), "rb").read())
     return h.hexdigest()
 
@@ -586,8 +609,243 @@ def timed_variant(stride, dtype, fast_trig, steps, warmup=300, path="fused"):
             "step_frac": N_PER_GPU * 4 * scalar4 / (dt / steps) / 1e9 / HBM_PEAK_GBS}
 
 
+def init_ranks(args):
+    """(dist or None, rank, world, rehearsal) — one process per GPU as the driver launches them; a rehearsal puts every rank on cuda:0"""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        raise SystemExit("bench.py --gpus %d inside a launch of %d rank(s): call it plainly (it starts its ranks itself) or with "
+                         "torch.distributed.run --nproc-per-node %d" % (args.gpus, world, args.gpus))
+    rehearsal = os.environ.get("MTD_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = 0
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        if rehearsal:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    return dist, rank, world, rehearsal
+
+
+def main_config(args):
+    """--config 3 | 5 at any N: BASELINE.json's mesh and Steinhardt configurations DOMAIN-DECOMPOSED through the reference-shaped
+    API — the same metadynamics.cv / integrate script on every rank, System::run in C++, the xGMI mailbox in the role of HOOMD's MPI
+    communicator (every CV reduces its own sums inside the host classes: SURVEY.md 8e).
+      config 3  particles sharded by index; cv.mesh: replicated mesh, M + 1 doubles summed over the ranks per step (RCCL on real
+                GPUs, remote loads through the mailbox's exported buffers in a rehearsal) or --mesh slab; cv.lamellar: one double
+      config 5  z slabs of the crystal with ghost layers (full neighbour lists); the (lmax+1)(lmax+2) Q'_lm sums per step
+    weak scaling: 10^6 (2.56 x 10^5) particles per GPU, constant density; --scaling strong: the named configuration split."""
+    from metadynamics import context, cv, integrate, xgmi
+    dist, rank, world, rehearsal = init_ranks(args)
+    ctl = "cpu" if (dist is None or dist.get_backend() != "nccl") else "cuda"
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    box = rccl = None
+    if dist is not None:
+        n_small = 64 if args.config == 3 else 256
+        box = xgmi.connect(dist, max_doubles=n_small)
+        if box is None:
+            raise SystemExit("bench.py --config %d --gpus %d: the xGMI mailbox could not be set up (%s) — the host classes' domain "
+                             "decomposition has no other communicator" % (args.config, world, xgmi.last_failure()))
+        if dist.get_backend() == "nccl" and args.config == 3 and args.mesh == "replicated":
+            from metadynamics.sharded import RcclAllReduce
+            rccl = RcclAllReduce(dist)             # the library's own RCCL binding for the M + 1 doubles of the replicated mesh
+    _abi.check(_abi.load().mtd_lamellar_set_fast_trig(int(args.fast_trig)))
+    strong = args.scaling == "strong"
+    info = {}
+    if args.config == 3:
+        n_base = args.particles if args.particles is not None else N_PER_GPU
+        n_global = n_base if strong else n_base * world
+        if n_global % world:
+            raise SystemExit("--config 3: %d particles do not divide over %d ranks" % (n_global, world))
+        n_local = n_global // world
+        L = BOX_L * (n_global / N_PER_GPU) ** (1.0 / 3.0)
+        nx = 128
+        pos, types = util.snapshot_random(n_global, L, seed=12345, modulated=True, dtype=np.float32)
+        pos = (np.mod(pos.astype(np.float64) + L / 2, L) - L / 2).astype(np.float32)
+        pos[pos >= L / 2] = -L / 2
+        sl = slice(rank * n_local, (rank + 1) * n_local)
+        n_cv = 2
+
+        def build(lo, hi, sigma):
+            context.initialize(pos[sl].copy(), types[sl].copy(), ["A", "B"], L, dtype=np.float32, n_global=n_global)
+            if box is not None:
+                xgmi.attach(dist, context.exec_conf, box, communicator=rccl.handle if rccl is not None else None)
+            meta = integrate.mode_metadynamics(dt=0.005, stride=args.stride, mode="well_tempered", W=W, deltaT=DELTA_T, T=T)
+            lam = cv.lamellar(sigma=0.02, mode=dict(A=1.0, B=-1.0), lattice_vectors=util.CV1_VECTORS)
+            lam.set_grid(-1.0, 1.0, 256)
+            main_cv = cv.mesh(nx=nx, mode={"A": 1.0, "B": -1.0}, sigma=sigma)
+            main_cv.set_grid(lo, hi, 256)
+            if dist is not None:
+                main_cv.set_decomposition(args.mesh)
+            return meta, main_cv
+
+        workload = ("%dxMI355X: %d particles%s, OrderParameterMesh CV on 128^3 mesh (bug-compatible) + 1 lamellar CV, 256^2 bias grid, well-tempered"
+                    % (world, n_global, "" if world == 1 else " sharded by index (%s scaling)" % args.scaling))
+        M, hfrac = nx ** 3, 72.0 / 128.0
+        step_bytes = 48 * n_local + 68 * M + (64 - 16) * n_local                 # SURVEY 8d per GPU: every rank transforms the whole mesh
+        info["step_algorithmic_bytes_definition"] = "SURVEY 8d, per GPU: 48 B N_local + 68 B M (fp32 / C2C layout of the reference) + 48 B N_local for the lamellar CV"
+    else:
+        cells = args.particles if args.particles is not None else 40      # (--particles: fcc cells per box edge here)
+        nz_cells = cells if strong else cells * world
+        a = np.sqrt(2.0)
+        basis = np.array([[0, 0, 0], [0.5, 0.5, 0], [0.5, 0, 0.5], [0, 0.5, 0.5]])
+        grid = np.stack(np.meshgrid(np.arange(cells), np.arange(cells), np.arange(nz_cells), indexing="ij"), -1).reshape(-1, 3)
+        Lbox = np.array([cells * a, cells * a, nz_cells * a])
+        pos = (grid[:, None, :] + basis[None, :, :]).reshape(-1, 3) * a - Lbox / 2 + 0.25 * a
+        pos = pos + np.random.default_rng(777).normal(0, 0.05, pos.shape)
+        pos = np.mod(pos + Lbox / 2, Lbox) - Lbox / 2
+        n_global = len(pos)
+        r_list = 1.4
+        z = pos[:, 2]
+        owner = np.minimum((np.mod(z + Lbox[2] / 2, Lbox[2]) / Lbox[2] * world).astype(int), world - 1)
+        mine = np.where(owner == rank)[0]
+        lo_z, hi_z = -Lbox[2] / 2 + rank * Lbox[2] / world, -Lbox[2] / 2 + (rank + 1) * Lbox[2] / world
+
+        def zdist(u, v):
+            d = np.abs(u - v)
+            return np.minimum(d, Lbox[2] - d)
+
+        ghosts = np.where((owner != rank) & ((zdist(z, lo_z) <= r_list) | (zdist(z, hi_z) <= r_list)))[0] if world > 1 else np.zeros(0, dtype=int)
+        n_local = len(mine)
+        L = tuple(float(x) for x in Lbox)
+        n_cv = 1
+        pair_entries = [0]
+
+        def build(lo, hi, sigma):
+            context.initialize(pos[mine], np.zeros(n_local, dtype=np.int32), ["A"], L, dtype=np.float64, n_global=n_global,
+                               ghost_positions=pos[ghosts] if len(ghosts) else None, ghost_types=np.zeros(len(ghosts), dtype=np.int32))
+            if box is not None:
+                xgmi.attach(dist, context.exec_conf, box)
+            meta = integrate.mode_metadynamics(dt=0.005, stride=args.stride, mode="well_tempered", W=W, deltaT=DELTA_T, T=T)
+            nl = cv.nlist_cell(r_cut=r_list)
+            pair_entries[0] = len(nl.update()[2])
+            main_cv = cv.steinhardt(r_cut=1.4, r_on=1.2, lmax=6, Ql_ref=[0, 0, 0, 0, 1, 0, 1], nlist=nl, type="A", sigma=sigma)
+            main_cv.set_grid(lo, hi, 512)
+            return meta, main_cv
+
+        workload = ("%dxMI355X: %d particles (noisy fcc, %s), SteinhardtQl l<=6 CV with full neighbour list, 1D 512-bin bias grid"
+                    % (world, n_global, "one box" if world == 1 else "z slabs with ghost layers, %s scaling" % args.scaling))
+        step_bytes = None
+    # the grid of SURVEY.md 8d: value x [0, 2], sigma 1 % of the range — one untimed evaluation supplies the value (collective)
+    barrier()
+    meta, main_cv = build(0.0, 1.0, 1.0)
+    context.run(1)
+    s0 = main_cv.cpp_force.getCurrentValue(context.current.system.getCurrentTimeStep())
+    context.current = None
+    lo, hi = (0.0, 2.0 * s0) if s0 > 0 else (2.0 * s0, 0.0)
+    barrier()
+    meta, main_cv = build(lo, hi, 0.01 * (hi - lo))
+    exchange_large = context.exec_conf.largeExchangeName()
+    context.run(100)
+    barrier()
+    if args.warmup > 0:
+        context.current.system.run(args.warmup - 1)
+    barrier()
+    t0 = time.perf_counter()
+    context.current.system.run(args.steps - 1)      # run(k) = prepRun (one bias update) + k updates: exactly `steps` bias steps
+    barrier()
+    elapsed = time.perf_counter() - t0
+    steady = None
+    if not args.no_variants:
+        k_steady = max(500, args.steps)
+        barrier()
+        t1 = time.perf_counter()
+        context.current.system.run(k_steady - 1)
+        barrier()
+        steady = (time.perf_counter() - t1, k_steady)
+    t_now = context.current.system.getCurrentTimeStep()
+    s_now = main_cv.cpp_force.getCurrentValue(t_now)
+    integ = meta.cpp_integrator
+    st = dict(cv=list(integ.getCurrentValues()), V=integ.getLogValue("bias", t_now), w=integ.getLogValue("weight", t_now),
+              num_gaussians=integ.getNumGaussians(), bias_factors=list(integ.getBiasFactors()), fused=bool(integ.usedFusedPath()))
+    timeouts = None
+    if dist is not None:
+        tt = torch.tensor([elapsed, steady[0] if steady else 0.0], dtype=torch.float64, device=ctl)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt[0].item())
+        if steady:
+            steady = (float(tt[1].item()), steady[1])
+        # the replicated state must be the same bits on every rank
+        mine_bits = torch.from_numpy(np.array(st["cv"] + st["bias_factors"] + [st["V"], st["w"]]).view(np.int64).copy()).to(ctl)
+        lo_b, hi_b = mine_bits.clone(), mine_bits.clone()
+        dist.all_reduce(lo_b, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi_b, op=dist.ReduceOp.MAX)
+        st["identical_on_all_ranks"] = bool((lo_b == hi_b).all().item())
+        tq = torch.tensor([box.timeouts()], dtype=torch.int64, device=ctl)
+        dist.all_reduce(tq, op=dist.ReduceOp.MAX)
+        timeouts = int(tq.item())
+    if rank == 0:
+        per_step = elapsed / args.steps
+        out = {"metric": "particle_cv_evals_per_s", "value": n_global * n_cv / per_step, "unit": "particle-CV-evals/s", "n_gpus": world,
+               "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * per_step, "md_bias_steps_per_s": 1.0 / per_step,
+               "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
+               "dtype": "f64 meshes, f32 particles" if args.config == 3 else "f64", "data": "synthetic",
+               "config": {"workload": workload, "bench_config": args.config, "particles_per_gpu": n_local, "particles_global": n_global,
+                          "n_cv": n_cv, "stride": args.stride, "driver": "host", "fast_trig": int(args.fast_trig),
+                          "mode": "single" if world == 1 else "sharded", "grid": [lo, hi], "on_grid": bool(lo <= s_now < hi)},
+               "state": st}
+        if world > 1:
+            out["config"]["exchange"] = ("xgmi-mailbox (per-CV sums, mtd_comm_allreduce_small inside the host classes)" +
+                                         ("; mesh: %s" % ("slab decomposition over the mailbox's exported buffers" if args.mesh == "slab" else
+                                                          "replicated, M + 1 doubles per step through %s" % exchange_large) if args.config == 3 else
+                                          "; Q'_lm sums: 56 doubles per step"))
+            out["config"]["mailbox_timeouts"] = timeouts
+            out["config"]["HSA_ENABLE_IPC_MODE_LEGACY"] = os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY")
+            if args.config == 5:
+                out["config"]["ghosts_rank0"] = int(len(ghosts))
+        if rehearsal:
+            out["config"]["rehearsal"] = "all %d ranks share cuda:0, control plane gloo: the code path is real, the numbers mean nothing" % world
+        if args.config == 3:
+            out["roofline"] = {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "achieved": step_bytes / per_step / 1e9,
+                               "frac": step_bytes / per_step / 1e9 / HBM_PEAK_GBS, "traffic": None, "level": "step, per GPU",
+                               "step_algorithmic_bytes": step_bytes, "definition": info["step_algorithmic_bytes_definition"]}
+        else:
+            out["roofline"] = {"bound": "valu_fp64", "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s", "traffic": None, "level": "step, per GPU",
+                               "pair_entries_rank0": pair_entries[0], "achieved": None, "frac": None,
+                               "note": "flops from the instruction counters: profiles/%s (single-GPU sub-record extra.config5 of the default run)" % PROFILE_ROUND}
+        if steady is not None:
+            out["extra"] = {"steady_state": {"ms_per_step": 1e3 * steady[0] / steady[1], "steps": steady[1], "value": n_global * n_cv / (steady[0] / steady[1])}}
+        if not args.no_cpu_baseline and n_global <= 2_000_000:
+            # checker (untimed): the CV the ranks agreed on against the oracle on the WHOLE snapshot
+            sys.path.insert(0, os.path.join(ROOT, "oracle"))
+            import mtd_ref
+            if args.config == 3:
+                rbox, opt = mtd_ref.Box.make(L), util.oracle_postype(pos, types)
+                s_ref = mtd_ref.Mesh(nx, nx, nx, [1.0, -1.0]).cv(opt, rbox)
+                l_ref = mtd_ref.lamellar_cv(util.CV1_VECTORS, opt, util.MODE_AB, rbox)
+                out["cv_check"] = {"cv_oracle": [l_ref, s_ref], "rel_err": [abs(st["cv"][0] - l_ref) / abs(l_ref), abs(st["cv"][1] - s_ref) / abs(s_ref)],
+                                   "tolerance": 1e-6}
+            elif L[0] == L[2]:
+                rbox, pt = mtd_ref.Box.make(L[0]), util.oracle_postype(pos, np.zeros(n_global, dtype=np.int32))
+                lists = util.build_nlist(pos, L[0], r_list)
+                val = mtd_ref.ql_compute_cv(pt, rbox, *lists, 1.4, 1.2, 6, 0, [0, 0, 0, 0, 1, 0, 1])[0]
+                out["cv_check"] = {"cv_oracle": [val], "rel_err": [abs(st["cv"][0] - val) / abs(val)], "tolerance": 1e-6}
+        print(json.dumps(out), flush=True)
+    context.current = None
+    if dist is not None:
+        dist.barrier()
+        if rccl is not None:
+            rccl.close()
+        box.close()
+        dist.destroy_process_group()
+
+
 def main():
     args = parse()
+    if args.config != 2:
+        return main_config(args)
     lib_default_trig = int(_abi.load().mtd_lamellar_get_fast_trig())     # before anything sets the process-wide switch
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -793,6 +1051,17 @@ def main():
         barrier()
         steady = (time.perf_counter() - t1, k_steady)
         st = host.state() if host is not None else eng.state()
+    # the driver's call times ONE region of K steps; the same bracket ten more times shows where that one sample sits
+    more_regions = None
+    if not args.no_variants and dist is None:
+        more_regions = []
+        for _ in range(10):
+            barrier()
+            t2 = time.perf_counter()
+            run_steps(args.steps)
+            barrier()
+            more_regions.append(1e3 * (time.perf_counter() - t2) / args.steps)
+        st = host.state() if host is not None else eng.state()
     if dist is not None:
         vals = [elapsed, steady[0] if steady else 0.0]
         tt = torch.tensor(vals, dtype=torch.float64, device=ctl_device())
@@ -905,6 +1174,9 @@ def main():
                                              "fixed cost of a timed region (~40 us: doorbell on an idle queue, completion signal) is 2 us per "
                                              "step at K = 20 and < 0.03 us here"}
             out["roofline"]["step_frac_steady_state"] = extra["steady_state"]["step_frac"]
+        if more_regions:
+            extra["timed_region_repeats"] = {"ms_per_step": more_regions, "steps": args.steps,
+                                             "note": "ten more regions of the same K steps, same barrier + synchronise bracket, right after the steady-state run"}
         if not args.no_cpu_baseline and st.get("num_gaussians") and args.stride == 1 and not walkers:      # any N: the grid is replicated
             out["self_check"] = self_check(st, args.stride)
         if not args.no_cpu_baseline and eng.full is not None:

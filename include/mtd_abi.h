@@ -344,6 +344,18 @@ int mtd_comm_status(mtd_comm *c, unsigned int *timeouts, mtd_stream_t stream);
 #define MTD_COMM_MAX_SHARED 8
 int mtd_comm_share(mtd_comm *c, size_t bytes, void **d_local, unsigned int *slot, void *out_handle);
 int mtd_comm_open(mtd_comm *c, unsigned int slot, const void *handles, void **peers);
+/* Large all-reduce (sum, doubles, in place) through the mailbox's exported buffers instead of a collective library — for the
+ * MB-sized per-step buffers of a domain-decomposed run (the replicated mesh of cv.mesh: M + 1 doubles; replaces the ghost-cell
+ * exchange + distributed FFT of OrderParameterMesh.cc:263-316, 659-746 and the MPI_Allreduce of :630) where no RCCL communicator
+ * is at hand (mtd_comm_allreduce_large is the RCCL form).  Every rank stages its buffer in an exported one, rank r sums slice r
+ * of all ranks' staging buffers in rank order by remote loads (a reduce-scatter), every rank copies all slices home (an
+ * all-gather); two mailbox exchanges are the barriers.  Same bits on every rank; an expired wait poisons the whole result (NaN)
+ * and the communicator (MTD_ERR_COMM_TIMEOUT from then on).
+ * Set-up: two buffers of mtd_comm_pull_bytes(max_doubles) bytes per rank from mtd_comm_share, opened by every rank
+ * (mtd_comm_open), handed over once with mtd_comm_pull_attach (in_peers / out_peers: rank r's buffer as mapped here). */
+size_t mtd_comm_pull_bytes(size_t max_doubles);
+int mtd_comm_pull_attach(mtd_comm *c, size_t max_doubles, void *const *in_peers, void *const *out_peers);
+int mtd_comm_allreduce_pull(mtd_comm *c, double *d_buffer, size_t count, mtd_stream_t stream);
 unsigned int mtd_comm_world(const mtd_comm *c);
 unsigned int mtd_comm_rank(const mtd_comm *c);
 int mtd_comm_destroy(mtd_comm *c);

@@ -64,6 +64,57 @@ __global__ __launch_bounds__(AR_THREADS) void k_comm_allreduce(const CommK k, do
         }
     }
 
+// ---- large all-reduce by remote loads ("pull"), no collective library ------------------------------------------------
+// Every rank stages its contribution in an exported (uncached) buffer; after a mailbox barrier rank r adds up slice r of all
+// ranks' staging buffers IN RANK ORDER (remote loads over xGMI, one reduce-scatter) into its exported slice buffer; after a
+// second barrier every rank copies all slices home (an all-gather by remote loads).  Every rank ends with the same bits.
+// Re-use is safe without further barriers: a staging buffer is rewritten by the NEXT call's stage kernel, which stream
+// order puts after this call's second barrier — by then every peer has finished reading it (its reduce kernel precedes its
+// send of barrier 2); a slice buffer is rewritten by the next call's reduce kernel, which follows the next call's first
+// barrier — which every peer sends only after its gather of this call.
+struct PullK
+    {
+    const double *in[COMM_MAX_RANKS];
+    const double *out[COMM_MAX_RANKS];
+    unsigned int rank, world;
+    size_t count, chunk;                                // chunk: doubles per slice (a multiple of 32)
+    const double *token;                                // the last barrier's sum: the comm poison when a wait expired
+    };
+
+constexpr int PULL_THREADS = 256;
+
+__global__ __launch_bounds__(PULL_THREADS) void k_pull_stage(const double *__restrict__ src, double *__restrict__ staged, const size_t n, double *token)
+    {
+    const size_t stride = (size_t)gridDim.x * PULL_THREADS;
+    for (size_t i = (size_t)blockIdx.x * PULL_THREADS + threadIdx.x; i < n; i += stride) staged[i] = src[i];
+    if (blockIdx.x == 0 && threadIdx.x == 0) *token = 1.0;
+    }
+
+__global__ __launch_bounds__(PULL_THREADS) void k_pull_reduce(const PullK p, double *__restrict__ slice_out, double *token_next)
+    {
+    const bool failed = is_comm_poison(*p.token);
+    const size_t lo = (size_t)p.rank * p.chunk, hi = lo + p.chunk < p.count ? lo + p.chunk : p.count;
+    const size_t stride = (size_t)gridDim.x * PULL_THREADS;
+    for (size_t i = lo + (size_t)blockIdx.x * PULL_THREADS + threadIdx.x; i < hi; i += stride)
+        {
+        double t = 0.0;
+        for (unsigned int q = 0; q < p.world; ++q) t += ld_exported(p.in[q] + i);
+        slice_out[i] = failed ? comm_poison() : t;
+        }
+    if (blockIdx.x == 0 && threadIdx.x == 0) *token_next = failed ? comm_poison() : 1.0;
+    }
+
+__global__ __launch_bounds__(PULL_THREADS) void k_pull_gather(const PullK p, double *__restrict__ dst)
+    {
+    const bool failed = is_comm_poison(*p.token);
+    const size_t stride = (size_t)gridDim.x * PULL_THREADS;
+    for (size_t i = (size_t)blockIdx.x * PULL_THREADS + threadIdx.x; i < p.count; i += stride)
+        {
+        const double v = ld_exported(p.out[i / p.chunk] + i);
+        dst[i] = failed ? comm_poison() : v;
+        }
+    }
+
 // Uncached device buffers are never handed back to the runtime while the process lives.  Measured with a stand-alone
 // program that contains no code of this library (tools/probe_uncached.hip, log in profiles/r2/uncached_reuse_probe.log;
 // ROCm 7.2, gfx950): once a range of device addresses has lived as a hipDeviceMallocUncached allocation and has been freed,
@@ -212,6 +263,7 @@ int mtd_comm_create(mtd_comm **out, unsigned int rank, unsigned int world, unsig
     c->k.err_host = d_err_host;
     c->k.err = (unsigned int *)aux;
     c->k.ll = (unsigned long long *)((char *)aux + 64);
+    c->pull_token = (double *)((char *)aux + 32);        // (bytes 32 .. 47 of the header: two barrier tokens)
     c->k.box[rank] = (unsigned long long *)c->local;
     if (world == 1) c->connected = 1;
     *out = c;
@@ -315,6 +367,62 @@ int mtd_comm_allreduce_small(mtd_comm *c, double *d_values, unsigned int n, mtd_
     const size_t lds = sizeof(unsigned int) * 2 * n * k.world;
     if (lds > 60000) return MTD_ERR_UNSUPPORTED;
     k_comm_allreduce<<<1, AR_THREADS, lds, (hipStream_t)stream>>>(k, d_values, n);
+    MTD_LAUNCH_CHECK();
+    return MTD_SUCCESS;
+    }
+
+size_t mtd_comm_pull_bytes(size_t max_doubles)
+    {
+    return ((max_doubles * sizeof(double) + 255) / 256) * 256;
+    }
+
+int mtd_comm_pull_attach(mtd_comm *c, size_t max_doubles, void *const *in_peers, void *const *out_peers)
+    {
+    if (!c || !c->connected || max_doubles == 0 || !in_peers || !out_peers) return MTD_ERR_INVALID_ARGUMENT;
+    for (unsigned int r = 0; r < c->k.world; ++r)
+        {
+        if (!in_peers[r] || !out_peers[r]) return MTD_ERR_INVALID_ARGUMENT;
+        c->pull_in[r] = (const double *)in_peers[r];
+        c->pull_out[r] = (const double *)out_peers[r];
+        }
+    c->pull_max = max_doubles;
+    return MTD_SUCCESS;
+    }
+
+int mtd_comm_allreduce_pull(mtd_comm *c, double *d_buffer, size_t count, mtd_stream_t stream)
+    {
+    if (!c || !d_buffer || count == 0) return MTD_ERR_INVALID_ARGUMENT;
+    if (!c->connected) return MTD_ERR_INVALID_ARGUMENT;
+    if (comm_failed(c)) return MTD_ERR_COMM_TIMEOUT;
+    if (c->k.world == 1) return MTD_SUCCESS;                     // the sum over one rank
+    if (count > c->pull_max) return MTD_ERR_INVALID_ARGUMENT;    // (also: never attached)
+    hipStream_t s = (hipStream_t)stream;
+    PullK p;
+    std::memset(&p, 0, sizeof(p));
+    for (unsigned int r = 0; r < c->k.world; ++r)
+        {
+        p.in[r] = c->pull_in[r];
+        p.out[r] = c->pull_out[r];
+        }
+    p.rank = c->k.rank;
+    p.world = c->k.world;
+    p.count = count;
+    p.chunk = (((count + p.world - 1) / p.world + 31) / 32) * 32;
+    double *tok = c->pull_token;
+    size_t nb = (count + PULL_THREADS - 1) / PULL_THREADS;
+    const unsigned int blocks = (unsigned int)(nb > 2048 ? 2048 : nb);
+    k_pull_stage<<<blocks, PULL_THREADS, 0, s>>>(d_buffer, (double *)c->pull_in[p.rank], count, tok);
+    MTD_LAUNCH_CHECK();
+    int rc = mtd_comm_allreduce_small(c, tok, 1, stream);        // barrier 1: every rank's contribution is staged
+    if (rc) return rc;
+    p.token = tok;
+    nb = (p.chunk + PULL_THREADS - 1) / PULL_THREADS;
+    k_pull_reduce<<<(unsigned int)(nb > 2048 ? 2048 : nb), PULL_THREADS, 0, s>>>(p, (double *)c->pull_out[p.rank], tok + 1);
+    MTD_LAUNCH_CHECK();
+    rc = mtd_comm_allreduce_small(c, tok + 1, 1, stream);        // barrier 2: every slice is reduced
+    if (rc) return rc;
+    p.token = tok + 1;
+    k_pull_gather<<<blocks, PULL_THREADS, 0, s>>>(p, d_buffer);
     MTD_LAUNCH_CHECK();
     return MTD_SUCCESS;
     }

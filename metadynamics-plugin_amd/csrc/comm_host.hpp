@@ -22,6 +22,12 @@ struct mtd_comm
     void *shared_local[MTD_COMM_MAX_SHARED];
     void *shared_peer[MTD_COMM_MAX_SHARED][MTD_COMM_MAX_RANKS];
     unsigned int n_shared;
+    // large all-reduce by remote loads (mtd_comm_pull_attach / mtd_comm_allreduce_pull): every rank's staging buffer and
+    // its buffer of reduced slices as mapped in this process, the capacity in doubles, and a device token for the barriers
+    const double *pull_in[MTD_COMM_MAX_RANKS];
+    const double *pull_out[MTD_COMM_MAX_RANKS];
+    size_t pull_max;
+    double *pull_token;
     };
 
 namespace mtd

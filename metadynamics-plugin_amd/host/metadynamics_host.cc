@@ -138,9 +138,20 @@ void LamellarOrderParameterGPU::enqueuePartials()
 void LamellarOrderParameterGPU::enqueueCurrentValue(unsigned int timestep, mtd_metad *engine, unsigned int slot)
     {
     enqueuePartials();
-    mtd_check(mtd_metad_set_cv_source(engine, slot, (const double *)m_partials.data(), m_n_partials, 1, 0,
-                                      1.0 / (double)m_pdata->getNGlobal(), 0.0),
-              "mtd_metad_set_cv_source");
+    if (distributed())
+        {
+        // reduce Fourier modes on all processors (LamellarOrderParameterGPU.cc:69-77): this rank's sum, the mailbox, then 1 / N_global
+        hipStream_t s = m_exec_conf->getStream();
+        mtd_check(mtd_reduce_partials((const double *)m_partials.data(), m_n_partials, 1, 1, 1.0, 0.0, (double *)m_cv_dev.data(), s),
+                  "mtd_reduce_partials");
+        m_exec_conf->allreduceSmall((double *)m_cv_dev.data(), 1, s);
+        mtd_check(mtd_metad_set_cv_source(engine, slot, (const double *)m_cv_dev.data(), 1, 1, 0, 1.0 / (double)m_pdata->getNGlobal(), 0.0),
+                  "mtd_metad_set_cv_source");
+        }
+    else
+        mtd_check(mtd_metad_set_cv_source(engine, slot, (const double *)m_partials.data(), m_n_partials, 1, 0,
+                                          1.0 / (double)m_pdata->getNGlobal(), 0.0),
+                  "mtd_metad_set_cv_source");
     m_cv_last_updated = timestep;
     }
 
@@ -148,11 +159,15 @@ double LamellarOrderParameterGPU::getCurrentValue(unsigned int timestep)
     {
     ProfRange prof_range("Lamellar");
     enqueuePartials();
-    mtd_check(mtd_reduce_partials((const double *)m_partials.data(), m_n_partials, 1, 1, 1.0 / (double)m_pdata->getNGlobal(), 0.0,
-                                  (double *)m_cv_dev.data(), m_exec_conf->getStream()),
+    hipStream_t s = m_exec_conf->getStream();
+    const double inv_n = 1.0 / (double)m_pdata->getNGlobal();
+    mtd_check(mtd_reduce_partials((const double *)m_partials.data(), m_n_partials, 1, 1, distributed() ? 1.0 : inv_n, 0.0,
+                                  (double *)m_cv_dev.data(), s),
               "mtd_reduce_partials");
+    if (distributed()) m_exec_conf->allreduceSmall((double *)m_cv_dev.data(), 1, s);   // LamellarOrderParameterGPU.cc:69-77
     m_exec_conf->sync();
     m_cv_dev.download(&m_cv, sizeof(double));
+    if (distributed()) m_cv = 0.0 + inv_n * m_cv;                      // (shift + scale * sum: the grid engine's own expression)
     m_cv_last_updated = timestep;
     return m_cv;
     }
@@ -204,6 +219,17 @@ void WellTemperedEnsemble::enqueueCurrentValue(unsigned int, mtd_metad *engine, 
     {
     enqueuePartials();
     // PE = sum_j net_force_j.w + external energy (WellTemperedEnsemble.cc:45-56)
+    if (distributed())
+        {
+        // ... of this rank, then the sum over the ranks (:57-63: every rank adds ITS external energy before the MPI_Allreduce)
+        hipStream_t s = m_exec_conf->getStream();
+        mtd_check(mtd_reduce_partials((const double *)m_partials.data(), m_n_partials, 1, 1, 1.0, m_pdata->getExternalEnergy(),
+                                      (double *)m_sum.data(), s),
+                  "mtd_reduce_partials");
+        m_exec_conf->allreduceSmall((double *)m_sum.data(), 1, s);
+        mtd_check(mtd_metad_set_cv_source(engine, slot, (const double *)m_sum.data(), 1, 1, 0, 1.0, 0.0), "mtd_metad_set_cv_source");
+        return;
+        }
     mtd_check(mtd_metad_set_cv_source(engine, slot, (const double *)m_partials.data(), m_n_partials, 1, 0, 1.0,
                                       m_pdata->getExternalEnergy()),
               "mtd_metad_set_cv_source");
@@ -216,6 +242,7 @@ double WellTemperedEnsemble::getCurrentValue(unsigned int)
     mtd_check(mtd_reduce_partials((const double *)m_partials.data(), m_n_partials, 1, 1, 1.0, m_pdata->getExternalEnergy(),
                                   (double *)m_sum.data(), m_exec_conf->getStream()),
               "mtd_reduce_partials");
+    if (distributed()) m_exec_conf->allreduceSmall((double *)m_sum.data(), 1, m_exec_conf->getStream());   // :57-63
     m_exec_conf->sync();
     m_sum.download(&m_pe, sizeof(double));
     return m_pe;
@@ -351,9 +378,35 @@ void OrderParameterMeshGPU::computeVirial()
     for (unsigned int i = 0; i < 6; ++i) m_external_virial[i] = v[i];
     }
 
+void OrderParameterMeshGPU::setSlabDecomposition(bool on)
+    {
+    if (m_slab_attached && !on) throw std::runtime_error("cv.mesh: the slab decomposition cannot be switched off once it is attached");
+    m_slab = on;
+    m_is_first_step = true;
+    }
+
+// the four exported buffers of the slab decomposition (local assignment, transformed slab, pencils of G, slab of Re(inv)):
+// allocated on every rank, their handles gathered through the control plane, mapped, handed to the mesh.  Collective.
+void OrderParameterMeshGPU::attachSlab()
+    {
+    if (m_slab_attached) return;
+    const unsigned int world = m_exec_conf->getNRanks();
+    size_t sizes[4];
+    int rc = mtd_mesh_slab_bytes(m_mesh, world, sizes);
+    if (rc == MTD_ERR_INVALID_ARGUMENT || rc == MTD_ERR_UNSUPPORTED)
+        throw std::runtime_error("cv.mesh: the slab decomposition needs ny and nz to be multiples of the number of ranks");
+    mtd_check(rc, "mtd_mesh_slab_bytes");
+    std::vector<void *> peers[4];
+    for (int k = 0; k < 4; ++k) m_exec_conf->shareBuffer(sizes[k], peers[k]);
+    mtd_check(mtd_mesh_slab_attach(m_mesh, m_exec_conf->getMailbox(), peers[0].data(), peers[1].data(), peers[2].data(), peers[3].data()),
+              "mtd_mesh_slab_attach");
+    m_slab_attached = true;
+    }
+
 bool OrderParameterMeshGPU::armLamellarRider(unsigned int timestep, mtd_metad *engine, const mtd_lamellar_set *set, double *d_partials,
                                              unsigned int *n_partials)
     {
+    if (distributed()) return false;                                   // the riders' sums are this rank's only
     if (m_cv_last_updated == timestep && !m_is_first_step) return false;    // enqueueCV would not launch anything this step
     const mtd_box box = m_pdata->getGlobalBox().toMtd();
     const int rc = mtd_mesh_set_lamellar_rider(m_mesh, engine, set, &box, m_pdata->getN(), d_partials, n_partials, m_exec_conf->getStream());
@@ -374,9 +427,34 @@ void OrderParameterMeshGPU::enqueueCV(unsigned int timestep)
     ProfRange prof_range("Mesh");
     if (m_cv_last_updated == timestep && !m_is_first_step) return;   // :927-928
     const mtd_box box = m_pdata->getGlobalBox().toMtd();
-    mtd_check(mtd_mesh_compute_cv(m_mesh, m_pdata->getN(), m_pdata->positionsPtr(), m_pdata->getDtype(), &box,
-                                  m_pdata->getNGlobal(), &m_partials, &m_n_partials, m_exec_conf->getStream()),
-              "mtd_mesh_compute_cv");
+    hipStream_t s = m_exec_conf->getStream();
+    if (distributed() && m_slab)
+        {
+        // the mesh decomposed over the ranks: z slabs for the x / y passes, y rows for the z pass, the transposes as remote loads
+        // (OrderParameterMesh.cc:263-316, 659-746: ghost-cell exchange + dfft); every exchange is inside the call
+        attachSlab();
+        mtd_check(mtd_mesh_slab_compute_cv(m_mesh, m_pdata->getN(), m_pdata->positionsPtr(), m_pdata->getDtype(), &box,
+                                           m_pdata->getNGlobal(), &m_slab_sum, s),
+                  "mtd_mesh_slab_compute_cv");
+        m_partials = m_slab_sum;
+        m_n_partials = 1;
+        }
+    else if (distributed())
+        {
+        // replicated mesh: this rank's particles are spread, the ranks sum their meshes and sum(mode^2) — M + 1 doubles, what the
+        // reference moves as ghost cells + the MPI_Allreduce of :630 (OrderParameterMeshGPU.cc:235) — and every rank transforms
+        // the whole mesh; the CV is then the same on every rank (the reference's sum over local cells, :911 / GPU.cc:494)
+        mtd_check(mtd_mesh_assign(m_mesh, m_pdata->getN(), m_pdata->positionsPtr(), m_pdata->getDtype(), &box, s), "mtd_mesh_assign");
+        double *buf = nullptr;
+        size_t count = 0;
+        mtd_check(mtd_mesh_exchange_buffer(m_mesh, &buf, &count), "mtd_mesh_exchange_buffer");
+        m_exec_conf->allreduceLarge(buf, count, s);
+        mtd_check(mtd_mesh_spectral(m_mesh, &box, m_pdata->getNGlobal(), &m_partials, &m_n_partials, s), "mtd_mesh_spectral");
+        }
+    else
+        mtd_check(mtd_mesh_compute_cv(m_mesh, m_pdata->getN(), m_pdata->positionsPtr(), m_pdata->getDtype(), &box,
+                                      m_pdata->getNGlobal(), &m_partials, &m_n_partials, s),
+                  "mtd_mesh_compute_cv");
     m_is_first_step = false;
     m_cv_last_updated = timestep;
     }
@@ -437,6 +515,16 @@ void CollectiveWrapper::enqueueCurrentValue(unsigned int timestep, mtd_metad *en
     {
     enqueuePartials(timestep);
     // energy = sum_j force_j.w + external energy of the wrapped compute (:50-61)
+    if (distributed())
+        {
+        hipStream_t s = m_exec_conf->getStream();                      // :64-70: summed over the ranks
+        mtd_check(mtd_reduce_partials((const double *)m_partials.data(), m_n_partials, 1, 1, 1.0, m_fc->getExternalEnergy(),
+                                      (double *)m_sum.data(), s),
+                  "mtd_reduce_partials");
+        m_exec_conf->allreduceSmall((double *)m_sum.data(), 1, s);
+        mtd_check(mtd_metad_set_cv_source(engine, slot, (const double *)m_sum.data(), 1, 1, 0, 1.0, 0.0), "mtd_metad_set_cv_source");
+        return;
+        }
     mtd_check(mtd_metad_set_cv_source(engine, slot, (const double *)m_partials.data(), m_n_partials, 1, 0, 1.0,
                                       m_fc->getExternalEnergy()),
               "mtd_metad_set_cv_source");
@@ -448,6 +536,7 @@ double CollectiveWrapper::getCurrentValue(unsigned int timestep)
     mtd_check(mtd_reduce_partials((const double *)m_partials.data(), m_n_partials, 1, 1, 1.0, m_fc->getExternalEnergy(),
                                   (double *)m_sum.data(), m_exec_conf->getStream()),
               "mtd_reduce_partials");
+    if (distributed()) m_exec_conf->allreduceSmall((double *)m_sum.data(), 1, m_exec_conf->getStream());   // :64-70
     m_exec_conf->sync();
     m_sum.download(&m_energy, sizeof(double));
     return m_energy;
@@ -528,10 +617,30 @@ void SteinhardtQl::computeCV(unsigned int timestep)
     m_nlist->compute(timestep);                                      // :68
     const mtd_box box = m_pdata->getBox().toMtd();
     const Lists l = lists();
-    mtd_check(mtd_ql_accumulate(m_pdata->getN(), m_pdata->positionsPtr(), m_pdata->getDtype(), &box, l.head, l.n_neigh, l.nlist, l.mode,
-                                m_rcut, m_ron, m_lmax, m_type, m_Ql_ref.data(), m_pdata->getNGlobal(), (double *)m_scratch.data(),
-                                &m_d_value, &m_d_Ql, &m_d_Qlm, m_exec_conf->getStream()),
-              "mtd_ql_accumulate");
+    if (distributed())
+        {
+        // this rank's central particles (their neighbours may be ghosts, stored behind the local particles), the sum of the
+        // Q'_lm over the ranks (SteinhardtQl.cc:183-191), then Q_lm, Q_l and the value on every rank
+        if (l.mode == 1 && m_pdata->getNGhosts())
+            throw std::runtime_error("cv.steinhardt: a half neighbour list cannot be combined with ghost particles (the reaction "
+                                     "force on a ghost is dropped, SteinhardtQl.cc:328): use a full list in domain-decomposed runs");
+        hipStream_t s = m_exec_conf->getStream();
+        double *d_sums = nullptr;
+        unsigned int n_sums = 0;
+        mtd_check(mtd_ql_accumulate_local(m_pdata->getN(), m_pdata->positionsPtr(), m_pdata->getDtype(), &box, l.head, l.n_neigh, l.nlist,
+                                          l.mode, m_rcut, m_ron, m_lmax, m_type, m_pdata->getNGlobal(), (double *)m_scratch.data(), &d_sums,
+                                          &n_sums, s),
+                  "mtd_ql_accumulate_local");
+        m_exec_conf->allreduceSmall(d_sums, n_sums, s);
+        mtd_check(mtd_ql_finalize(l.mode, m_lmax, m_Ql_ref.data(), m_pdata->getNGlobal(), (double *)m_scratch.data(), &m_d_value, &m_d_Ql,
+                                  &m_d_Qlm, s),
+                  "mtd_ql_finalize");
+        }
+    else
+        mtd_check(mtd_ql_accumulate(m_pdata->getN(), m_pdata->positionsPtr(), m_pdata->getDtype(), &box, l.head, l.n_neigh, l.nlist, l.mode,
+                                    m_rcut, m_ron, m_lmax, m_type, m_Ql_ref.data(), m_pdata->getNGlobal(), (double *)m_scratch.data(),
+                                    &m_d_value, &m_d_Ql, &m_d_Qlm, m_exec_conf->getStream()),
+                  "mtd_ql_accumulate");
     m_have_computed = true;
     m_cv_last_updated = timestep;
     }
@@ -756,8 +865,19 @@ void IntegratorMetaDynamics::computeSigma()
     mtd_check(mtd_sigma_products(ncv, force.data(), m_pdata->getN(), m_pdata->getDtype(), m_sigma_g,
                                  (double *)m_sigma_scratch.data(), sigmasq.data(), m_exec_conf->getStream()),
               "mtd_sigma_products");
+    const bool is_root = m_exec_conf->getRank() == 0;
     for (unsigned int i = 0; i < ncv; ++i)
-        if (!force[i]) sigmasq[i * ncv + i] = m_variables[i].m_sigma * m_variables[i].m_sigma;   // :1249
+        if (!force[i] && is_root) sigmasq[i * ncv + i] = m_variables[i].m_sigma * m_variables[i].m_sigma;   // :1249 (root only: summed below)
+    if (m_exec_conf->getMailbox())
+        {
+        // the products of this rank's particles, summed over the ranks (:1259-1268)
+        m_sigma_exchange.resize(sizeof(double) * ncv * ncv);
+        m_exec_conf->sync();
+        m_sigma_exchange.upload(sigmasq.data(), sizeof(double) * ncv * ncv);
+        m_exec_conf->allreduceSmall((double *)m_sigma_exchange.data(), ncv * ncv, m_exec_conf->getStream());
+        m_exec_conf->sync();
+        m_sigma_exchange.download(sigmasq.data(), sizeof(double) * ncv * ncv);
+        }
     m_sigma_inv.assign(ncv * ncv, 0.0);
     mtd_check(mtd_sigma_inverse(ncv, sigmasq.data(), m_sigma_inv.data()), "mtd_sigma_inverse");
     mtd_check(mtd_metad_set_sigma_inv(m_engine, m_sigma_inv.data()), "mtd_metad_set_sigma_inv");
@@ -824,13 +944,7 @@ void IntegratorMetaDynamics::setupGrid()
     mtd_check(rc, "mtd_metad_create");
     // domain decomposition (the reference: MPI_Allreduce of the CV sums, root computes the bias, MPI_Bcast, :346-351, :571-575):
     // here every rank keeps the replicated grid and the CV sums of the fused step travel through the xGMI mailbox
-    if (m_exec_conf->getMailbox())
-        {
-        if (!fusedLamellarPossible())
-            throw std::runtime_error("metadynamics: a domain-decomposed run through the host classes needs a set of at most three "
-                                     "lamellar collective variables (fused step); other sets: metadynamics.sharded.HipCvSetBackend");
-        mtd_check(mtd_metad_set_comm(m_engine, m_exec_conf->getMailbox()), "mtd_metad_set_comm");
-        }
+    // (the mailbox is attached to the engine per step, where the step's form is known: updateBiasPotential)
     }
 
 // :121-217
@@ -1029,24 +1143,29 @@ void IntegratorMetaDynamics::updateBiasPotential(unsigned int timestep)
 
     if (m_adaptive && (timestep % m_stride == 0))                      // :333-341
         {
-        if (m_exec_conf->getNRanks() > 1)
-            throw std::runtime_error("integrate.mode_metadynamics: adaptive Gaussians are not available in a domain-decomposed run of "
-                                     "this build (the derivative products of computeSigma, :1252-1268, are not summed over ranks)");
         // compute derivatives of collective variables, then the instantaneous estimate of the standard deviation matrix
         for (auto &it : m_variables) it.m_cv->computeDerivatives(timestep);
         computeSigma();
         }
 
-    if (fusedLamellarPossible())
+    // Domain decomposition (the reference: MPI_Allreduce inside every CV's computeCV, the root rank computes the bias and broadcasts
+    // it, :346-351, :571-575): every rank keeps the replicated grid.  A pure lamellar set takes the fused step, whose two launches
+    // carry the sums through the mailbox themselves; any other set goes CV by CV — each variable reduces its own sums over the
+    // ranks inside enqueueCurrentValue (mailbox; the mesh: allreduceLarge or its slab decomposition) and the grid engine then
+    // runs on identical values everywhere, no broadcast.
+    mtd_comm *const mailbox = m_exec_conf->getMailbox();
+    if (fusedLamellarPossible() && (!mailbox || m_variables.size() <= 3))          // (the mailbox form of the step: at most three sums)
+        {
+        if (mailbox) mtd_check(mtd_metad_set_comm(m_engine, mailbox), "mtd_metad_set_comm");
         fusedLamellarStep(timestep);
+        }
     else
         {
-        if (m_exec_conf->getMailbox())
-            throw std::runtime_error("metadynamics: this set of collective variables cannot take the fused step, which is the only "
-                                     "domain-decomposed path of the host classes");
+        if (mailbox) mtd_check(mtd_metad_set_comm(m_engine, nullptr), "mtd_metad_set_comm");
         m_used_fused = false;
         // collect values of collective variables (:321-327) — they stay on the device
-        const std::vector<unsigned int> lam_slots = mixedLamellarSlots();
+        // (the shared launches of a mixed set sum this rank's particles only: off in a domain-decomposed run)
+        const std::vector<unsigned int> lam_slots = mailbox ? std::vector<unsigned int>() : mixedLamellarSlots();
         // The lamellar CVs' two launches depend on little of what the other CVs do: they go to a SIDE STREAM — launch A (one
         // pass over the positions + the deferred grid pass) runs beside the other CVs' kernels (the mesh assignment), the
         // grid-engine launch with the lamellar force blocks waits for the event that says "all CV values are there" and runs

@@ -75,6 +75,9 @@ class CollectiveVariable : public ForceCompute
         double getUmbrellaPotential(unsigned int timestep);           // CollectiveVariable.cc:68-106
         virtual bool requiresNetForce() { return false; }
         bool hasUmbrella() const { return m_umbrella != no_umbrella; }
+        //! a domain-decomposed run (m_pdata->getDomainDecomposition() in the reference): this rank holds a shard of the
+        //! particles and the per-step sums are reduced over the ranks of the execution configuration's mailbox
+        bool distributed() const { return m_exec_conf->getMailbox() != nullptr; }
 
         std::vector<std::string> getProvidedLogQuantities() override
             {
@@ -187,6 +190,11 @@ class OrderParameterMeshGPU : public CollectiveVariable
         void setUseTable(bool use_table);                             // OrderParameterMesh.h:60-63
         //! this build: false = interpolation function as intended instead of the reference's unsigned division (Q6)
         void setBugCompatible(bool on);
+        //! this build, domain-decomposed runs: true = the mesh is DECOMPOSED into slabs over the ranks (mtd_mesh_slab_*: the
+        //! reference's ghost-cell exchange + distributed FFT, OrderParameterMesh.cc:263-316, 659-746); false (default) = every
+        //! rank keeps the whole mesh and the ranks sum their assignments (M + 1 doubles per step, :630).  Before the first step.
+        void setSlabDecomposition(bool on);
+        bool getSlabDecomposition() const { return m_slab; }
         //! event recorded when the CV partial sums of the next compute are complete (mtd_mesh_set_cv_event); nullptr clears
         void setCvEvent(hipEvent_t e) { mtd_mesh_set_cv_event(m_mesh, (void *)e); }
         //! the lamellar CVs of a mixed set (and the engine's deferred grid pass) ride in this mesh's next particle pass
@@ -205,6 +213,9 @@ class OrderParameterMeshGPU : public CollectiveVariable
 
     private:
         void enqueueCV(unsigned int timestep);
+        void attachSlab();
+        bool m_slab = false, m_slab_attached = false;
+        const double *m_slab_sum = nullptr;
         void needFourierMesh();
         bool m_keep_fourier;
         void computeQmax(unsigned int timestep);                      // :1108-1179
@@ -408,7 +419,7 @@ class IntegratorMetaDynamics
         bool m_adaptive;
         void computeSigma();                                           // :1205-1294
         std::vector<double> m_sigma_inv;
-        DeviceBuffer m_sigma_scratch;
+        DeviceBuffer m_sigma_scratch, m_sigma_exchange;
         double m_temp;
         Enum m_mode;
         bool m_multiple_walkers, m_warned_single_walker;

@@ -10,6 +10,7 @@
 #include <array>
 #include <cmath>
 #include <cstring>
+#include <functional>
 #include <memory>
 #include <stdexcept>
 #include <string>
@@ -153,6 +154,73 @@ class ExecutionConfiguration
         mtd_comm *getMailbox() const { return m_comm; }
         unsigned int getNRanks() const { return m_comm ? mtd_comm_world(m_comm) : 1; }
         unsigned int getRank() const { return m_comm ? mtd_comm_rank(m_comm) : 0; }
+        //! Control plane of a domain-decomposed run — the role MPI_Allgather on getMPICommunicator() plays in HOOMD: gathers
+        //! `bytes` bytes from every rank into `all` (world * bytes, rank order).  Only used at SET-UP (IPC handles of exported
+        //! buffers: the mesh CV's large all-reduce and its slab decomposition); supplied by the launcher (metadynamics.xgmi.attach).
+        using AllgatherFn = std::function<void(const void *mine, size_t bytes, void *all)>;
+        void setAllgather(AllgatherFn f) { m_allgather = std::move(f); }
+        void allgather(const void *mine, size_t bytes, void *all) const
+            {
+            if (getNRanks() == 1)
+                {
+                std::memcpy(all, mine, bytes);
+                return;
+                }
+            if (!m_allgather)
+                throw std::runtime_error("metadynamics: this collective variable needs the control plane of the domain-decomposed run "
+                                         "(ExecutionConfiguration::setAllgather; metadynamics.xgmi.attach sets it)");
+            m_allgather(mine, bytes, all);
+            }
+        //! a buffer of `bytes` on every rank that all ranks can read (mtd_comm_share + allgather of the handles + mtd_comm_open):
+        //! returns this rank's buffer, peers[r] = rank r's as mapped here.  Collective.
+        void *shareBuffer(size_t bytes, std::vector<void *> &peers)
+            {
+            if (!m_comm) throw std::runtime_error("metadynamics: shareBuffer needs the mailbox (ExecutionConfiguration::setMailbox)");
+            const unsigned int world = getNRanks();
+            void *local = nullptr;
+            unsigned int slot = 0;
+            unsigned char mine[MTD_COMM_HANDLE_BYTES];
+            mtd_check(mtd_comm_share(m_comm, bytes, &local, &slot, mine), "mtd_comm_share");
+            std::vector<unsigned char> all((size_t)world * MTD_COMM_HANDLE_BYTES);
+            allgather(mine, MTD_COMM_HANDLE_BYTES, all.data());
+            peers.assign(world, nullptr);
+            mtd_check(mtd_comm_open(m_comm, slot, all.data(), peers.data()), "mtd_comm_open");
+            return local;
+            }
+        //! sum over the ranks of a few device doubles (the xGMI mailbox; LamellarOrderParameterGPU.cc:69-77, SteinhardtQl.cc:183-191,
+        //! WellTemperedEnsemble.cc:57-63, CollectiveWrapper.cc:64-70, IntegratorMetaDynamics.cc:1259-1268); no-op on one rank without a mailbox
+        void allreduceSmall(double *d_values, unsigned int n, hipStream_t s) const
+            {
+            if (m_comm) mtd_check(mtd_comm_allreduce_small(m_comm, d_values, n, s), "mtd_comm_allreduce_small");
+            }
+        //! sum over the ranks of a LARGE device buffer (the replicated mesh, OrderParameterMesh.cc:263-316, 630): RCCL when a
+        //! communicator was set (setCommunicator), else remote loads through the mailbox's exported buffers (mtd_comm_allreduce_pull,
+        //! set up on first use with the capacity asked for — collective)
+        void allreduceLarge(double *d_values, size_t count, hipStream_t s)
+            {
+            if (getNRanks() == 1) return;
+            if (m_large)
+                {
+                mtd_check(mtd_comm_allreduce_large(m_large, d_values, count, MTD_ELEM_F64, s), "mtd_comm_allreduce_large");
+                return;
+                }
+            if (count > m_pull_capacity)
+                {
+                if (m_pull_capacity) throw std::runtime_error("metadynamics: the large all-reduce was set up for a smaller buffer");
+                std::vector<void *> in, out;
+                const size_t bytes = mtd_comm_pull_bytes(count);
+                shareBuffer(bytes, in);
+                shareBuffer(bytes, out);
+                mtd_check(mtd_comm_pull_attach(m_comm, count, in.data(), out.data()), "mtd_comm_pull_attach");
+                m_pull_capacity = count;
+                }
+            mtd_check(mtd_comm_allreduce_pull(m_comm, d_values, count, s), "mtd_comm_allreduce_pull");
+            }
+        //! RCCL communicator between the ranks of the domain decomposition (mtd_rccl_create) for the large buffers; optional
+        void setCommunicator(uintptr_t rccl) { m_large = reinterpret_cast<mtd_rccl *>(rccl); }
+        mtd_rccl *getCommunicator() const { return m_large; }
+        //! which path allreduceLarge takes (reported by bench.py)
+        const char *largeExchangeName() const { return getNRanks() == 1 ? "none" : (m_large ? "rccl" : "xgmi-pull"); }
         //! the communicator between WALKERS (one simulation per GPU sharing one bias grid): HOOMD's m_partition_comm
         //! (IntegratorMetaDynamics.cc:393-409).  An RCCL communicator (mtd_rccl_create), borrowed.
         void setWalkerCommunicator(uintptr_t rccl) { m_walkers = reinterpret_cast<mtd_rccl *>(rccl); }
@@ -164,6 +232,9 @@ class ExecutionConfiguration
         hipEvent_t m_events[3] = {nullptr, nullptr, nullptr};
         mtd_comm *m_comm = nullptr;
         mtd_rccl *m_walkers = nullptr;
+        mtd_rccl *m_large = nullptr;
+        AllgatherFn m_allgather;
+        size_t m_pull_capacity = 0;
     };
 
 //! Particle arrays in HOOMD layout; Scalar is chosen per system (dtype), the arrays live in HBM
@@ -181,6 +252,14 @@ class ParticleData
             m_net_virial.resize(scalarBytes() * 6 * m_virial_pitch);
             }
         unsigned int getN() const { return m_N; }
+        //! ghost particles of a domain-decomposed run: stored BEHIND the local ones in the position array (HOOMD's layout);
+        //! neighbour lists index them as N, N + 1, ...  Set before the positions are uploaded (the array is reallocated).
+        unsigned int getNGhosts() const { return m_n_ghosts; }
+        void setNGhosts(unsigned int n)
+            {
+            m_n_ghosts = n;
+            m_postype.resize(scalar4Bytes() * ((size_t)m_N + n));
+            }
         unsigned int getNGlobal() const { return m_N_global; }
         void setNGlobal(unsigned int n) { m_N_global = n; }   // a shard of a domain-decomposed system
         unsigned int getNTypes() const { return (unsigned int)m_type_names.size(); }
@@ -209,6 +288,7 @@ class ParticleData
 
     private:
         unsigned int m_N, m_N_global;
+        unsigned int m_n_ghosts = 0;
         int m_dtype;
         std::vector<std::string> m_type_names;
         BoxDim m_box;

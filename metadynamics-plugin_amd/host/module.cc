@@ -149,6 +149,23 @@ PYBIND11_MODULE(_metadynamics, m)
         .def("isCUDAEnabled", &ExecutionConfiguration::isCUDAEnabled)
         .def("setMailbox", &ExecutionConfiguration::setMailbox)
         .def("setStream", &ExecutionConfiguration::setStream)
+        .def("setCommunicator", &ExecutionConfiguration::setCommunicator)
+        .def("largeExchangeName", &ExecutionConfiguration::largeExchangeName)
+        .def("setAllgather", [](ExecutionConfiguration &e, py::object fn) {
+            // fn(bytes) -> bytes of every rank, concatenated in rank order (the launcher's control plane: torch.distributed / MPI)
+            if (fn.is_none())
+                {
+                e.setAllgather(nullptr);
+                return;
+                }
+            e.setAllgather([fn](const void *mine, size_t bytes, void *all) {
+                py::gil_scoped_acquire gil;                             // (System::run releases the GIL)
+                py::bytes got = fn(py::bytes((const char *)mine, bytes));
+                const std::string blob = got;
+                if (blob.size() % bytes != 0 || blob.empty()) throw std::runtime_error("setAllgather: the callback returned a blob of the wrong size");
+                std::memcpy(all, blob.data(), blob.size());
+            });
+        })
         .def("setWalkerCommunicator", &ExecutionConfiguration::setWalkerCommunicator)
         .def("getNRanks", &ExecutionConfiguration::getNRanks)
         .def("getRank", &ExecutionConfiguration::getRank)
@@ -157,6 +174,8 @@ PYBIND11_MODULE(_metadynamics, m)
     py::class_<ParticleData, std::shared_ptr<ParticleData>>(m, "ParticleData")
         .def(py::init<unsigned int, int, const std::vector<std::string> &, const BoxDim &>())
         .def("getN", &ParticleData::getN)
+        .def("getNGhosts", &ParticleData::getNGhosts)
+        .def("setNGhosts", &ParticleData::setNGhosts)
         .def("getNGlobal", &ParticleData::getNGlobal)
         .def("setNGlobal", &ParticleData::setNGlobal)
         .def("getNTypes", &ParticleData::getNTypes)
@@ -164,8 +183,9 @@ PYBIND11_MODULE(_metadynamics, m)
         .def("getDtype", &ParticleData::getDtype)
         .def("getGlobalBox", &ParticleData::getGlobalBox)
         .def("setGlobalBox", &ParticleData::setGlobalBox)
-        .def("setPositions", [](ParticleData &p, py::array a) { upload_array(p.getPositions(), a, p.scalar4Bytes() * p.getN(), "setPositions"); })
-        .def("getPositions", [](ParticleData &p) { return download_scalar_array(p.getPositions(), p.getDtype(), {(ssize_t)p.getN(), 4}); })
+        .def("setPositions", [](ParticleData &p, py::array a) { upload_array(p.getPositions(), a, p.scalar4Bytes() * ((size_t)p.getN() + p.getNGhosts()), "setPositions"); },
+             "Scalar4[N + n_ghosts]: the local particles followed by the ghost particles")
+        .def("getPositions", [](ParticleData &p) { return download_scalar_array(p.getPositions(), p.getDtype(), {(ssize_t)p.getN() + (ssize_t)p.getNGhosts(), 4}); })
         .def("borrowPositions", [](ParticleData &p, size_t ptr) { p.borrowPositions((void *)ptr); },
              "use caller-owned device memory (Scalar4[N], e.g. tensor.data_ptr()) for the positions")
         .def("setNetForce", [](ParticleData &p, py::array a) { upload_array(p.getNetForce(), a, p.scalar4Bytes() * p.getN(), "setNetForce"); })
@@ -207,6 +227,8 @@ PYBIND11_MODULE(_metadynamics, m)
         .def("setScale", &CollectiveVariable::setScale)
         .def("requiresNetForce", &CollectiveVariable::requiresNetForce)
         .def("setBiasFactor", &CollectiveVariable::setBiasFactor)
+        .def("computeDerivatives", &CollectiveVariable::computeDerivatives)
+        .def("canComputeDerivatives", &CollectiveVariable::canComputeDerivatives)
         .def("getName", &CollectiveVariable::getName)
         .def("getUmbrellaPotential", &CollectiveVariable::getUmbrellaPotential)
         .def("getForceArray", [](CollectiveVariable &cv) {
@@ -232,7 +254,9 @@ PYBIND11_MODULE(_metadynamics, m)
         .def(py::init<std::shared_ptr<SystemDefinition>, unsigned int, unsigned int, unsigned int, std::vector<double>, std::vector<int3>>())
         .def("setTable", &OrderParameterMeshGPU::setTable)
         .def("setUseTable", &OrderParameterMeshGPU::setUseTable)
-        .def("setBugCompatible", &OrderParameterMeshGPU::setBugCompatible);
+        .def("setBugCompatible", &OrderParameterMeshGPU::setBugCompatible)
+        .def("setSlabDecomposition", &OrderParameterMeshGPU::setSlabDecomposition)
+        .def("getSlabDecomposition", &OrderParameterMeshGPU::getSlabDecomposition);
 
     py::class_<NeighborList, std::shared_ptr<NeighborList>> nlist(m, "NeighborList");
     nlist.def(py::init<std::shared_ptr<SystemDefinition>>())

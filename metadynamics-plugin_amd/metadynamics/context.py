@@ -19,10 +19,12 @@ class _context:
         self.type_names = []
 
 
-def initialize(positions, types, type_names, box, dtype=np.float32, n_global=None, timestep=0):
+def initialize(positions, types, type_names, box, dtype=np.float32, n_global=None, timestep=0, ghost_positions=None, ghost_types=None):
     """Create a SystemDefinition from a particle snapshot (the role of ``init.read_snapshot``).
 
     positions (N,3), types (N,) int, type_names list[str], box = L | (Lx,Ly,Lz) | _metadynamics.BoxDim.
+    A shard of a domain-decomposed system: ``n_global`` = particles of the whole system, ``ghost_positions`` / ``ghost_types`` =
+    the ghost particles of this rank (stored behind the local ones, as HOOMD does; neighbour lists index them from N on).
     """
     global current, exec_conf
     positions = np.asarray(positions)
@@ -33,7 +35,12 @@ def initialize(positions, types, type_names, box, dtype=np.float32, n_global=Non
     code = _metadynamics.MTD_F32 if np.dtype(dtype) == np.float32 else _metadynamics.MTD_F64
     exec_conf = _metadynamics.ExecutionConfiguration()
     pdata = _metadynamics.ParticleData(N, code, list(type_names), box)
-    pdata.setPositions(_metadynamics.pack_postype(np.asarray(positions, dtype=np.float64), np.asarray(types, dtype=np.int32), code))
+    positions, types = np.asarray(positions, dtype=np.float64).reshape(-1, 3), np.asarray(types, dtype=np.int32)
+    if ghost_positions is not None and len(ghost_positions):
+        pdata.setNGhosts(len(ghost_positions))
+        positions = np.concatenate([positions, np.asarray(ghost_positions, dtype=np.float64).reshape(-1, 3)])
+        types = np.concatenate([types, np.asarray(ghost_types, dtype=np.int32)])
+    pdata.setPositions(_metadynamics.pack_postype(positions, types, code))
     if n_global is not None:
         pdata.setNGlobal(int(n_global))
     sysdef = _metadynamics.SystemDefinition(pdata, exec_conf)

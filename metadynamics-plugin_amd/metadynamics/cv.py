@@ -163,6 +163,13 @@ class mesh(_collective_variable):
         self.cpp_force = _metadynamics.OrderParameterMeshGPU(context.current.system_definition, int(nx), int(ny), int(nz),
                                                              cpp_mode, cpp_zero_modes)
 
+    def set_decomposition(self, kind):
+        """this build, domain-decomposed runs: "replicated" (default: every rank keeps the whole mesh, the ranks sum their
+        assignments) or "slab" (the mesh itself is decomposed over the ranks; ny and nz multiples of the number of ranks)"""
+        if kind not in ("replicated", "slab"):
+            raise RuntimeError("Error setting parameters of collective variable.")
+        self.cpp_force.setSlabDecomposition(kind == "slab")
+
     def set_params(self, use_table=None, **args):                  # cv.py:423-436
         if use_table is not None:
             self.cpp_force.setUseTable(use_table)
@@ -223,13 +230,18 @@ class nlist_cell(object):
         from scipy.spatial import cKDTree
         pdata = context.current.system_definition.getParticleData()
         L = np.asarray(pdata.getGlobalBox().getL())
+        n_local = pdata.getN()
+        # (a shard: the ghost particles sit behind the local ones; heads for the local particles only, entries may index ghosts)
         p = np.mod(np.asarray(pdata.getPositions()[:, :3], dtype=np.float64) + L / 2, L)
         p[p >= L] = 0.0
         pairs = cKDTree(p, boxsize=L).query_pairs(self.r_cut, output_type="ndarray")
         i = np.concatenate([pairs[:, 0], pairs[:, 1]])
         j = np.concatenate([pairs[:, 1], pairs[:, 0]])
+        keep = i < n_local
+        i, j = i[keep], j[keep]
         order = np.lexsort((j, i))
         i, j = i[order], j[order]
+        p = p[:n_local]
         n_neigh = np.bincount(i, minlength=len(p)).astype(np.uint32)
         head = np.zeros(len(p), dtype=np.uint32)
         head[1:] = np.cumsum(n_neigh)[:-1]

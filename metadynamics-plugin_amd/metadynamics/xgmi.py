@@ -56,6 +56,27 @@ class Mailbox:
             self.handle = None
 
 
+def attach(dist, exec_conf, mailbox, communicator=None):
+    """Make ``exec_conf`` (``_metadynamics.ExecutionConfiguration``) the execution configuration of a DOMAIN-DECOMPOSED run: the
+    mailbox plays the role of HOOMD's MPI communicator for the per-step sums of every collective variable, ``dist`` is the control
+    plane the host classes use at set-up (an all-gather of IPC handles: the mesh CV's exported buffers), ``communicator`` an
+    optional ``mtd_rccl`` handle (``sharded.RcclAllReduce(dist).handle``) for the large per-step buffers — without it they go
+    through the mailbox's exported buffers (``mtd_comm_allreduce_pull``)."""
+    import torch
+    dev = _control_device(dist)
+    world = dist.get_world_size()
+
+    def allgather(blob):
+        out = torch.empty(world * len(blob), dtype=torch.uint8, device=dev)
+        dist.all_gather_into_tensor(out, torch.frombuffer(bytearray(blob), dtype=torch.uint8).to(dev))
+        return out.cpu().numpy().tobytes()
+
+    exec_conf.setMailbox(mailbox.handle.value)
+    exec_conf.setAllgather(allgather)
+    if communicator is not None:
+        exec_conf.setCommunicator(communicator.value if hasattr(communicator, "value") else int(communicator))
+
+
 _last_failure = None
 
 

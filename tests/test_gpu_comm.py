@@ -174,7 +174,8 @@ def test_mailbox_between_processes(world):
 
 def test_host_classes_take_the_mailbox_as_communicator(abi):
     """metadynamics.cv / integrate over the C++ host classes with a (one-rank) mailbox in the execution configuration:
-    same step as without; a CV set that cannot take the fused step is refused in a domain-decomposed run"""
+    same step as without; a CV set that cannot take the fused step goes CV by CV (round 4: every variable reduces its own sums over
+    the ranks — tests/test_gpu_host_dd.py runs that between processes)"""
     import ctypes as C
     from metadynamics import context, cv, integrate, xgmi
     lib = abi.load()
@@ -213,8 +214,12 @@ def test_host_classes_take_the_mailbox_as_communicator(abi):
         assert dd["V"] == pytest.approx(plain["V"], rel=1e-10) and dd["w"] == pytest.approx(plain["w"], rel=1e-10)
         assert np.abs(dd["f"] - plain["f"]).max() <= 1e-6 * np.abs(plain["f"]).max()
         assert box.timeouts() == 0
-        with pytest.raises(RuntimeError):
-            run(box, umbrella=True)
+        plain_u, dd_u = run(None, umbrella=True), run(box, umbrella=True)
+        assert not dd_u["fused"] and not plain_u["fused"] and dd_u["n"] == plain_u["n"]
+        assert np.allclose(dd_u["cv"], plain_u["cv"], rtol=1e-12, atol=0)
+        assert dd_u["V"] == pytest.approx(plain_u["V"], rel=1e-9)
+        assert np.abs(dd_u["f"] - plain_u["f"]).max() <= 1e-6 * np.abs(plain_u["f"]).max()
+        assert box.timeouts() == 0
     finally:
         context.current = None
         box.close()

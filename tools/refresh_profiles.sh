@@ -1,10 +1,11 @@
 #!/bin/bash
-# Developer tool (GPU box): re-collect everything under profiles/r3 that bench.py's line refers to, into gpurun_out/profiles_r3/
-# (copy what is to be judged into profiles/r3 afterwards).  Every rocprofv3 run has the python program itself after `--`;
+# Developer tool (GPU box): re-collect everything under profiles/<round> that bench.py's line refers to, into gpurun_out/profiles_<round>/
+# (copy what is to be judged into profiles/<round> afterwards; ROUND=r4 unless set).  Every rocprofv3 run has the python program itself after `--`;
 # counters are collected in runs of their own (--pmc with --kernel-trace only), one counter set per pass.
 # usage: tools/refresh_profiles.sh [bench|mesh|ql|sharded ...]   (default: all)
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-O=gpurun_out/profiles_r3; mkdir -p $O
+ROUND=${ROUND:-r4}
+O=gpurun_out/profiles_$ROUND; mkdir -p $O
 WHAT="${*:-bench mesh ql sharded}"
 rocprofv3 -L > $O/counters_list.txt 2>&1 || true
 pmc_pass() {   # pmc_pass <tag> <counters...> -- <program...>
@@ -43,6 +44,8 @@ if [[ " $WHAT " == *" ql "* ]]; then
   for c in FETCH_SIZE WRITE_SIZE; do pmc_pass ql_$c $c -- python3 tools/bench_ql.py 20; done
   pmc_pass ql_SQ SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT -- python3 tools/bench_ql.py 12
   pmc_pass ql_SQ2 SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES SQ_BUSY_CYCLES SQ_WAIT_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR -- python3 tools/bench_ql.py 12
+  # the fp64 arithmetic actually issued (bench.py prices config 5's roofline with these: 2 FMA + MUL + ADD, 64 lanes each)
+  pmc_pass ql_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_TRANS_F64 -- python3 tools/bench_ql.py 12
 fi
 if [[ " $WHAT " == *" mesh "* || " $WHAT " == *" ql "* ]]; then
   python3 tools/pmc_summary.py kernels $O $O/pmc_mesh_ql_summary.json > $O/pmc_mesh_ql_summary.txt
