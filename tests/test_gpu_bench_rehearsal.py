@@ -84,3 +84,28 @@ def test_bench_single_gpu_through_the_same_entry():
         assert d["extra"][k]["ms_per_step"] > 0, k
     assert d["roofline"]["measured_peak"]["copy_512MB_GBs"] > 1000.0
     assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] == 1
+
+
+def test_bench_config3_two_ranks_through_the_host_classes():
+    """`bench.py --config 3 --gpus 2`: cv.mesh + cv.lamellar DOMAIN-DECOMPOSED inside the C++ host classes (System::run on every rank):
+    replicated mesh summed by remote loads through the mailbox's exported buffers in this rehearsal (RCCL on real GPUs), and the
+    slab-decomposed mesh; the CV values the ranks agreed on against the oracle on the whole snapshot, identical state on all ranks"""
+    for mesh, word in (("replicated", "xgmi-pull"), ("slab", "slab decomposition")):
+        d = _bench(["--config", "3", "--gpus", "2", "--particles", "100000", "--steps", "20", "--warmup", "5", "--no-variants", "--mesh", mesh])
+        assert d["n_gpus"] == 2 and d["config"]["bench_config"] == 3 and d["config"]["particles_global"] == 200000 and "rehearsal" in d["config"]
+        assert d["config"]["driver"] == "host" and d["config"]["mailbox_timeouts"] == 0 and word in d["config"]["exchange"], d["config"]
+        assert d["config"]["on_grid"] and d["state"]["num_gaussians"] >= 20 and d["state"]["identical_on_all_ranks"] and not d["state"]["fused"]
+        assert max(d["cv_check"]["rel_err"]) <= d["cv_check"]["tolerance"], d["cv_check"]
+        assert d["value"] == pytest.approx(200000 * 2 / (d["ms_per_step"] * 1e-3), rel=1e-6)
+        assert d["roofline"]["bound"] == "hbm" and d["roofline"]["frac"] > 0
+
+
+def test_bench_config5_two_ranks_and_one():
+    """`bench.py --config 5 --gpus 2`: cv.steinhardt over z slabs with ghost layers inside the host classes; the same entry at N = 1"""
+    d = _bench(["--config", "5", "--gpus", "2", "--particles", "10", "--steps", "20", "--warmup", "5", "--no-variants"])
+    assert d["n_gpus"] == 2 and d["config"]["particles_global"] == 8000 and d["config"]["particles_per_gpu"] > 3000, d["config"]
+    assert d["config"]["ghosts_rank0"] > 0 and d["config"]["mailbox_timeouts"] == 0 and "Q'_lm" in d["config"]["exchange"]
+    assert d["config"]["on_grid"] and d["state"]["identical_on_all_ranks"] and d["state"]["num_gaussians"] >= 20
+    d1 = _bench(["--config", "5", "--gpus", "1", "--particles", "10", "--steps", "20", "--warmup", "5", "--no-variants"])
+    assert d1["n_gpus"] == 1 and d1["config"]["particles_global"] == 4000 and "exchange" not in d1["config"]
+    assert max(d1["cv_check"]["rel_err"]) <= d1["cv_check"]["tolerance"], d1["cv_check"]
