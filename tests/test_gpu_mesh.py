@@ -59,6 +59,13 @@ class GpuMesh:
         return (out[0::2] + 1j * out[1::2]).reshape(nz, ny, nx)
 
 
+def assign_info(abi, g):
+    """(pipeline, particles through the overflow list) of the mesh's last assignment: mtd_mesh_assign_info"""
+    pl, ovf = C.c_int(-1), C.c_uint(0)
+    abi.check(abi.load().mtd_mesh_assign_info(g.h, C.byref(pl), C.byref(ovf), None))
+    return pl.value, ovf.value
+
+
 @pytest.fixture(params=["tiles", "tiles-ids", "cells"])
 def assign_path(request, monkeypatch):
     """the assignment / force pipelines of mesh.hip: by tiles with the sorted place kernel (default: position records travel into
@@ -339,6 +346,32 @@ def test_mesh_config3_size(abi, ref):
         sl = slice(0, 50_000)
         F_ref = r.forces(util.oracle_postype(pos, types)[sl], rbox, 1.0, n_global=N)
         assert np.abs(F[sl, :3] - F_ref[:, :3]).max() <= 1e-5 * np.abs(F_ref[:, :3]).max()
+        assert assign_info(abi, g) == (1, 0)                             # the first assignment of a mesh: counting pipeline
+
+        # The BENCHMARKED assignment is the bin pipeline (every assignment of a mesh but its first: one launch bins on tile segments
+        # planned from the previous snapshot) — it meets the oracle directly here, at 10^6 particles / 128^3: the same
+        # snapshot again (planned from its own exact counts), once more, then a DISPLACED snapshot binned on the plan of the old one
+        for rep in range(2):
+            s2 = g.cv(d_pos, abi.MTD_F32, box, N)
+            pl, ovf = assign_info(abi, g)
+            assert pl == 2, "bin pipeline expected"
+            assert s2 == pytest.approx(s_ref, rel=1e-6)
+            assert np.array_equal(g.array(0), rho)                      # integer sums: the mesh does not depend on the pipeline
+            F2 = g.forces(d_pos, abi.MTD_F32, box, N, 1.0)
+            assert np.abs(F2[sl, :3] - F_ref[:, :3]).max() <= 1e-5 * np.abs(F_ref[:, :3]).max()
+        rng = np.random.default_rng(99)
+        pos2 = pos.astype(np.float64) + rng.normal(0.0, 0.1 * L / 128, size=pos.shape)      # rms 0.1 mesh cells per coordinate
+        pos2 = (np.mod(pos2 + L / 2, L) - L / 2).astype(np.float32)
+        pos2[pos2 >= L / 2] = -L / 2
+        d_pos2 = torch.from_numpy(util.pack_postype(pos2, types, np.float32)).cuda()
+        s3 = g.cv(d_pos2, abi.MTD_F32, box, N)
+        assert assign_info(abi, g)[0] == 2
+        opt2 = util.oracle_postype(pos2, types)
+        s3_ref = r.cv(opt2, rbox)
+        assert s3 == pytest.approx(s3_ref, rel=1e-6) and abs(s3_ref - s_ref) > 1e-9 * abs(s_ref)
+        F3 = g.forces(d_pos2, abi.MTD_F32, box, N, 1.0)
+        F3_ref = r.forces(opt2[sl], rbox, 1.0, n_global=N)
+        assert np.abs(F3[sl, :3] - F3_ref[:, :3]).max() <= 1e-5 * np.abs(F3_ref[:, :3]).max()
     finally:
         g.close()
 

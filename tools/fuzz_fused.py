@@ -2,8 +2,10 @@
 """Developer tool (GPU box): randomised check of the fused two-launch lamellar bias step (the headline path) against the
 oracle: 1-3 CVs, random Miller indices (incl. second harmonics, which the CV pass folds into their fundamentals, negative and
 zero components; |index| <= 6 like the configs of BASELINE.json: the fp32 phase carries its rounding |h|+|k|+|l| times), 1-4 particle types, orthorhombic / triclinic boxes, 1 ... 40 000 particles, stride, standard / well-tempered,
-fp32 / fp64 particles, fast and accurate trigonometry, values on and off the grid.  usage: fuzz_fused.py [seconds] [seed]"""
-import ctypes as C, os, sys, time
+fp32 / fp64 particles, fast and accurate trigonometry, values on and off the grid.  usage: fuzz_fused.py [seconds] [seed]
+       fuzz_fused.py --replay <case.json>   one case from a recorded generator state (tests/golden/fuzz_*.json: cases a long campaign
+       stopped at; FUZZ_DUMP=<file> makes a failing campaign record the state, FUZZ_OLD_TOL=1 applies round 3's first tolerance formula)"""
+import ctypes as C, json, os, sys, time
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [os.path.join(root, "metadynamics-plugin_amd"), os.path.join(root, "tests"), os.path.join(root, "oracle")]
 import numpy as np, torch
@@ -12,15 +14,15 @@ from metadynamics import _abi
 from test_gpu_metad import GpuMetad, compare
 
 lib = _abi.load()
-budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
-rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+replay = sys.argv[2] if len(sys.argv) > 2 and sys.argv[1] == "--replay" else None
+budget = float(sys.argv[1]) if len(sys.argv) > 1 and not replay else 120.0
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 and not replay else 1)
+OLD_TOL = os.environ.get("FUZZ_OLD_TOL") == "1"
 t0, t_print, it = time.time(), time.time(), 0
 worst = dict(cv=0.0, force=0.0, force_fast=0.0)
-while time.time() - t0 < budget:
-    it += 1
-    if time.time() - t_print > 30.0:
-        t_print = time.time()
-        print("fuzz_fused: %d cases so far" % it, flush=True)
+
+
+def one_case(rng):
     n_cv = int(rng.integers(1, 4))
     n_types = int(rng.integers(1, 5))
     N = int(rng.choice([1, 2, 63, 700, 5000, 40000]))
@@ -80,7 +82,8 @@ while time.time() - t0 < budget:
                 # (the index SUM, as the line above says: until the end of round 3 this used the largest single index, which is the same
                 # for axis-aligned modes and three times too strict for (-3, 3, -3) — one case in 2.5e4 at 1.1 of that tolerance,
                 # bit for bit the same value from the library of the round's first half)
-                floor = len(v) * amax * max(1, max(sum(abs(x) for x in hkl) for hkl in v)) / np.sqrt(N)
+                index = max(max(abs(x) for x in hkl) for hkl in v) if OLD_TOL else max(sum(abs(x) for x in hkl) for hkl in v)
+                floor = len(v) * amax * max(1, index) / np.sqrt(N)
                 tol = (1e-6 if not fast else 3e-6) * max(abs(s_ref), floor)
                 worst["cv"] = max(worst["cv"], abs(st["cv"][c] - s_ref) / max(abs(s_ref), floor, 1e-300))
                 assert abs(st["cv"][c] - s_ref) <= tol, ("cv", c, st["cv"][c], s_ref, N, n_cv, dtype, fast, cvs[c])
@@ -106,5 +109,27 @@ while time.time() - t0 < budget:
                     assert dev <= 1e-5, ("force", c, dev, N, n_cv, dtype, fast, b[c])
     finally:
         g.close()
+
+
+if replay:
+    rec = json.load(open(replay))
+    st = rec["state"]
+    st["state"] = {k: int(v) for k, v in st["state"].items()}
+    rng.bit_generator.state = st
+    one_case(rng)
+    print("fuzz_fused: replayed %s within the tolerances, worst relative deviations %s" % (os.path.basename(replay), {k: float("%.2e" % v) for k, v in worst.items()}))
+    sys.exit(0)
+while time.time() - t0 < budget:
+    it += 1
+    if time.time() - t_print > 30.0:
+        t_print = time.time()
+        print("fuzz_fused: %d cases so far" % it, flush=True)
+    state = rng.bit_generator.state
+    try:
+        one_case(rng)
+    except AssertionError as e:
+        if os.environ.get("FUZZ_DUMP"):
+            json.dump({"tool": "fuzz_fused.py", "case": it, "seed_args": sys.argv[1:], "error": repr(e)[:600], "state": state}, open(os.environ["FUZZ_DUMP"], "w"), default=str)
+        raise
 _abi.check(lib.mtd_lamellar_set_fast_trig(0))
 print("fuzz_fused: %d random cases in %.0f s, worst relative deviations %s" % (it, time.time() - t0, {k: float("%.2e" % v) for k, v in worst.items()}))

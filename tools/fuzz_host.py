@@ -2,23 +2,24 @@
 """Developer tool (GPU box): the reference-shaped API (metadynamics.cv / integrate over the C++ host classes) with the fused
 paths on (pure lamellar sets: two launches; mixed sets: lamellar CVs through launch A + the grid-engine launch) against the
 same run with setFusedPath(False) (every CV its own kernels, mtd_metad_update_bias): random CV sets of 1-3 variables out of
-lamellar / mesh / lamellar-with-umbrella, random grids, strides, modes.  usage: fuzz_host.py [seconds] [seed]"""
-import os, sys, time
+lamellar / mesh / lamellar-with-umbrella, random grids, strides, modes.  usage: fuzz_host.py [seconds] [seed]
+       fuzz_host.py --replay <case.json>   one case from a recorded generator state (FUZZ_DUMP / FUZZ_OLD_TOL as in fuzz_fused.py)"""
+import json, os, sys, time
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [os.path.join(root, "metadynamics-plugin_amd"), os.path.join(root, "tests")]
 import numpy as np, torch
 import util
 from metadynamics import context, cv, integrate
 
-budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
-rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+replay = sys.argv[2] if len(sys.argv) > 2 and sys.argv[1] == "--replay" else None
+budget = float(sys.argv[1]) if len(sys.argv) > 1 and not replay else 60.0
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 and not replay else 1)
+OLD_TOL = os.environ.get("FUZZ_OLD_TOL") == "1"
 t0, t_print, it, worst = time.time(), time.time(), 0, dict(cv=0.0, V=0.0, force=0.0)
-n_fused = n_mixed = 0
-while time.time() - t0 < budget:
-    it += 1
-    if time.time() - t_print > 30.0:
-        t_print = time.time()
-        print("fuzz_host: %d cases so far" % it, flush=True)
+counts = dict(fused=0, mixed=0)
+
+
+def one_case(rng):
     N = int(rng.choice([200, 2000, 12000]))
     L = float(rng.uniform(8.0, 20.0))
     dtype = np.float32 if rng.random() < 0.5 else np.float64
@@ -59,11 +60,11 @@ while time.time() - t0 < budget:
                           F=[c.cpp_force.getForces().astype(np.float64) for c in cvs], used=integ.usedFusedPath())
         context.current = None
     a, b = out[True], out[False]
-    if it <= 3 and os.environ.get("FUZZ_HOST_VERBOSE"):
+    if os.environ.get("FUZZ_HOST_VERBOSE"):
         print("case", it, spec, "N", N, "steps", steps, "\n fused", a["cv"], a["V"], a["n"], a["used"], float(np.abs(a["F"][0]).max()),
               "\n plain", b["cv"], b["V"], b["n"], b["used"], float(np.abs(b["F"][0]).max()), flush=True)
-    if a["used"]: n_fused += 1
-    elif any(k == "lam" for k, _ in spec) and len(spec) <= 3: n_mixed += 1
+    if a["used"]: counts["fused"] += 1
+    elif any(k == "lam" for k, _ in spec) and len(spec) <= 3: counts["mixed"] += 1
     assert a["n"] == b["n"]
     for (k, par), x, y in zip(spec, a["cv"], b["cv"]):
         worst["cv"] = max(worst["cv"], abs(x - y) / max(abs(y), 1e-3))
@@ -84,13 +85,35 @@ while time.time() - t0 < budget:
             # (an umbrella adds its own derivative to the factor the force kernel multiplies with — CollectiveVariable.cc:22-66,
             # harmonic: bias + kappa (s - cv0) — so THAT sum is the unit; dividing by the grid's bias factor alone left
             # kappa (s - cv0) (1 / bias_a - 1 / bias_b) in the comparison: 2.5e-4 in one of 1.7e5 sets once the riders were the default)
-            ua = 0.7 * (a["cv"][c] - 0.1) if spec[c][0] == "lam_umbrella" else 0.0
-            ub = 0.7 * (b["cv"][c] - 0.1) if spec[c][0] == "lam_umbrella" else 0.0
+            ua = 0.7 * (a["cv"][c] - 0.1) if spec[c][0] == "lam_umbrella" and not OLD_TOL else 0.0
+            ub = 0.7 * (b["cv"][c] - 0.1) if spec[c][0] == "lam_umbrella" and not OLD_TOL else 0.0
             if abs(a["bias"][c] + ua) > 1e-300 and abs(b["bias"][c] + ub) > 1e-300:
                 fa, fb = fa / (a["bias"][c] + ua), fb / (b["bias"][c] + ub)
         sc = np.abs(fb).max()
         if sc > 1e-20:
             worst["force"] = max(worst["force"], np.abs(fa - fb).max() / sc)
             assert np.abs(fa - fb).max() <= 2e-4 * sc, ("force", c, spec, np.abs(fa - fb).max() / sc)
+
+
+if replay:
+    rec = json.load(open(replay))
+    st = rec["state"]
+    st["state"] = {k: int(v) for k, v in st["state"].items()}
+    rng.bit_generator.state = st
+    one_case(rng)
+    print("fuzz_host: replayed %s within the tolerances, worst relative deviations %s" % (os.path.basename(replay), {k: float("%.2e" % v) for k, v in worst.items()}))
+    sys.exit(0)
+while time.time() - t0 < budget:
+    it += 1
+    if time.time() - t_print > 30.0:
+        t_print = time.time()
+        print("fuzz_host: %d cases so far" % it, flush=True)
+    state = rng.bit_generator.state
+    try:
+        one_case(rng)
+    except AssertionError as e:
+        if os.environ.get("FUZZ_DUMP"):
+            json.dump({"tool": "fuzz_host.py", "case": it, "seed_args": sys.argv[1:], "error": repr(e)[:600], "state": state}, open(os.environ["FUZZ_DUMP"], "w"), default=str)
+        raise
 print("fuzz_host: %d random CV sets in %.0f s (%d took the two-launch step, %d the mixed-set launches), worst relative deviations fused vs generic %s"
-      % (it, time.time() - t0, n_fused, n_mixed, {k: float("%.2e" % v) for k, v in worst.items()}))
+      % (it, time.time() - t0, counts["fused"], counts["mixed"], {k: float("%.2e" % v) for k, v in worst.items()}))
