@@ -333,7 +333,9 @@ def _timed_host_steps(context, steps, repeats=3):
     for _ in range(repeats):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        context.current.system.run(steps - 1)      # run(k) = prepRun (one bias update) + k updates
+        # run(k) = prepRun + k updates.  prepRun re-evaluates at the timestep of the last update, where cv.mesh and cv.steinhardt are
+        # cached (OrderParameterMesh.cc:927-928, SteinhardtQl.cc:64-65): one small launch, not a step — k steps are counted, no more
+        context.current.system.run(steps)
         torch.cuda.synchronize()
         out.append((time.perf_counter() - t0) / steps)
     _timed_host_steps.last = out
@@ -751,10 +753,12 @@ def main_config(args):
     context.run(100)
     barrier()
     if args.warmup > 0:
-        context.current.system.run(args.warmup - 1)
+        context.current.system.run(args.warmup)
     barrier()
     t0 = time.perf_counter()
-    context.current.system.run(args.steps - 1)      # run(k) = prepRun (one bias update) + k updates: exactly `steps` bias steps
+    # run(k) = prepRun + k updates; the main CV of these configurations is cached for the timestep prepRun re-evaluates (one small
+    # launch, not a step): exactly `steps` steps are counted
+    context.current.system.run(args.steps)
     barrier()
     elapsed = time.perf_counter() - t0
     steady = None
@@ -762,7 +766,7 @@ def main_config(args):
         k_steady = max(500, args.steps)
         barrier()
         t1 = time.perf_counter()
-        context.current.system.run(k_steady - 1)
+        context.current.system.run(k_steady)
         barrier()
         steady = (time.perf_counter() - t1, k_steady)
     t_now = context.current.system.getCurrentTimeStep()

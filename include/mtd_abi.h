@@ -503,6 +503,17 @@ int mtd_ql_accumulate_local(unsigned int n_particles, const void *d_postype, int
 int mtd_ql_finalize(int half_nlist, unsigned int lmax, const double *Ql_ref, unsigned int n_global, double *d_scratch,
                     const double **d_value, const double **d_Ql, const double **d_Qlm, mtd_stream_t stream);
 
+/* cv.steinhardt as the ONLY variable of a bias grid: mtd_ql_finalize and mtd_metad_update_bias(engine, timestep) in ONE launch
+ * (SteinhardtQl.cc:173-199 + IntegratorMetaDynamics.cc:314-588): every block of the grid engine's launch forms Q_lm, Q_l and the
+ * value from the sums mtd_ql_accumulate_local left in d_scratch (all-reduced by the caller in a particle-sharded run) and hands the
+ * value to the engine's scalar chain in registers; the value is also registered as the variable's source.  The engine's deferred
+ * pass of the deposit then travels in the next mtd_ql_forces on the same stream (full lists) instead of a launch of its own.
+ * MTD_ERR_UNSUPPORTED when the grid has more than one variable or a mailbox attached (call mtd_ql_finalize +
+ * mtd_metad_update_bias then).  Between the two pair passes of a step this leaves two launches where there were three. */
+int mtd_ql_finalize_update_bias(mtd_metad *engine, int half_nlist, unsigned int lmax, const double *Ql_ref, unsigned int n_global,
+                                double *d_scratch, unsigned int timestep, const double **d_value, const double **d_Ql,
+                                const double **d_Qlm, mtd_stream_t stream);
+
 /* SteinhardtQl::computeBiasForces (:203-339) with the Q_lm the last mtd_ql_accumulate left in d_scratch (Q20);
  * bias = *d_bias when d_bias != NULL, else bias_host.  Writes d_force[0..n_particles); with half lists the reaction force goes
  * to LOCAL partners only (j < n_particles, SteinhardtQl.cc:328), so particle-sharded runs use full lists. */
@@ -523,6 +534,14 @@ int mtd_ql_set_half_list_exact(int enable);
 int mtd_ql_symmetrize_half_list(unsigned int n_particles, const unsigned int *d_head_list, const unsigned int *d_n_neigh,
                                 const unsigned int *d_nlist, unsigned int *d_full_head, unsigned int *d_full_n_neigh,
                                 unsigned int *d_full_nlist, size_t full_capacity, size_t *n_full_entries, mtd_stream_t stream);
+/* The same with a caller-owned workspace of mtd_ql_symmetrize_workspace_uints(n_particles) device unsigned ints (a host class
+ * keeps it across the list updates of a run): no allocation, ONE synchronisation (the entry count must reach the host before the
+ * arrays can be trusted); the fill itself is only stream-ordered. */
+size_t mtd_ql_symmetrize_workspace_uints(unsigned int n_particles);
+int mtd_ql_symmetrize_half_list_ws(unsigned int n_particles, const unsigned int *d_head_list, const unsigned int *d_n_neigh,
+                                   const unsigned int *d_nlist, unsigned int *d_full_head, unsigned int *d_full_n_neigh,
+                                   unsigned int *d_full_nlist, size_t full_capacity, size_t *n_full_entries, unsigned int *d_workspace,
+                                   mtd_stream_t stream);
 
 int mtd_ql_forces(unsigned int n_particles, const void *d_postype, void *d_force, int dtype, const mtd_box *box,
                   const unsigned int *d_head_list, const unsigned int *d_n_neigh, const unsigned int *d_nlist, int half_nlist,

@@ -2122,9 +2122,42 @@ __device__ __forceinline__ void xy_twiddles(double2 *T, const double2 *__restric
 
 constexpr int XY_PREFETCH = 10;     // elements per thread of the next batch held in registers while this one is transformed
 
+// TILES: the real mesh is never written — the forward transform sums, for every cell it loads, the entries of the per-tile
+// fixed-point images that stand for it (own tile + the halos of the neighbours that overlap it: k_tile_combine's sum, integers
+// added, one conversion) straight out of the scatter pass's buffers.  One launch (10 us) and the 16.8 MB write + 16.8 MB read of
+// the mesh less per step; the tile images (29.6 MB) are read either way.  Offsets by arithmetic (no table: the y / z terms are
+// wave-uniform), for meshes whose tiles divide the axes and are powers of two, at least two cells wide (xy_tiles_ok).
+struct XYTiles
+    {
+    const long long *buf;
+    unsigned int log2t[3], nt[3];               // tile width (log2) and tiles per axis
+    unsigned int tile_mul[3], loc_mul[3];       // entry offset = sum over axes of tile * tile_mul + loc * loc_mul
+    double inv_scale;
+    };
+
+// the (up to two) entries along one axis that stand for coordinate c: its own tile's, and the halo of the neighbour it borders
+__device__ __forceinline__ bool xy_tile_src(const XYTiles &tl, const int a, const unsigned int c, unsigned int &o0, unsigned int &o1)
+    {
+    const unsigned int T = 1u << tl.log2t[a], t = c >> tl.log2t[a], l = c & (T - 1);
+    o0 = t * tl.tile_mul[a] + (l + 1) * tl.loc_mul[a];
+    o1 = o0;
+    if (l == 0)
+        {
+        o1 = (t == 0 ? tl.nt[a] - 1 : t - 1) * tl.tile_mul[a] + (T + 1) * tl.loc_mul[a];    // the left neighbour's right halo
+        return true;
+        }
+    if (l == T - 1)
+        {
+        o1 = (t == tl.nt[a] - 1 ? 0 : t + 1) * tl.tile_mul[a];                              // the right neighbour's left halo
+        return true;
+        }
+    return false;
+    }
+
+template<bool TILES>
 __global__ __launch_bounds__(XY_THREADS) void k_fft_xy_forward(const double *__restrict__ real_in, double2 *__restrict__ half_out,
                                                                const double2 *__restrict__ tw_x, const double2 *__restrict__ tw_y,
-                                                               const XYPlan pl)
+                                                               const XYPlan pl, const XYTiles tl)
     {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double2 *X = (double2 *)smem, *Y = X + (size_t)pl.nx * pl.xs, *TX = Y + (size_t)pl.ny * pl.ys, *TY = TX + pl.nx / 2;
@@ -2136,6 +2169,15 @@ __global__ __launch_bounds__(XY_THREADS) void k_fft_xy_forward(const double *__r
     const size_t line_base = (size_t)plane * ny;
     const unsigned int n_batches = ny / 2 / pb;
     double2 pre[XY_PREFETCH];
+    // TILES: this thread's x position is the same for every element it fetches (XY_THREADS is a multiple of nx): its x entries and the
+    // plane's z entries once per block
+    unsigned int ox0 = 0, ox1 = 0, oz0 = 0, oz1 = 0;
+    bool x2 = false, z2 = false;
+    if (TILES)
+        {
+        x2 = xy_tile_src(tl, 0, threadIdx.x & (nx - 1), ox0, ox1);
+        z2 = xy_tile_src(tl, 2, plane, oz0, oz1);
+        }
     auto fetch = [&](const unsigned int batch)
         {
 #pragma unroll
@@ -2143,8 +2185,43 @@ __global__ __launch_bounds__(XY_THREADS) void k_fft_xy_forward(const double *__r
             {
             const unsigned int idx = min(threadIdx.x + i * XY_THREADS, nx * pb - 1);   // clamped: see xy_fetch_columns
             const unsigned int u = idx >> pl.log2nx, p = idx & (nx - 1);
-            const size_t la = line_base + 2 * (batch * pb + u);
-            pre[i] = make_double2(real_in[la * nx + p], real_in[(la + 1) * nx + p]);
+            if (!TILES)
+                {
+                const size_t la = line_base + 2 * (batch * pb + u);
+                pre[i] = make_double2(real_in[la * nx + p], real_in[(la + 1) * nx + p]);
+                }
+            else
+                {
+                // rows gy, gy + 1 of this plane: every entry that stands for the two cells, integers added, one conversion each
+                const unsigned int gy = 2 * (batch * pb + u);
+                long long sum[2];
+#pragma unroll
+                for (int r = 0; r < 2; ++r)
+                    {
+                    unsigned int oy0, oy1;
+                    const bool y2 = xy_tile_src(tl, 1, gy + r, oy0, oy1);              // (wave-uniform: a wave holds one line pair)
+                    const long long *b = tl.buf;
+                    long long v = b[oz0 + oy0 + ox0];
+                    if (x2) v += b[oz0 + oy0 + ox1];
+                    if (y2)
+                        {
+                        v += b[oz0 + oy1 + ox0];
+                        if (x2) v += b[oz0 + oy1 + ox1];
+                        }
+                    if (z2)
+                        {
+                        v += b[oz1 + oy0 + ox0];
+                        if (x2) v += b[oz1 + oy0 + ox1];
+                        if (y2)
+                            {
+                            v += b[oz1 + oy1 + ox0];
+                            if (x2) v += b[oz1 + oy1 + ox1];
+                            }
+                        }
+                    sum[r] = v;
+                    }
+                pre[i] = make_double2((double)sum[0] * tl.inv_scale, (double)sum[1] * tl.inv_scale);
+                }
             }
         };
     XY_STAMP(0, 0);
@@ -2356,8 +2433,14 @@ __global__ __launch_bounds__(FFT_THREADS) void k_fft_z_spectral(const MeshGeom g
                                                                 const unsigned int tile, const unsigned int tiles_per_row,
                                                                 const double *__restrict__ mode_sq, const double n_global,
                                                                 const double *__restrict__ itab, double *__restrict__ cv_partials,
-                                                                const SlabArgs sl, const int keep_f)
+                                                                const SlabArgs sl, const int keep_f, const unsigned int n_regular,
+                                                                const unsigned int edge_col)
     {
+    // EDGE blocks (whole-mesh path, blockIdx >= n_regular): the half spectrum has nx/2 + 1 columns in rows of pitch hxp — at
+    // nx = 128 that is 8 tiles of 8 columns and ONE more column, for which a ninth tile per row moved, transformed and stored seven
+    // columns of padding (10 % of the pass).  The lone column `edge_col` is gathered instead: an edge block takes it from `tile`
+    // consecutive ROWS (element t of the tile = row first_row + t), so that the launch has ny * 8 + ny / 8 blocks instead of ny * 9.
+    // n_regular = UINT_MAX: no edge blocks, every tile lies in one row (the padding columns of a last tile are zeroed).
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ double s_red[16];
     const unsigned int n = g.nz;
@@ -2379,9 +2462,13 @@ __global__ __launch_bounds__(FFT_THREADS) void k_fft_z_spectral(const MeshGeom g
         {
         double2 *s = (double2 *)smem;
         const unsigned int tile_id = blockIdx.x * TPB + it;
-        const unsigned int wy = (DIST ? sl.y0 : 0u) + tile_id / tiles_per_row;      // row = y index (global)
-        const unsigned int x_first = (tile_id % tiles_per_row) * tile;
+        const bool edge = !DIST && TPB == 1 && tile_id >= n_regular;                // (block-uniform)
+        const unsigned int edge_row = edge ? (tile_id - n_regular) * tile : 0u;     // first row of an edge block
+        const unsigned int wy = edge ? edge_row : (DIST ? sl.y0 : 0u) + tile_id / tiles_per_row;      // row = y index (global)
+        const unsigned int x_first = edge ? edge_col : (tile_id % tiles_per_row) * tile;
         const size_t base = (size_t)wy * g.hxp + x_first;
+        const unsigned int t_step = edge ? g.hxp : 1u;                              // element t of the tile: the next column, or the next row
+        const unsigned int t_valid = edge ? min(tile, g.ny - edge_row) : tile;      // (an edge block at the end of the rows may run short)
 
         if (TPB > 1 && it > 0)
             {
@@ -2403,7 +2490,7 @@ __global__ __launch_bounds__(FFT_THREADS) void k_fft_z_spectral(const MeshGeom g
                     s[lds_slot(p, log2n) * tile + t] = ld_exported(sl.f[q] + base + t + (size_t)zl * plane);
                     }
                 else
-                    s[lds_slot(p, log2n) * tile + t] = fmesh[base + t + (size_t)p * plane];
+                    s[lds_slot(p, log2n) * tile + t] = t < t_valid ? fmesh[base + (size_t)t * t_step + (size_t)p * plane] : make_double2(0.0, 0.0);
                 }
         lds_barrier();
         if (TPB > 1 && it + 1 < TPB)
@@ -2434,17 +2521,20 @@ __global__ __launch_bounds__(FFT_THREADS) void k_fft_z_spectral(const MeshGeom g
         // I(-k) (they differ in bug-compatible mode, Q6).  Stored for the inverse transform: the Hermitian part
         // G_H(k) = (G(k) + conj G(-k)) / 2 = f (|f|^2 - (I(k)^2 + I(-k)^2) / 2 * sum mode^2 / 2 N^2), whose inverse is Re(inv).
         const unsigned int my = wy ? g.ny - wy : 0u;                       // mirror row (-k_y as an array index)
-        const double Iy = itab[g.nx + wy], Imy = itab[g.nx + my];
+        const double Iy_b = itab[g.nx + wy], Imy_b = itab[g.nx + my];
         for (unsigned int idx = threadIdx.x; idx < total; idx += FFT_THREADS)
             {
             const unsigned int p = idx >> log2tile, t = idx & (tile - 1);  // p = k_z index
-            const unsigned int wx = x_first + t;
-            if (wx > nxh)                                                  // padding column of the half-spectrum rows
+            const unsigned int wx = edge ? x_first : x_first + t;
+            if (wx > nxh || t >= t_valid)                                  // padding column of the half-spectrum rows (or no such row)
                 {
                 s[p * tile + t] = make_double2(0.0, 0.0);
-                if (!DIST && keep_f) fmesh[base + t + (size_t)p * plane] = make_double2(0.0, 0.0);
+                if (!DIST && keep_f && !edge) fmesh[base + t + (size_t)p * plane] = make_double2(0.0, 0.0);
                 continue;
                 }
+            // (an edge block's elements lie in different rows: their y factors are per element)
+            const unsigned int wy_t = edge ? wy + t : wy;
+            const double Iy = edge ? itab[g.nx + wy_t] : Iy_b, Imy = edge ? itab[g.nx + (wy_t ? g.ny - wy_t : 0u)] : Imy_b;
             const unsigned int mx = wx ? g.nx - wx : 0u, mz = p ? g.nz - p : 0u;
             const double I = itab[wx] * Iy * itab[g.nx + g.ny + p];
             const double Im = itab[mx] * Imy * itab[g.nx + g.ny + mz];
@@ -2458,9 +2548,9 @@ __global__ __launch_bounds__(FFT_THREADS) void k_fft_z_spectral(const MeshGeom g
             G.y -= f.y * diagonal_term;
             // the normalised Fourier mesh is only read by the log quantities (q_max) and the virial: written when asked for
             // (mtd_mesh_set_keep_fourier; 18.9 MB per step at 128^3).  Slab runs keep none.
-            if (!DIST && keep_f) fmesh[base + t + (size_t)p * plane] = f;
+            if (!DIST && keep_f) fmesh[base + (size_t)t * t_step + (size_t)p * plane] = f;
             s[p * tile + t] = G;
-            if (wx != 0 || wy != 0 || p != 0)                              // exclude the DC bin (:889-894)
+            if (wx != 0 || wy_t != 0 || p != 0)                            // exclude the DC bin (:889-894)
                 {
                 // Re(G f*) - |f|^2 I^2 sum mode^2 / 2 N^2 (:896-905) = |f|^4 - I^2 |f|^2 sum mode^2 / N^2 for the cell itself ...
                 double tk = val * val - val * (I * I) * msq_nn;
@@ -2484,9 +2574,9 @@ __global__ __launch_bounds__(FFT_THREADS) void k_fft_z_spectral(const MeshGeom g
             const unsigned int z = lds_slot(q, log2n);
             if (DIST)
                 gmesh[((size_t)z * sl.ny_loc + (wy - sl.y0)) * g.hxp + x_first + t] = s[q * tile + t];
-            else
+            else if (t < t_valid)
                 {
-                nt_store(s[q * tile + t], gmesh + base + t + (size_t)z * plane);
+                nt_store(s[q * tile + t], gmesh + base + (size_t)t * t_step + (size_t)z * plane);
                 }
             }
         if (TPB > 1 && it + 1 < TPB) lds_barrier();                      // the image is free for the next tile (its stores drain meanwhile)
@@ -2781,6 +2871,8 @@ struct mtd_mesh
     unsigned int plan_n;
     TileLists lists;                // where the last assignment left the tiles' particles (the force pass walks the same lists)
     int last_pipeline;              // of the last assignment: 0 cells, 1 counting, 2 bin (mtd_mesh_assign_info)
+    int rho_valid;                  // the real mesh d_rho holds the last assignment (0: it lives in the tile images only — mtd_mesh_compute_cv
+                                    // lets the forward transform read those; anyone who needs d_rho runs the combine pass first: mesh_need_rho)
     double amax;               // max |mode coefficient| (fixed-point scale)
     // slab decomposition over the ranks of a mailbox (mtd_mesh_slab_attach): exported buffers of every rank as mapped here
     struct mtd_comm *slab_comm;
@@ -2881,6 +2973,41 @@ FastDiv fast_div(unsigned int d)
 // plan of the fused x/y passes (k_fft_xy_*), or false when the mesh does not qualify (sizes that are not powers of two,
 // planes whose images do not fit the 160 KB of LDS) and the separate passes run
 constexpr size_t XY_LDS_MAX = 160 * 1024;
+// the forward transform can read the tile images itself (k_fft_xy_forward<true>): tiles that divide the axes, powers of two, at
+// least two cells wide (a coordinate then has at most two sources per axis), a thread's x position fixed over its elements
+bool xy_tiles_ok(const mtd_mesh *m, XYTiles &tl)
+    {
+    // MEASURED SLOWER, opt-in (MTD_FFT_FROM_TILES=1): config 3 takes 162.7 us per step with it against 132.2 (alternating processes,
+    // profiles/r4/mesh_ab.log).  The combine launch (10 us) is gone, but the transform's register prefetch — twenty independent
+    // loads per thread in one memory round trip — becomes a chain of conditional loads and adds (own tile; +1 source on a tile's
+    // first / last row, on the first / last plane of a tile, in the first / last lane of every wave) that the compiler waits for
+    // one by one, in the launch whose load phase was already exposed; issuing every possible source unconditionally instead is
+    // sixteen loads per cell pair, more cycles of the vector L1 than the combine pass costs.  Same bits either way (tests).
+    static const bool off = [] { const char *e = std::getenv("MTD_FFT_FROM_TILES"); return !(e && e[0] == '1'); }();
+    if (off || !m->tile_path || !m->combine_two) return false;
+    const TileGeom &tg = m->tg;
+    const unsigned int dims[3] = {m->nx, m->ny, m->nz}, tws[3] = {tg.tx, tg.ty, tg.tz}, nts[3] = {tg.ntx, tg.nty, tg.ntz};
+    if ((unsigned int)XY_THREADS % m->nx) return false;
+    std::memset(&tl, 0, sizeof(tl));
+    for (int a = 0; a < 3; ++a)
+        {
+        if (tws[a] < 2 || !is_pow2(tws[a]) || dims[a] % tws[a] || nts[a] * tws[a] != dims[a]) return false;
+        tl.log2t[a] = ilog2(tws[a]);
+        tl.nt[a] = nts[a];
+        }
+    const unsigned long long tile_mul[3] = {1ull * tg.hcells, 1ull * tg.ntx * tg.hcells, 1ull * tg.ntx * tg.nty * tg.hcells};
+    const unsigned long long loc_mul[3] = {1ull, tg.hx, 1ull * tg.hx * tg.hy};
+    if (tile_mul[2] * tg.ntz >= (1ull << 32)) return false;            // (32-bit offsets, like the combine pass's table)
+    for (int a = 0; a < 3; ++a)
+        {
+        tl.tile_mul[a] = (unsigned int)tile_mul[a];
+        tl.loc_mul[a] = (unsigned int)loc_mul[a];
+        }
+    tl.buf = m->d_tilebuf;
+    tl.inv_scale = tg.inv_scale;
+    return true;
+    }
+
 bool xy_plan(const mtd_mesh *m, int inverse, XYPlan &pl, size_t &lds)
     {
     if (!is_pow2(m->nx) || !is_pow2(m->ny) || m->nx < 4 || m->ny < 2 * XY_PARTS) return false;
@@ -3033,7 +3160,7 @@ int mtd_mesh_create(mtd_mesh **out, unsigned int nx, unsigned int ny, unsigned i
         m->d_ovf_tile = (unsigned int *)(p + o_ovft);
         m->ovf_base = (unsigned int)n_slots_extra;
         }
-    m->plan_valid = 0; m->bin_parity = 0; m->plan_n = 0; m->last_pipeline = 0;
+    m->plan_valid = 0; m->bin_parity = 0; m->plan_n = 0; m->last_pipeline = 0; m->rho_valid = 1;
     std::memset(&m->lists, 0, sizeof(m->lists));
     m->d_tsrc = (uint4 *)(p + o_tsrc);
     m->d_tile_total = (unsigned int *)(p + o_ttot);
@@ -3209,14 +3336,40 @@ static bool dyn_lds_ok(const int group, const void *const *fns, const int n, con
     return e == hipSuccess;
     }
 
-static int mesh_assign_local(mtd_mesh *m, unsigned int n_particles, const void *d_postype, int dtype, const mtd_box *box, mtd_stream_t stream);
+static int mesh_assign_local(mtd_mesh *m, unsigned int n_particles, const void *d_postype, int dtype, const mtd_box *box, mtd_stream_t stream,
+                             bool combine = true);
+
+// per-tile images -> the real mesh (tile path); afterwards d_rho holds the last assignment
+static int mesh_combine(mtd_mesh *m, const MeshGeom &g, hipStream_t s)
+    {
+    const unsigned int cthreads = m->nx >= 256 ? 256 : (m->nx > 64 ? 128 : 64);
+    if (m->combine_two)
+        k_tile_combine_rows<<<dim3((m->nx + cthreads - 1) / cthreads, (m->ny + TCB_ROWS - 1) / TCB_ROWS, m->nz), cthreads, 0, s>>>(g, m->tg, m->d_tilebuf, m->d_tsrc, m->d_rho);
+    else
+        k_tile_combine<<<dim3((m->nx + cthreads - 1) / cthreads, m->ny, m->nz), cthreads, 0, s>>>(g, m->tg, m->d_tilebuf, m->d_tsrc, m->d_rho);
+    MTD_LAUNCH_CHECK();
+    m->rho_valid = 1;
+    return MTD_SUCCESS;
+    }
+
+// whoever reads d_rho (the separate transform passes, the replicated-mesh exchange, mtd_mesh_get_array(0)) after an assignment that
+// left the mesh in the tile images only
+static int mesh_need_rho(mtd_mesh *m, hipStream_t s)
+    {
+    if (m->rho_valid || !m->tile_path) return MTD_SUCCESS;
+    MeshGeom g;
+    std::memset(&g, 0, sizeof(g));
+    g.nx = m->nx; g.ny = m->ny; g.nz = m->nz; g.hxp = m->hxp;           // (the combine pass reads the dimensions only)
+    return mesh_combine(m, g, s);
+    }
 
 int mtd_mesh_assign(mtd_mesh *m, unsigned int n_particles, const void *d_postype, int dtype, const mtd_box *box, mtd_stream_t stream)
     {
-    return mesh_assign_local(m, n_particles, d_postype, dtype, box, stream);
+    return mesh_assign_local(m, n_particles, d_postype, dtype, box, stream, true);
     }
 
-static int mesh_assign_local(mtd_mesh *m, unsigned int n_particles, const void *d_postype, int dtype, const mtd_box *box, mtd_stream_t stream)
+static int mesh_assign_local(mtd_mesh *m, unsigned int n_particles, const void *d_postype, int dtype, const mtd_box *box, mtd_stream_t stream,
+                             bool combine)
     {
     if (!m || (n_particles && !d_postype)) return MTD_ERR_INVALID_ARGUMENT;
     if (dtype != MTD_F32 && dtype != MTD_F64) return MTD_ERR_INVALID_ARGUMENT;
@@ -3404,15 +3557,9 @@ static int mesh_assign_local(mtd_mesh *m, unsigned int n_particles, const void *
             }
             }
         MTD_LAUNCH_CHECK();
-        {
-        const unsigned int cthreads = m->nx >= 256 ? 256 : (m->nx > 64 ? 128 : 64);
-        if (m->combine_two)
-            k_tile_combine_rows<<<dim3((m->nx + cthreads - 1) / cthreads, (m->ny + TCB_ROWS - 1) / TCB_ROWS, m->nz), cthreads, 0, s>>>(g, tg, m->d_tilebuf, m->d_tsrc, m->d_rho);
-        else
-            k_tile_combine<<<dim3((m->nx + cthreads - 1) / cthreads, m->ny, m->nz), cthreads, 0, s>>>(g, tg, m->d_tilebuf, m->d_tsrc, m->d_rho);
-        }
-        MTD_LAUNCH_CHECK();
         m->n_last = N;
+        m->rho_valid = 0;
+        if (combine) return mesh_combine(m, g, s);
         return MTD_SUCCESS;
         }
 
@@ -3441,6 +3588,7 @@ static int mesh_assign_local(mtd_mesh *m, unsigned int n_particles, const void *
     k_mesh_gather<<<tl.ntx * tl.nty * tl.ntz, GT_THREADS, 0, s>>>(g, tl, m->d_start, m->d_packed, m->d_rho);
     MTD_LAUNCH_CHECK();
     m->n_last = N;
+    m->rho_valid = 1;
     return MTD_SUCCESS;
     }
 
@@ -3491,16 +3639,28 @@ int mtd_mesh_spectral(mtd_mesh *m, const mtd_box *box, unsigned int n_global, co
     size_t xy_lds_f = 0, xy_lds_i = 0;
     static const bool xy_off = [] { const char *e = std::getenv("MTD_FFT_XY"); return e && e[0] == '0'; }();
     // (a runtime that refuses the 160 KB of dynamic LDS leaves the separate passes, it does not fail the step)
-    static const void *const xy_fns[2] = { (const void *)k_fft_xy_forward, (const void *)k_fft_xy_inverse };
-    const bool xy_lds_ok = dyn_lds_ok(2, xy_fns, 2, XY_LDS_MAX);
+    static const void *const xy_fns[3] = { (const void *)k_fft_xy_forward<false>, (const void *)k_fft_xy_inverse, (const void *)k_fft_xy_forward<true> };
+    const bool xy_lds_ok = dyn_lds_ok(2, xy_fns, 3, XY_LDS_MAX);
     const bool xy = !xy_off && xy_lds_ok && xy_plan(m, 0, xy_f, xy_lds_f) && xy_plan(m, 1, xy_i, xy_lds_i);
-    if (xy)
+    XYTiles tiles;
+    std::memset(&tiles, 0, sizeof(tiles));
+    if (xy && !m->rho_valid && xy_tiles_ok(m, tiles))
         {
-        k_fft_xy_forward<<<m->nz * XY_PARTS, XY_THREADS, xy_lds_f, s>>>(m->d_rho, m->d_f, m->d_tw[0], m->d_tw[1], xy_f);
+        // the assignment left the mesh in the per-tile images (mtd_mesh_compute_cv): the transform sums them itself
+        k_fft_xy_forward<true><<<m->nz * XY_PARTS, XY_THREADS, xy_lds_f, s>>>(nullptr, m->d_f, m->d_tw[0], m->d_tw[1], xy_f, tiles);
+        MTD_LAUNCH_CHECK();
+        }
+    else if (xy)
+        {
+        rc = mesh_need_rho(m, s);
+        if (rc) return rc;
+        k_fft_xy_forward<false><<<m->nz * XY_PARTS, XY_THREADS, xy_lds_f, s>>>(m->d_rho, m->d_f, m->d_tw[0], m->d_tw[1], xy_f, tiles);
         MTD_LAUNCH_CHECK();
         }
     else
         {
+        rc = mesh_need_rho(m, s);
+        if (rc) return rc;
         k_fft_x_r2c<<<x_blocks, FFT_THREADS, x_lds, s>>>(m->d_rho, m->d_f, m->d_tw[0], m->nx, ilog2(m->nx), x_tile, m->hxp, n_lines);
         MTD_LAUNCH_CHECK();
         rc = launch_fft_y(m, m->d_f, 0, s);
@@ -3510,16 +3670,31 @@ int mtd_mesh_spectral(mtd_mesh *m, const mtd_box *box, unsigned int n_global, co
     SlabArgs none;
     std::memset(&none, 0, sizeof(none));
     const unsigned int tpb = fft_z_tpb(pz);
-    const unsigned int z_blocks_whole = pz.n_blocks / tpb;
-    if (tpb == 3)
+    unsigned int z_blocks_whole = pz.n_blocks / tpb;
+    // a half spectrum of 8 k + 1 columns: the lone last column goes to edge blocks instead of a ninth tile per row (k_fft_z_spectral)
+    // MEASURED SLOWER, opt-in (MTD_FFT_Z_EDGE=1): config 3 at 128^3 takes 133.2 / 133.7 us per step with the edge blocks against 132.1 /
+    // 132.2 without (alternating processes on one box, profiles/r4/mesh_ab.log): 112 blocks fewer, but the edge blocks gather 16-byte
+    // elements a row pitch apart and look up their y factors per element
+    static const bool edge_off = [] { const char *e = std::getenv("MTD_FFT_Z_EDGE"); return !(e && e[0] == '1'); }();
+    const unsigned int hx_cols = m->nx / 2 + 1;
+    const bool z_edge = !edge_off && tpb == 1 && pz.tile > 1 && hx_cols % pz.tile == 1 && (hx_cols / pz.tile + 1) == pz.tiles_per_row && m->ny >= pz.tile;
+    if (z_edge)
+        {
+        const unsigned int full = hx_cols / pz.tile, n_regular = full * m->ny, n_edge = (m->ny + pz.tile - 1) / pz.tile;
+        z_blocks_whole = n_regular + n_edge;
+        k_fft_z_spectral<false, 1><<<z_blocks_whole, FFT_THREADS, fft_lds_bytes(pz.n, pz.tile), s>>>(
+            g, m->d_f, m->d_g, pz.tw, ilog2(pz.n), pz.tile, full, m->d_mode_sq, (double)n_global, m->d_itab, m->d_cv_partials, none, m->keep_fourier,
+            n_regular, full * pz.tile);
+        }
+    else if (tpb == 3)
         k_fft_z_spectral<false, 3><<<z_blocks_whole, FFT_THREADS, fft_lds_bytes(pz.n, pz.tile), s>>>(
-            g, m->d_f, m->d_g, pz.tw, ilog2(pz.n), pz.tile, pz.tiles_per_row, m->d_mode_sq, (double)n_global, m->d_itab, m->d_cv_partials, none, m->keep_fourier);
+            g, m->d_f, m->d_g, pz.tw, ilog2(pz.n), pz.tile, pz.tiles_per_row, m->d_mode_sq, (double)n_global, m->d_itab, m->d_cv_partials, none, m->keep_fourier, 0xffffffffu, 0u);
     else if (tpb == 2)
         k_fft_z_spectral<false, 2><<<z_blocks_whole, FFT_THREADS, fft_lds_bytes(pz.n, pz.tile), s>>>(
-            g, m->d_f, m->d_g, pz.tw, ilog2(pz.n), pz.tile, pz.tiles_per_row, m->d_mode_sq, (double)n_global, m->d_itab, m->d_cv_partials, none, m->keep_fourier);
+            g, m->d_f, m->d_g, pz.tw, ilog2(pz.n), pz.tile, pz.tiles_per_row, m->d_mode_sq, (double)n_global, m->d_itab, m->d_cv_partials, none, m->keep_fourier, 0xffffffffu, 0u);
     else
         k_fft_z_spectral<false, 1><<<z_blocks_whole, FFT_THREADS, fft_lds_bytes(pz.n, pz.tile), s>>>(
-            g, m->d_f, m->d_g, pz.tw, ilog2(pz.n), pz.tile, pz.tiles_per_row, m->d_mode_sq, (double)n_global, m->d_itab, m->d_cv_partials, none, m->keep_fourier);
+            g, m->d_f, m->d_g, pz.tw, ilog2(pz.n), pz.tile, pz.tiles_per_row, m->d_mode_sq, (double)n_global, m->d_itab, m->d_cv_partials, none, m->keep_fourier, 0xffffffffu, 0u);
     m->fourier_valid = m->keep_fourier;
     bool fold_cv = false;
     unsigned int n_folded = 0;
@@ -3552,7 +3727,14 @@ int mtd_mesh_compute_cv(mtd_mesh *m, unsigned int n_particles, const void *d_pos
                         unsigned int n_global, const double **d_partials, unsigned int *n_partials, mtd_stream_t stream)
     {
     if (!m || !d_partials || !n_partials || n_global == 0) return MTD_ERR_INVALID_ARGUMENT;
-    int rc = mtd_mesh_assign(m, n_particles, d_postype, dtype, box, stream);
+    // assignment and transforms in one call: the combine pass (tile images -> real mesh, a 10 us launch whose output the forward
+    // transform would read back one launch later) is skipped where the transform can sum the tile images itself
+    XYPlan xy_probe;
+    XYTiles tl_probe;
+    size_t lds_probe = 0;
+    static const bool xy_off = [] { const char *e = std::getenv("MTD_FFT_XY"); return e && e[0] == '0'; }();
+    const bool from_tiles = m->tile_path && !xy_off && xy_plan(m, 0, xy_probe, lds_probe) && xy_tiles_ok(m, tl_probe);
+    int rc = mesh_assign_local(m, n_particles, d_postype, dtype, box, stream, !from_tiles);
     if (rc) return rc;
     return mtd_mesh_spectral(m, box, n_global, d_partials, n_partials, stream);
     }
@@ -3681,7 +3863,7 @@ int mtd_mesh_slab_compute_cv(mtd_mesh *m, unsigned int n_particles, const void *
     sl.world = W; sl.nz_loc = nzl; sl.ny_loc = nyl; sl.y0 = r * nyl;
     const unsigned int z_blocks = pz.tiles_per_row * nyl;
     k_fft_z_spectral<true, 1><<<z_blocks, FFT_THREADS, fft_lds_bytes(pz.n, pz.tile), s>>>(
-        g, nullptr, g_x, pz.tw, ilog2(pz.n), pz.tile, pz.tiles_per_row, m->d_mode_sq, (double)n_global, m->d_itab, m->d_cv_partials, sl, 0);
+        g, nullptr, g_x, pz.tw, ilog2(pz.n), pz.tile, pz.tiles_per_row, m->d_mode_sq, (double)n_global, m->d_itab, m->d_cv_partials, sl, 0, 0xffffffffu, 0u);
     m->fourier_valid = 0;
     MTD_LAUNCH_CHECK();
     rc = mtd_reduce_partials(m->d_cv_partials, z_blocks, 1, 1, 1.0, 0.0, m->d_slab_sum, stream);
@@ -3813,7 +3995,13 @@ int mtd_mesh_get_array(mtd_mesh *m, int which, void *host_out, mtd_stream_t stre
     size_t bytes = 0;
     switch (which)
         {
-        case 0: src = m->d_rho; bytes = sizeof(double) * m->M; break;            // real mesh (assignParticles)
+        case 0:                                                                  // real mesh (assignParticles)
+            {
+            const int rc0 = mesh_need_rho(m, (hipStream_t)stream);
+            if (rc0) return rc0;
+            src = m->d_rho; bytes = sizeof(double) * m->M;
+            break;
+            }
         case 1:                                                                  // fourier_mesh, normalised: full mesh from the stored half
             {
             if (!m->fourier_valid) return MTD_ERR_INVALID_ARGUMENT;

@@ -21,6 +21,9 @@
 //                     normalisation is applied once per block, the Condon-Shortley phase in the finalize step
 //   k_reduce_partials (lamellar.hip) -> Q'_lm ; [multi-GPU: all-reduce of (lmax+1)(lmax+2) doubles here]
 //   k_ql_finalize     full Q_lm table in the reference's order, third-law scaling, Q_l, CV value
+//   k_ql_finalize_chain  (round 4) the same as the HEAD of the bias-grid engine's launch when cv.steinhardt is the grid's only
+//                     variable: value -> scalar chain -> first grid pass in one launch (mtd_ql_finalize_update_bias); the
+//                     engine's deferred pass then rides in the force pass of the same step
 //   k_ql_forces       the spherical-basis gradient of :287-321 contracted BEFORE it is expanded: with Z_lm = h^m q_lm
 //                     (q_lm = nrm w_l conj(Q_lm) in LDS) the pair force is -(alpha U + beta V + gamma W) with three scalars
 //                     U = sum P Re Z, V = cot sum m P Re Z + sin sum d_lm p_m+1,l-m-1 Re Z, W = -sum m P Im Z and three real
@@ -263,13 +266,14 @@ template<typename S4, int LMAX> struct QlFeed
     const unsigned int *__restrict__ head_list;
     const unsigned int *__restrict__ n_neigh;
     unsigned int n_chunks, lane;
+    unsigned int n_work;                  // blocks that walk the chunks (gridDim.x, minus the passenger blocks of a carrying launch)
     S4 pos;                               // requested ahead: the next chunk's particle, list head and count
     unsigned int start, cnt;
     unsigned int pend_kind, pend_chunk;   // the next unit to publish: 0 none, 1 first batch of chunk pend_chunk, 2 next batch of the same chunk
 
     __device__ __forceinline__ QlFeed(const QlArgs<LMAX> &a_, const S4 *p_, const unsigned int *h_, const unsigned int *n_)
         : a(a_), postype(p_), head_list(h_), n_neigh(n_), n_chunks((a_.N + QL_PPB - 1) / QL_PPB), lane(threadIdx.x & 63u),
-          pos(zero_s4<S4>()), start(0), cnt(0), pend_kind(0), pend_chunk(0)
+          n_work(gridDim.x), pos(zero_s4<S4>()), start(0), cnt(0), pend_kind(0), pend_chunk(0)
         {
         }
     __device__ __forceinline__ void request(const unsigned int chunk)
@@ -331,7 +335,7 @@ template<typename S4, int LMAX> struct QlFeed
             pend_kind = 2;
             return;
             }
-        pend_chunk = chunk + gridDim.x;
+        pend_chunk = chunk + n_work;
         pend_kind = pend_chunk < n_chunks ? 1 : 0;
         if (pend_kind) request(pend_chunk);
         }
@@ -731,7 +735,8 @@ __global__ __launch_bounds__(256) void k_ql_finalize_carrier(const QlArgs<LMAX> 
 
 template<int LMAX>
 __device__ __forceinline__ void ql_finalize_body(const QlArgs<LMAX> &a, const double *__restrict__ qprime,
-                                                 double *__restrict__ qlm_full, double *__restrict__ ql, double *__restrict__ value)
+                                                 double *__restrict__ qlm_full, double *__restrict__ ql, double *__restrict__ value,
+                                                 const bool write = true, double *s_value = nullptr)
     {
     // one thread per entry of the full table (<= 169 at lmax = 12), the sums over m and l in the serial order of the reference
     __shared__ double s_sq[(LMAX + 1) * (LMAX + 1)];
@@ -757,8 +762,11 @@ __device__ __forceinline__ void ql_finalize_body(const QlArgs<LMAX> &a, const do
             else
                 q = {0.0, 0.0};
             }
-        qlm_full[2 * n] = q.re;
-        qlm_full[2 * n + 1] = q.im;
+        if (write)
+            {
+            qlm_full[2 * n] = q.re;
+            qlm_full[2 * n + 1] = q.im;
+            }
         double sq = q.re * q.re + q.im * q.im;
         sq *= (4.0 * M_PI / (2 * l + 1)) / (ng * ng);                       // nc = 1 (:182)
         s_sq[n] = sq;
@@ -769,7 +777,7 @@ __device__ __forceinline__ void ql_finalize_body(const QlArgs<LMAX> &a, const do
         const int l = threadIdx.x;
         double Ql = 0.0;
         for (int p = 0; p < 2 * l + 1; ++p) Ql += s_sq[l * l + p];
-        ql[l] = Ql;
+        if (write) ql[l] = Ql;
         s_ql[l] = Ql;
         }
     __syncthreads();
@@ -777,7 +785,8 @@ __device__ __forceinline__ void ql_finalize_body(const QlArgs<LMAX> &a, const do
         {
         double val = 0.0;
         for (int l = 0; l <= (int)a.lmax; ++l) val += a.ql_ref[l] * s_ql[l];   // :190-194
-        *value = val;
+        if (write) *value = val;
+        if (s_value) *s_value = val;
         }
     }
 
@@ -801,6 +810,122 @@ __global__ __launch_bounds__(256) void k_ql_finalize_carrier(const QlArgs<LMAX> 
         return;
         }
     ql_finalize_body<LMAX>(a, qprime, qlm_full, ql, value);
+    }
+
+// ---- finalize + the bias-grid engine's launch in ONE (cv.steinhardt as the only variable of the grid) ---------------
+// Between the two pair passes of a step sat three launches that do next to nothing but wait for memory: the reduction of the
+// block sums (4.7 us), the finalize step (5.2 us: a few hundred flops) and the grid engine's launch (7.0 us: its scalar chain).
+// Here the finalize step IS the head of the grid engine's launch: every block of it (the grid's first-pass blocks, at least one)
+// forms Q_lm, Q_l and the value from the reduced sums — the same arithmetic in every block, so all of them hold the same bits —,
+// hands the value to the engine's scalar chain in registers (chain_wave's `given`: no trip through memory), and goes on with
+// the first grid pass of a deposit (updateGrid :1002-1047, updateHistogram :1092-1119, updateSigmaGrid :1122-1155, first loop of
+// updateReweightedEstimator :1070-1075); block 0 writes the tables the force pass reads and publishes the step's scalars.  The
+// grid-pass and publishing code is the twin of k_fused_force's (fused.hip): tests hold the two against each other bit for bit
+// (tests/test_gpu_steinhardt.py::test_ql_merged_launch_matches_separate_launches).  The engine's DEFERRED pass of the previous
+// deposit cannot ride here (this launch's chain reads the grid it writes): it travels in the force pass of its own step
+// (k_ql_forces<..., CARRY>), which follows the deposit's launch directly.
+template<int LMAX>
+__global__ __launch_bounds__(256) void k_ql_finalize_chain(const QlArgs<LMAX> a, const double *__restrict__ qprime,
+                                                           double *__restrict__ qlm_full, double *__restrict__ ql,
+                                                           double *__restrict__ value, const mtd::MetadCfg c, const int deposit,
+                                                           const unsigned int n_grid_blocks)
+    {
+    using namespace mtd;
+    __shared__ double s_given[3];
+    __shared__ ChainResult s_chain;
+    __shared__ double s_red[16];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    ChainPre<1> pre;
+    if (wave == 0) chain_preload<1, false>(c, pre);                  // the grid patch around the last value: in flight during the finalize step
+    if (threadIdx.x < 3) s_given[threadIdx.x] = 0.0;
+    ql_finalize_body<LMAX>(a, qprime, qlm_full, ql, value, blockIdx.x == 0, &s_given[0]);
+    __syncthreads();
+    if (wave == 0)
+        {
+        const ChainResult r = chain_wave(c, deposit != 0, true, nullptr, s_given, false, &pre.patch, pre.patch_ok != 0);
+        if (lane == 0)
+            {
+            s_chain.cv[0] = r.cv[0]; s_chain.cv[1] = r.cv[1]; s_chain.cv[2] = r.cv[2];
+            s_chain.bias[0] = r.bias[0]; s_chain.bias[1] = r.bias[1]; s_chain.bias[2] = r.bias[2];
+            s_chain.scal = r.scal; s_chain.V = r.V; s_chain.w = r.w;
+            s_chain.bin = r.bin; s_chain.on_grid = r.on_grid; s_chain.oob = r.oob; s_chain.failed = r.failed;
+            }
+        }
+    __syncthreads();
+    if (blockIdx.x < n_grid_blocks)
+        {
+        const unsigned int g = blockIdx.x * 256 + threadIdx.x;
+        double s1 = 0.0, s2 = 0.0;
+        if (g < c.len && !s_chain.failed)
+            {
+            const double dV = (c.W * s_chain.scal) * exp(-gauss_exponent3(c, g, s_chain.cv[0], s_chain.cv[1], s_chain.cv[2]));
+            c.grid_delta[g] = dV;
+            unsigned int hd = c.hist_delta[g];
+            if (s_chain.on_grid && g == s_chain.bin)
+                {
+                hd += 1;
+                c.hist_delta[g] = hd;
+                c.sigma_grid_delta[g] += c.det_sigma;
+                c.hist_gauss_delta[g] += 1;
+                }
+            const double Rw = c.rew[g] + (double)hd;
+            c.rew[g] = Rw;
+            s1 = Rw * dV;
+            s2 = Rw;
+            }
+        s1 = wave_sum(s1);
+        s2 = wave_sum(s2);
+        if (lane == 0)
+            {
+            s_red[2 * wave] = s1;
+            s_red[2 * wave + 1] = s2;
+            }
+        __syncthreads();
+        if (threadIdx.x == 0)
+            {
+            double t1 = 0.0, t2 = 0.0;
+            for (int w = 0; w < 256 / MTD_WAVE; ++w)
+                {
+                t1 += s_red[2 * w];
+                t2 += s_red[2 * w + 1];
+                }
+            c.gpart[2 * blockIdx.x] = t1;
+            c.gpart[2 * blockIdx.x + 1] = t2;
+            }
+        }
+    if (blockIdx.x == 0 && wave == 0)
+        {
+        double w_now = 1.0;
+        if (!deposit) w_now = chain_wave(c, false, false, nullptr, s_given).w;       // w(s) from the (final) weight grid
+        if (lane < (int)c.n_cv)
+            {
+            const double s_l = lane == 0 ? s_chain.cv[0] : (lane == 1 ? s_chain.cv[1] : s_chain.cv[2]);
+            c.st->cv[lane] = s_l;
+            c.st->bias[lane] = lane == 0 ? s_chain.bias[0] : (lane == 1 ? s_chain.bias[1] : s_chain.bias[2]);
+            const double dl = lane == 0 ? c.delta[0] : (lane == 1 ? c.delta[1] : c.delta[2]);
+            const double ml = lane == 0 ? c.cv_min[0] : (lane == 1 ? c.cv_min[1] : c.cv_min[2]);
+            const double ll = (double)(lane == 0 ? c.lengths[0] : (lane == 1 ? c.lengths[1] : c.lengths[2]));
+            double q = (s_l - ml) / dl;
+            if (!(q > 0.0)) q = 0.0;
+            if (q > ll) q = ll;
+            c.st->guess_org[lane] = (int)q - 2;
+            }
+        if (lane == 0)
+            {
+            c.st->V = s_chain.V;
+            c.st->failed = (unsigned int)s_chain.failed;
+            c.st->bin = s_chain.bin;
+            c.st->on_grid = (unsigned int)s_chain.on_grid;
+            if (deposit)
+                c.st->scal = s_chain.scal;
+            else
+                {
+                c.st->w = s_chain.failed ? s_chain.V : w_now;
+                if (s_chain.on_grid) c.hist_delta[s_chain.bin] += 1;
+                }
+            if (s_chain.oob) c.st->n_oob += (deposit && c.mode == MTD_MODE_WELL_TEMPERED) ? 2 : 1;
+            }
+        }
     }
 
 // ---- half lists: order-independent (exact) sums of the pair forces ---------------------------------------------
@@ -972,15 +1097,36 @@ __device__ __forceinline__ void ql_pair_force(const QlArgs<LMAX> &a, const doubl
     fpz = -(fa * dz - fb * st);
     }
 
-template<typename S4, int LMAX, bool HALF, bool EXACT>
+// CARRY: the launch carries the bias-grid engine's deferred pass (second reweighting pass + accumulate of the deposit that has
+// just been made, metad.hip: take_pending_apply) in its LAST n_apply blocks — the working blocks are fewer than the resident
+// capacity by that many, so the passengers start with everybody else and are gone after ~2 us.  NoCarry: an empty struct, the
+// plain instantiations keep their argument list and their code.
+struct QlNoCarry { };
+struct QlCarry { mtd::MetadCfg cfg; unsigned int n_apply; };
+template<bool CARRY> struct QlCarryArg { typedef QlNoCarry type; };
+template<> struct QlCarryArg<true> { typedef QlCarry type; };
+
+template<typename S4, int LMAX, bool HALF, bool EXACT, bool CARRY = false>
 __global__ __launch_bounds__(QL_THREADS, (LMAX <= 6 ? 3 : 2)) void k_ql_forces(const QlArgs<LMAX> a, const S4 *__restrict__ postype,
                                                              const unsigned int *__restrict__ head_list,
                                                              const unsigned int *__restrict__ n_neigh,
                                                              const unsigned int *__restrict__ nlist, const double *__restrict__ qlm_full,
                                                              S4 *__restrict__ force, const double *__restrict__ d_bias, const double bias_host,
                                                              unsigned long long *__restrict__ exact_acc, double *__restrict__ own,
-                                                             const double *__restrict__ tab)
+                                                             const double *__restrict__ tab, const typename QlCarryArg<CARRY>::type carry)
     {
+    unsigned int n_work = gridDim.x;
+    if constexpr (CARRY)
+        {
+        n_work = gridDim.x - carry.n_apply;
+        if (blockIdx.x >= n_work)
+            {
+            __shared__ double s_red_apply[16];
+            const unsigned int c0 = (blockIdx.x - n_work) * 256;
+            mtd::apply_cells(carry.cfg, c0, min(carry.cfg.len, c0 + 256u), blockIdx.x == n_work, s_red_apply);
+            return;
+            }
+        }
     typedef typename scalar4_traits<S4>::scalar scalar;
     constexpr int NLM = (LMAX + 1) * (LMAX + 2) / 2;
     constexpr unsigned int PPB = QL_PPB, CAP = QL_CAP;
@@ -1018,6 +1164,7 @@ __global__ __launch_bounds__(QL_THREADS, (LMAX <= 6 ? 3 : 2)) void k_ql_forces(c
         }
     // ---- prologue: units 0 and 1 published, unit 2 planned; entries of units 0 and 1 and the first neighbour requested ----
     QlFeed<S4, LMAX> feed(a, postype, head_list, n_neigh);
+    feed.n_work = n_work;
     if (setup_wave) feed.template begin<2>(su);
     lds_barrier();
     unsigned int j_cur[K], j_next[K], own_cur, own_next;
@@ -1270,9 +1417,27 @@ void launch_forces(const QlArgs<LMAX> &a, const S4 *postype, const unsigned int 
                    const double *d_qlm, S4 *force, const double *d_bias, const double bias_host, unsigned long long *acc, double *own, const double *tab,
                    hipStream_t s)
     {
+    if constexpr (!HALF && !EXACT)
+        {
+        QlCarry carry;
+        if (mtd_metad *engine = mtd::take_pending_apply(s, carry.cfg))
+            {
+            carry.n_apply = (carry.cfg.len + 255) / 256;
+            const unsigned int cap = ql_resident_blocks(k_ql_forces<S4, LMAX, false, false, true>);
+            if (carry.n_apply + 1 <= cap && carry.n_apply <= 64)          // (a grid of at most 16 384 cells: the passengers stay a sliver of the launch)
+                {
+                const unsigned int blocks = ql_blocks(a.N, QL_PPB, cap - carry.n_apply);
+                k_ql_forces<S4, LMAX, false, false, true><<<blocks + carry.n_apply, QL_THREADS, 0, s>>>(a, postype, d_head, d_nneigh, d_nlist, d_qlm, force, d_bias,
+                                                                                                     bias_host, acc, own, tab, carry);
+                if (hipPeekAtLastError() == hipSuccess) mtd::commit_pending_apply(engine);      // a failed launch leaves the pass pending
+                return;
+                }
+            // (not taken: the pass stays pending, metad_flush runs it as a launch of its own)
+            }
+        }
     const unsigned int cap = ql_resident_blocks(k_ql_forces<S4, LMAX, HALF, EXACT>);
     const unsigned int blocks = ql_blocks(a.N, QL_PPB, cap);
-    k_ql_forces<S4, LMAX, HALF, EXACT><<<blocks, QL_THREADS, 0, s>>>(a, postype, d_head, d_nneigh, d_nlist, d_qlm, force, d_bias, bias_host, acc, own, tab);
+    k_ql_forces<S4, LMAX, HALF, EXACT><<<blocks, QL_THREADS, 0, s>>>(a, postype, d_head, d_nneigh, d_nlist, d_qlm, force, d_bias, bias_host, acc, own, tab, QlNoCarry());
     }
 
 template<int LMAX>
@@ -1531,6 +1696,25 @@ __global__ void k_debug_sph(const unsigned int n, const unsigned int lmax, const
     }
 } // namespace
 
+namespace
+{
+template<int LMAX>
+int finalize_chain_impl(mtd_metad *m, int half, unsigned int lmax, const double *ql_ref, unsigned int n_global, const double *d_qprime,
+                               double *d_qlm, double *d_ql, double *d_value, int dep, unsigned int n_grid, hipStream_t s)
+    {
+    mtd_box box;
+    std::memset(&box, 0, sizeof(box));
+    box.L[0] = box.L[1] = box.L[2] = 1.0;                               // (geometry is not used by the finalize step)
+    QlArgs<LMAX> a;
+    int rc = fill_args<LMAX>(a, 0, &box, 1.0, 0.5, lmax, 0, ql_ref, n_global, half != 0);
+    if (rc) return rc;
+    k_ql_finalize_chain<LMAX><<<n_grid ? n_grid : 1, 256, 0, s>>>(a, d_qprime, d_qlm, d_ql, d_value, m->cfg, dep, n_grid);
+    MTD_LAUNCH_CHECK();
+    return MTD_SUCCESS;
+    }
+
+} // namespace
+
 extern "C" {
 
 int mtd_ql_set_half_list_exact(int enable)
@@ -1539,54 +1723,62 @@ int mtd_ql_set_half_list_exact(int enable)
     return MTD_SUCCESS;
     }
 
-int mtd_ql_symmetrize_half_list(unsigned int n_particles, const unsigned int *d_head_list, const unsigned int *d_n_neigh,
-                                const unsigned int *d_nlist, unsigned int *d_full_head, unsigned int *d_full_n_neigh,
-                                unsigned int *d_full_nlist, size_t full_capacity, size_t *n_full_entries, mtd_stream_t stream)
+size_t mtd_ql_symmetrize_workspace_uints(unsigned int n_particles)
     {
-    if (!n_full_entries || (n_particles && (!d_head_list || !d_n_neigh || !d_full_head || !d_full_n_neigh)))
+    return 2 * (size_t)n_particles + 2;                               // counts[n] | cursor[n] | total | flag
+    }
+
+int mtd_ql_symmetrize_half_list_ws(unsigned int n_particles, const unsigned int *d_head_list, const unsigned int *d_n_neigh,
+                                   const unsigned int *d_nlist, unsigned int *d_full_head, unsigned int *d_full_n_neigh,
+                                   unsigned int *d_full_nlist, size_t full_capacity, size_t *n_full_entries, unsigned int *d_workspace,
+                                   mtd_stream_t stream)
+    {
+    if (!n_full_entries || (n_particles && (!d_head_list || !d_n_neigh || !d_full_head || !d_full_n_neigh || !d_workspace)))
         return MTD_ERR_INVALID_ARGUMENT;
     *n_full_entries = 0;
     if (n_particles == 0) return MTD_SUCCESS;
     hipStream_t s = (hipStream_t)stream;
-    unsigned int *work = nullptr;                                     // counts[n] | cursor[n] | total | flag
-    MTD_HIP_TRY(hipMalloc(&work, (2 * (size_t)n_particles + 2) * sizeof(unsigned int)));
+    unsigned int *work = d_workspace;
     unsigned int *counts = work, *cursor = work + n_particles, *total = work + 2 * (size_t)n_particles, *flag = total + 1;
-    hipError_t e = hipMemsetAsync(work, 0, (2 * (size_t)n_particles + 2) * sizeof(unsigned int), s);
+    MTD_HIP_TRY(hipMemsetAsync(work, 0, (2 * (size_t)n_particles + 2) * sizeof(unsigned int), s));
     const unsigned int blocks = (n_particles + 255) / 256;
     unsigned int host[2] = {0, 0};
-    if (e == hipSuccess)
+    k_sym_count<<<blocks, 256, 0, s>>>(n_particles, d_head_list, d_n_neigh, d_nlist, counts, flag);
+    k_sym_scan<<<1, 1024, 0, s>>>(n_particles, counts, d_full_head, total);
+    MTD_LAUNCH_CHECK();
+    // the one synchronisation of the call: the number of entries decides whether the caller's arrays hold the result
+    MTD_HIP_TRY(hipMemcpyAsync(host, total, 2 * sizeof(unsigned int), hipMemcpyDeviceToHost, s));
+    MTD_HIP_TRY(hipStreamSynchronize(s));
+    *n_full_entries = host[0];
+    if (host[1]) return MTD_ERR_UNSUPPORTED;                         // ghost particles in a half list: use the third-law pass (or a full list)
+    if (host[0] > full_capacity || (host[0] && !d_full_nlist)) return MTD_ERR_INVALID_ARGUMENT;   // *n_full_entries tells the caller what to provide
+    if (host[0])
         {
-        k_sym_count<<<blocks, 256, 0, s>>>(n_particles, d_head_list, d_n_neigh, d_nlist, counts, flag);
-        k_sym_scan<<<1, 1024, 0, s>>>(n_particles, counts, d_full_head, total);
-        e = hipGetLastError();
+        k_sym_fill<<<blocks, 256, 0, s>>>(n_particles, d_head_list, d_n_neigh, d_nlist, d_full_head, cursor, d_full_nlist, full_capacity);
+        k_sym_sort<<<blocks, 256, 0, s>>>(n_particles, d_full_head, counts, d_full_nlist, d_full_n_neigh, full_capacity);
+        MTD_LAUNCH_CHECK();
         }
-    if (e == hipSuccess) e = hipMemcpyAsync(host, total, 2 * sizeof(unsigned int), hipMemcpyDeviceToHost, s);
-    if (e == hipSuccess) e = hipStreamSynchronize(s);
-    int rc = (int)e;
-    if (e == hipSuccess)
-        {
-        *n_full_entries = host[0];
-        if (host[1])
-            rc = MTD_ERR_UNSUPPORTED;                                 // ghost particles in a half list: use the third-law pass (or a full list)
-        else if (host[0] > full_capacity || (host[0] && !d_full_nlist))
-            rc = MTD_ERR_INVALID_ARGUMENT;                            // *n_full_entries tells the caller what to provide
-        else if (host[0])
-            {
-            k_sym_fill<<<blocks, 256, 0, s>>>(n_particles, d_head_list, d_n_neigh, d_nlist, d_full_head, cursor, d_full_nlist, full_capacity);
-            k_sym_sort<<<blocks, 256, 0, s>>>(n_particles, d_full_head, counts, d_full_nlist, d_full_n_neigh, full_capacity);
-            e = hipGetLastError();
-            if (e == hipSuccess) e = hipStreamSynchronize(s);         // `work` is released below
-            rc = (int)e;
-            }
-        else
-            {
-            e = hipMemsetAsync(d_full_n_neigh, 0, (size_t)n_particles * sizeof(unsigned int), s);
-            if (e == hipSuccess) e = hipStreamSynchronize(s);
-            rc = (int)e;
-            }
-        }
+    else
+        MTD_HIP_TRY(hipMemsetAsync(d_full_n_neigh, 0, (size_t)n_particles * sizeof(unsigned int), s));
+    return MTD_SUCCESS;                                               // (stream order: consumers on `stream` see the finished list)
+    }
+
+int mtd_ql_symmetrize_half_list(unsigned int n_particles, const unsigned int *d_head_list, const unsigned int *d_n_neigh,
+                                const unsigned int *d_nlist, unsigned int *d_full_head, unsigned int *d_full_n_neigh,
+                                unsigned int *d_full_nlist, size_t full_capacity, size_t *n_full_entries, mtd_stream_t stream)
+    {
+    if (!n_full_entries) return MTD_ERR_INVALID_ARGUMENT;
+    *n_full_entries = 0;
+    if (n_particles == 0) return MTD_SUCCESS;
+    // the form that owns its workspace for the duration of the call: an allocation, and a second synchronisation before it is
+    // released.  A caller that rebuilds lists regularly keeps the workspace itself (mtd_ql_symmetrize_half_list_ws).
+    unsigned int *work = nullptr;
+    MTD_HIP_TRY(hipMalloc(&work, mtd_ql_symmetrize_workspace_uints(n_particles) * sizeof(unsigned int)));
+    int rc = mtd_ql_symmetrize_half_list_ws(n_particles, d_head_list, d_n_neigh, d_nlist, d_full_head, d_full_n_neigh, d_full_nlist,
+                                            full_capacity, n_full_entries, work, stream);
+    const hipError_t e = hipStreamSynchronize((hipStream_t)stream);
     (void)hipFree(work);
-    return rc;
+    return rc ? rc : (int)e;
     }
 
 int mtd_debug_sph_harmonics(unsigned int lmax, unsigned int n, const double *h_separations, double *h_out)
@@ -1718,6 +1910,42 @@ int mtd_ql_finalize(int half_nlist, unsigned int lmax, const double *Ql_ref, uns
     box.L[0] = box.L[1] = box.L[2] = 1.0;
     return ql_dispatch(0, nullptr, MTD_F64, &box, nullptr, nullptr, nullptr, half_nlist, 1.0, 0.5, lmax, 0, Ql_ref, n_global, d_scratch,
                        d_value, d_Ql, d_Qlm, false, true, stream);
+    }
+
+int mtd_ql_finalize_update_bias(mtd_metad *m, int half_nlist, unsigned int lmax, const double *Ql_ref, unsigned int n_global,
+                                double *d_scratch, unsigned int timestep, const double **d_value, const double **d_Ql,
+                                const double **d_Qlm, mtd_stream_t stream)
+    {
+    if (!m || !Ql_ref || !d_scratch || n_global == 0) return MTD_ERR_INVALID_ARGUMENT;
+    if (lmax > 12) return MTD_ERR_UNSUPPORTED;
+    if (m->cfg.n_cv != 1 || m->comm) return MTD_ERR_UNSUPPORTED;        // the value feeds a one-variable chain directly
+    if (m->h_step_err && *m->h_step_err) return MTD_ERR_COMM_TIMEOUT;
+    double *partials, *qprime, *qlm, *ql, *value;
+    ql_layout(d_scratch, lmax, &partials, &qprime, &qlm, &ql, &value);
+    hipStream_t s = (hipStream_t)stream;
+    // the value stays registered as the variable's source: what a later mtd_metad_get_state evaluates w(s) at
+    int rc = mtd_metad_set_cv_source(m, 0, value, 1, 1, 0, 1.0, 0.0);
+    if (rc) return rc;
+    rc = mtd::metad_flush(m, s);                                        // (nothing to do when the force pass carried the deferred pass)
+    if (rc) return rc;
+    const int dep = (m->add_bias && (timestep % m->stride == 0)) ? 1 : 0;      // IntegratorMetaDynamics.cc:368
+    const unsigned int n_grid = dep ? m->cfg.n_gblocks : 0;
+    if (lmax <= 4)
+        rc = finalize_chain_impl<4>(m, half_nlist, lmax, Ql_ref, n_global, qprime, qlm, ql, value, dep, n_grid, s);
+    else if (lmax <= 6)
+        rc = finalize_chain_impl<6>(m, half_nlist, lmax, Ql_ref, n_global, qprime, qlm, ql, value, dep, n_grid, s);
+    else if (lmax <= 8)
+        rc = finalize_chain_impl<8>(m, half_nlist, lmax, Ql_ref, n_global, qprime, qlm, ql, value, dep, n_grid, s);
+    else
+        rc = finalize_chain_impl<12>(m, half_nlist, lmax, Ql_ref, n_global, qprime, qlm, ql, value, dep, n_grid, s);
+    if (rc) return rc;
+    m->pending_apply = dep;
+    m->w_stale = dep;
+    if (dep) mtd::announce_pending_apply(m, s);                         // the force pass of this step takes the deferred pass along
+    if (d_value) *d_value = value;
+    if (d_Ql) *d_Ql = ql;
+    if (d_Qlm) *d_Qlm = qlm;
+    return MTD_SUCCESS;
     }
 
 int mtd_ql_forces(unsigned int n_particles, const void *d_postype, void *d_force, int dtype, const mtd_box *box,

@@ -592,10 +592,11 @@ SteinhardtQl::Lists SteinhardtQl::lists()
         m_sym_head.resize(sizeof(unsigned int) * (N ? N : 1));
         m_sym_nneigh.resize(sizeof(unsigned int) * (N ? N : 1));
         m_sym_nlist.resize(sizeof(unsigned int) * (cap ? cap : 1));
+        m_sym_work.resize(sizeof(unsigned int) * mtd_ql_symmetrize_workspace_uints(N));      // (kept across the list updates of a run)
         size_t n_full = 0;
-        const int rc = mtd_ql_symmetrize_half_list(N, l.head, l.n_neigh, l.nlist, (unsigned int *)m_sym_head.data(),
-                                                   (unsigned int *)m_sym_nneigh.data(), (unsigned int *)m_sym_nlist.data(), cap, &n_full,
-                                                   m_exec_conf->getStream());
+        const int rc = mtd_ql_symmetrize_half_list_ws(N, l.head, l.n_neigh, l.nlist, (unsigned int *)m_sym_head.data(),
+                                                      (unsigned int *)m_sym_nneigh.data(), (unsigned int *)m_sym_nlist.data(), cap, &n_full,
+                                                      (unsigned int *)m_sym_work.data(), m_exec_conf->getStream());
         if (rc != MTD_SUCCESS && rc != MTD_ERR_UNSUPPORTED) mtd_check(rc, "mtd_ql_symmetrize_half_list");
         m_sym_ok = rc == MTD_SUCCESS;
         m_sym_version = m_nlist->getVersion();
@@ -610,39 +611,64 @@ SteinhardtQl::Lists SteinhardtQl::lists()
     return l;
     }
 
+// the pair pass of computeCV and, in a domain-decomposed run, the sum of its result over the ranks: Q'_lm (m >= 0) in m_scratch
+void SteinhardtQl::accumulateSums(unsigned int timestep)
+    {
+    m_nlist->compute(timestep);                                      // :68
+    const mtd_box box = m_pdata->getBox().toMtd();
+    const Lists l = lists();
+    // this rank's central particles (their neighbours may be ghosts, stored behind the local particles), the sum of the
+    // Q'_lm over the ranks (SteinhardtQl.cc:183-191)
+    if (distributed() && l.mode == 1 && m_pdata->getNGhosts())
+        throw std::runtime_error("cv.steinhardt: a half neighbour list cannot be combined with ghost particles (the reaction "
+                                 "force on a ghost is dropped, SteinhardtQl.cc:328): use a full list in domain-decomposed runs");
+    hipStream_t s = m_exec_conf->getStream();
+    double *d_sums = nullptr;
+    unsigned int n_sums = 0;
+    mtd_check(mtd_ql_accumulate_local(m_pdata->getN(), m_pdata->positionsPtr(), m_pdata->getDtype(), &box, l.head, l.n_neigh, l.nlist,
+                                      l.mode, m_rcut, m_ron, m_lmax, m_type, m_pdata->getNGlobal(), (double *)m_scratch.data(), &d_sums,
+                                      &n_sums, s),
+              "mtd_ql_accumulate_local");
+    if (distributed()) m_exec_conf->allreduceSmall(d_sums, n_sums, s);
+    }
+
 void SteinhardtQl::computeCV(unsigned int timestep)
     {
     ProfRange prof_range("CV");
     if (m_cv_last_updated == timestep && m_have_computed) return;    // :64-65
-    m_nlist->compute(timestep);                                      // :68
-    const mtd_box box = m_pdata->getBox().toMtd();
-    const Lists l = lists();
-    if (distributed())
-        {
-        // this rank's central particles (their neighbours may be ghosts, stored behind the local particles), the sum of the
-        // Q'_lm over the ranks (SteinhardtQl.cc:183-191), then Q_lm, Q_l and the value on every rank
-        if (l.mode == 1 && m_pdata->getNGhosts())
-            throw std::runtime_error("cv.steinhardt: a half neighbour list cannot be combined with ghost particles (the reaction "
-                                     "force on a ghost is dropped, SteinhardtQl.cc:328): use a full list in domain-decomposed runs");
-        hipStream_t s = m_exec_conf->getStream();
-        double *d_sums = nullptr;
-        unsigned int n_sums = 0;
-        mtd_check(mtd_ql_accumulate_local(m_pdata->getN(), m_pdata->positionsPtr(), m_pdata->getDtype(), &box, l.head, l.n_neigh, l.nlist,
-                                          l.mode, m_rcut, m_ron, m_lmax, m_type, m_pdata->getNGlobal(), (double *)m_scratch.data(), &d_sums,
-                                          &n_sums, s),
-                  "mtd_ql_accumulate_local");
-        m_exec_conf->allreduceSmall(d_sums, n_sums, s);
-        mtd_check(mtd_ql_finalize(l.mode, m_lmax, m_Ql_ref.data(), m_pdata->getNGlobal(), (double *)m_scratch.data(), &m_d_value, &m_d_Ql,
-                                  &m_d_Qlm, s),
-                  "mtd_ql_finalize");
-        }
-    else
-        mtd_check(mtd_ql_accumulate(m_pdata->getN(), m_pdata->positionsPtr(), m_pdata->getDtype(), &box, l.head, l.n_neigh, l.nlist, l.mode,
-                                    m_rcut, m_ron, m_lmax, m_type, m_Ql_ref.data(), m_pdata->getNGlobal(), (double *)m_scratch.data(),
-                                    &m_d_value, &m_d_Ql, &m_d_Qlm, m_exec_conf->getStream()),
-                  "mtd_ql_accumulate");
+    accumulateSums(timestep);
+    // Q_lm, Q_l and the value on every rank
+    mtd_check(mtd_ql_finalize(lists().mode, m_lmax, m_Ql_ref.data(), m_pdata->getNGlobal(), (double *)m_scratch.data(), &m_d_value, &m_d_Ql,
+                              &m_d_Qlm, m_exec_conf->getStream()),
+              "mtd_ql_finalize");
     m_have_computed = true;
     m_cv_last_updated = timestep;
+    }
+
+// the only variable of the grid: the finalize step is the head of the grid engine's launch (mtd_ql_finalize_update_bias)
+bool SteinhardtQl::enqueueValueAndBias(unsigned int timestep, mtd_metad *engine)
+    {
+    static const bool off = [] { const char *e = std::getenv("MTD_QL_MERGED"); return e && e[0] == '0'; }();   // diagnostic: the separate launches
+    if (off) return false;
+    ProfRange prof_range("CV");
+    const bool cached = m_cv_last_updated == timestep && m_have_computed;     // (its sums are still in m_scratch)
+    if (!cached) accumulateSums(timestep);
+    const int rc = mtd_ql_finalize_update_bias(engine, lists().mode, m_lmax, m_Ql_ref.data(), m_pdata->getNGlobal(), (double *)m_scratch.data(),
+                                               timestep, &m_d_value, &m_d_Ql, &m_d_Qlm, m_exec_conf->getStream());
+    if (rc == MTD_ERR_UNSUPPORTED)
+        {
+        if (!cached)
+            mtd_check(mtd_ql_finalize(lists().mode, m_lmax, m_Ql_ref.data(), m_pdata->getNGlobal(), (double *)m_scratch.data(), &m_d_value,
+                                      &m_d_Ql, &m_d_Qlm, m_exec_conf->getStream()),
+                      "mtd_ql_finalize");
+        m_have_computed = true;
+        m_cv_last_updated = timestep;
+        return false;
+        }
+    mtd_check(rc, "mtd_ql_finalize_update_bias");
+    m_have_computed = true;
+    m_cv_last_updated = timestep;
+    return true;
     }
 
 void SteinhardtQl::enqueueCurrentValue(unsigned int timestep, mtd_metad *engine, unsigned int slot)
@@ -1215,7 +1241,9 @@ void IntegratorMetaDynamics::updateBiasPotential(unsigned int timestep)
             if (ridden) setMixedLamellarSources(lam_slots, n_partials);
             }
         if (!lam_slots.empty() && !ridden) mixedLamellarCvPass(lam_slots, ls);
-        for (unsigned int i = 0; i < m_variables.size(); ++i)
+        // a variable that is alone on the grid may run the engine's update fused with the tail of its own value (cv.steinhardt)
+        const bool self_updated = m_variables.size() == 1 && !m_multiple_walkers && m_variables[0].m_cv->enqueueValueAndBias(timestep, m_engine);
+        for (unsigned int i = 0; i < m_variables.size() && !self_updated; ++i)
             if (std::find(lam_slots.begin(), lam_slots.end(), i) == lam_slots.end())
                 m_variables[i].m_cv->enqueueCurrentValue(timestep, m_engine, i);
         if (ridden && carrier->clearRider())
@@ -1250,7 +1278,7 @@ void IntegratorMetaDynamics::updateBiasPotential(unsigned int timestep)
                 }
             mtd_check(mtd_metad_update_bias_walkers(m_engine, m_exec_conf->getWalkerCommunicator(), timestep, s), "mtd_metad_update_bias_walkers");
             }
-        else
+        else if (!self_updated)
             mtd_check(mtd_metad_update_bias(m_engine, timestep, s), "mtd_metad_update_bias");
         // update current bias potential derivative for every collective variable (:578-584)
         const double *d_bias = mtd_metad_bias_device(m_engine);
@@ -1399,11 +1427,171 @@ void IntegratorMetaDynamics::readGrid(const std::string &filename)
 // System
 // ------------------------------------------------------------------------------------------------
 
+unsigned int IntegratorMetaDynamics::graphPeriod() const
+    {
+    if (!m_is_initialized || !m_use_grid || !m_engine || m_variables.empty()) return 0;
+    if (m_adaptive || m_multiple_walkers || m_file.is_open() || m_grid_period) return 0;
+    if (m_exec_conf->getMailbox() || m_exec_conf->getSideStream()) return 0;
+    if (fusedLamellarPossible()) return 0;                             // two launches per step: measured slower from a graph
+    if (m_pdata->getPressureFlag()) return 0;                          // (the mesh CV's virial is read back on the host)
+    for (const auto &it : m_variables)
+        {
+        if (it.m_cv->hasUmbrella()) return 0;                           // the umbrella adds to a HOST bias factor every step
+        const bool known = std::dynamic_pointer_cast<LamellarOrderParameterGPU>(it.m_cv) || std::dynamic_pointer_cast<OrderParameterMeshGPU>(it.m_cv)
+                           || std::dynamic_pointer_cast<SteinhardtQl>(it.m_cv);
+        if (!known) return 0;
+        if (auto st = std::dynamic_pointer_cast<SteinhardtQl>(it.m_cv))
+            if (!st->graphSafe()) return 0;
+        }
+    for (const auto &f : m_forces)                                     // every compute of the step is one of the variables
+        {
+        bool mine = false;
+        for (const auto &it : m_variables) mine = mine || it.m_cv.get() == f.get();
+        if (!mine) return 0;
+        }
+    unsigned int period = m_stride;
+    if (period % 2) period *= 2;
+    return period <= 64 ? period : 0;
+    }
+
+System::~System()
+    {
+    if (m_graph_stream) (void)hipStreamDestroy(m_graph_stream);
+    }
+
+// `nsteps` >= 3 periods of update() calls, most of them replayed from a capture of one period.  The captured sequence has to be
+// PERIODIC: the same launches with the same arguments every `period` steps, and host-side hand-offs (the engine's pending deferred
+// pass, keyed by stream; the mesh's alternating cursor sets) in the same state at its end as at its start.  Hence: one period of
+// plain steps on the capture stream first (settles everything that is keyed by the stream), then the capture — which executes
+// NOTHING, while the host state of the classes advances by a period — and at least one replay, which brings the device to where
+// the host already is.  MTD_GRAPH_VERIFY=1 captures a second period and compares the two graphs node by node (kernel, grid,
+// block, dynamic LDS): a sequence that is not periodic is then run with plain launches.  Returns the steps done.
+unsigned int System::runGraph(unsigned int nsteps, unsigned int period)
+    {
+    auto exec = m_sysdef->getExecConf();
+    if (!m_graph_stream) hip_check(hipStreamCreateWithFlags(&m_graph_stream, hipStreamNonBlocking), "hipStreamCreateWithFlags");
+    const hipStream_t user_stream = exec->getStream();
+    struct Restore
+        {
+        std::shared_ptr<ExecutionConfiguration> e;
+        hipStream_t s;
+        ~Restore() { e->setStream(reinterpret_cast<uintptr_t>(s)); }
+        } restore{exec, user_stream};
+    // nothing orders the caller's stream against ours: what it has enqueued is waited for here, and this function returns only
+    // when its own stream has drained
+    hip_check(hipStreamSynchronize(user_stream), "hipStreamSynchronize");
+    exec->setStream(reinterpret_cast<uintptr_t>(m_graph_stream));
+    unsigned int done = 0;
+    for (unsigned int i = 0; i < period; ++i, ++done) m_integrator->update(m_cur_tstep++);       // settle
+    // one graph = several periods, ~24 steps: every graph launch costs ~13 us in front of its first kernel (measured: two-step graphs
+    // ran config 5 at 105.6 us per step against 99.0 with plain launches, twenty-step graphs at 94.5 — profiles/r4/graph_ab.log)
+    const unsigned int base_period = period;
+    period *= std::max(1u, 24u / period);
+    if (nsteps < done + 2 * period) period = base_period;
+
+    auto capture = [&](hipGraph_t &graph)
+        {
+        hip_check(hipStreamBeginCapture(m_graph_stream, hipStreamCaptureModeRelaxed), "hipStreamBeginCapture");
+        try
+            {
+            for (unsigned int i = 0; i < period; ++i) m_integrator->update(m_cur_tstep + i);
+            }
+        catch (...)
+            {
+            hipGraph_t broken = nullptr;
+            (void)hipStreamEndCapture(m_graph_stream, &broken);
+            if (broken) (void)hipGraphDestroy(broken);
+            throw;
+            }
+        hip_check(hipStreamEndCapture(m_graph_stream, &graph), "hipStreamEndCapture");
+        m_cur_tstep += period;
+        done += period;
+        };
+    auto signature = [](hipGraph_t graph)
+        {
+        std::vector<std::array<size_t, 8>> sig;
+        size_t n = 0;
+        hip_check(hipGraphGetNodes(graph, nullptr, &n), "hipGraphGetNodes");
+        std::vector<hipGraphNode_t> nodes(n);
+        if (n) hip_check(hipGraphGetNodes(graph, nodes.data(), &n), "hipGraphGetNodes");
+        for (hipGraphNode_t node : nodes)
+            {
+            hipGraphNodeType type;
+            hip_check(hipGraphNodeGetType(node, &type), "hipGraphNodeGetType");
+            std::array<size_t, 8> e{};
+            e[0] = (size_t)type;
+            if (type == hipGraphNodeTypeKernel)
+                {
+                hipKernelNodeParams p;
+                hip_check(hipGraphKernelNodeGetParams(node, &p), "hipGraphKernelNodeGetParams");
+                e = {(size_t)type, (size_t)p.func, p.gridDim.x, p.gridDim.y, p.gridDim.z, p.blockDim.x, p.sharedMemBytes, 0};
+                }
+            sig.push_back(e);
+            }
+        std::sort(sig.begin(), sig.end());                             // (the node list of a graph has no defined order)
+        return sig;
+        };
+
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t gexec = nullptr;
+    capture(graph);
+    bool periodic = true;
+    static const bool verify = [] { const char *e = std::getenv("MTD_GRAPH_VERIFY"); return e && e[0] == '1'; }();
+    if (verify && nsteps >= done + 2 * period)
+        {
+        hipGraphExec_t first = nullptr;
+        hip_check(hipGraphInstantiate(&first, graph, nullptr, nullptr, 0), "hipGraphInstantiate");
+        hip_check(hipGraphLaunch(first, m_graph_stream), "hipGraphLaunch");                  // the device catches up with the host state
+        hipGraph_t second = nullptr;
+        capture(second);
+        periodic = signature(graph) == signature(second);
+        (void)hipGraphExecDestroy(first);
+        (void)hipGraphDestroy(graph);
+        graph = second;
+        if (!periodic) std::cerr << "System::run: the captured steps are not periodic — plain launches" << std::endl;
+        }
+    hip_check(hipGraphInstantiate(&gexec, graph, nullptr, nullptr, 0), "hipGraphInstantiate");
+    hip_check(hipGraphLaunch(gexec, m_graph_stream), "hipGraphLaunch");                      // (the captured period itself)
+    unsigned int replayed = period;
+    if (periodic)
+        while (nsteps - done >= period)
+            {
+            hip_check(hipGraphLaunch(gexec, m_graph_stream), "hipGraphLaunch");
+            m_cur_tstep += period;
+            done += period;
+            replayed += period;
+            }
+    m_last_graph_steps = periodic ? replayed : 0;
+    m_last_graph_period = base_period;
+    // the handles may go while the launches are still in flight? No: the executable graph must outlive them
+    hip_check(hipStreamSynchronize(m_graph_stream), "hipStreamSynchronize");
+    (void)hipGraphExecDestroy(gexec);
+    (void)hipGraphDestroy(graph);
+    return done;
+    }
+
 void System::run(unsigned int nsteps)
     {
     if (!m_integrator) throw std::runtime_error("System::run: no integrator set");
     m_integrator->prepRun(m_cur_tstep);      // HOOMD calls prepRun at the start of every run() (Q17)
-    for (unsigned int i = 0; i < nsteps; ++i)
+    m_last_graph_steps = 0;
+    unsigned int i = 0;
+    // MEASURED SLOWER, opt-in (setGraphMode(1) / MTD_GRAPH=1): replaying the steps from a HIP graph costs config 5 102.7 us per
+    // step against 99.3 with plain launches and config 3 134.3 against 132.7 (System::run, 24-step graphs, alternating processes on
+    // one box); the headline's two-launch step 18.86 against 18.72 (profiles/r4/graph_ab.log).  The launches of a step are long
+    // enough for the host to stay ahead; what a graph removes — the host's per-launch work — was never on the critical path.
+    int mode = m_graph_mode;
+    if (mode < 0)
+        {
+        static const int env = [] { const char *e = std::getenv("MTD_GRAPH"); return (e && e[0] == '1') ? 1 : 0; }();
+        mode = env;
+        }
+    if (mode > 0)
+        {
+        const unsigned int period = m_integrator->graphPeriod();
+        if (period && nsteps >= 4u * period) i = runGraph(nsteps, period);
+        }
+    for (; i < nsteps; ++i)
         {
         m_integrator->update(m_cur_tstep);
         m_cur_tstep++;

@@ -46,6 +46,10 @@ class CollectiveVariable : public ForceCompute
         //! device-resident form of getCurrentValue: make `engine` take CV `slot` from this variable.
         //! Default: the host value of getCurrentValue() travels in the next launch's arguments.
         virtual void enqueueCurrentValue(unsigned int timestep, mtd_metad *engine, unsigned int slot);
+        //! A variable that is the ONLY one of the grid may run the engine's update itself, fused with the tail of its own value
+        //! (cv.steinhardt: mtd_ql_finalize_update_bias): true = updateBiasPotential(timestep) is enqueued, the integrator skips
+        //! mtd_metad_update_bias; false (default) = nothing fused, the integrator goes on with enqueueCurrentValue
+        virtual bool enqueueValueAndBias(unsigned int timestep, mtd_metad *engine) { return false; }
 
         virtual void setBiasFactor(double bias)                        // CollectiveVariable.h:63-66
             {
@@ -271,12 +275,16 @@ class SteinhardtQl : public CollectiveVariable
                      const std::string &log_suffix = "");
         double getCurrentValue(unsigned int timestep) override;        // SteinhardtQl.h:44-48
         void enqueueCurrentValue(unsigned int timestep, mtd_metad *engine, unsigned int slot) override;
+        bool enqueueValueAndBias(unsigned int timestep, mtd_metad *engine) override;
+        //! this build: the steps of this variable can be replayed from a captured graph (no half-list scratch from a pool, no list rebuild pending)
+        bool graphSafe() { return lists().mode != 1; }
         void computeBiasForces(unsigned int timestep) override;        // SteinhardtQl.cc:203-339
         std::vector<std::string> getProvidedLogQuantities() override;  // SteinhardtQl.h:34-42
         double getLogValue(const std::string &quantity, unsigned int timestep) override;   // :49-67
 
     private:
         void computeCV(unsigned int timestep);                         // SteinhardtQl.cc:62-201
+        void accumulateSums(unsigned int timestep);                    // :62-171 + the sum over the ranks (:183-191): Q'_lm in m_scratch
         double m_rcut, m_ron;
         unsigned int m_lmax;
         std::shared_ptr<NeighborList> m_nlist;
@@ -295,7 +303,7 @@ class SteinhardtQl : public CollectiveVariable
             int mode;                                                 // half_nlist of the mtd_ql_* calls
             };
         Lists lists();
-        DeviceBuffer m_sym_head, m_sym_nneigh, m_sym_nlist;
+        DeviceBuffer m_sym_head, m_sym_nneigh, m_sym_nlist, m_sym_work;
         unsigned int m_sym_version;
         bool m_sym_ok;
     };
@@ -369,6 +377,13 @@ class IntegratorMetaDynamics
         void resetHistogram();                                         // :1195-1203
 
         //! this build's own knobs
+        //! Steps of the stand-alone run loop as a HIP graph (System::run): the number of consecutive update() calls after which
+        //! the sequence of launches repeats itself with the same arguments — lcm(2, stride): the mesh CV alternates between two
+        //! sets of tile cursors, a deposit comes every `stride` steps — or 0 when the steps cannot be replayed from a capture:
+        //! anything that reads a value back on the host or changes arguments from step to step (hills file, grid dumps, adaptive
+        //! widths, umbrellas, walkers, a domain decomposition's exchange numbers, box CVs, the potential energy, wrapped computes),
+        //! and pure lamellar sets, whose two-launch step measures SLOWER from a graph (profiles/r4/graph_ab.log).
+        unsigned int graphPeriod() const;
         void setFusedPath(bool enable) { m_allow_fused = enable; }     // default on: two launches per step for lamellar CVs
         bool usedFusedPath() const { return m_used_fused; }
         mtd_metad *getEngine() { return m_engine; }
@@ -439,13 +454,26 @@ class System
         System(std::shared_ptr<SystemDefinition> sysdef, unsigned int initial_tstep) : m_sysdef(sysdef), m_cur_tstep(initial_tstep) {}
         void setIntegrator(std::shared_ptr<IntegratorMetaDynamics> integrator) { m_integrator = integrator; }
         std::shared_ptr<IntegratorMetaDynamics> getIntegrator() { return m_integrator; }
+        ~System();
         void run(unsigned int nsteps);
         unsigned int getCurrentTimeStep() const { return m_cur_tstep; }
+        //! this build: replay runs of at least four periods from a HIP graph where the integrator allows it
+        //! (IntegratorMetaDynamics::graphPeriod).  OFF by default — measured slower than plain launches for every configuration of
+        //! BASELINE.json (profiles/r4/graph_ab.log); MTD_GRAPH=1 or setGraphMode(1) switches it on
+        void setGraphMode(int mode) { m_graph_mode = mode; }           // -1 default (environment), 0 off, 1 on
+        //! steps of the last run() that were replayed from a graph (0: plain launches), and the period of the step sequence
+        //! (a graph holds several periods, ~24 steps)
+        unsigned int lastRunGraphSteps() const { return m_last_graph_steps; }
+        unsigned int lastRunGraphPeriod() const { return m_last_graph_period; }
 
     private:
+        unsigned int runGraph(unsigned int nsteps, unsigned int period);
         std::shared_ptr<SystemDefinition> m_sysdef;
         std::shared_ptr<IntegratorMetaDynamics> m_integrator;
         unsigned int m_cur_tstep;
+        int m_graph_mode = -1;
+        hipStream_t m_graph_stream = nullptr;
+        unsigned int m_last_graph_steps = 0, m_last_graph_period = 0;
     };
 
 } // namespace mtdhost

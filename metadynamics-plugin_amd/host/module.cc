@@ -333,6 +333,7 @@ PYBIND11_MODULE(_metadynamics, m)
         // this build
         .def("setFusedPath", &IntegratorMetaDynamics::setFusedPath)
         .def("usedFusedPath", &IntegratorMetaDynamics::usedFusedPath)
+        .def("graphPeriod", &IntegratorMetaDynamics::graphPeriod)
         .def("getCurrentValues", &IntegratorMetaDynamics::getCurrentValues)
         .def("getBiasFactors", &IntegratorMetaDynamics::getBiasFactors)
         .def("getEngineHandle", [](IntegratorMetaDynamics &i) { return (size_t)i.getEngine(); });
@@ -345,7 +346,10 @@ PYBIND11_MODULE(_metadynamics, m)
         .def(py::init<std::shared_ptr<SystemDefinition>, unsigned int>())
         .def("setIntegrator", &System::setIntegrator)
         .def("run", &System::run, py::call_guard<py::gil_scoped_release>())
-        .def("getCurrentTimeStep", &System::getCurrentTimeStep);
+        .def("getCurrentTimeStep", &System::getCurrentTimeStep)
+        .def("setGraphMode", &System::setGraphMode)
+        .def("lastRunGraphSteps", &System::lastRunGraphSteps)
+        .def("lastRunGraphPeriod", &System::lastRunGraphPeriod);
 
     // the reference also exports the host-path class names (module.cc:29-31: export_LamellarOrderParameter,
     // export_OrderParameterMesh), which cv.py instantiates when the execution configuration has no GPU (cv.py:262-268,

@@ -188,6 +188,11 @@ _SIGNATURES = {
     "mtd_ql_accumulate_local": (C.c_int, [C.c_uint, _vp, C.c_int, C.POINTER(Box), _vp, _vp, _vp, C.c_int, C.c_double, C.c_double,
                                            C.c_uint, C.c_uint, C.c_uint, _vp, C.POINTER(_vp), _up, _vp]),
     "mtd_ql_finalize": (C.c_int, [C.c_int, C.c_uint, _dp, C.c_uint, _vp, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp), _vp]),
+    "mtd_ql_finalize_update_bias": (C.c_int, [_vp, C.c_int, C.c_uint, _dp, C.c_uint, _vp, C.c_uint, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp), _vp]),
+    "mtd_metad_grid_touched": (C.c_int, [_vp, _vp]),
+    "mtd_comm_pull_bytes": (C.c_size_t, [C.c_size_t]),
+    "mtd_comm_pull_attach": (C.c_int, [_vp, C.c_size_t, C.POINTER(_vp), C.POINTER(_vp)]),
+    "mtd_comm_allreduce_pull": (C.c_int, [_vp, _vp, C.c_size_t, _vp]),
     "mtd_ql_accumulate": (C.c_int, [C.c_uint, _vp, C.c_int, C.POINTER(Box), _vp, _vp, _vp, C.c_int, C.c_double, C.c_double, C.c_uint,
                                      C.c_uint, _dp, C.c_uint, _vp, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp), _vp]),
     "mtd_ql_set_half_list_exact": (C.c_int, [C.c_int]),

@@ -528,3 +528,99 @@ def test_umbrella_force_descends_the_umbrella_energy(api):
         assert max(energies[1:]) < energies[0] and min(energies) < 0.2 * energies[0], (name, energies)
         assert abs(values[-1] - cv0) < abs(values[0] - cv0)
         c.set_params(umbrella="no_umbrella")
+
+
+@pytest.mark.parametrize("kind,stride", [("mesh", 1), ("mesh", 3), ("steinhardt", 1), ("steinhardt", 2)])
+def test_graph_replay_matches_plain_launches(api, kind, stride, monkeypatch):
+    """System::run replays long runs from a HIP graph where the integrator allows it (IntegratorMetaDynamics::graphPeriod): one
+    period of lcm(2, stride) steps is captured after a settling period and replayed.  The replay must leave EXACTLY what the plain
+    launches leave — hill count, CV values, V, w, dV/ds, every cell of the bias grid, the forces: a captured sequence that is not
+    periodic (an extra deferred pass in the capture, the mesh's alternating cursor sets out of phase) would show here."""
+    import ctypes as C
+    from metadynamics import _abi
+    context, cv, integrate = api
+    monkeypatch.setenv("MTD_GRAPH_VERIFY", "1")
+    lib = _abi.load()
+
+    s_probe = [None]
+
+    def build():
+        if kind == "mesh":
+            N, L = 20000, 20.0
+            pos, types = util.snapshot_random(N, L, seed=21, modulated=True, dtype=np.float32)
+            pos = (np.mod(pos.astype(np.float64) + L / 2, L) - L / 2).astype(np.float32)
+            if s_probe[0] is None:                                   # one evaluation supplies the value the grid is laid around
+                context.initialize(pos, types, ["A", "B"], L, dtype=np.float32)
+                integrate.mode_metadynamics(dt=0.005, stride=1, mode="well_tempered", W=1.0, deltaT=7.0, T=1.0)
+                probe = cv.mesh(nx=32, mode={"A": 1.0, "B": -1.0})
+                probe.set_grid(0.0, 1.0, 8)
+                context.run(1)
+                s_probe[0] = probe.cpp_force.getCurrentValue(1)
+                context.current = None
+            sm = s_probe[0]
+            context.initialize(pos, types, ["A", "B"], L, dtype=np.float32)
+            meta = integrate.mode_metadynamics(dt=0.005, stride=stride, mode="well_tempered", W=1.0, deltaT=7.0, T=1.0)
+            lam = cv.lamellar(sigma=0.02, mode=dict(A=1.0, B=-1.0), lattice_vectors=util.CV1_VECTORS)
+            lam.set_grid(-0.6, 0.4, 48)
+            mesh = cv.mesh(nx=32, mode={"A": 1.0, "B": -1.0}, sigma=0.05 * abs(sm))
+            mesh.set_grid(0.25 * sm, 1.6 * sm, 40)
+            return meta, [lam, mesh]
+        pos, L = util.fcc_lattice(6)
+        pos = pos + np.random.default_rng(12).normal(0, 0.05, pos.shape)
+        N = len(pos)
+        context.initialize(pos, np.zeros(N, dtype=np.int32), ["A"], L, dtype=np.float64)
+        meta = integrate.mode_metadynamics(dt=0.005, stride=stride, mode="well_tempered", W=1.0, deltaT=7.0, T=1.0)
+        nl = cv.nlist_cell(r_cut=1.5)
+        nl.update()
+        st = cv.steinhardt(r_cut=1.4, r_on=1.2, lmax=6, Ql_ref=[0, 0, 0, 0, 1, 0, 1], nlist=nl, type="A", sigma=0.5)
+        st.set_grid(20.0, 60.0, 64)
+        return meta, [st]
+
+    def run(graph):
+        meta, cvs = build()
+        context.current.system.setGraphMode(1 if graph else 0)
+        context.run(3)                      # short: plain launches in both arms
+        assert context.current.system.lastRunGraphSteps() == 0
+        context.run(61)
+        integ = meta.cpp_integrator
+        t = context.current.system.getCurrentTimeStep()
+        h = C.c_void_p(integ.getEngineHandle())
+        G = lib.mtd_metad_num_elements(h)
+        arrays = {}
+        for which, name in enumerate(_abi.ARRAY_NAMES):
+            out = np.zeros(G, dtype=np.float64 if which < 6 else np.uint32)
+            _abi.check(lib.mtd_metad_get_array(h, which, out.ctypes.data, None))
+            arrays[name] = out
+        res = dict(cv=list(integ.getCurrentValues()), bias=list(integ.getBiasFactors()), V=integ.getLogValue("bias", t), w=integ.getLogValue("weight", t),
+                   n=integ.getNumGaussians(), arrays=arrays, F=[c.cpp_force.getForceArray().copy() for c in cvs],
+                   graph_steps=context.current.system.lastRunGraphSteps(), period=integ.graphPeriod(), t=t)
+        context.current = None
+        return res
+
+    plain, graph = run(False), run(True)
+    period = 2 * stride if stride % 2 else stride
+    assert plain["graph_steps"] == 0 and graph["period"] == period
+    assert graph["graph_steps"] >= 2 * period and graph["graph_steps"] % period == 0      # (a graph holds several periods)
+    assert graph["t"] == plain["t"] == 64 and graph["n"] == plain["n"] and plain["n"] >= 60 // stride
+    assert graph["cv"] == plain["cv"] and graph["bias"] == plain["bias"] and graph["V"] == plain["V"] and graph["w"] == plain["w"]
+    for name in _abi.ARRAY_NAMES:
+        assert np.array_equal(graph["arrays"][name], plain["arrays"][name], equal_nan=True), name
+    assert np.isfinite(plain["arrays"]["reweighted"]).all() and plain["arrays"]["grid"].max() > 0 and plain["V"] > 0     # (on the grid: a real bias)
+    for a, b in zip(graph["F"], plain["F"]):
+        assert np.array_equal(a, b) and np.abs(a).max() > 0
+
+
+def test_graph_replay_is_refused_where_steps_are_not_replayable(api, tmp_path):
+    """a hills file (host values every deposit), an umbrella, a pure lamellar set (two-launch step: slower from a graph): plain launches"""
+    context, cv, integrate = api
+    pos, types = util.snapshot_random(4000, 12.0, seed=3, modulated=True, dtype=np.float32)
+    context.initialize(pos, types, ["A", "B"], 12.0, dtype=np.float32)
+    meta = integrate.mode_metadynamics(dt=0.005, stride=1, mode="well_tempered", W=1.0, deltaT=7.0, T=1.0)
+    lam = cv.lamellar(sigma=0.02, mode=dict(A=1.0, B=-1.0), lattice_vectors=util.CV1_VECTORS)
+    lam.set_grid(-1.0, 1.0, 32)
+    context.current.system.setGraphMode(1)
+    context.run(40)
+    assert meta.cpp_integrator.graphPeriod() == 0 and context.current.system.lastRunGraphSteps() == 0 and meta.cpp_integrator.usedFusedPath()
+    lam.set_params(umbrella="harmonic", kappa=1.0, cv0=0.0)
+    context.run(40)
+    assert meta.cpp_integrator.graphPeriod() == 0 and context.current.system.lastRunGraphSteps() == 0

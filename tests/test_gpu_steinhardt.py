@@ -305,3 +305,87 @@ def test_deferred_grid_pass_rides_in_the_finalize_launch(abi, ref):
         assert vals[0] == pytest.approx(vals[-1], rel=1e-14)
     finally:
         g.close()
+
+
+@pytest.mark.parametrize("dtype,stride,mode,off_grid", [(np.float64, 1, "well_tempered", False), (np.float32, 2, "standard", False),
+                                                       (np.float64, 3, "well_tempered", True)])
+def test_ql_merged_launch_matches_separate_launches(abi, ref, dtype, stride, mode, off_grid):
+    """mtd_ql_finalize_update_bias (finalize step + scalar chain + first grid pass in ONE launch, the engine's deferred pass riding
+    in the force pass) against mtd_ql_accumulate + mtd_metad_update_bias + mtd_ql_forces on a moving snapshot: every grid array,
+    V, w, dV/ds, the hill count and the forces the same BITS (the grid-pass code of k_ql_finalize_chain is the twin of
+    k_fused_force's), deposit and non-deposit steps, a value that leaves the grid; and the separate path against the oracle"""
+    from test_gpu_metad import GpuMetad
+    lib = abi.load()
+    pos0, L = noisy_fcc(5, seed=3)
+    N = len(pos0)
+    types = np.zeros(N, dtype=np.int32)
+    rcut, ron, lmax, Ql_ref = 1.4, 1.2, 6, [0, 0, 0, 0, 1, 0, 1]
+    box, dt = abi.Box.make(L), abi.MTD_F32 if dtype == np.float32 else abi.MTD_F64
+    rng = np.random.default_rng(8)
+    snaps = [(pos0 + rng.normal(0, 0.01 * k, pos0.shape)).astype(dtype) for k in range(6)]
+    val0 = run_ref(ref, snaps[0].astype(np.float64), types, L, util.build_nlist(snaps[0].astype(np.float64), L, rcut + 0.15), rcut, ron, lmax, 0, Ql_ref)[0]
+    lo, hi = (0.6 * val0, 1.2 * val0) if not off_grid else (1.0005 * val0, 1.4 * val0)       # off_grid: the first values lie below the grid
+    kw = dict(sigma=[0.01 * val0], cv_min=[lo], cv_max=[hi], num_points=[96], W=1.3, T_shift=5.0, T=1.0, stride=stride, mode=mode)
+    ql = util.dbl_array(Ql_ref)
+
+    def run(merged):
+        g = GpuMetad(abi, **kw)
+        scratch = torch.zeros(lib.mtd_ql_scratch_doubles(lmax), dtype=torch.float64, device="cuda")
+        force = torch.zeros((N, 4), dtype=torch.float32 if dtype == np.float32 else torch.float64, device="cuda")
+        out = []
+        try:
+            for t, p in enumerate(snaps):
+                nl = util.build_nlist(p.astype(np.float64), L, rcut + 0.15)
+                d_pos = torch.from_numpy(util.pack_postype(p, types, dtype)).cuda()
+                d_head, d_nn, d_nl = (torch.from_numpy(x.astype(np.int32)).cuda() for x in nl)
+                geo = (N, abi.ptr(d_pos), dt, C.byref(box), abi.ptr(d_head), abi.ptr(d_nn), abi.ptr(d_nl), 0, rcut, ron, lmax, 0)
+                p_val = C.c_void_p()
+                if merged:
+                    sums, n_sums = C.c_void_p(), C.c_uint()
+                    abi.check(lib.mtd_ql_accumulate_local(*geo, N, abi.ptr(scratch), C.byref(sums), C.byref(n_sums), None))
+                    abi.check(lib.mtd_ql_finalize_update_bias(g.h, 0, lmax, ql, N, abi.ptr(scratch), t, C.byref(p_val), None, None, None))
+                else:
+                    abi.check(lib.mtd_ql_accumulate(*geo, ql, N, abi.ptr(scratch), C.byref(p_val), None, None, None))
+                    abi.check(lib.mtd_metad_set_cv_source(g.h, 0, p_val.value, 1, 1, 0, 1.0, 0.0))
+                    abi.check(lib.mtd_metad_update_bias(g.h, t, None))
+                abi.check(lib.mtd_ql_forces(N, abi.ptr(d_pos), abi.ptr(force), dt, C.byref(box), abi.ptr(d_head), abi.ptr(d_nn), abi.ptr(d_nl), 0,
+                                            rcut, ron, lmax, 0, ql, N, abi.ptr(scratch), lib.mtd_metad_bias_device(g.h), 0.0, None))
+                torch.cuda.synchronize()
+                st = g.state()
+                out.append(dict(st=st, F=force.cpu().numpy().copy(), arrays={n: g.array(n) for n in abi.ARRAY_NAMES}))
+        finally:
+            g.close()
+        return out
+
+    a, b = run(True), run(False)
+    for t, (x, y) in enumerate(zip(a, b)):
+        for k in ("cv", "bias"):
+            assert np.array_equal(x["st"][k], y["st"][k], equal_nan=True), (t, k, x["st"][k], y["st"][k])
+        for k in ("V", "w", "num_gaussians", "oob"):
+            assert x["st"][k] == y["st"][k] or (np.isnan(x["st"][k]) and np.isnan(y["st"][k])), (t, k, x["st"][k], y["st"][k])
+        for n in abi.ARRAY_NAMES:
+            assert np.array_equal(x["arrays"][n], y["arrays"][n], equal_nan=True), (t, n)
+        assert np.array_equal(x["F"], y["F"]), t
+    assert a[-1]["st"]["num_gaussians"] == len([t for t in range(len(snaps)) if t % stride == 0])
+    if off_grid:
+        assert a[0]["st"]["oob"] > 0                               # (the first values lie below the grid: V = 0 there, :677-683)
+    else:
+        assert abs(a[-1]["st"]["bias"][0]) > 0 and np.abs(a[-1]["F"][:, :3]).max() > 0
+    # the separate path against the oracle (grid driven with the device's values)
+    r = ref.Metad(**kw)
+    for t, y in enumerate(b):
+        bias = r.update_bias(t, y["st"]["cv"])
+        assert np.allclose(y["st"]["bias"], bias, rtol=1e-8, atol=1e-9 * max(1.0, np.abs(r.array("grid")).max())), t
+        assert y["st"]["V"] == pytest.approx(r.curr_bias, rel=1e-10, abs=1e-300)
+
+
+def test_ql_merged_launch_refuses_other_grids(abi):
+    """more than one variable on the grid: MTD_ERR_UNSUPPORTED (the caller then finalizes and updates the grid separately)"""
+    from test_gpu_metad import GpuMetad
+    lib = abi.load()
+    g = GpuMetad(abi, sigma=[0.1, 0.1], cv_min=[0.0, 0.0], cv_max=[1.0, 1.0], num_points=[8, 8])
+    scratch = torch.zeros(lib.mtd_ql_scratch_doubles(6), dtype=torch.float64, device="cuda")
+    try:
+        assert lib.mtd_ql_finalize_update_bias(g.h, 0, 6, util.dbl_array([0, 0, 0, 0, 1, 0, 1]), 10, abi.ptr(scratch), 0, None, None, None, None) == -2
+    finally:
+        g.close()

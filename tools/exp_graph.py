@@ -1,11 +1,10 @@
 #!/usr/bin/env python3
 """Developer tool (GPU box): the bias step as a HIP GRAPH against plain stream launches.
 
-Every configuration runs through the reference-shaped API (metadynamics.cv / integrate, C++ run loop System::run) on a
-stream of its own (ExecutionConfiguration::setStream: the null stream cannot be captured).  K consecutive steps are
-captured once (hipStreamBeginCapture around System::run(K - 1) = prepRun + K - 1 updates, i.e. K bias steps) and replayed;
-the same K steps as plain launches are timed beside it.  Timed regions are synchronised on both sides (wall clock), as the
-driver's are.  Fresh process per (config, mode), rounds interleaved.
+Every configuration runs through the reference-shaped API (metadynamics.cv / integrate, C++ run loop System::run): mode "graph" switches
+on System::run's own graph replay (whole periods captured after a settling period, ~24 steps per graph), "stream" runs plain launches
+on a stream of its own, "null" on the null stream.  Timed regions are synchronised on both sides (wall clock), as the driver's are.
+Fresh process per (config, mode), rounds interleaved.
 
 usage: exp_graph.py [rounds] [config ...]      config in {2, 3, 5}; worker: exp_graph.py --worker <config> <mode>
 """
@@ -81,29 +80,15 @@ def worker(config, mode):
     context.run(50)                     # registers the CVs, allocates, first deposits, mesh: the bin pipeline's plan
     sync()
     out = {}
-    for K, reps in ((20, 60), (2000, 5)):
-        if mode in ("stream", "null"):
-            def go():
-                sysm.run(K - 1)
-        else:
-            k_graph = 20                # a 20-step graph, replayed K / 20 times
-            graph, gexec = C.c_void_p(), C.c_void_p()
-            chk(hip.hipStreamBeginCapture(stream, 2), "hipStreamBeginCapture")                 # relaxed
-            try:
-                sysm.run(k_graph - 1)
-            finally:
-                rc = hip.hipStreamEndCapture(stream, C.byref(graph))
-            chk(rc, "hipStreamEndCapture")
-            n_nodes = C.c_size_t()
-            chk(hip.hipGraphGetNodes(graph, None, C.byref(n_nodes)), "hipGraphGetNodes")
-            out["nodes_per_%d_steps" % k_graph] = n_nodes.value
-            t0 = time.perf_counter()
-            chk(hip.hipGraphInstantiate(C.byref(gexec), graph, None, None, C.c_size_t(0)), "hipGraphInstantiate")
-            out["instantiate_us"] = 1e6 * (time.perf_counter() - t0)
-
-            def go():
-                for _ in range(K // k_graph):
-                    chk(hip.hipGraphLaunch(gexec, stream), "hipGraphLaunch")
+    # System::run(K) = prepRun + K updates.  prepRun re-evaluates at the timestep of the last update: a FULL step for cv.lamellar (it
+    # always recomputes, LamellarOrderParameter.h:75-79), one small launch for cv.mesh / cv.steinhardt (cached per timestep) — counted
+    # as K + 1 and K steps.  (The first version of this tool captured run(19) and counted 20 steps: for configs 3 and 5 that graph
+    # held 19 real steps, which read as a 5 % gain of the graph — profiles/r4/graph_ab.log.)
+    sysm.setGraphMode(1 if mode == "graph" else 0)
+    for K, reps in ((24, 40), (2000, 5)):
+        def go():
+            sysm.run(K)
+        steps = K + (1 if config == 2 else 0)
         for _ in range(3):
             go()
         sync()
@@ -113,9 +98,10 @@ def worker(config, mode):
             t0 = time.perf_counter()
             go()
             sync()
-            ts.append(1e6 * (time.perf_counter() - t0) / K)
+            ts.append(1e6 * (time.perf_counter() - t0) / steps)
         out["K%d_us_per_step_median" % K] = float(np.median(ts))
         out["K%d_us_per_step_min" % K] = float(np.min(ts))
+        out["K%d_graph_steps" % K] = sysm.lastRunGraphSteps()
     integ = meta.cpp_integrator
     out["hills"] = integ.getNumGaussians()
     out["cv"] = list(integ.getCurrentValues())
