@@ -42,6 +42,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <type_traits>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -1365,7 +1366,13 @@ __global__ __launch_bounds__(TP_THREADS) void k_tile_scatter(const MeshGeom g, c
                     // round to nearest integer through the mantissa (|value| < 2^51 by the choice of the scale): the 64-bit
                     // convert instruction sequence is ten times longer
                     const double shifted = wx[i] * wyz + 6755399441055744.0;                 // 1.5 * 2^52
+#ifdef MTD_EXP_LDS_NOCONFLICT
+                    // DIAGNOSTIC build (wrong sums): every lane of a wave adds to its own 8-byte word — no bank conflicts
+                    atomicAdd(&s_t[(threadIdx.x + TP_THREADS * ((k * 3 + j) * 3 + i)) % 6144u], (unsigned long long)(__double_as_longlong(shifted) - 0x4338000000000000ll));
+                    (void)row;
+#else
                     atomicAdd(&s_t[row + i], (unsigned long long)(__double_as_longlong(shifted) - 0x4338000000000000ll));
+#endif
                     }
                 }
         };
@@ -1578,8 +1585,14 @@ __global__ __launch_bounds__(TF_THREADS) void k_tile_forces(const MeshGeom g, co
 #pragma unroll
             for (int j = 0; j < 3; ++j)
                 {
+#ifdef MTD_EXP_LDS_NOCONFLICT
+                // DIAGNOSTIC build (wrong forces): consecutive lanes read consecutive words — no bank conflicts
+                const unsigned int row = (threadIdx.x + 3 * TF_THREADS * (k * 3 + j)) % 6000u + 0u * cib.y;
+                const double r0 = s_inv[row], r1 = s_inv[row + TF_THREADS], r2 = s_inv[(row + 2 * TF_THREADS) % 6144u];
+#else
                 const unsigned int row = cib.y + tg.hx * (j + tg.hy * k);
                 const double r0 = s_inv[row], r1 = s_inv[row + 1], r2 = s_inv[row + 2];
+#endif
                 const double aw = wxv[0] * r0 + wxv[1] * r1 + wxv[2] * r2;       // row sums with W and with W'
                 const double ad = dxv[0] * r0 + dxv[1] * r1 + dxv[2] * r2;
                 pd += wyv[j] * ad;
@@ -2185,47 +2198,105 @@ __global__ __launch_bounds__(XY_THREADS) void k_fft_xy_forward(const double *__r
             {
             const unsigned int idx = min(threadIdx.x + i * XY_THREADS, nx * pb - 1);   // clamped: see xy_fetch_columns
             const unsigned int u = idx >> pl.log2nx, p = idx & (nx - 1);
-            if (!TILES)
-                {
-                const size_t la = line_base + 2 * (batch * pb + u);
-                pre[i] = make_double2(real_in[la * nx + p], real_in[(la + 1) * nx + p]);
-                }
-            else
-                {
-                // rows gy, gy + 1 of this plane: every entry that stands for the two cells, integers added, one conversion each
-                const unsigned int gy = 2 * (batch * pb + u);
-                long long sum[2];
+            const size_t la = line_base + 2 * (batch * pb + u);
+            pre[i] = make_double2(real_in[la * nx + p], real_in[(la + 1) * nx + p]);
+            }
+        };
+    // TILES: the sources of a cell are its own tile's entry plus one per axis on which the cell is the first / last of its tile.
+    // Which lines of a thread's elements are first / last rows of a tile is the same for all its elements (xy_tiles_ok checks that
+    // the row step between a thread's elements and between batches is a multiple of the tile height), the plane's z sources are
+    // block-uniform, and the x halo concerns the first / last lane of every wave: so the loads are written with FIXED counts per
+    // (z, row class), every one of them issued before the first add — a conditional chain of loads and adds made the compiler
+    // wait for them one by one (162.7 us per step against 132.2, profiles/r4/mesh_ab.log).  The x-halo entry is loaded by every
+    // lane (lanes without one repeat their own entry's address: same cache line, no traffic) and masked.
+    auto fetch_tiles = [&](const unsigned int batch, auto z2c, auto yclsc)
+        {
+        constexpr bool Z2 = decltype(z2c)::value;
+        constexpr int YCLS = decltype(yclsc)::value;                 // 0: neither row of the pair borders a tile, 1: the first does, 2: the second
+        constexpr int NA = (YCLS == 1 ? 2 : 1) * (Z2 ? 2 : 1), NB = (YCLS == 2 ? 2 : 1) * (Z2 ? 2 : 1), NS = NA + NB;
+        constexpr int G = NS <= 2 ? XY_PREFETCH : (NS <= 4 ? XY_PREFETCH / 2 : 2);      // elements whose loads are in flight together
+        const long long *b = tl.buf;
+        const unsigned int oxe = x2 ? ox1 : ox0;
+        for (int i0 = 0; i0 < XY_PREFETCH; i0 += G)
+            {
+            long long m[G][NS], e[G][NS];
 #pragma unroll
-                for (int r = 0; r < 2; ++r)
+            for (int g = 0; g < G; ++g)
+                {
+                const int i = i0 + g;
+                if (i < XY_PREFETCH)
                     {
-                    unsigned int oy0, oy1;
-                    const bool y2 = xy_tile_src(tl, 1, gy + r, oy0, oy1);              // (wave-uniform: a wave holds one line pair)
-                    const long long *b = tl.buf;
-                    long long v = b[oz0 + oy0 + ox0];
-                    if (x2) v += b[oz0 + oy0 + ox1];
-                    if (y2)
+                    const unsigned int idx = min(threadIdx.x + i * XY_THREADS, nx * pb - 1);
+                    const unsigned int gy = 2 * (batch * pb + (idx >> pl.log2nx));
+                    unsigned int oa0, oa1, ob0, ob1;
+                    (void)xy_tile_src(tl, 1, gy, oa0, oa1);
+                    (void)xy_tile_src(tl, 1, gy + 1, ob0, ob1);
+                    unsigned int off[NS];
+                    int k = 0;
+                    off[k++] = oz0 + oa0;
+                    if (YCLS == 1) off[k++] = oz0 + oa1;
+                    if (Z2)
                         {
-                        v += b[oz0 + oy1 + ox0];
-                        if (x2) v += b[oz0 + oy1 + ox1];
+                        off[k++] = oz1 + oa0;
+                        if (YCLS == 1) off[k++] = oz1 + oa1;
                         }
-                    if (z2)
+                    off[k++] = oz0 + ob0;
+                    if (YCLS == 2) off[k++] = oz0 + ob1;
+                    if (Z2)
                         {
-                        v += b[oz1 + oy0 + ox0];
-                        if (x2) v += b[oz1 + oy0 + ox1];
-                        if (y2)
-                            {
-                            v += b[oz1 + oy1 + ox0];
-                            if (x2) v += b[oz1 + oy1 + ox1];
-                            }
+                        off[k++] = oz1 + ob0;
+                        if (YCLS == 2) off[k++] = oz1 + ob1;
                         }
-                    sum[r] = v;
+#pragma unroll
+                    for (int q = 0; q < NS; ++q)
+                        {
+                        m[g][q] = b[off[q] + ox0];
+                        e[g][q] = b[off[q] + oxe];
+                        }
                     }
-                pre[i] = make_double2((double)sum[0] * tl.inv_scale, (double)sum[1] * tl.inv_scale);
+                }
+#pragma unroll
+            for (int g = 0; g < G; ++g)
+                {
+                const int i = i0 + g;
+                if (i < XY_PREFETCH)
+                    {
+                    long long sa = 0, sb = 0;
+#pragma unroll
+                    for (int q = 0; q < NA; ++q) sa += m[g][q] + (x2 ? e[g][q] : 0ll);
+#pragma unroll
+                    for (int q = NA; q < NS; ++q) sb += m[g][q] + (x2 ? e[g][q] : 0ll);
+                    pre[i] = make_double2((double)sa * tl.inv_scale, (double)sb * tl.inv_scale);
+                    }
                 }
             }
         };
+    // the row class of this thread's elements (constant over them, see above)
+    int ycls = 0;
+    if (TILES)
+        {
+        const unsigned int gy0 = 2 * (threadIdx.x >> pl.log2nx), T = 1u << tl.log2t[1];
+        ycls = (gy0 & (T - 1)) == 0 ? 1 : (((gy0 + 1) & (T - 1)) == T - 1 ? 2 : 0);
+        }
+    auto fetch_any = [&](const unsigned int batch)
+        {
+        if (!TILES)
+            fetch(batch);
+        else if (z2)
+            {
+            if (ycls == 0) fetch_tiles(batch, std::true_type(), std::integral_constant<int, 0>());
+            else if (ycls == 1) fetch_tiles(batch, std::true_type(), std::integral_constant<int, 1>());
+            else fetch_tiles(batch, std::true_type(), std::integral_constant<int, 2>());
+            }
+        else
+            {
+            if (ycls == 0) fetch_tiles(batch, std::false_type(), std::integral_constant<int, 0>());
+            else if (ycls == 1) fetch_tiles(batch, std::false_type(), std::integral_constant<int, 1>());
+            else fetch_tiles(batch, std::false_type(), std::integral_constant<int, 2>());
+            }
+        };
     XY_STAMP(0, 0);
-    fetch(0);
+    fetch_any(0);
     xy_twiddles(TX, tw_x, tw_y, pl);
     for (unsigned int batch = 0; batch < n_batches; ++batch)
         {
@@ -2253,7 +2324,7 @@ __global__ __launch_bounds__(XY_THREADS) void k_fft_xy_forward(const double *__r
             }
         lds_barrier();
         XY_STAMP(0, 1 + 3 * min(batch, 1u));
-        if (batch + 1 < n_batches) fetch(batch + 1);             // in flight during the sweeps below
+        if (batch + 1 < n_batches) fetch_any(batch + 1);         // in flight during the sweeps below
         fft_dit_xy(X, TX, pl.log2nx, pl.d_pb, 0, xs);
         XY_STAMP(0, 2 + 3 * min(batch, 1u));
         // the two real lines of a pair, k_x columns of this part only, to their (bit-reversed) y rows of the column image
@@ -2977,17 +3048,16 @@ constexpr size_t XY_LDS_MAX = 160 * 1024;
 // least two cells wide (a coordinate then has at most two sources per axis), a thread's x position fixed over its elements
 bool xy_tiles_ok(const mtd_mesh *m, XYTiles &tl)
     {
-    // MEASURED SLOWER, opt-in (MTD_FFT_FROM_TILES=1): config 3 takes 162.7 us per step with it against 132.2 (alternating processes,
-    // profiles/r4/mesh_ab.log).  The combine launch (10 us) is gone, but the transform's register prefetch — twenty independent
-    // loads per thread in one memory round trip — becomes a chain of conditional loads and adds (own tile; +1 source on a tile's
-    // first / last row, on the first / last plane of a tile, in the first / last lane of every wave) that the compiler waits for
-    // one by one, in the launch whose load phase was already exposed; issuing every possible source unconditionally instead is
-    // sixteen loads per cell pair, more cycles of the vector L1 than the combine pass costs.  Same bits either way (tests).
+    // NOT FASTER, opt-in (MTD_FFT_FROM_TILES=1): config 3 takes 132.6 / 132.7 us per step with it against 132.2 / 131.7 (alternating
+    // processes, profiles/r4/mesh_ab.log).  The combine launch (10.1 us) is gone and the transform is exactly that much longer
+    // (29.2 us against 19.3): both blocks of a plane sum the whole plane's sources (6 eight-byte loads per cell pair on average
+    // where the plain kernel has 2), in the launch whose load phase was already exposed.  A first form with conditional loads and
+    // adds was 30 us SLOWER (162.7): the compiler waited for them one by one.  Same bits either way (tests run both).
     static const bool off = [] { const char *e = std::getenv("MTD_FFT_FROM_TILES"); return !(e && e[0] == '1'); }();
     if (off || !m->tile_path || !m->combine_two) return false;
     const TileGeom &tg = m->tg;
     const unsigned int dims[3] = {m->nx, m->ny, m->nz}, tws[3] = {tg.tx, tg.ty, tg.tz}, nts[3] = {tg.ntx, tg.nty, tg.ntz};
-    if ((unsigned int)XY_THREADS % m->nx) return false;
+    if ((unsigned int)XY_THREADS % m->nx || tg.ty < 4) return false;    // (ty >= 4: only ONE row of a line pair can border a tile)
     std::memset(&tl, 0, sizeof(tl));
     for (int a = 0; a < 3; ++a)
         {
@@ -3644,7 +3714,9 @@ int mtd_mesh_spectral(mtd_mesh *m, const mtd_box *box, unsigned int n_global, co
     const bool xy = !xy_off && xy_lds_ok && xy_plan(m, 0, xy_f, xy_lds_f) && xy_plan(m, 1, xy_i, xy_lds_i);
     XYTiles tiles;
     std::memset(&tiles, 0, sizeof(tiles));
-    if (xy && !m->rho_valid && xy_tiles_ok(m, tiles))
+    // (the row class of a thread's elements must not change over its elements nor over the batches: k_fft_xy_forward<true>)
+    const bool tile_rows_ok = xy && m->tg.ty && (2 * ((unsigned int)XY_THREADS / m->nx)) % m->tg.ty == 0 && (2 * xy_f.pb) % m->tg.ty == 0;
+    if (xy && tile_rows_ok && !m->rho_valid && xy_tiles_ok(m, tiles))
         {
         // the assignment left the mesh in the per-tile images (mtd_mesh_compute_cv): the transform sums them itself
         k_fft_xy_forward<true><<<m->nz * XY_PARTS, XY_THREADS, xy_lds_f, s>>>(nullptr, m->d_f, m->d_tw[0], m->d_tw[1], xy_f, tiles);
@@ -3733,7 +3805,8 @@ int mtd_mesh_compute_cv(mtd_mesh *m, unsigned int n_particles, const void *d_pos
     XYTiles tl_probe;
     size_t lds_probe = 0;
     static const bool xy_off = [] { const char *e = std::getenv("MTD_FFT_XY"); return e && e[0] == '0'; }();
-    const bool from_tiles = m->tile_path && !xy_off && xy_plan(m, 0, xy_probe, lds_probe) && xy_tiles_ok(m, tl_probe);
+    const bool from_tiles = m->tile_path && !xy_off && xy_plan(m, 0, xy_probe, lds_probe) && xy_tiles_ok(m, tl_probe) && m->tg.ty &&
+                            (2 * ((unsigned int)XY_THREADS / m->nx)) % m->tg.ty == 0 && (2 * xy_probe.pb) % m->tg.ty == 0;
     int rc = mesh_assign_local(m, n_particles, d_postype, dtype, box, stream, !from_tiles);
     if (rc) return rc;
     return mtd_mesh_spectral(m, box, n_global, d_partials, n_partials, stream);
