@@ -234,3 +234,73 @@ def test_fast_trig_only_inside_the_instructions_domain(abi, ref):
     F_fast = gpu_forces(abi, cvs, pt, box, [0.7], fast=True)[0]
     F_acc = gpu_forces(abi, cvs, pt, box, [0.7], fast=False)[0]
     assert np.array_equal(F_fast, F_acc)
+
+
+def test_trig_mode_per_set(abi, ref):
+    """The trigonometry mode is a property of the CV SET (mtd_lamellar_set::trig_mode); the process switch is only the default of
+    sets that leave it open.  Two sets with different modes evaluated side by side in one process, under BOTH values of the process
+    default: each gives bit for bit what the process-wide switch gave in its mode, and both meet the oracle; the host classes carry
+    the mode per variable (cv.lamellar.set_trig_mode) and a fused launch runs accurately if any of its variables asks to."""
+    lib = abi.load()
+    N, L = 50000, 30.0
+    pos, types = util.snapshot_random(N, L, seed=11, modulated=True, dtype=np.float32)
+    pt = util.pack_postype(pos, types, np.float32)
+    box, rbox = _box(abi, ref, L)
+    cvs = [(util.CV1_VECTORS, util.MODE_AB)]
+    d_pos = torch.from_numpy(pt).cuda()
+
+    def run(set_mode, process_default):
+        abi.check(lib.mtd_lamellar_set_fast_trig(int(process_default)))
+        lset = abi.LamellarSet.make(cvs, trig_mode=set_mode)
+        scratch = torch.zeros(lib.mtd_lamellar_scratch_doubles(N), dtype=torch.float64, device="cuda")
+        n_part = C.c_uint(0)
+        abi.check(lib.mtd_lamellar_cv_partials(C.byref(lset), N, abi.ptr(d_pos), abi.MTD_F32, C.byref(box), abi.ptr(scratch), C.byref(n_part), None))
+        out = torch.zeros(1, dtype=torch.float64, device="cuda")
+        abi.check(lib.mtd_reduce_partials(abi.ptr(scratch), n_part.value, 1, 1, 1.0 / N, 0.0, abi.ptr(out), None))
+        force = torch.zeros((N, 4), dtype=torch.float32, device="cuda")
+        fptr = (C.c_void_p * 1)(force.data_ptr())
+        d_bias = torch.tensor([0.7], dtype=torch.float64, device="cuda")
+        abi.check(lib.mtd_lamellar_forces(C.byref(lset), N, abi.ptr(d_pos), fptr, abi.MTD_F32, N, abi.ptr(d_bias), C.byref(box), None))
+        torch.cuda.synchronize()
+        abi.check(lib.mtd_lamellar_set_fast_trig(0))
+        return out.item(), force.cpu().numpy()
+
+    hw_global, acc_global = run(0, 1), run(0, 0)                       # the process-wide switch, as before
+    assert hw_global[0] != acc_global[0] or not np.array_equal(hw_global[1], acc_global[1])      # (the two modes are distinguishable)
+    for default in (0, 1):
+        hw, acc = run(1, default), run(2, default)                      # per-set modes, whatever the default says
+        assert hw[0] == hw_global[0] and np.array_equal(hw[1], hw_global[1])
+        assert acc[0] == acc_global[0] and np.array_equal(acc[1], acc_global[1])
+    opt = util.oracle_postype(pos, types)
+    s_ref = ref.lamellar_cv(util.CV1_VECTORS, opt, util.MODE_AB, rbox)
+    F_ref = ref.lamellar_forces(util.CV1_VECTORS, opt, util.MODE_AB, rbox, 0.7)
+    for s, F in (hw_global, acc_global):
+        assert s == pytest.approx(s_ref, rel=1e-6)
+        check_forces(F.astype(np.float64), F_ref)
+    bad = abi.LamellarSet.make(cvs, trig_mode=7)
+    n_part = C.c_uint(0)
+    assert lib.mtd_lamellar_cv_partials(C.byref(bad), N, abi.ptr(d_pos), abi.MTD_F32, C.byref(box), abi.ptr(d_pos), C.byref(n_part), None) == -1
+
+    # host classes: two lamellar CVs with different modes in one fused step = the accurate functions for the launch
+    from metadynamics import context, cv, integrate
+    try:
+        res = {}
+        for modes in (("hardware", "accurate"), ("accurate", "accurate"), ("hardware", "hardware")):
+            abi.check(lib.mtd_lamellar_set_fast_trig(1))
+            context.initialize(pos, types, ["A", "B"], L, dtype=np.float32)
+            meta = integrate.mode_metadynamics(dt=0.005, stride=1, mode="well_tempered", W=1.0, deltaT=7.0, T=1.0)
+            cs = []
+            for i, (vecs, mode) in enumerate(zip((util.CV1_VECTORS, util.CV2_VECTORS), modes)):
+                c = cv.lamellar(sigma=0.02, mode=dict(A=1.0, B=-1.0), lattice_vectors=vecs, name="c%d" % i)
+                c.set_grid(-1.0, 1.0, 48)
+                c.set_trig_mode(mode)
+                cs.append(c)
+            context.run(2)
+            assert meta.cpp_integrator.usedFusedPath()
+            res[modes] = list(meta.cpp_integrator.getCurrentValues())
+            context.current = None
+        assert res[("hardware", "accurate")] == res[("accurate", "accurate")]
+        assert res[("hardware", "hardware")] != res[("accurate", "accurate")]
+    finally:
+        context.current = None
+        abi.check(lib.mtd_lamellar_set_fast_trig(0))

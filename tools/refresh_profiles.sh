@@ -57,6 +57,13 @@ if [[ " $WHAT " == *" sharded "* ]]; then
   timeout -k 10 400 python3 bench.py --gpus 2 --particles 500000 > $O/rehearsal2.log 2>&1; grep '^{"metric"' $O/rehearsal2.log | tail -1 > $O/bench_rehearsal_2ranks_weak.json
   timeout -k 10 400 python3 bench.py --gpus 2 --scaling strong --particles 1000000 > $O/rehearsal2s.log 2>&1; grep '^{"metric"' $O/rehearsal2s.log | tail -1 > $O/bench_rehearsal_2ranks_strong.json
   timeout -k 10 400 python3 bench.py --gpus 2 --walkers --particles 500000 --steps 500 --warmup 50 > $O/rehearsal2w.log 2>&1; grep '^{"metric"' $O/rehearsal2w.log | tail -1 > $O/bench_rehearsal_2walkers.json
+  # configs 3 and 5 domain decomposed inside the C++ host classes (two processes on this GPU: the code path is real, the numbers mean nothing)
+  timeout -k 10 400 python3 bench.py --config 3 --gpus 2 --particles 500000 --steps 200 --warmup 20 > $O/rehearsal_c3r.log 2>&1; grep '^{"metric"' $O/rehearsal_c3r.log | tail -1 > $O/bench_rehearsal_config3_replicated.json
+  timeout -k 10 400 python3 bench.py --config 3 --gpus 2 --particles 500000 --steps 200 --warmup 20 --mesh slab > $O/rehearsal_c3s.log 2>&1; grep '^{"metric"' $O/rehearsal_c3s.log | tail -1 > $O/bench_rehearsal_config3_slab.json
+  timeout -k 10 400 python3 bench.py --config 5 --gpus 2 --steps 200 --warmup 20 > $O/rehearsal_c5.log 2>&1; grep '^{"metric"' $O/rehearsal_c5.log | tail -1 > $O/bench_rehearsal_config5.json
+  # the same entry at N = 1 (the single-GPU lines of configs 3 and 5 through bench.py --config)
+  timeout -k 10 400 python3 bench.py --config 3 > $O/config3_n1.log 2>&1; grep '^{"metric"' $O/config3_n1.log | tail -1 > $O/bench_config3_n1.json
+  timeout -k 10 400 python3 bench.py --config 5 > $O/config5_n1.log 2>&1; grep '^{"metric"' $O/config5_n1.log | tail -1 > $O/bench_config5_n1.json
 fi
 set +x
 ls -la $O
