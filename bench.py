@@ -152,6 +152,7 @@ import torch
 import util
 from metadynamics import _abi
 
+
 CVS = [(util.CV1_VECTORS, util.MODE_AB), (util.CV2_VECTORS, util.MODE_AB)]
 
 
@@ -950,8 +951,55 @@ def main():
     elif walkers:
         barrier()
         host = WalkerEngine(eng.pos_np, eng.types_np, eng.L, args.stride, args.fast_trig, dist, dtype=np_dtype)
-    # (measured BEFORE the timed region: the per-launch figures are then taken on a GPU in the same state as the timed steps
-    # and the timed region starts on clocks that are already up)
+    def run_steps(k):
+        if host is not None:
+            if isinstance(host, HostEngine):
+                host.run(k - 1)             # run(k) = prepRun (one bias update) + k updates: exactly k bias steps
+            else:
+                host.run(k)
+        else:
+            for _ in range(k):
+                eng.step()
+
+    # A stretch of plain, untimed steps in front of the warm-up: building the host-API system left the GPU idle for ~0.1 s, and after
+    # 50 ms of idling a region of 20 steps runs 1.5 us per step slower, the next one still 1 us (tools/k20_shape_probe.py).
+    for _ in range(8):
+        run_steps(250)
+        barrier()
+    barrier()                              # ranks enter the first exchange together (the mailbox waits are bounded)
+    if args.warmup > 0:
+        run_steps(args.warmup)
+    barrier()
+    t0 = time.perf_counter()
+    run_steps(args.steps)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    st = host.state() if host is not None else eng.state()
+    # steady state: the same loop over >= 2000 steps in the same process (a timed region has a fixed cost of ~40 us —
+    # doorbell on an idle queue, completion signal — which is 2 us per step at K = 20 and nothing at K = 2000)
+    steady = None
+    if not args.no_variants:
+        k_steady = max(2000, args.steps)
+        barrier()
+        t1 = time.perf_counter()
+        run_steps(k_steady)
+        barrier()
+        steady = (time.perf_counter() - t1, k_steady)
+        st = host.state() if host is not None else eng.state()
+    # the driver's call times ONE region of K steps; the same bracket ten more times shows where that one sample sits
+    more_regions = None
+    if not args.no_variants and dist is None:
+        more_regions = []
+        for _ in range(10):
+            barrier()
+            t2 = time.perf_counter()
+            run_steps(args.steps)
+            barrier()
+            more_regions.append(1e3 * (time.perf_counter() - t2) / args.steps)
+        st = host.state() if host is not None else eng.state()
+    # (measured AFTER the timed regions since round 4: two events around every launch leave the queue in a state in which the
+    # following plain steps run ~2.5 us slower for thousands of steps — tools/k20_barrier_probe.py, tools/k20_shape_probe.py: regions
+    # of 20 steps take 19.4-19.7 us per step whatever ran before them, 21-22 after event traffic or after 50 ms of idling)
     # dominant kernel (launch B, the force pass): per-launch durations over the same loop from HIP events on the launch stream.
     # Fused path: every launch carries its own start / stop events (hipExtLaunchKernelGGL, armed by mtd_profile_force_begin):
     # the begin and end of that dispatch and nothing else — no subtraction.  Two cross-checks are reported beside it: the
@@ -1019,53 +1067,6 @@ def main():
         alt["event_pair_minus_empty_pair_us"] = float(np.mean(pair[pair <= 3.0 * np.median(pair)]))
     alt["empty_event_pair_us"] = ev_overhead_us
 
-    def run_steps(k):
-        if host is not None:
-            if isinstance(host, HostEngine):
-                host.run(k - 1)             # run(k) = prepRun (one bias update) + k updates: exactly k bias steps
-            else:
-                host.run(k)
-        else:
-            for _ in range(k):
-                eng.step()
-
-    # The per-launch measurements above put two events around every launch; the queue works through such traffic more slowly
-    # for a while after it has stopped (tools/k20_barrier_probe.py).  A stretch of plain, untimed steps in front of the warm-up
-    # lets the timed region start from the state a production run is in.
-    for _ in range(8):
-        run_steps(100)
-        barrier()
-    barrier()                              # ranks enter the first exchange together (the mailbox waits are bounded)
-    if args.warmup > 0:
-        run_steps(args.warmup)
-    barrier()
-    t0 = time.perf_counter()
-    run_steps(args.steps)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    st = host.state() if host is not None else eng.state()
-    # steady state: the same loop over >= 2000 steps in the same process (a timed region has a fixed cost of ~40 us —
-    # doorbell on an idle queue, completion signal — which is 2 us per step at K = 20 and nothing at K = 2000)
-    steady = None
-    if not args.no_variants:
-        k_steady = max(2000, args.steps)
-        barrier()
-        t1 = time.perf_counter()
-        run_steps(k_steady)
-        barrier()
-        steady = (time.perf_counter() - t1, k_steady)
-        st = host.state() if host is not None else eng.state()
-    # the driver's call times ONE region of K steps; the same bracket ten more times shows where that one sample sits
-    more_regions = None
-    if not args.no_variants and dist is None:
-        more_regions = []
-        for _ in range(10):
-            barrier()
-            t2 = time.perf_counter()
-            run_steps(args.steps)
-            barrier()
-            more_regions.append(1e3 * (time.perf_counter() - t2) / args.steps)
-        st = host.state() if host is not None else eng.state()
     if dist is not None:
         vals = [elapsed, steady[0] if steady else 0.0]
         tt = torch.tensor(vals, dtype=torch.float64, device=ctl_device())
