@@ -428,6 +428,11 @@ int mtd_mesh_assign(mtd_mesh *m, unsigned int n_particles, const void *d_postype
  * slack planned from the previous snapshot's exact counts).  *n_overflow: particles of a bin step that did not fit
  * their tile's planned segment and travelled through the overflow list (correct, only slower; 0 in a well-planned step). */
 int mtd_mesh_assign_info(mtd_mesh *m, int *pipeline, unsigned int *n_overflow, mtd_stream_t stream);
+/* Which kernels ran the last forward transform (mtd_mesh_spectral / mtd_mesh_compute_cv): 0 separate x and y passes (meshes whose
+ * planes do not fit the LDS, sizes that are not powers of two), 1 x and y of a plane in one launch on the combined mesh, 2 the same
+ * launch reading the assignment's per-tile images itself (meshes 128 cells wide after mtd_mesh_compute_cv: no combine launch;
+ * MTD_FFT_FROM_TILES=0 switches it off).  The results are the same bits in all three. */
+int mtd_mesh_transform_info(mtd_mesh *m, int *forward);
 int mtd_mesh_exchange_buffer(mtd_mesh *m, double **d_buffer, size_t *count);
 int mtd_mesh_spectral(mtd_mesh *m, const mtd_box *box, unsigned int n_global, const double **d_partials, unsigned int *n_partials,
                       mtd_stream_t stream);

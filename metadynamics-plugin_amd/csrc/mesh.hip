@@ -2184,13 +2184,9 @@ __global__ __launch_bounds__(XY_THREADS) void k_fft_xy_forward(const double *__r
     double2 pre[XY_PREFETCH];
     // TILES: this thread's x position is the same for every element it fetches (XY_THREADS is a multiple of nx): its x entries and the
     // plane's z entries once per block
-    unsigned int ox0 = 0, ox1 = 0, oz0 = 0, oz1 = 0;
-    bool x2 = false, z2 = false;
-    if (TILES)
-        {
-        x2 = xy_tile_src(tl, 0, threadIdx.x & (nx - 1), ox0, ox1);
-        z2 = xy_tile_src(tl, 2, plane, oz0, oz1);
-        }
+    unsigned int oz0 = 0, oz1 = 0;
+    bool z2 = false;
+    if (TILES) z2 = xy_tile_src(tl, 2, plane, oz0, oz1);
     auto fetch = [&](const unsigned int batch)
         {
 #pragma unroll
@@ -2203,79 +2199,102 @@ __global__ __launch_bounds__(XY_THREADS) void k_fft_xy_forward(const double *__r
             }
         };
     // TILES: the sources of a cell are its own tile's entry plus one per axis on which the cell is the first / last of its tile.
-    // Which lines of a thread's elements are first / last rows of a tile is the same for all its elements (xy_tiles_ok checks that
-    // the row step between a thread's elements and between batches is a multiple of the tile height), the plane's z sources are
-    // block-uniform, and the x halo concerns the first / last lane of every wave: so the loads are written with FIXED counts per
-    // (z, row class), every one of them issued before the first add — a conditional chain of loads and adds made the compiler
-    // wait for them one by one (162.7 us per step against 132.2, profiles/r4/mesh_ab.log).  The x-halo entry is loaded by every
-    // lane (lanes without one repeat their own entry's address: same cache line, no traffic) and masked.
+    // A thread takes TWO adjacent cells of a line pair per slot pair (slots 2 i and 2 i + 1: positions 2 lane and 2 lane + 1 of the
+    // pair u = wave + 8 i): adjacent cells of a row are adjacent entries of a tile image, so one 16-byte load serves both — half
+    // the load instructions of one cell per lane, and it was their number (six eight-byte loads per cell pair where the plain
+    // kernel has two), not the bytes, that made the first forms slower (profiles/r4/mesh_ab.log).  Which rows of a thread's pairs
+    // are first / last rows of a tile is the same for all of them (their row step, 16, and the batches' are multiples of the tile
+    // height: xy_tiles_ok), the plane's z sources are block-uniform: the loads are written with FIXED counts per (z, row class),
+    // all of them issued before the first add (a conditional chain of loads and adds made the compiler wait for them one by one).
+    // The x halo concerns four lanes of a wave (cells 0, 63, 64, 127): one eight-byte load more per source, which every lane issues
+    // (lanes without a halo repeat their own entry's address: same cache line) and masks.
+    struct __attribute__((aligned(8))) ll2 { long long a, b; };
+    constexpr int TSLOTS = 8;                                          // slots in use: 4 line pairs x 2 cells (nx = 128, 32 pairs per batch)
+    const unsigned int t_lane = threadIdx.x & 63u, t_wave = threadIdx.x >> 6;
+    unsigned int tx0 = 0, tx1 = 0, txe = 0;                            // entry of cell 2 lane; (unused); the halo entry of this lane, if any
+    int edge_j = -1;                                                   // which of the two cells has an x halo (-1: none)
+    if (TILES)
+        {
+        unsigned int o0, o1;
+        const bool e0 = xy_tile_src(tl, 0, 2 * t_lane, o0, o1);
+        tx0 = o0;
+        txe = o0;
+        if (e0) { txe = o1; edge_j = 0; }
+        unsigned int p0, p1;
+        const bool e1 = xy_tile_src(tl, 0, 2 * t_lane + 1, p0, p1);
+        tx1 = p0;
+        if (e1) { txe = p1; edge_j = 1; }
+        (void)tx1;
+        }
     auto fetch_tiles = [&](const unsigned int batch, auto z2c, auto yclsc)
         {
         constexpr bool Z2 = decltype(z2c)::value;
         constexpr int YCLS = decltype(yclsc)::value;                 // 0: neither row of the pair borders a tile, 1: the first does, 2: the second
         constexpr int NA = (YCLS == 1 ? 2 : 1) * (Z2 ? 2 : 1), NB = (YCLS == 2 ? 2 : 1) * (Z2 ? 2 : 1), NS = NA + NB;
-        constexpr int G = NS <= 2 ? XY_PREFETCH : (NS <= 4 ? XY_PREFETCH / 2 : 2);      // elements whose loads are in flight together
+        constexpr int NP = TSLOTS / 2;                                // line pairs per thread and batch
+        constexpr int G = NS <= 3 ? NP : 2;                           // line pairs whose loads are in flight together
         const long long *b = tl.buf;
-        const unsigned int oxe = x2 ? ox1 : ox0;
-        for (int i0 = 0; i0 < XY_PREFETCH; i0 += G)
+        for (int i0 = 0; i0 < NP; i0 += G)
             {
-            long long m[G][NS], e[G][NS];
+            ll2 m[G][NS];
+            long long e[G][NS];
 #pragma unroll
             for (int g = 0; g < G; ++g)
                 {
-                const int i = i0 + g;
-                if (i < XY_PREFETCH)
+                const unsigned int u = t_wave + 8u * (unsigned int)(i0 + g);
+                const unsigned int gy = 2 * (batch * pb + min(u, pb - 1));
+                unsigned int oa0, oa1, ob0, ob1;
+                (void)xy_tile_src(tl, 1, gy, oa0, oa1);
+                (void)xy_tile_src(tl, 1, gy + 1, ob0, ob1);
+                unsigned int off[NS];
+                int k = 0;
+                off[k++] = oz0 + oa0;
+                if (YCLS == 1) off[k++] = oz0 + oa1;
+                if (Z2)
                     {
-                    const unsigned int idx = min(threadIdx.x + i * XY_THREADS, nx * pb - 1);
-                    const unsigned int gy = 2 * (batch * pb + (idx >> pl.log2nx));
-                    unsigned int oa0, oa1, ob0, ob1;
-                    (void)xy_tile_src(tl, 1, gy, oa0, oa1);
-                    (void)xy_tile_src(tl, 1, gy + 1, ob0, ob1);
-                    unsigned int off[NS];
-                    int k = 0;
-                    off[k++] = oz0 + oa0;
-                    if (YCLS == 1) off[k++] = oz0 + oa1;
-                    if (Z2)
-                        {
-                        off[k++] = oz1 + oa0;
-                        if (YCLS == 1) off[k++] = oz1 + oa1;
-                        }
-                    off[k++] = oz0 + ob0;
-                    if (YCLS == 2) off[k++] = oz0 + ob1;
-                    if (Z2)
-                        {
-                        off[k++] = oz1 + ob0;
-                        if (YCLS == 2) off[k++] = oz1 + ob1;
-                        }
+                    off[k++] = oz1 + oa0;
+                    if (YCLS == 1) off[k++] = oz1 + oa1;
+                    }
+                off[k++] = oz0 + ob0;
+                if (YCLS == 2) off[k++] = oz0 + ob1;
+                if (Z2)
+                    {
+                    off[k++] = oz1 + ob0;
+                    if (YCLS == 2) off[k++] = oz1 + ob1;
+                    }
 #pragma unroll
-                    for (int q = 0; q < NS; ++q)
-                        {
-                        m[g][q] = b[off[q] + ox0];
-                        e[g][q] = b[off[q] + oxe];
-                        }
+                for (int q = 0; q < NS; ++q)
+                    {
+                    __builtin_memcpy(&m[g][q], b + (off[q] + tx0), sizeof(ll2));      // cells 2 lane and 2 lane + 1: adjacent entries
+                    e[g][q] = b[off[q] + txe];
                     }
                 }
 #pragma unroll
             for (int g = 0; g < G; ++g)
                 {
-                const int i = i0 + g;
-                if (i < XY_PREFETCH)
+                long long sa0 = 0, sa1 = 0, sb0 = 0, sb1 = 0;
+#pragma unroll
+                for (int q = 0; q < NA; ++q)
                     {
-                    long long sa = 0, sb = 0;
-#pragma unroll
-                    for (int q = 0; q < NA; ++q) sa += m[g][q] + (x2 ? e[g][q] : 0ll);
-#pragma unroll
-                    for (int q = NA; q < NS; ++q) sb += m[g][q] + (x2 ? e[g][q] : 0ll);
-                    pre[i] = make_double2((double)sa * tl.inv_scale, (double)sb * tl.inv_scale);
+                    sa0 += m[g][q].a + (edge_j == 0 ? e[g][q] : 0ll);
+                    sa1 += m[g][q].b + (edge_j == 1 ? e[g][q] : 0ll);
                     }
+#pragma unroll
+                for (int q = NA; q < NS; ++q)
+                    {
+                    sb0 += m[g][q].a + (edge_j == 0 ? e[g][q] : 0ll);
+                    sb1 += m[g][q].b + (edge_j == 1 ? e[g][q] : 0ll);
+                    }
+                pre[2 * (i0 + g)] = make_double2((double)sa0 * tl.inv_scale, (double)sb0 * tl.inv_scale);
+                pre[2 * (i0 + g) + 1] = make_double2((double)sa1 * tl.inv_scale, (double)sb1 * tl.inv_scale);
                 }
             }
         };
-    // the row class of this thread's elements (constant over them, see above)
+    // the row class of this thread's line pairs (constant over them, see above)
     int ycls = 0;
     if (TILES)
         {
-        const unsigned int gy0 = 2 * (threadIdx.x >> pl.log2nx), T = 1u << tl.log2t[1];
+        const unsigned int gy0 = 2 * t_wave, T = 1u << tl.log2t[1];
         ycls = (gy0 & (T - 1)) == 0 ? 1 : (((gy0 + 1) & (T - 1)) == T - 1 ? 2 : 0);
         }
     auto fetch_any = [&](const unsigned int batch)
@@ -2301,11 +2320,24 @@ __global__ __launch_bounds__(XY_THREADS) void k_fft_xy_forward(const double *__r
     for (unsigned int batch = 0; batch < n_batches; ++batch)
         {
         const unsigned int pair0 = batch * pb;
-#pragma unroll
-        for (int i = 0; i < XY_PREFETCH; ++i)
+        if (!TILES)
             {
-            const unsigned int idx = threadIdx.x + i * XY_THREADS;
-            if (idx < nx * pb) X[(idx & (nx - 1)) * xs + (idx >> pl.log2nx)] = pre[i];
+#pragma unroll
+            for (int i = 0; i < XY_PREFETCH; ++i)
+                {
+                const unsigned int idx = threadIdx.x + i * XY_THREADS;
+                if (idx < nx * pb) X[(idx & (nx - 1)) * xs + (idx >> pl.log2nx)] = pre[i];
+                }
+            }
+        else
+            {
+            // (slot 2 i + j: cell 2 lane + j of line pair wave + 8 i)
+#pragma unroll
+            for (int sl = 0; sl < TSLOTS; ++sl)
+                {
+                const unsigned int u = t_wave + 8u * (unsigned int)(sl >> 1), p = 2 * t_lane + (unsigned int)(sl & 1);
+                if (u < pb) X[p * xs + u] = pre[sl];
+                }
             }
         lds_barrier();
         // rows to bit-reversed order, lanes along a row: written straight to their bit-reversed rows, the lanes of a wave
@@ -2942,6 +2974,7 @@ struct mtd_mesh
     unsigned int plan_n;
     TileLists lists;                // where the last assignment left the tiles' particles (the force pass walks the same lists)
     int last_pipeline;              // of the last assignment: 0 cells, 1 counting, 2 bin (mtd_mesh_assign_info)
+    int last_forward;               // of the last forward transform: 0 separate x / y passes, 1 k_fft_xy_forward on the combined mesh, 2 on the tile images
     int rho_valid;                  // the real mesh d_rho holds the last assignment (0: it lives in the tile images only — mtd_mesh_compute_cv
                                     // lets the forward transform read those; anyone who needs d_rho runs the combine pass first: mesh_need_rho)
     double amax;               // max |mode coefficient| (fixed-point scale)
@@ -3048,12 +3081,14 @@ constexpr size_t XY_LDS_MAX = 160 * 1024;
 // least two cells wide (a coordinate then has at most two sources per axis), a thread's x position fixed over its elements
 bool xy_tiles_ok(const mtd_mesh *m, XYTiles &tl)
     {
-    // NOT FASTER, opt-in (MTD_FFT_FROM_TILES=1): config 3 takes 132.6 / 132.7 us per step with it against 132.2 / 131.7 (alternating
-    // processes, profiles/r4/mesh_ab.log).  The combine launch (10.1 us) is gone and the transform is exactly that much longer
-    // (29.2 us against 19.3): both blocks of a plane sum the whole plane's sources (6 eight-byte loads per cell pair on average
-    // where the plain kernel has 2), in the launch whose load phase was already exposed.  A first form with conditional loads and
-    // adds was 30 us SLOWER (162.7): the compiler waited for them one by one.  Same bits either way (tests run both).
-    static const bool off = [] { const char *e = std::getenv("MTD_FFT_FROM_TILES"); return !(e && e[0] == '1'); }();
+    // The default where the shapes allow it (MTD_FFT_FROM_TILES=0 switches it off): config 3 takes 129.3 / 128.9 us per step with it
+    // against 135.0 / 135.1 on the same box (alternating processes, profiles/r4/mesh_ab.log), the combine launch (10.1 us) is gone.
+    // History: with one cell per lane and eight-byte loads the transform grew by exactly the combine launch's time (29.2 us against
+    // 19.3: 6 loads per cell pair where the plain kernel has 2, in the launch whose load phase was already exposed); a form with
+    // conditional loads and adds was 30 us SLOWER (the compiler waited for them one by one).  Two cells per lane and 16-byte loads
+    // (k_fft_xy_forward<true>) halve the load instructions.  Same bits in every form (tests run both).
+    const char *ft_env = std::getenv("MTD_FFT_FROM_TILES");            // (read per call: a test runs both forms in one process)
+    const bool off = ft_env && ft_env[0] == '0';
     if (off || !m->tile_path || !m->combine_two) return false;
     const TileGeom &tg = m->tg;
     const unsigned int dims[3] = {m->nx, m->ny, m->nz}, tws[3] = {tg.tx, tg.ty, tg.tz}, nts[3] = {tg.ntx, tg.nty, tg.ntz};
@@ -3679,6 +3714,13 @@ int mtd_mesh_assign_info(mtd_mesh *m, int *pipeline, unsigned int *n_overflow, m
     return MTD_SUCCESS;
     }
 
+int mtd_mesh_transform_info(mtd_mesh *m, int *forward)
+    {
+    if (!m || !forward) return MTD_ERR_INVALID_ARGUMENT;
+    *forward = m->last_forward;
+    return MTD_SUCCESS;
+    }
+
 int mtd_mesh_exchange_buffer(mtd_mesh *m, double **d_buffer, size_t *count)
     {
     if (!m || !d_buffer || !count) return MTD_ERR_INVALID_ARGUMENT;
@@ -3715,12 +3757,14 @@ int mtd_mesh_spectral(mtd_mesh *m, const mtd_box *box, unsigned int n_global, co
     XYTiles tiles;
     std::memset(&tiles, 0, sizeof(tiles));
     // (the row class of a thread's elements must not change over its elements nor over the batches: k_fft_xy_forward<true>)
-    const bool tile_rows_ok = xy && m->tg.ty && (2 * ((unsigned int)XY_THREADS / m->nx)) % m->tg.ty == 0 && (2 * xy_f.pb) % m->tg.ty == 0;
+    // (two cells per lane: a wave spans a line of 128 cells; a thread's line pairs are 8 apart, the batches 32: multiples of the tile height)
+    const bool tile_rows_ok = xy && m->nx == 128 && XY_THREADS == 512 && xy_f.pb == 32 && m->tg.ty && 16 % m->tg.ty == 0 && (2 * xy_f.pb) % m->tg.ty == 0;
     if (xy && tile_rows_ok && !m->rho_valid && xy_tiles_ok(m, tiles))
         {
         // the assignment left the mesh in the per-tile images (mtd_mesh_compute_cv): the transform sums them itself
         k_fft_xy_forward<true><<<m->nz * XY_PARTS, XY_THREADS, xy_lds_f, s>>>(nullptr, m->d_f, m->d_tw[0], m->d_tw[1], xy_f, tiles);
         MTD_LAUNCH_CHECK();
+        m->last_forward = 2;
         }
     else if (xy)
         {
@@ -3728,6 +3772,7 @@ int mtd_mesh_spectral(mtd_mesh *m, const mtd_box *box, unsigned int n_global, co
         if (rc) return rc;
         k_fft_xy_forward<false><<<m->nz * XY_PARTS, XY_THREADS, xy_lds_f, s>>>(m->d_rho, m->d_f, m->d_tw[0], m->d_tw[1], xy_f, tiles);
         MTD_LAUNCH_CHECK();
+        m->last_forward = 1;
         }
     else
         {
@@ -3737,6 +3782,7 @@ int mtd_mesh_spectral(mtd_mesh *m, const mtd_box *box, unsigned int n_global, co
         MTD_LAUNCH_CHECK();
         rc = launch_fft_y(m, m->d_f, 0, s);
         if (rc) return rc;
+        m->last_forward = 0;
         }
     const FftPass pz = fft_z_pass(m);
     SlabArgs none;
@@ -3806,7 +3852,7 @@ int mtd_mesh_compute_cv(mtd_mesh *m, unsigned int n_particles, const void *d_pos
     size_t lds_probe = 0;
     static const bool xy_off = [] { const char *e = std::getenv("MTD_FFT_XY"); return e && e[0] == '0'; }();
     const bool from_tiles = m->tile_path && !xy_off && xy_plan(m, 0, xy_probe, lds_probe) && xy_tiles_ok(m, tl_probe) && m->tg.ty &&
-                            (2 * ((unsigned int)XY_THREADS / m->nx)) % m->tg.ty == 0 && (2 * xy_probe.pb) % m->tg.ty == 0;
+                            m->nx == 128 && XY_THREADS == 512 && xy_probe.pb == 32 && 16 % m->tg.ty == 0 && (2 * xy_probe.pb) % m->tg.ty == 0;
     int rc = mesh_assign_local(m, n_particles, d_postype, dtype, box, stream, !from_tiles);
     if (rc) return rc;
     return mtd_mesh_spectral(m, box, n_global, d_partials, n_partials, stream);

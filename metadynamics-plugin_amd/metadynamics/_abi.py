@@ -109,6 +109,7 @@ _SIGNATURES = {
     "mtd_rccl_last_error": (C.c_char_p, []),
     "mtd_mesh_clear_rider": (C.c_int, [_vp, C.POINTER(C.c_int)]),
     "mtd_mesh_assign_info": (C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_uint), _vp]),
+    "mtd_mesh_transform_info": (C.c_int, [_vp, C.POINTER(C.c_int)]),
     "mtd_mesh_set_lamellar_rider": (C.c_int, [_vp, _vp, _vp, _vp, C.c_uint, _vp, C.POINTER(C.c_uint), _vp]),
     "mtd_ql_symmetrize_half_list": (C.c_int, [C.c_uint, _vp, _vp, _vp, _vp, _vp, _vp, C.c_size_t, C.POINTER(C.c_size_t), _vp]),
     "mtd_debug_index_decode": (C.c_int, [C.c_uint, _vp, C.c_uint, _vp, _vp, _vp]),

@@ -376,6 +376,44 @@ def test_mesh_config3_size(abi, ref):
         g.close()
 
 
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("N,dims", [(3, (128, 16, 16)), (30011, (128, 32, 64)), (400009, (128, 128, 128)), (20011, (128, 64, 8)), (3, (128, 128, 16))])
+def test_forward_transform_from_tile_images_against_combined_mesh(abi, monkeypatch, dtype, N, dims):
+    """k_fft_xy_forward<true> (the default on meshes 128 cells wide: the transform sums the tile images' halo entries itself, two
+    cells per lane with 16-byte loads, no combine launch) against k_tile_combine_rows + k_fft_xy_forward<false>
+    (MTD_FFT_FROM_TILES=0): the sums are integers, so the CV, the spectrum's mesh, the combined mesh read back afterwards and
+    every particle's force are the same BITS; over two snapshots (counting pipeline, then the bin pipeline's other cursor set)."""
+    L = 21.0
+    box = abi.Box.make(L)
+    dt = abi.MTD_F32 if dtype == np.float32 else abi.MTD_F64
+    snaps = []
+    for seed in (3, 4):
+        pos, types = util.snapshot_random(N, L, seed=seed + N, modulated=True, dtype=dtype)
+        snaps.append(torch.from_numpy(util.pack_postype(pos, types, dtype)).cuda())
+    out = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("MTD_FFT_FROM_TILES", mode)
+        g = GpuMesh(abi, dims, [1.0, -0.6], N)
+        try:
+            res = []
+            for d_pos in snaps:
+                s = g.cv(d_pos, dt, box, N)
+                fwd = C.c_int(-1)
+                abi.check(g.lib.mtd_mesh_transform_info(g.h, C.byref(fwd)))
+                # (the tile form needs batches of 32 line pairs: at least 64 rows; smaller planes keep the combine launch)
+                assert fwd.value == (2 if mode == "1" and dims[1] >= 64 else 1)
+                F = g.forces(d_pos, dt, box, N, 0.7)
+                res.append((s, F.copy(), g.array(0).copy(), g.array(1).copy()))
+            out[mode] = res
+        finally:
+            g.close()
+    for a, b in zip(out["1"], out["0"]):
+        assert a[0] == b[0] and a[0] != 0.0
+        for x, y in zip(a[1:], b[1:]):
+            assert np.array_equal(x, y)
+        assert np.abs(a[1]).max() > 0
+
+
 @pytest.mark.parametrize("tilt", [{}, dict(xy=0.1, xz=-0.05, yz=0.2)])
 def test_qmax_virial_table(abi, ref, tilt):
     """q_max / sq_max log quantities (OrderParameterMesh.cc:1108-1179), convolution-kernel table
