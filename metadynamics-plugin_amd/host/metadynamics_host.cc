@@ -1241,13 +1241,37 @@ void IntegratorMetaDynamics::updateBiasPotential(unsigned int timestep)
             if (ridden) setMixedLamellarSources(lam_slots, n_partials);
             }
         if (!lam_slots.empty() && !ridden) mixedLamellarCvPass(lam_slots, ls);
+        // The grid-engine launch of such a step (chain + grid pass + lamellar forces, 11 us, HBM-bound) needs the CV sums, which
+        // are complete after the mesh's z pass; the inverse x/y transform that follows (17 us, one LDS-filling block per CU,
+        // latency-bound) needs nothing of the engine: the engine's launch can go to a second stream BESIDE the inverse transform.
+        // Two events: "z pass done" (mtd_mesh_set_cv_event) lets the second stream start; "engine done" holds the main stream
+        // before the first kernel that reads the bias factors.
+        // MEASURED SLOWER, opt-in (MTD_MESH_OVERLAP=1): config 3 takes 141.1 / 142.9 / 142.8 us per step with it against 126.7 /
+        // 126.3 / 126.5 on one stream (alternating processes on one box, profiles/r4/mesh_ab.log) — the two cross-queue
+        // dependencies cost more than twice what the overlap of an 11 us launch can return, as round 3's wider form did (mini_hoomd.h).
+        static const bool overlap_on = [] { const char *e = std::getenv("MTD_MESH_OVERLAP"); return e && e[0] == '1'; }();
+        hipStream_t beside = nullptr;
+        if (ridden && !side && overlap_on)
+            {
+            beside = m_exec_conf->getSideStream(true);
+            carrier->setCvEvent(m_exec_conf->getEvent(1));
+            }
         // a variable that is alone on the grid may run the engine's update fused with the tail of its own value (cv.steinhardt)
         const bool self_updated = m_variables.size() == 1 && !m_multiple_walkers && m_variables[0].m_cv->enqueueValueAndBias(timestep, m_engine);
         for (unsigned int i = 0; i < m_variables.size() && !self_updated; ++i)
             if (std::find(lam_slots.begin(), lam_slots.end(), i) == lam_slots.end())
                 m_variables[i].m_cv->enqueueCurrentValue(timestep, m_engine, i);
         if (ridden && carrier->clearRider())
+            {
             mixedLamellarCvPass(lam_slots, ls);                        // (nothing consumed the riders: the sums are formed by launch A after all)
+            if (beside) hip_check(hipEventRecord(m_exec_conf->getEvent(1), s), "hipEventRecord");      // (no z pass ran either)
+            }
+        if (beside)
+            {
+            carrier->setCvEvent(nullptr);
+            hip_check(hipStreamWaitEvent(beside, m_exec_conf->getEvent(1), 0), "hipStreamWaitEvent");
+            ls = beside;
+            }
         if (side)
             {
             if (hooked)
@@ -1259,9 +1283,9 @@ void IntegratorMetaDynamics::updateBiasPotential(unsigned int timestep)
         if (!lam_slots.empty())
             {
             mixedLamellarForcePass(lam_slots, timestep, ls);
-            if (side)
+            if (side || beside)
                 {
-                hip_check(hipEventRecord(m_exec_conf->getEvent(2), side), "hipEventRecord");       // bias factors, grid arrays, lamellar forces
+                hip_check(hipEventRecord(m_exec_conf->getEvent(2), ls), "hipEventRecord");         // bias factors, grid arrays, lamellar forces
                 hip_check(hipStreamWaitEvent(s, m_exec_conf->getEvent(2), 0), "hipStreamWaitEvent");
                 }
             }

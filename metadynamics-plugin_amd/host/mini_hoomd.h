@@ -133,10 +133,12 @@ class ExecutionConfiguration
         //! the main stream by the three events below.  OFF unless MTD_SIDE_STREAM=1: measured at config 3 (10^6 particles,
         //! 128^3 mesh + one lamellar CV) the step takes 187.9 us with it against 180.6 us on one stream — the kernels it lets
         //! run side by side are all memory-bound, and three cross-stream events cost more than the overlap returns.
-        hipStream_t getSideStream()
+        //! (unconditional = true: the stream itself, whatever the switch says — the integrator's narrower use of it, one launch
+        //! beside the mesh's inverse transform, is decided there)
+        hipStream_t getSideStream(bool unconditional = false)
             {
             static const bool on = [] { const char *e = std::getenv("MTD_SIDE_STREAM"); return e && e[0] == '1'; }();
-            if (!on) return nullptr;
+            if (!on && !unconditional) return nullptr;
             if (!m_side)
                 {
                 hip_check(hipStreamCreateWithFlags(&m_side, hipStreamNonBlocking), "hipStreamCreateWithFlags");
