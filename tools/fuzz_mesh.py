@@ -22,6 +22,10 @@ while time.time() - t0 < budget:
         t_print = time.time()
         print("fuzz_mesh: %d cases so far, Q9 events %d" % (it, q9_events), flush=True)
     dims = tuple(int(rng.choice(DIMS)) for _ in range(3))
+    if rng.random() < 0.15:
+        # meshes 128 cells wide with at least 64 rows: the forward transform reads the tile images itself (k_fft_xy_forward<true>)
+        # where the tiles divide the axes, and falls back to the combine launch where they do not (nz = 4, 20)
+        dims = (128, int(rng.choice([64, 128])), int(rng.choice([4, 8, 16, 20, 24])))
     N = int(rng.choice([0, 1, 2, 37, 500, 4000, 20000]))
     Ls = tuple(float(x) for x in rng.uniform(3.0, 15.0, 3))
     tilt = dict(xy=float(rng.uniform(-0.3, 0.3)), xz=float(rng.uniform(-0.3, 0.3)), yz=float(rng.uniform(-0.3, 0.3))) if rng.random() < 0.5 else {}
