@@ -892,7 +892,7 @@ def main():
 
     def barrier():
         # (plain synchronise: recording an event and polling it first measured ~1 us per step SLOWER at K = 20 —
-        # tools/k20_barrier_probe.py, 22.6 against 23.5 us — and the slower state outlasts the event traffic by thousands of steps)
+        # tools/diag/k20_barrier_probe.py, 22.6 against 23.5 us — and the slower state outlasts the event traffic by thousands of steps)
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
@@ -943,7 +943,7 @@ def main():
         eng.exchange = "%s process group (packed grid increments, 4 G elements per deposit)" % dist.get_backend()
     if driver == "host":
         # every piece of set-up comes first — building the host-API system copies the snapshot again and leaves the GPU idle for
-        # ~0.1 s, after which the first milliseconds of work run on lowered clocks (tools/ramp_probe.py: +6-8 % per step after
+        # ~0.1 s, after which the first milliseconds of work run on lowered clocks (tools/diag/ramp_probe.py: +6-8 % per step after
         # 20-200 ms of idling, and W = 5 warm-up steps are 0.1 ms of work)
         barrier()                          # ranks enter the first exchange (prepRun's deposit) together
         host = HostEngine(eng.pos_np, eng.types_np, eng.L, n_global, args.stride, args.fast_trig, path, dtype=np_dtype,
@@ -962,7 +962,7 @@ def main():
                 eng.step()
 
     # A stretch of plain, untimed steps in front of the warm-up: building the host-API system left the GPU idle for ~0.1 s, and after
-    # 50 ms of idling a region of 20 steps runs 1.5 us per step slower, the next one still 1 us (tools/k20_shape_probe.py).
+    # 50 ms of idling a region of 20 steps runs 1.5 us per step slower, the next one still 1 us (tools/diag/k20_shape_probe.py).
     for _ in range(8):
         run_steps(250)
         barrier()
@@ -998,7 +998,7 @@ def main():
             more_regions.append(1e3 * (time.perf_counter() - t2) / args.steps)
         st = host.state() if host is not None else eng.state()
     # (measured AFTER the timed regions since round 4: two events around every launch leave the queue in a state in which the
-    # following plain steps run ~2.5 us slower for thousands of steps — tools/k20_barrier_probe.py, tools/k20_shape_probe.py: regions
+    # following plain steps run ~2.5 us slower for thousands of steps — tools/diag/k20_barrier_probe.py, tools/diag/k20_shape_probe.py: regions
     # of 20 steps take 19.4-19.7 us per step whatever ran before them, 21-22 after event traffic or after 50 ms of idling)
     # dominant kernel (launch B, the force pass): per-launch durations over the same loop from HIP events on the launch stream.
     # Fused path: every launch carries its own start / stop events (hipExtLaunchKernelGGL, armed by mtd_profile_force_begin):

@@ -116,13 +116,13 @@ __global__ __launch_bounds__(PULL_THREADS) void k_pull_gather(const PullK p, dou
     }
 
 // Uncached device buffers are never handed back to the runtime while the process lives.  Measured with a stand-alone
-// program that contains no code of this library (tools/probe_uncached.hip, log in profiles/r2/uncached_reuse_probe.log;
+// program that contains no code of this library (tools/diag/probe_uncached.hip, log in profiles/r2/uncached_reuse_probe.log;
 // ROCm 7.2, gfx950): once a range of device addresses has lived as a hipDeviceMallocUncached allocation and has been freed,
 // an ORDINARY hipMalloc that lands on it is no longer coherent between the L2 and HBM — kernels see what kernels wrote, but a
 // copy engine (hipMemcpy to the host) reads stale HBM under it, and host-to-device copies (twiddle tables, mode
 // coefficients) can be shadowed by stale L2 lines: 77 of 480 regions came back with wrong contents, none before the first
 // uncached life.  That is what round 1's slab fuzzing hit (a later mesh on those addresses read garbage tables and, with
-// garbage particle offsets, faulted) — with this library's own kernels in bounds (the replay tools/diag_slab_fault.py maps
+// garbage particle offsets, faulted) — with this library's own kernels in bounds (the replay tools/diag/diag_slab_fault.py maps
 // every allocation; same wrong results from the stand-alone probe).  The other direction exists as well: PLAIN loads from an
 // uncached buffer can hit stale L2 lines of an earlier ordinary life of its addresses, so every read of an exported buffer
 // goes past the L2 (system-scope loads: comm_device.hpp ld_exported) and nothing is transformed in place in one.
@@ -132,7 +132,7 @@ struct PooledBuffer { void *p; size_t bytes; bool in_use; };
 std::vector<PooledBuffer> g_uncached_pool;
 std::mutex g_uncached_mutex;
 
-// diagnostic switches (tools/diag_slab_fault.py): MTD_COMM_POOL=0 hands released buffers back to the runtime (reproduces the
+// diagnostic switches (tools/diag/diag_slab_fault.py): MTD_COMM_POOL=0 hands released buffers back to the runtime (reproduces the
 // hazard above), MTD_TRACE_ALLOC=1 prints every allocation
 bool pool_off() { const char *e = std::getenv("MTD_COMM_POOL"); return e && e[0] == '0'; }
 bool trace_on() { const char *e = std::getenv("MTD_TRACE_ALLOC"); return e && e[0] == '1'; }

@@ -1,7 +1,7 @@
 // Developer micro-benchmark (GPU box): what does the FIRST pass of a wave through straight-line code cost on gfx950?
 // A kernel of KB kilobytes of s_nop (4 bytes, one cycle each) run `iters` times in a loop by 256 blocks x 8 waves (one block per CU,
 // like the mesh transforms): time(iters = 2) - time(iters = 1) is a warm pass, time(iters = 1) - launch floor a cold one.
-// build: hipcc --offload-arch=gfx950 -O3 -o tools/bin/icache tools/ubench/icache.hip
+// build: hipcc --offload-arch=gfx950 -O3 -o tools/bin/icache tools/diag/icache.hip
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <vector>

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Developer tool (GPU box): the driver's call (bench.py --steps 20 --warmup 5) under runtime wait knobs, alternating fresh processes.
-# usage: tools/k20_env_probe.sh [rounds]     output: one line per run (official region, the ten repeats' median / min, steady state)
+# usage: tools/diag/k20_env_probe.sh [rounds]     output: one line per run (official region, the ten repeats' median / min, steady state)
 cd "$GRAFT_REPO_ROOT" || exit 1
 mkdir -p gpurun_out/r4
 R=${1:-8}

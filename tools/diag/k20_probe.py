@@ -3,7 +3,7 @@
 (System::run in C++) and the C-ABI driver (a Python loop of two launches per step), bracketed exactly as bench.py does.
 usage: k20_probe.py"""
 import os, sys, time
-root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [root, os.path.join(root, "metadynamics-plugin_amd"), os.path.join(root, "tests")]
 import numpy as np, torch
 import bench

@@ -3,7 +3,7 @@
 lengths, each bracketed by synchronise like bench.py's, printed as us per step: is it the FIRST region after a region of another
 length (or after a pause) that pays, whatever its own length?"""
 import os, sys, time
-root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [root, os.path.join(root, "metadynamics-plugin_amd"), os.path.join(root, "tests")]
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 import numpy as np, torch

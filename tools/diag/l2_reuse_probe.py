@@ -4,7 +4,7 @@ twice per step (same time step: the second only deposits another hill) — the s
 same block -> particle mapping read 13 us earlier, i.e. on the same XCDs.  Per-launch durations from the launch's own events.
 usage: l2_reuse_probe.py"""
 import ctypes as C, os, sys
-root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [root, os.path.join(root, "metadynamics-plugin_amd"), os.path.join(root, "tests")]
 import numpy as np, torch
 import bench

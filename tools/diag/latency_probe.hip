@@ -1,7 +1,7 @@
 // Developer tool (not product): calibrates fixed per-kernel costs on MI355X so the step structure can be
 // chosen from measurements: back-to-back launch cost of trivial kernels, cost of dependent global
 // round trips, block reductions, double exp chains, kernarg->LDS staging.
-//   hipcc --offload-arch=gfx950 -O3 -o /tmp/latency_probe tools/latency_probe.hip && /tmp/latency_probe
+//   hipcc --offload-arch=gfx950 -O3 -o /tmp/latency_probe tools/diag/latency_probe.hip && /tmp/latency_probe
 #include <hip/hip_runtime.h>
 
 #include <cmath>

@@ -1,6 +1,6 @@
 // Developer probe (GPU box): exact_div (csrc/exact_div.hpp: multiply + four FMAs with a host reciprocal) against the hardware
 // double division, bit for bit, over random numerators for divisors of the kinds mesh.hip::locate uses (box lengths, mesh
-// dimensions) and adversarial ones.  build: hipcc --offload-arch=gfx950 -O2 -ffp-contract=on -Imetadynamics-plugin_amd/csrc tools/probe_div.hip -o tools/bin/probe_div
+// dimensions) and adversarial ones.  build: hipcc --offload-arch=gfx950 -O2 -ffp-contract=on -Imetadynamics-plugin_amd/csrc tools/diag/probe_div.hip -o tools/bin/probe_div
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>

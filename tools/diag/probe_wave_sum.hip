@@ -1,6 +1,6 @@
 // Developer tool (GPU box): wave_sum (DPP + v_readlane, mtd_device.hpp) against the xor butterfly it replaces, bit for bit,
 // on random floats and doubles (wide range of magnitudes and signs), and the quad broadcasts chain_wave uses.
-// build: hipcc --offload-arch=gfx950 -O3 -I include -I metadynamics-plugin_amd/csrc tools/probe_wave_sum.hip -o tools/bin/probe_wave_sum
+// build: hipcc --offload-arch=gfx950 -O3 -I include -I metadynamics-plugin_amd/csrc tools/diag/probe_wave_sum.hip -o tools/bin/probe_wave_sum
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>

@@ -2,7 +2,7 @@
 """Developer tool (GPU box): per-step duration of the headline step for the first steps after an idle gap of the queue
 (events around every step).  usage: ramp_probe.py"""
 import os, sys, time
-root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [root, os.path.join(root, "metadynamics-plugin_amd"), os.path.join(root, "tests")]
 import numpy as np, torch
 import bench
