@@ -428,6 +428,18 @@ int mtd_mesh_assign(mtd_mesh *m, unsigned int n_particles, const void *d_postype
  * slack planned from the previous snapshot's exact counts).  *n_overflow: particles of a bin step that did not fit
  * their tile's planned segment and travelled through the overflow list (correct, only slower; 0 in a well-planned step). */
 int mtd_mesh_assign_info(mtd_mesh *m, int *pipeline, unsigned int *n_overflow, mtd_stream_t stream);
+/* The end of a step of a MIXED set — one mesh variable (grid variable `mesh_slot`) and the lamellar CVs of `set` (grid variables
+ * slots[0 .. set->n_cv)) — in ONE launch: what mtd_fused_force_pass_slots (scalar chain on the CV sums -> bias factors, first grid
+ * pass, lamellar forces) followed by mtd_mesh_forces with the mesh's device bias factor do in two (OrderParameterMesh.cc:925-968,
+ * IntegratorMetaDynamics.cc:329-588, LamellarOrderParameterGPU.cu:60-118).  The chain runs in wave 0 of every block of the mesh's
+ * force pass while the other waves stage their tile; every block streams a share of the particles for the lamellar forces and the
+ * first blocks take the grid pass.  Same results as the two calls (engine state and lamellar forces to the last bits of a
+ * contraction, mesh forces bitwise).  MTD_ERR_UNSUPPORTED where the shapes do not allow it (cell-level mesh pipeline, an engine with a
+ * mailbox, more than three grid variables, more 256-cell grid blocks than mesh tiles, MTD_MESH_FORCE_MERGED=0): make the two calls. */
+int mtd_mesh_forces_update_bias(mtd_mesh *mesh, mtd_metad *engine, unsigned int mesh_slot, const mtd_lamellar_set *set,
+                                const unsigned int *slots, unsigned int n_particles, const void *d_postype, void *d_force_mesh,
+                                void *const *d_force_lamellar, int dtype, unsigned int n_global, const mtd_box *global_box,
+                                unsigned int timestep, mtd_stream_t stream);
 /* Which kernels ran the last forward transform (mtd_mesh_spectral / mtd_mesh_compute_cv): 0 separate x and y passes (meshes whose
  * planes do not fit the LDS, sizes that are not powers of two), 1 x and y of a plane in one launch on the combined mesh, 2 the same
  * launch reading the assignment's per-tile images itself (meshes 128 cells wide after mtd_mesh_compute_cv: no combine launch;

@@ -1479,6 +1479,94 @@ __global__ __launch_bounds__(256) void k_tile_combine_rows(const MeshGeom g, con
 
 constexpr int TF_THREADS = MTD_TF_THREADS;        // two blocks of eight waves per CU (128 VGPRs): one stages its tile while the other sums
 
+// Re(inv) of a tile + halo into LDS by NT threads (thread `tid` of them): loads into registers first (tile_stage_load: a dozen
+// instructions per element, every lane busy, all loads of a thread issued before its first LDS store), stores behind them
+template<int NT> struct TileStage
+    {
+    static constexpr int E = (TP_HMAX + NT - 1) / NT;
+    double v[E];
+    unsigned int dst[E];                                               // ~0u: nothing to stage
+    };
+
+template<int NT>
+__device__ __forceinline__ void tile_stage_load(TileStage<NT> &st, const unsigned int tid, const unsigned int n_rows, const unsigned int wxn,
+                                                const unsigned int *s_grow, const unsigned short *s_lrow, const unsigned short *s_gx,
+                                                const double *__restrict__ inv)
+    {
+    const unsigned int n_img = n_rows * wxn;
+    static_assert(TP_HMAX < 12288 && TP_HMAX * (TP_X + 2) <= (1 << 20), "multiply-shift division of the flat image index");
+    const unsigned int inv_w = ((1u << 20) + wxn - 1) / wxn;           // idx / wxn = (idx * inv_w) >> 20: exact while idx * wxn < 2^20 (wxn >= 3: no overflow)
+#pragma unroll
+    for (int e = 0; e < TileStage<NT>::E; ++e)
+        {
+        const unsigned int idx = tid + e * NT;
+        st.v[e] = 0.0;
+        st.dst[e] = ~0u;
+        if (idx < n_img)
+            {
+            const unsigned int row = (idx * inv_w) >> 20, lx = idx - row * wxn;
+            st.v[e] = inv[s_grow[row] + s_gx[lx]];
+            st.dst[e] = s_lrow[row] + lx;
+            }
+        }
+    }
+
+template<int NT>
+__device__ __forceinline__ void tile_stage_store(const TileStage<NT> &st, double *s_inv)
+    {
+#pragma unroll
+    for (int e = 0; e < TileStage<NT>::E; ++e)
+        if (st.dst[e] != ~0u) s_inv[st.dst[e]] = st.v[e];
+    }
+
+// the force on one particle from its record (k_tile_scatter) and Re(inv) of its tile + halo in LDS; s = 2 / N x bias factor (:861)
+template<typename S4>
+__device__ __forceinline__ void tile_force_of(const MeshGeom &g, const TileGeom &tg, const double *s_inv, const double *s_mode,
+                                              const double *__restrict__ mode, const double4 &cur, const double s, S4 *__restrict__ force)
+    {
+    typedef typename scalar4_traits<S4>::scalar scalar;
+    const unsigned int bt = (unsigned int)__double2hiint(cur.w);          // the record of k_tile_scatter
+    const uint2 cib = make_uint2((unsigned int)__double2loint(cur.w), bt & 0xffffu);
+    const double a = mode_of(s_mode, mode, bt >> 16), sx = cur.x, sy = cur.y, sz = cur.z;
+    double wxv[3], wyv[3], wzv[3], dxv[3], dyv[3], dzv[3];
+    tsc3_deriv(sx, wxv, dxv);
+    tsc3_deriv(sy, wyv, dyv);
+    tsc3_deriv(sz, wzv, dzv);
+    // contracted axis by axis: rows with W and W' (x), then planes (y), then the three sums (z) — 90 multiply-adds
+    // instead of 108 with the weight products formed per row
+    double g1 = 0.0, g2 = 0.0, g3 = 0.0;   // sums multiplying n_x b1, n_y b2, n_z b3
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+        {
+        double pd = 0.0, pdy = 0.0, pw = 0.0;                                // plane k: sum_j of W_y ad, W'_y aw, W_y aw
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+            {
+#ifdef MTD_EXP_LDS_NOCONFLICT
+            // DIAGNOSTIC build (wrong forces): consecutive lanes read consecutive words — no bank conflicts
+            const unsigned int row = (threadIdx.x + 3 * TF_THREADS * (k * 3 + j)) % 6000u + 0u * cib.y;
+            const double r0 = s_inv[row], r1 = s_inv[row + TF_THREADS], r2 = s_inv[(row + 2 * TF_THREADS) % 6144u];
+#else
+            const unsigned int row = cib.y + tg.hx * (j + tg.hy * k);
+            const double r0 = s_inv[row], r1 = s_inv[row + 1], r2 = s_inv[row + 2];
+#endif
+            const double aw = wxv[0] * r0 + wxv[1] * r1 + wxv[2] * r2;       // row sums with W and with W'
+            const double ad = dxv[0] * r0 + dxv[1] * r1 + dxv[2] * r2;
+            pd += wyv[j] * ad;
+            pdy += dyv[j] * aw;
+            pw += wyv[j] * aw;
+            }
+        g1 += wzv[k] * pd;
+        g2 += wzv[k] * pdy;
+        g3 += dzv[k] * pw;
+        }
+    const double c1 = -(double)g.nx * a * g1, c2 = -(double)g.ny * a * g2, c3 = -(double)g.nz * a * g3;
+    const double fx = (c1 * g.binv[0][0] + c2 * g.binv[1][0] + c3 * g.binv[2][0]) * s;
+    const double fy = (c1 * g.binv[0][1] + c2 * g.binv[1][1] + c3 * g.binv[2][1]) * s;
+    const double fz = (c1 * g.binv[0][2] + c2 * g.binv[1][2] + c3 * g.binv[2][2]) * s;
+    force[cib.x] = scalar4_traits<S4>::make((scalar)fx, (scalar)fy, (scalar)fz, (scalar)0);
+    }
+
 template<typename S4>
 __global__ __launch_bounds__(TF_THREADS) void k_tile_forces(const MeshGeom g, const TileGeom tg, const TileLists L,
                                                             const double *__restrict__ mode, const double4 *__restrict__ packed,
@@ -1486,7 +1574,6 @@ __global__ __launch_bounds__(TF_THREADS) void k_tile_forces(const MeshGeom g, co
                                                             const double *__restrict__ d_bias, const double bias_host,
                                                             const double two_over_n, const unsigned int n_types)
     {
-    typedef typename scalar4_traits<S4>::scalar scalar;
     __shared__ double s_inv[TP_HMAX];
     __shared__ double s_mode[TP_MODE_LDS];
     stage_modes(s_mode, mode, n_types);                              // (published by the barrier behind the staging of Re(inv))
@@ -1518,7 +1605,6 @@ __global__ __launch_bounds__(TF_THREADS) void k_tile_forces(const MeshGeom g, co
     // lane busy, all loads of a thread issued before its first LDS store.
     const unsigned int wxn = min(tg.tx, g.nx - x0) + 2, wyn = min(tg.ty, g.ny - y0) + 2, wzn = min(tg.tz, g.nz - z0) + 2;
     constexpr int TF_MAXROWS = (TP_Y + 2) * (TP_Z + 2);
-    constexpr int TF_ELEMS = (TP_HMAX + TF_THREADS - 1) / TF_THREADS;
     __shared__ unsigned int s_grow[TF_MAXROWS];                        // global offset of the row's x = 0 cell
     __shared__ unsigned short s_lrow[TF_MAXROWS];                      // LDS offset of the row's lx = 0 entry
     __shared__ unsigned short s_gx[TP_X + 2];                          // wrapped global x of image column lx
@@ -1540,75 +1626,15 @@ __global__ __launch_bounds__(TF_THREADS) void k_tile_forces(const MeshGeom g, co
         }
     __syncthreads();
     {
-    const unsigned int n_img = n_rows * wxn;
-    static_assert(TP_HMAX < 12288 && TP_HMAX * (TP_X + 2) <= (1 << 20), "multiply-shift division of the flat image index");
-    const unsigned int inv_w = ((1u << 20) + wxn - 1) / wxn;           // idx / wxn = (idx * inv_w) >> 20: exact while idx * wxn < 2^20 (wxn >= 3: no overflow)
-    double v[TF_ELEMS];
-    unsigned int dst[TF_ELEMS];                                        // ~0u: nothing to stage
-#pragma unroll
-    for (int e = 0; e < TF_ELEMS; ++e)
-        {
-        const unsigned int idx = threadIdx.x + e * TF_THREADS;
-        v[e] = 0.0;
-        dst[e] = ~0u;
-        if (idx < n_img)
-            {
-            const unsigned int row = (idx * inv_w) >> 20, lx = idx - row * wxn;
-            v[e] = inv[s_grow[row] + s_gx[lx]];
-            dst[e] = s_lrow[row] + lx;
-            }
-        }
-#pragma unroll
-    for (int e = 0; e < TF_ELEMS; ++e)
-        if (dst[e] != ~0u) s_inv[dst[e]] = v[e];
+    TileStage<TF_THREADS> st;
+    tile_stage_load<TF_THREADS>(st, threadIdx.x, n_rows, wxn, s_grow, s_lrow, s_gx, inv);
+    tile_stage_store<TF_THREADS>(st, s_inv);
     }
     __syncthreads();
     TILE_STAMP(1, 1);
     const double bias = d_bias ? *d_bias : bias_host;
     const double s = two_over_n * bias;                                // :861
-    auto force_of = [&](const double4 &cur)
-        {
-        const unsigned int bt = (unsigned int)__double2hiint(cur.w);          // the record of k_tile_scatter
-        const uint2 cib = make_uint2((unsigned int)__double2loint(cur.w), bt & 0xffffu);
-        const double a = mode_of(s_mode, mode, bt >> 16), sx = cur.x, sy = cur.y, sz = cur.z;
-        double wxv[3], wyv[3], wzv[3], dxv[3], dyv[3], dzv[3];
-        tsc3_deriv(sx, wxv, dxv);
-        tsc3_deriv(sy, wyv, dyv);
-        tsc3_deriv(sz, wzv, dzv);
-        // contracted axis by axis: rows with W and W' (x), then planes (y), then the three sums (z) — 90 multiply-adds
-        // instead of 108 with the weight products formed per row
-        double g1 = 0.0, g2 = 0.0, g3 = 0.0;   // sums multiplying n_x b1, n_y b2, n_z b3
-#pragma unroll
-        for (int k = 0; k < 3; ++k)
-            {
-            double pd = 0.0, pdy = 0.0, pw = 0.0;                                // plane k: sum_j of W_y ad, W'_y aw, W_y aw
-#pragma unroll
-            for (int j = 0; j < 3; ++j)
-                {
-#ifdef MTD_EXP_LDS_NOCONFLICT
-                // DIAGNOSTIC build (wrong forces): consecutive lanes read consecutive words — no bank conflicts
-                const unsigned int row = (threadIdx.x + 3 * TF_THREADS * (k * 3 + j)) % 6000u + 0u * cib.y;
-                const double r0 = s_inv[row], r1 = s_inv[row + TF_THREADS], r2 = s_inv[(row + 2 * TF_THREADS) % 6144u];
-#else
-                const unsigned int row = cib.y + tg.hx * (j + tg.hy * k);
-                const double r0 = s_inv[row], r1 = s_inv[row + 1], r2 = s_inv[row + 2];
-#endif
-                const double aw = wxv[0] * r0 + wxv[1] * r1 + wxv[2] * r2;       // row sums with W and with W'
-                const double ad = dxv[0] * r0 + dxv[1] * r1 + dxv[2] * r2;
-                pd += wyv[j] * ad;
-                pdy += dyv[j] * aw;
-                pw += wyv[j] * aw;
-                }
-            g1 += wzv[k] * pd;
-            g2 += wzv[k] * pdy;
-            g3 += dzv[k] * pw;
-            }
-        const double c1 = -(double)g.nx * a * g1, c2 = -(double)g.ny * a * g2, c3 = -(double)g.nz * a * g3;
-        const double fx = (c1 * g.binv[0][0] + c2 * g.binv[1][0] + c3 * g.binv[2][0]) * s;
-        const double fy = (c1 * g.binv[0][1] + c2 * g.binv[1][1] + c3 * g.binv[2][1]) * s;
-        const double fz = (c1 * g.binv[0][2] + c2 * g.binv[1][2] + c3 * g.binv[2][2]) * s;
-        force[cib.x] = scalar4_traits<S4>::make((scalar)fx, (scalar)fy, (scalar)fz, (scalar)0);
-        };
+    auto force_of = [&](const double4 &cur) { tile_force_of<S4>(g, tg, s_inv, s_mode, mode, cur, s, force); };
     while (q < q1)
         {
         const double4 cur = pk;
@@ -1622,6 +1648,167 @@ __global__ __launch_bounds__(TF_THREADS) void k_tile_forces(const MeshGeom g, co
     for (unsigned int k = threadIdx.x; k < n_ovf; k += TF_THREADS)
         if (L.ovf_tile[k] == t) force_of(packed[L.ovf_base + k]);
     TILE_STAMP(1, 3);
+    }
+
+// ---- 9b. the force pass WITH the bias-grid engine's launch inside (mtd_mesh_forces_update_bias) -----------------------------------
+// A mixed set of one mesh CV and up to three lamellar CVs ends its step with two launches that need each other's neighbourhood but
+// not each other's hardware: the engine's launch (scalar chain on the CV sums -> bias factors; first grid pass; lamellar forces:
+// k_fused_force, 11 us, HBM streaming) and this file's force pass (22 us, LDS images, scattered stores), which waits for the
+// mesh's bias factor.  Here they are ONE launch of the force pass's shape: wave 0 of every block runs the chain (chain_wave, as in
+// k_fused_force: everything it reads requested at entry) while waves 1-7 stage Re(inv) of the block's tile; every block streams
+// its 1/n_blocks share of the particles for the lamellar forces (group 0 requested at entry and summed beside the staging loads,
+// scaled and stored behind the barrier that publishes the chain), the first n_grid_blocks blocks take 256 cells of the first
+// grid pass each (grid_first_pass_256: k_fused_force's sums in its order), block 0 publishes the step's scalars.  The mesh's
+// bias factor comes out of LDS.  The engine's state and the lamellar forces are what k_fused_force produces for the same input,
+// the mesh forces what k_tile_forces produces (same statements; this file is compiled with -ffp-contract=on, fused.hip with
+// =fast: the chain's and the lamellar forces' last bits may differ between the two forms — tests hold them together at 1e-13
+// / one fp32 rounding).
+constexpr int TFC_STREAM_THREADS = TF_THREADS - MTD_WAVE;
+constexpr int TFC_U = 4;           // particles per register group of a streaming thread (lamellar_device.hpp: ForceRegs)
+
+template<typename S4, int NCV, bool FAST>
+__global__ __launch_bounds__(TF_THREADS, 4) void k_tile_forces_chain(const MeshGeom g, const TileGeom tg, const TileLists L,
+                                                                  const double *__restrict__ mode, const double4 *__restrict__ packed,
+                                                                  const double *__restrict__ inv, S4 *__restrict__ force,
+                                                                  const double two_over_n, const unsigned int n_types, const unsigned int mesh_slot,
+                                                                  const mtd::LamKArgs a, const S4 *__restrict__ postype, const mtd::ForcePtrs out,
+                                                                  const unsigned int N, const mtd::MetadCfg c, const int deposit,
+                                                                  const unsigned int n_grid_blocks)
+    {
+    using namespace mtd;
+    static_assert(TF_THREADS >= 320, "threads 0 .. 255 of a block take a grid block's cells, wave 0 runs the chain");
+    __shared__ double s_inv[TP_HMAX];
+    __shared__ double s_mode[TP_MODE_LDS];
+    __shared__ ChainResult s_chain;
+    __shared__ float s_wcoef[MTD_MAX_CV * MTD_MAX_TYPES];
+    __shared__ double s_red[8];
+    __shared__ ModeTables s_mt;
+    constexpr int TF_MAXROWS = (TP_Y + 2) * (TP_Z + 2);
+    __shared__ unsigned int s_grow[TF_MAXROWS];
+    __shared__ unsigned short s_lrow[TF_MAXROWS];
+    __shared__ unsigned short s_gx[TP_X + 2];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+
+    // ---- entry: every memory request that needs nothing but the arguments
+    constexpr int NCH = CHAIN_MAX_CV;
+    ChainPre<NCH> pre;
+    float4 th = make_float4(0.f, 0.f, 0.f, 0.f), tq = th;
+    float tc = 0.0f;
+    if (wave == 0)
+        {
+        if (lane < (int)a.n_modes)
+            {
+            th = a.h[lane];
+            tq = a.q[lane];
+            }
+        if (lane < NCV * MTD_MAX_TYPES) tc = a.coeff[lane / MTD_MAX_TYPES][lane % MTD_MAX_TYPES];
+        chain_preload<NCH>(c, pre);
+        }
+    // this block's share of the particles (lamellar forces): streaming thread sid of n_blocks x TFC_STREAM_THREADS
+    const unsigned int sid = threadIdx.x - MTD_WAVE;                  // (waves 1 .. 7)
+    const unsigned int stride = gridDim.x * TFC_STREAM_THREADS;
+    const unsigned int first = blockIdx.x * TFC_STREAM_THREADS + sid;
+    RawGroup<S4, TFC_U> raw0;
+    if (wave != 0 && N) lam_force_request<S4, TFC_U>(postype, N, first, stride, raw0);
+    // this block's tile (k_tile_forces: contiguous ranges of tiles per XCD)
+    const unsigned int per_xcd = (tg.n_tiles + 7) / 8;
+    const unsigned int t = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
+    const bool has_tile = (blockIdx.x >> 3) < per_xcd && t < tg.n_tiles;
+    const unsigned int tt = has_tile ? t : 0u;
+    const unsigned int tix = tt % tg.ntx, tiy = (tt / tg.ntx) % tg.nty, tiz = tt / (tg.ntx * tg.nty);
+    const int x0 = tix * tg.tx, y0 = tiy * tg.ty, z0 = tiz * tg.tz;
+    const unsigned int n_all = has_tile ? L.count[(size_t)tt * L.cstride] : 0u;
+    const unsigned int q0 = L.first[tt], q1 = q0 + (L.cap ? min(n_all, L.cap[tt]) : n_all);
+    const unsigned int n_ovf = L.ovf_count ? *L.ovf_count : 0u;
+    const bool work = n_all != 0;                                     // (uniform over the block)
+    unsigned int q = q0 + threadIdx.x;
+    const unsigned int q_last = q1 > q0 ? q1 - 1 : q0;
+    double4 pk = make_double4(0.0, 0.0, 0.0, 0.0);
+    if (work) pk = packed[min(q, q_last)];
+    stage_modes(s_mode, mode, n_types);
+    const unsigned int wxn = min(tg.tx, g.nx - x0) + 2, wyn = min(tg.ty, g.ny - y0) + 2, wzn = min(tg.tz, g.nz - z0) + 2;
+    const unsigned int n_rows = wyn * wzn;
+    if (work)
+        {
+        for (unsigned int r = threadIdx.x; r < n_rows; r += TF_THREADS)
+            {
+            const unsigned int lz = r / wyn, ly = r - lz * wyn;
+            int gy = y0 + (int)ly - 1, gz = z0 + (int)lz - 1;
+            gy = gy < 0 ? gy + (int)g.ny : (gy >= (int)g.ny ? gy - (int)g.ny : gy);
+            gz = gz < 0 ? gz + (int)g.nz : (gz >= (int)g.nz ? gz - (int)g.nz : gz);
+            s_grow[r] = g.nx * ((unsigned int)gy + g.ny * (unsigned int)gz);
+            s_lrow[r] = (unsigned short)(tg.hx * (ly + tg.hy * lz));
+            }
+        if (threadIdx.x < wxn)
+            {
+            int gx = x0 + (int)threadIdx.x - 1;
+            gx = gx < 0 ? gx + (int)g.nx : (gx >= (int)g.nx ? gx - (int)g.nx : gx);
+            s_gx[threadIdx.x] = (unsigned short)gx;
+            }
+        }
+    if (wave == 0)
+        {
+        if (lane < (int)a.n_modes)
+            {
+            s_mt.h[lane] = th;
+            s_mt.q[lane] = tq;
+            }
+        if (lane < NCV * MTD_MAX_TYPES) s_wcoef[lane] = tc;            // raw coefficient; scaled in place behind the chain
+        }
+    lds_barrier();                 // mode tables, row tables (LDS only: the chain's and the particles' loads stay in flight across it)
+
+    // ---- wave 0: the chain.  Waves 1-7: Re(inv) of the tile into LDS, the unscaled lamellar forces of group 0 beside its loads
+    ForceRegs<NCV, TFC_U> R;
+    if (wave == 0)
+        {
+        double vi[3];
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) vi[i] = (pre.x[i][0] + pre.x[i][1]) + (pre.x[i][2] + pre.x[i][3]);
+        const ChainResult r = chain_wave(c, deposit != 0, true, nullptr, nullptr, false, &pre.patch, pre.patch_ok != 0, true, vi[0], vi[1], vi[2]);
+        if (lane == 0) chain_share(s_chain, r);
+        if (lane < NCV * MTD_MAX_TYPES)
+            {
+            const unsigned int cv = lane / MTD_MAX_TYPES;
+            const unsigned int gs = cv < a.n_cv ? a.slot[cv] : 0u;                 // the grid's variable behind CV cv of the set
+            const double b = gs == 0 ? r.bias[0] : (gs == 1 ? r.bias[1] : r.bias[2]);
+            s_wcoef[lane] = (cv < a.n_cv) ? (float)((double)s_wcoef[lane] * b * two_over_n) : 0.0f;
+            }
+        }
+    else
+        {
+        TileStage<TFC_STREAM_THREADS> st;
+        if (work) tile_stage_load<TFC_STREAM_THREADS>(st, sid, n_rows, wxn, s_grow, s_lrow, s_gx, inv);
+        if (N) lam_force_unscaled_from<S4, NCV, FAST, TFC_U>(a, N, first, stride, s_mt, raw0, R);
+        if (work) tile_stage_store<TFC_STREAM_THREADS>(st, s_inv);
+        }
+    __syncthreads();               // publishes s_chain / s_wcoef / s_inv
+
+    // ---- behind the chain
+    if (wave != 0 && N)
+        {
+        lam_force_store<S4, NCV, TFC_U>(a, out, first, stride, s_wcoef, R);
+        // (further groups: a launch whose blocks x 448 x 4 particles do not cover N)
+        for (unsigned int f = first + TFC_U * stride; f < N; f += TFC_U * stride)
+            {
+            lam_force_unscaled<S4, NCV, FAST, TFC_U>(a, postype, N, f, stride, s_mt, R);
+            lam_force_store<S4, NCV, TFC_U>(a, out, f, stride, s_wcoef, R);
+            }
+        }
+    if (blockIdx.x < n_grid_blocks) grid_first_pass_256(c, s_chain, blockIdx.x, s_red);
+    if (blockIdx.x == 0 && wave == 0) publish_step(c, s_chain, deposit);
+    if (!work) return;
+    const double bias = mesh_slot == 0 ? s_chain.bias[0] : (mesh_slot == 1 ? s_chain.bias[1] : s_chain.bias[2]);
+    const double s = two_over_n * bias;                                // :861
+    while (q < q1)
+        {
+        const double4 cur = pk;
+        const unsigned int qn = q + TF_THREADS;
+        pk = packed[min(qn, q_last)];
+        tile_force_of<S4>(g, tg, s_inv, s_mode, mode, cur, s, force);
+        q = qn;
+        }
+    for (unsigned int k = threadIdx.x; k < n_ovf; k += TF_THREADS)
+        if (L.ovf_tile[k] == tt) tile_force_of<S4>(g, tg, s_inv, s_mode, mode, packed[L.ovf_base + k], s, force);
     }
 
 // ---- 6/8. DFT of lines staged in LDS ---------------------------------------------------------------
@@ -3887,6 +4074,67 @@ int mtd_mesh_forces(mtd_mesh *m, unsigned int n_particles, const void *d_postype
     else
         k_mesh_forces<double4><<<blocks, 256, 0, s>>>(g, n_particles, m->d_idcell, m->d_packed, m->d_inv, (double4 *)d_force, d_bias, bias_host, two_over_n);
     MTD_LAUNCH_CHECK();
+    return MTD_SUCCESS;
+    }
+
+// The force pass of a mixed set with the bias-grid engine's launch inside (k_tile_forces_chain): what mtd_fused_force_pass_slots
+// followed by mtd_mesh_forces does, in one launch.  MTD_ERR_UNSUPPORTED where the shapes do not allow it (the caller then makes the
+// two calls): cell-level pipeline, a sharded engine, more than three grid variables, more grid blocks than tiles.
+int mtd_mesh_forces_update_bias(mtd_mesh *mesh, mtd_metad *m, unsigned int mesh_slot, const mtd_lamellar_set *set, const unsigned int *slots,
+                                unsigned int n_particles, const void *d_postype, void *d_force_mesh, void *const *d_force_lamellar,
+                                int dtype, unsigned int n_global, const mtd_box *box, unsigned int timestep, mtd_stream_t stream)
+    {
+    if (!mesh || !m || !set || !slots || !d_force_lamellar || n_global == 0 || !box) return MTD_ERR_INVALID_ARGUMENT;
+    if (dtype != MTD_F32 && dtype != MTD_F64) return MTD_ERR_INVALID_ARGUMENT;
+    if (n_particles == 0 || !d_postype || !d_force_mesh) return MTD_ERR_UNSUPPORTED;
+    static const bool off = [] { const char *e = std::getenv("MTD_MESH_FORCE_MERGED"); return e && e[0] == '0'; }();
+    if (off || !mesh->tile_path || m->comm) return MTD_ERR_UNSUPPORTED;
+    if (m->cfg.n_cv > (unsigned int)mtd::CHAIN_MAX_CV || mesh_slot >= m->cfg.n_cv) return MTD_ERR_UNSUPPORTED;
+    if (set->n_cv == 0 || set->n_cv > 3 || set->n_cv >= m->cfg.n_cv) return MTD_ERR_UNSUPPORTED;
+    if (n_particles != mesh->n_last) return MTD_ERR_INVALID_ARGUMENT;    // (the force pass walks the last assignment's lists)
+    if (m->h_step_err && *m->h_step_err) return MTD_ERR_COMM_TIMEOUT;
+    mtd::LamKArgs k;
+    int rc = mtd::fill_kargs(k, set, box);
+    if (rc) return rc;
+    for (unsigned int cv = 0; cv < set->n_cv; ++cv)
+        {
+        if (slots[cv] >= m->cfg.n_cv || slots[cv] == mesh_slot) return MTD_ERR_INVALID_ARGUMENT;
+        if (!d_force_lamellar[cv]) return MTD_ERR_INVALID_ARGUMENT;
+        k.slot[cv] = (unsigned char)slots[cv];
+        }
+    const int dep = (m->add_bias && (timestep % m->stride == 0)) ? 1 : 0;   // .cc:368
+    const unsigned int n_grid = dep ? m->cfg.n_gblocks : 0;
+    const unsigned int blocks = 8 * ((mesh->tg.n_tiles + 7) / 8);
+    if (n_grid > blocks) return MTD_ERR_UNSUPPORTED;
+    if ((unsigned long long)blocks * TFC_STREAM_THREADS * TFC_U >= (1ull << 31)) return MTD_ERR_UNSUPPORTED;
+    MeshGeom g;
+    rc = fill_geom(g, mesh, box);
+    if (rc) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    rc = mtd::metad_flush(m, s);                                 // a deposit may only be pending across ONE cv pass
+    if (rc) return rc;
+    mtd::ForcePtrs out;
+    for (unsigned int cv = 0; cv < MTD_MAX_CV; ++cv) out.f[cv] = cv < set->n_cv ? d_force_lamellar[cv] : nullptr;
+    const double two_over_n = 2.0 / (double)n_global;
+    const bool fast = mtd::lam_fast_trig(k) != 0;
+#define MTD_LAUNCH_TFC(S4, NCV, FASTV) \
+    k_tile_forces_chain<S4, NCV, FASTV><<<blocks, TF_THREADS, 0, s>>>(g, mesh->tg, mesh->lists, mesh->d_mode, mesh->d_packed, mesh->d_inv, (S4 *)d_force_mesh, \
+        two_over_n, mesh->n_types, mesh_slot, k, (const S4 *)d_postype, out, n_particles, m->cfg, dep, n_grid)
+#define MTD_LAUNCH_TFC_NCV(S4, FASTV) \
+    switch (set->n_cv) { case 1: MTD_LAUNCH_TFC(S4, 1, FASTV); break; case 2: MTD_LAUNCH_TFC(S4, 2, FASTV); break; default: MTD_LAUNCH_TFC(S4, 3, FASTV); break; }
+    if (dtype == MTD_F32)
+        {
+        if (fast) { MTD_LAUNCH_TFC_NCV(float4, true) } else { MTD_LAUNCH_TFC_NCV(float4, false) }
+        }
+    else
+        {
+        if (fast) { MTD_LAUNCH_TFC_NCV(double4, true) } else { MTD_LAUNCH_TFC_NCV(double4, false) }
+        }
+#undef MTD_LAUNCH_TFC_NCV
+#undef MTD_LAUNCH_TFC
+    MTD_LAUNCH_CHECK();
+    m->pending_apply = dep;
+    m->w_stale = dep;
     return MTD_SUCCESS;
     }
 

@@ -875,4 +875,102 @@ __device__ __forceinline__ double gauss_exponent3(const MetadCfg &c, unsigned in
     return gauss_exp;
     }
 
+// ---- pieces of the bias-grid engine's launch for kernels of OTHER files that carry it (mesh.hip: k_tile_forces_chain) -----------
+// The same statements as k_fused_force's grid blocks and its publishing wave (fused.hip; k_ql_finalize_chain in steinhardt.hip is a
+// third copy): the same sums in the same order, so the grid arrays come out the same whichever launch carried the pass.
+
+// what the chain's wave returns, as the block shares it (lane 0 of the chain's wave writes, a barrier publishes)
+__device__ __forceinline__ void chain_share(ChainResult &s_chain, const ChainResult &r)
+    {
+    s_chain.cv[0] = r.cv[0]; s_chain.cv[1] = r.cv[1]; s_chain.cv[2] = r.cv[2];
+    s_chain.bias[0] = r.bias[0]; s_chain.bias[1] = r.bias[1]; s_chain.bias[2] = r.bias[2];
+    s_chain.scal = r.scal; s_chain.V = r.V; s_chain.w = r.w;
+    s_chain.bin = r.bin; s_chain.on_grid = r.on_grid; s_chain.oob = r.oob; s_chain.failed = r.failed;
+    }
+
+// First grid pass of a deposit step (updateGrid :1002-1047, updateHistogram :1092-1119, updateSigmaGrid :1122-1155, first loop of
+// updateReweightedEstimator :1070-1075) for the 256 cells of grid block `vb`, by threads 0 .. 255 of the calling block.  EVERY
+// thread of the block calls it (one __syncthreads inside); s_red: 8 doubles.
+__device__ __forceinline__ void grid_first_pass_256(const MetadCfg &c, const ChainResult &s_chain, const unsigned int vb, double *s_red)
+    {
+    const unsigned int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const bool mine = threadIdx.x < 256;
+    const unsigned int g = vb * 256 + threadIdx.x;
+    double s1 = 0.0, s2 = 0.0;
+    if (mine && g < c.len && !s_chain.failed)
+        {
+        const double dV = (c.W * s_chain.scal) * exp(-gauss_exponent3(c, g, s_chain.cv[0], s_chain.cv[1], s_chain.cv[2]));
+        c.grid_delta[g] = dV;
+        unsigned int hd = c.hist_delta[g];
+        if (s_chain.on_grid && g == s_chain.bin)
+            {
+            hd += 1;
+            c.hist_delta[g] = hd;
+            c.sigma_grid_delta[g] += c.det_sigma;
+            c.hist_gauss_delta[g] += 1;
+            }
+        const double Rw = c.rew[g] + (double)hd;
+        c.rew[g] = Rw;
+        s1 = Rw * dV;
+        s2 = Rw;
+        }
+    s1 = wave_sum(s1);
+    s2 = wave_sum(s2);
+    if (mine && lane == 0)
+        {
+        s_red[2 * wave] = s1;
+        s_red[2 * wave + 1] = s2;
+        }
+    __syncthreads();
+    if (threadIdx.x == 0)
+        {
+        double t1 = 0.0, t2 = 0.0;
+        for (int w = 0; w < 4; ++w)
+            {
+            t1 += s_red[2 * w];
+            t2 += s_red[2 * w + 1];
+            }
+        c.gpart[2 * vb] = t1;
+        c.gpart[2 * vb + 1] = t2;
+        }
+    }
+
+// One wave of one block publishes the step's scalars for the host (lazy read-back) and, on non-deposit steps, owns the histogram
+// increment (:366) and the weight read-out (the weight grid is final then).  Called by a FULL wave (chain_wave inside).
+__device__ __forceinline__ void publish_step(const MetadCfg &c, const ChainResult &s_chain, const int deposit)
+    {
+    const int lane = threadIdx.x & 63;
+    double w_now = 1.0;
+    if (!deposit) w_now = chain_wave(c, false, false, nullptr).w;       // w(s) from the (final) weight grid
+    if (lane < (int)c.n_cv)
+        {
+        const double s_l = lane == 0 ? s_chain.cv[0] : (lane == 1 ? s_chain.cv[1] : s_chain.cv[2]);
+        c.st->cv[lane] = s_l;
+        c.st->bias[lane] = lane == 0 ? s_chain.bias[0] : (lane == 1 ? s_chain.bias[1] : s_chain.bias[2]);
+        // where the grid patch of the next step should sit (apply_cells fills it at this origin): the cell of s, minus 2
+        const double dl = lane == 0 ? c.delta[0] : (lane == 1 ? c.delta[1] : c.delta[2]);
+        const double ml = lane == 0 ? c.cv_min[0] : (lane == 1 ? c.cv_min[1] : c.cv_min[2]);
+        const double ll = (double)(lane == 0 ? c.lengths[0] : (lane == 1 ? c.lengths[1] : c.lengths[2]));
+        double q = (s_l - ml) / dl;
+        if (!(q > 0.0)) q = 0.0;                                   // (NaN too)
+        if (q > ll) q = ll;
+        c.st->guess_org[lane] = (int)q - 2;
+        }
+    if (lane == 0)
+        {
+        c.st->V = s_chain.V;
+        c.st->failed = (unsigned int)s_chain.failed;
+        c.st->bin = s_chain.bin;
+        c.st->on_grid = (unsigned int)s_chain.on_grid;
+        if (deposit)
+            c.st->scal = s_chain.scal;
+        else
+            {
+            c.st->w = s_chain.failed ? s_chain.V : w_now;            // (V is NaN then)
+            if (s_chain.on_grid) c.hist_delta[s_chain.bin] += 1;
+            }
+        if (s_chain.oob) c.st->n_oob += (deposit && c.mode == MTD_MODE_WELL_TEMPERED) ? 2 : 1;
+        }
+    }
+
 } // namespace mtd

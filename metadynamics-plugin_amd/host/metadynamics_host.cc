@@ -476,6 +476,24 @@ double OrderParameterMeshGPU::getCurrentValue(unsigned int timestep)
     }
 
 // OrderParameterMesh.cc:1052-1075
+bool OrderParameterMeshGPU::forcesWithBiasUpdate(unsigned int timestep, mtd_metad *engine, unsigned int mesh_slot, const mtd_lamellar_set *set,
+                                                 const unsigned int *slots, void *const *lamellar_forces)
+    {
+    // (the pressure tensor is formed from the Fourier mesh on the host side of computeBiasForces; a distributed mesh reduces there too)
+    if (distributed() || m_pdata->getPressureFlag()) return false;
+    if (m_is_first_step || m_cv_last_updated != timestep) return false;  // (the force pass walks the lists of THIS step's assignment)
+    ProfRange prof_range("forces");
+    const mtd_box box = m_pdata->getGlobalBox().toMtd();
+    const int rc = mtd_mesh_forces_update_bias(m_mesh, engine, mesh_slot, set, slots, m_pdata->getN(), m_pdata->positionsPtr(), m_force.data(),
+                                               lamellar_forces, m_pdata->getDtype(), m_pdata->getNGlobal(), &box, timestep,
+                                               m_exec_conf->getStream());
+    if (rc == MTD_ERR_UNSUPPORTED) return false;
+    mtd_check(rc, "mtd_mesh_forces_update_bias");
+    for (unsigned int i = 0; i < 6; ++i) m_external_virial[i] = 0.0;
+    markComputed(timestep);
+    return true;
+    }
+
 void OrderParameterMeshGPU::computeBiasForces(unsigned int timestep)
     {
     ProfRange prof_range("forces");
@@ -1150,8 +1168,16 @@ void IntegratorMetaDynamics::mixedLamellarCvPass(const std::vector<unsigned int>
     setMixedLamellarSources(slots, n_partials);
     }
 
-void IntegratorMetaDynamics::mixedLamellarForcePass(const std::vector<unsigned int> &slots, unsigned int timestep, hipStream_t stream)
+void IntegratorMetaDynamics::mixedLamellarForcePass(const std::vector<unsigned int> &slots, unsigned int timestep, hipStream_t stream,
+                                                    const std::shared_ptr<OrderParameterMeshGPU> &mesh, unsigned int mesh_slot)
     {
+    // one mesh variable beside the lamellar ones: the engine's launch inside the mesh's force pass (one launch instead of two)
+    if (mesh && stream == m_exec_conf->getStream()
+        && mesh->forcesWithBiasUpdate(timestep, m_engine, mesh_slot, &m_fused_set, slots.data(), m_fused_force_ptrs.data()))
+        {
+        for (unsigned int i : slots) m_variables[i].m_cv->markComputed(timestep);
+        return;
+        }
     const mtd_box box = m_pdata->getGlobalBox().toMtd();
     mtd_check(mtd_fused_force_pass_slots(m_engine, &m_fused_set, slots.data(), m_pdata->getN(), m_pdata->positionsPtr(),
                                          m_fused_force_ptrs.data(), m_pdata->getDtype(), m_pdata->getNGlobal(), &box, timestep,
@@ -1282,7 +1308,10 @@ void IntegratorMetaDynamics::updateBiasPotential(unsigned int timestep)
             }
         if (!lam_slots.empty())
             {
-            mixedLamellarForcePass(lam_slots, timestep, ls);
+            unsigned int carrier_slot = 0;
+            for (unsigned int i = 0; i < m_variables.size(); ++i)
+                if (m_variables[i].m_cv == carrier) carrier_slot = i;
+            mixedLamellarForcePass(lam_slots, timestep, ls, carrier, carrier_slot);
             if (side || beside)
                 {
                 hip_check(hipEventRecord(m_exec_conf->getEvent(2), ls), "hipEventRecord");         // bias factors, grid arrays, lamellar forces

@@ -207,6 +207,12 @@ class OrderParameterMeshGPU : public CollectiveVariable
                               unsigned int *n_partials);
         //! true when riders armed earlier are still waiting (nothing consumed them): they are disarmed
         bool clearRider();
+        //! The end of a mixed set's step in ONE launch (mtd_mesh_forces_update_bias): the grid engine's launch — scalar chain, first
+        //! grid pass, the lamellar CVs' forces — inside this variable's force pass.  false: the shapes do not allow it (the caller
+        //! runs the engine's launch, the force pass follows in computeBiasForces as always).  true: the forces of `timestep` are
+        //! written (with the bias factor of this very step) and marked as computed.
+        bool forcesWithBiasUpdate(unsigned int timestep, mtd_metad *engine, unsigned int mesh_slot, const mtd_lamellar_set *set,
+                                  const unsigned int *slots, void *const *lamellar_forces);
         std::vector<std::string> getProvidedLogQuantities() override
             {
             auto l = CollectiveVariable::getProvidedLogQuantities();
@@ -412,7 +418,8 @@ class IntegratorMetaDynamics
         void buildMixedLamellarSet(const std::vector<unsigned int> &slots);
         void setMixedLamellarSources(const std::vector<unsigned int> &slots, unsigned int n_partials);
         void mixedLamellarCvPass(const std::vector<unsigned int> &slots, hipStream_t stream);
-        void mixedLamellarForcePass(const std::vector<unsigned int> &slots, unsigned int timestep, hipStream_t stream);
+        void mixedLamellarForcePass(const std::vector<unsigned int> &slots, unsigned int timestep, hipStream_t stream,
+                                    const std::shared_ptr<OrderParameterMeshGPU> &mesh = nullptr, unsigned int mesh_slot = 0);
 
         std::shared_ptr<SystemDefinition> m_sysdef;
         std::shared_ptr<ParticleData> m_pdata;

@@ -110,6 +110,8 @@ _SIGNATURES = {
     "mtd_mesh_clear_rider": (C.c_int, [_vp, C.POINTER(C.c_int)]),
     "mtd_mesh_assign_info": (C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_uint), _vp]),
     "mtd_mesh_transform_info": (C.c_int, [_vp, C.POINTER(C.c_int)]),
+    "mtd_mesh_forces_update_bias": (C.c_int, [_vp, _vp, C.c_uint, C.POINTER(LamellarSet), _up, C.c_uint, _vp, _vp, C.POINTER(_vp), C.c_int, C.c_uint,
+                                              C.POINTER(Box), C.c_uint, _vp]),
     "mtd_mesh_set_lamellar_rider": (C.c_int, [_vp, _vp, _vp, _vp, C.c_uint, _vp, C.POINTER(C.c_uint), _vp]),
     "mtd_ql_symmetrize_half_list": (C.c_int, [C.c_uint, _vp, _vp, _vp, _vp, _vp, _vp, C.c_size_t, C.POINTER(C.c_size_t), _vp]),
     "mtd_debug_index_decode": (C.c_int, [C.c_uint, _vp, C.c_uint, _vp, _vp, _vp]),

@@ -650,3 +650,112 @@ def test_lamellar_and_deferred_grid_pass_ride_in_the_binning_kernel(abi, ref, dt
         abi.check(lib.mtd_lamellar_set_fast_trig(0))
         for x in (plain, ridden, g):
             x.close()
+
+
+@pytest.mark.parametrize("dtype,fast", [(np.float32, 1), (np.float32, 0), (np.float64, 1)])
+@pytest.mark.parametrize("n_lam,stride", [(1, 1), (2, 3)])
+def test_force_pass_with_the_bias_update_inside(abi, ref, dtype, fast, n_lam, stride):
+    """mtd_mesh_forces_update_bias (k_tile_forces_chain: the bias-grid engine's launch — scalar chain, first grid pass, lamellar
+    forces — inside the mesh's force pass) against mtd_fused_force_pass_slots + mtd_mesh_forces on an identical engine, over a
+    trajectory with deposit and non-deposit steps: CV values the same bits; bias factors, V and the grid arrays to 1e-12 (the two
+    forms are compiled with different contraction settings); lamellar forces to one fp32 rounding, mesh forces to 1e-12 of the
+    largest (their bias factor differs by as much); and the mesh forces of the last step against the ORACLE with the oracle's own
+    bias factor from the oracle's grid driven with the device's CV values."""
+    from test_gpu_metad import compare
+    lib = abi.load()
+    N, L, T = 60013, 30.0, 5
+    dt = abi.MTD_F32 if dtype == np.float32 else abi.MTD_F64
+    tdt = torch.float32 if dtype == np.float32 else torch.float64
+    box, rbox = abi.Box.make(L), ref.Box.make(L)
+    cvs = [(util.CV1_VECTORS, util.MODE_AB), (util.CV2_VECTORS, util.MODE_AB)][:n_lam]
+    lset = abi.LamellarSet.make(cvs)
+    n_var = n_lam + 1
+    mesh_slot = 1 if n_lam == 2 else 0                                   # the mesh BETWEEN the lamellar variables / in front of it
+    lam_slots = [s for s in range(n_var) if s != mesh_slot]
+    slots = (C.c_uint * n_lam)(*lam_slots)
+    dbl = lambda v: (C.c_double * len(v))(*[float(x) for x in v])
+    abi.check(lib.mtd_lamellar_set_fast_trig(fast))
+    rng = np.random.default_rng(5)
+    base, types = util.snapshot_random(N, L, seed=321, modulated=True, dtype=np.float64)
+    meshes = [GpuMesh(abi, (128, 32, 16), util.MODE_AB, N) for _ in range(2)]       # 2 x 4 x 2 tiles of 64 x 8 x 8
+    # grids: the mesh CV's value is not known in advance — one untimed evaluation supplies it
+    d0 = torch.from_numpy(util.pack_postype(base.astype(dtype), types, dtype)).cuda()
+    s_mesh0 = meshes[0].cv(d0, dt, box, N)
+    sig = [0.05] * n_var
+    lo, hi, npts = [-1.0] * n_var, [1.0] * n_var, [16, 12, 10][:n_var]          # (at most as many 256-cell grid blocks as the mesh has tiles)
+    sig[mesh_slot], lo[mesh_slot], hi[mesh_slot] = 0.05 * s_mesh0, 0.0, 2.0 * s_mesh0
+
+    def engine():
+        h = C.c_void_p()
+        abi.check(lib.mtd_metad_create(C.byref(h), n_var, dbl(sig), dbl(lo), dbl(hi), (C.c_uint * n_var)(*npts), 1.0, 7.0, 1.0, stride, 1, 1))
+        return h
+
+    ha, hb = engine(), engine()
+    r = ref.Metad(sigma=sig, cv_min=lo, cv_max=hi, num_points=npts, W=1.0, T_shift=7.0, T=1.0, stride=stride, mode="well_tempered")
+    scratch = torch.zeros(lib.mtd_lamellar_scratch_doubles(N), dtype=torch.float64, device="cuda")
+    fa = [torch.zeros((N, 4), dtype=tdt, device="cuda") for _ in range(n_lam + 1)]
+    fb = [torch.zeros((N, 4), dtype=tdt, device="cuda") for _ in range(n_lam + 1)]
+    pa, pb = (C.c_void_p * n_lam)(*[f.data_ptr() for f in fa[:n_lam]]), (C.c_void_p * n_lam)(*[f.data_ptr() for f in fb[:n_lam]])
+    try:
+        for t in range(T):
+            pos = base + rng.normal(0.0, 0.02 * t, size=base.shape)
+            pos = np.mod(pos + L / 2, L) - L / 2
+            pos = pos.astype(dtype)
+            pos[pos >= L / 2] = -L / 2
+            d_pos = torch.from_numpy(util.pack_postype(pos, types, dtype)).cuda()
+            n_part = C.c_uint()
+            abi.check(lib.mtd_lamellar_cv_partials(C.byref(lset), N, d_pos.data_ptr(), dt, C.byref(box), scratch.data_ptr(), C.byref(n_part), None))
+            for h, mesh in ((ha, meshes[0]), (hb, meshes[1])):
+                parts, n = C.c_void_p(), C.c_uint()
+                abi.check(lib.mtd_mesh_compute_cv(mesh.h, N, d_pos.data_ptr(), dt, C.byref(box), N, C.byref(parts), C.byref(n), None))
+                abi.check(lib.mtd_metad_set_cv_source(h, mesh_slot, parts.value, n.value, 1, 0, 0.5, 0.0))
+                for c, slot in enumerate(lam_slots):
+                    abi.check(lib.mtd_metad_set_cv_source(h, slot, scratch.data_ptr(), n_part.value, n_lam, c, 1.0 / N, 0.0))
+            # A: one launch
+            abi.check(lib.mtd_mesh_forces_update_bias(meshes[0].h, ha, mesh_slot, C.byref(lset), slots, N, d_pos.data_ptr(), fa[n_lam].data_ptr(), pa,
+                                                      dt, N, C.byref(box), t, None))
+            # B: the engine's launch with the lamellar forces, then the mesh's force pass with the device bias factor
+            abi.check(lib.mtd_fused_force_pass_slots(hb, C.byref(lset), slots, N, d_pos.data_ptr(), pb, dt, N, C.byref(box), t, None))
+            d_bias = lib.mtd_metad_bias_device(hb)
+            abi.check(lib.mtd_mesh_forces(meshes[1].h, N, d_pos.data_ptr(), fb[n_lam].data_ptr(), dt, C.byref(box), N, d_bias + 8 * mesh_slot, 0.0, None))
+            torch.cuda.synchronize()
+            cv_a, cv_b, ba, bb = (C.c_double * n_var)(), (C.c_double * n_var)(), (C.c_double * n_var)(), (C.c_double * n_var)()
+            Va, Vb = C.c_double(), C.c_double()
+            abi.check(lib.mtd_metad_get_state(ha, cv_a, ba, C.byref(Va), None, None, None, None))
+            abi.check(lib.mtd_metad_get_state(hb, cv_b, bb, C.byref(Vb), None, None, None, None))
+            assert list(cv_a) == list(cv_b)
+            assert np.allclose(list(ba), list(bb), rtol=1e-11, atol=1e-300) and Va.value == pytest.approx(Vb.value, rel=1e-12, abs=1e-300)
+            b_ref = r.update_bias(t, list(cv_a))
+            assert np.allclose(list(ba), b_ref, rtol=1e-7, atol=1e-9 * np.abs(b_ref).max())
+            for c in range(n_lam + 1):
+                A, B = fa[c].cpu().numpy().astype(np.float64), fb[c].cpu().numpy().astype(np.float64)
+                if t > 0: assert np.abs(B).max() > 0
+                tol = 1e-11 if c == n_lam and dtype == np.float64 else 2e-6
+                assert np.abs(A - B).max() <= tol * max(np.abs(B).max(), 1e-300), (t, c)
+        for name in ("grid", "reweighted", "hist", "sigma_grid"):
+            which = abi.ARRAY_NAMES.index(name)
+            n_cells = int(np.prod(npts))
+            oa = np.zeros(n_cells, dtype=np.float64 if which < 6 else np.uint32)
+            ob = oa.copy()
+            abi.check(lib.mtd_metad_get_array(ha, which, oa.ctypes.data, None))
+            abi.check(lib.mtd_metad_get_array(hb, which, ob.ctypes.data, None))
+            assert np.allclose(oa, ob, rtol=1e-11, atol=1e-14 * max(np.abs(ob).max(), 1e-300), equal_nan=True), name
+            assert np.abs(ob.astype(np.float64)).max() > 0
+        # the mesh forces of the last step against the oracle (its own bias factor from its own grid)
+        rm = ref.Mesh(128, 32, 16, util.MODE_AB)
+        opt = util.oracle_postype(pos, types)
+        rm.cv(opt, rbox)
+        sl = slice(0, 20000)
+        F_ref = rm.forces(opt[sl], rbox, b_ref[mesh_slot], n_global=N)
+        F = fa[n_lam].cpu().numpy().astype(np.float64)
+        assert np.abs(F_ref[:, :3]).max() > 0
+        assert np.abs(F[sl, :3] - F_ref[:, :3]).max() <= (1e-5 if dtype == np.float32 else 1e-7) * np.abs(F_ref[:, :3]).max()
+        # refusals: a mesh slot that is a lamellar slot, an engine with more grid blocks than the mesh has tiles
+        assert lib.mtd_mesh_forces_update_bias(meshes[0].h, ha, lam_slots[0], C.byref(lset), slots, N, d_pos.data_ptr(), fa[n_lam].data_ptr(), pa,
+                                               dt, N, C.byref(box), T, None) == -1
+    finally:
+        abi.check(lib.mtd_lamellar_set_fast_trig(0))
+        for m in meshes:
+            m.close()
+        for h in (ha, hb):
+            abi.check(lib.mtd_metad_destroy(h))
