@@ -7,6 +7,9 @@ cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 ROUND=${ROUND:-r4}
 O=gpurun_out/profiles_$ROUND; mkdir -p $O
 WHAT="${*:-bench mesh ql sharded}"
+# (one summary file carries the mesh and the Steinhardt kernels and a box starts empty: the two are always collected together)
+if [[ " $WHAT " == *" mesh "* && " $WHAT " != *" ql "* ]]; then WHAT="$WHAT ql"; fi
+if [[ " $WHAT " == *" ql "* && " $WHAT " != *" mesh "* ]]; then WHAT="$WHAT mesh"; fi
 rocprofv3 -L > $O/counters_list.txt 2>&1 || true
 pmc_pass() {   # pmc_pass <tag> <counters...> -- <program...>
   local tag=$1; shift; local ctr=(); while [ "$1" != "--" ]; do ctr+=("$1"); shift; done; shift
@@ -17,17 +20,18 @@ pmc_pass() {   # pmc_pass <tag> <counters...> -- <program...>
 }
 set -x
 if [[ " $WHAT " == *" bench "* ]]; then
-  timeout -k 10 600 python3 bench.py > $O/bench_default.log 2>&1 && tail -1 $O/bench_default.log > $O/bench_default.json
-  timeout -k 10 300 python3 bench.py --steps 20 --warmup 5 > $O/bench_k20.log 2>&1 && tail -1 $O/bench_k20.log > $O/bench_driver_call_k20.json
+  # counters of the headline kernels first: the bench lines below read profiles/$ROUND/pmc_summary.json and report `traffic` only
+  # while its hash of the kernel sources matches
+  for c in FETCH_SIZE WRITE_SIZE; do
+    pmc_pass $c $c -- python3 bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-sub-records --no-variants --driver abi
+  done
   rm -rf $O/kt
   timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -o bench -- python3 bench.py --no-cpu-baseline --no-sub-records --no-variants > $O/bench_under_rocprof.log 2>&1
   grep '^{"metric"' $O/bench_under_rocprof.log | tail -1 > $O/bench_default_under_rocprof.json
   cp "$(find $O/kt -name '*kernel_stats.csv' | head -1)" $O/bench_default_kernel_stats.csv
   cp "$(find $O/kt -name '*agent_info.csv' | head -1)" $O/agent_info.csv; rm -rf $O/kt
-  for c in FETCH_SIZE WRITE_SIZE; do
-    pmc_pass $c $c -- python3 bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-sub-records --no-variants --driver abi
-  done
   python3 tools/pmc_summary.py fused $O/pmc_FETCH_SIZE_counter_collection.csv $O/pmc_WRITE_SIZE_counter_collection.csv $O/bench_default_kernel_stats.csv $O/pmc_summary.json > /dev/null
+  mkdir -p profiles/$ROUND && cp $O/pmc_summary.json $O/bench_default_kernel_stats.csv profiles/$ROUND/
 fi
 if [[ " $WHAT " == *" mesh "* ]]; then
   rm -rf $O/c3
@@ -49,6 +53,12 @@ if [[ " $WHAT " == *" ql "* ]]; then
 fi
 if [[ " $WHAT " == *" mesh "* || " $WHAT " == *" ql "* ]]; then
   python3 tools/pmc_summary.py kernels $O $O/pmc_mesh_ql_summary.json > $O/pmc_mesh_ql_summary.txt
+  mkdir -p profiles/$ROUND && cp $O/pmc_mesh_ql_summary.json profiles/$ROUND/
+fi
+if [[ " $WHAT " == *" bench "* ]]; then
+  # the lines themselves LAST: they read the counter summaries written above (profiles/$ROUND/ of this copy of the tree)
+  timeout -k 10 600 python3 bench.py > $O/bench_default.log 2>&1 && tail -1 $O/bench_default.log > $O/bench_default.json
+  timeout -k 10 300 python3 bench.py --steps 20 --warmup 5 > $O/bench_k20.log 2>&1 && tail -1 $O/bench_k20.log > $O/bench_driver_call_k20.json
 fi
 if [[ " $WHAT " == *" sharded "* ]]; then
   # the particle-sharded code path with one rank (mailbox to itself) and with two ranks sharing this GPU (rehearsal: software path only)
