@@ -876,8 +876,9 @@ __device__ __forceinline__ double gauss_exponent3(const MetadCfg &c, unsigned in
     }
 
 // ---- pieces of the bias-grid engine's launch for kernels of OTHER files that carry it (mesh.hip: k_tile_forces_chain) -----------
-// The same statements as k_fused_force's grid blocks and its publishing wave (fused.hip; k_ql_finalize_chain in steinhardt.hip is a
-// third copy): the same sums in the same order, so the grid arrays come out the same whichever launch carried the pass.
+// The same statements as k_fused_force's grid blocks and its publishing wave (fused.hip, which keeps its own copy with the diagnostic
+// time stamps in it): the same sums in the same order, so the grid arrays come out the same whichever launch carried the pass
+// (k_tile_forces_chain in mesh.hip, k_ql_finalize_chain in steinhardt.hip).
 
 // what the chain's wave returns, as the block shares it (lane 0 of the chain's wave writes, a barrier publishes)
 __device__ __forceinline__ void chain_share(ChainResult &s_chain, const ChainResult &r)
@@ -937,11 +938,12 @@ __device__ __forceinline__ void grid_first_pass_256(const MetadCfg &c, const Cha
 
 // One wave of one block publishes the step's scalars for the host (lazy read-back) and, on non-deposit steps, owns the histogram
 // increment (:366) and the weight read-out (the weight grid is final then).  Called by a FULL wave (chain_wave inside).
-__device__ __forceinline__ void publish_step(const MetadCfg &c, const ChainResult &s_chain, const int deposit)
+// given: the CV values handed to the chain in registers / LDS (k_ql_finalize_chain) instead of registered partial sums
+__device__ __forceinline__ void publish_step(const MetadCfg &c, const ChainResult &s_chain, const int deposit, const double *given = nullptr)
     {
     const int lane = threadIdx.x & 63;
     double w_now = 1.0;
-    if (!deposit) w_now = chain_wave(c, false, false, nullptr).w;       // w(s) from the (final) weight grid
+    if (!deposit) w_now = chain_wave(c, false, false, nullptr, given).w;    // w(s) from the (final) weight grid
     if (lane < (int)c.n_cv)
         {
         const double s_l = lane == 0 ? s_chain.cv[0] : (lane == 1 ? s_chain.cv[1] : s_chain.cv[2]);

@@ -820,7 +820,8 @@ __global__ __launch_bounds__(256) void k_ql_finalize_carrier(const QlArgs<LMAX> 
 // hands the value to the engine's scalar chain in registers (chain_wave's `given`: no trip through memory), and goes on with
 // the first grid pass of a deposit (updateGrid :1002-1047, updateHistogram :1092-1119, updateSigmaGrid :1122-1155, first loop of
 // updateReweightedEstimator :1070-1075); block 0 writes the tables the force pass reads and publishes the step's scalars.  The
-// grid-pass and publishing code is the twin of k_fused_force's (fused.hip): tests hold the two against each other bit for bit
+// grid-pass and publishing code (metad_device.hpp: grid_first_pass_256, publish_step) is the twin of k_fused_force's (fused.hip): tests
+// hold the two against each other bit for bit
 // (tests/test_gpu_steinhardt.py::test_ql_merged_launch_matches_separate_launches).  The engine's DEFERRED pass of the previous
 // deposit cannot ride here (this launch's chain reads the grid it writes): it travels in the force pass of its own step
 // (k_ql_forces<..., CARRY>), which follows the deposit's launch directly.
@@ -843,89 +844,11 @@ __global__ __launch_bounds__(256) void k_ql_finalize_chain(const QlArgs<LMAX> a,
     if (wave == 0)
         {
         const ChainResult r = chain_wave(c, deposit != 0, true, nullptr, s_given, false, &pre.patch, pre.patch_ok != 0);
-        if (lane == 0)
-            {
-            s_chain.cv[0] = r.cv[0]; s_chain.cv[1] = r.cv[1]; s_chain.cv[2] = r.cv[2];
-            s_chain.bias[0] = r.bias[0]; s_chain.bias[1] = r.bias[1]; s_chain.bias[2] = r.bias[2];
-            s_chain.scal = r.scal; s_chain.V = r.V; s_chain.w = r.w;
-            s_chain.bin = r.bin; s_chain.on_grid = r.on_grid; s_chain.oob = r.oob; s_chain.failed = r.failed;
-            }
+        if (lane == 0) chain_share(s_chain, r);
         }
     __syncthreads();
-    if (blockIdx.x < n_grid_blocks)
-        {
-        const unsigned int g = blockIdx.x * 256 + threadIdx.x;
-        double s1 = 0.0, s2 = 0.0;
-        if (g < c.len && !s_chain.failed)
-            {
-            const double dV = (c.W * s_chain.scal) * exp(-gauss_exponent3(c, g, s_chain.cv[0], s_chain.cv[1], s_chain.cv[2]));
-            c.grid_delta[g] = dV;
-            unsigned int hd = c.hist_delta[g];
-            if (s_chain.on_grid && g == s_chain.bin)
-                {
-                hd += 1;
-                c.hist_delta[g] = hd;
-                c.sigma_grid_delta[g] += c.det_sigma;
-                c.hist_gauss_delta[g] += 1;
-                }
-            const double Rw = c.rew[g] + (double)hd;
-            c.rew[g] = Rw;
-            s1 = Rw * dV;
-            s2 = Rw;
-            }
-        s1 = wave_sum(s1);
-        s2 = wave_sum(s2);
-        if (lane == 0)
-            {
-            s_red[2 * wave] = s1;
-            s_red[2 * wave + 1] = s2;
-            }
-        __syncthreads();
-        if (threadIdx.x == 0)
-            {
-            double t1 = 0.0, t2 = 0.0;
-            for (int w = 0; w < 256 / MTD_WAVE; ++w)
-                {
-                t1 += s_red[2 * w];
-                t2 += s_red[2 * w + 1];
-                }
-            c.gpart[2 * blockIdx.x] = t1;
-            c.gpart[2 * blockIdx.x + 1] = t2;
-            }
-        }
-    if (blockIdx.x == 0 && wave == 0)
-        {
-        double w_now = 1.0;
-        if (!deposit) w_now = chain_wave(c, false, false, nullptr, s_given).w;       // w(s) from the (final) weight grid
-        if (lane < (int)c.n_cv)
-            {
-            const double s_l = lane == 0 ? s_chain.cv[0] : (lane == 1 ? s_chain.cv[1] : s_chain.cv[2]);
-            c.st->cv[lane] = s_l;
-            c.st->bias[lane] = lane == 0 ? s_chain.bias[0] : (lane == 1 ? s_chain.bias[1] : s_chain.bias[2]);
-            const double dl = lane == 0 ? c.delta[0] : (lane == 1 ? c.delta[1] : c.delta[2]);
-            const double ml = lane == 0 ? c.cv_min[0] : (lane == 1 ? c.cv_min[1] : c.cv_min[2]);
-            const double ll = (double)(lane == 0 ? c.lengths[0] : (lane == 1 ? c.lengths[1] : c.lengths[2]));
-            double q = (s_l - ml) / dl;
-            if (!(q > 0.0)) q = 0.0;
-            if (q > ll) q = ll;
-            c.st->guess_org[lane] = (int)q - 2;
-            }
-        if (lane == 0)
-            {
-            c.st->V = s_chain.V;
-            c.st->failed = (unsigned int)s_chain.failed;
-            c.st->bin = s_chain.bin;
-            c.st->on_grid = (unsigned int)s_chain.on_grid;
-            if (deposit)
-                c.st->scal = s_chain.scal;
-            else
-                {
-                c.st->w = s_chain.failed ? s_chain.V : w_now;
-                if (s_chain.on_grid) c.hist_delta[s_chain.bin] += 1;
-                }
-            if (s_chain.oob) c.st->n_oob += (deposit && c.mode == MTD_MODE_WELL_TEMPERED) ? 2 : 1;
-            }
-        }
+    if (blockIdx.x < n_grid_blocks) grid_first_pass_256(c, s_chain, blockIdx.x, s_red);
+    if (blockIdx.x == 0 && wave == 0) publish_step(c, s_chain, deposit, s_given);
     }
 
 // ---- half lists: order-independent (exact) sums of the pair forces ---------------------------------------------
