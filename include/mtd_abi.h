@@ -435,7 +435,9 @@ int mtd_mesh_assign_info(mtd_mesh *m, int *pipeline, unsigned int *n_overflow, m
  * force pass while the other waves stage their tile; every block streams a share of the particles for the lamellar forces and the
  * first blocks take the grid pass.  Same results as the two calls (engine state and lamellar forces to the last bits of a
  * contraction, mesh forces bitwise).  MTD_ERR_UNSUPPORTED where the shapes do not allow it (cell-level mesh pipeline, an engine with a
- * mailbox, more than three grid variables, more 256-cell grid blocks than mesh tiles, MTD_MESH_FORCE_MERGED=0): make the two calls. */
+ * mailbox, more than three grid variables, more 256-cell grid blocks than mesh tiles, MTD_MESH_FORCE_MERGED=0): make the two calls.
+ * set == NULL (slots, d_force_lamellar ignored): no lamellar CVs — the mesh variable alone on the grid, or beside variables of other
+ * kinds whose sources are registered: mtd_metad_update_bias + mtd_mesh_forces in one launch. */
 int mtd_mesh_forces_update_bias(mtd_mesh *mesh, mtd_metad *engine, unsigned int mesh_slot, const mtd_lamellar_set *set,
                                 const unsigned int *slots, unsigned int n_particles, const void *d_postype, void *d_force_mesh,
                                 void *const *d_force_lamellar, int dtype, unsigned int n_global, const mtd_box *global_box,

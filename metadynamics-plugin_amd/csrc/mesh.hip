@@ -4084,19 +4084,24 @@ int mtd_mesh_forces_update_bias(mtd_mesh *mesh, mtd_metad *m, unsigned int mesh_
                                 unsigned int n_particles, const void *d_postype, void *d_force_mesh, void *const *d_force_lamellar,
                                 int dtype, unsigned int n_global, const mtd_box *box, unsigned int timestep, mtd_stream_t stream)
     {
-    if (!mesh || !m || !set || !slots || !d_force_lamellar || n_global == 0 || !box) return MTD_ERR_INVALID_ARGUMENT;
+    const unsigned int n_lam = set ? set->n_cv : 0u;               // (no set: the mesh variable alone, or beside variables of other kinds)
+    if (!mesh || !m || n_global == 0 || !box || (n_lam && (!slots || !d_force_lamellar))) return MTD_ERR_INVALID_ARGUMENT;
     if (dtype != MTD_F32 && dtype != MTD_F64) return MTD_ERR_INVALID_ARGUMENT;
     if (n_particles == 0 || !d_postype || !d_force_mesh) return MTD_ERR_UNSUPPORTED;
     static const bool off = [] { const char *e = std::getenv("MTD_MESH_FORCE_MERGED"); return e && e[0] == '0'; }();
     if (off || !mesh->tile_path || m->comm) return MTD_ERR_UNSUPPORTED;
     if (m->cfg.n_cv > (unsigned int)mtd::CHAIN_MAX_CV || mesh_slot >= m->cfg.n_cv) return MTD_ERR_UNSUPPORTED;
-    if (set->n_cv == 0 || set->n_cv > 3 || set->n_cv >= m->cfg.n_cv) return MTD_ERR_UNSUPPORTED;
+    if (n_lam > 3 || n_lam >= m->cfg.n_cv) return MTD_ERR_UNSUPPORTED;
     if (n_particles != mesh->n_last) return MTD_ERR_INVALID_ARGUMENT;    // (the force pass walks the last assignment's lists)
     if (m->h_step_err && *m->h_step_err) return MTD_ERR_COMM_TIMEOUT;
     mtd::LamKArgs k;
-    int rc = mtd::fill_kargs(k, set, box);
+    int rc = MTD_SUCCESS;
+    if (n_lam)
+        rc = mtd::fill_kargs(k, set, box);
+    else
+        std::memset(&k, 0, sizeof(k));                             // no modes, no CVs: the launch's streaming part has nothing to do
     if (rc) return rc;
-    for (unsigned int cv = 0; cv < set->n_cv; ++cv)
+    for (unsigned int cv = 0; cv < n_lam; ++cv)
         {
         if (slots[cv] >= m->cfg.n_cv || slots[cv] == mesh_slot) return MTD_ERR_INVALID_ARGUMENT;
         if (!d_force_lamellar[cv]) return MTD_ERR_INVALID_ARGUMENT;
@@ -4114,14 +4119,15 @@ int mtd_mesh_forces_update_bias(mtd_mesh *mesh, mtd_metad *m, unsigned int mesh_
     rc = mtd::metad_flush(m, s);                                 // a deposit may only be pending across ONE cv pass
     if (rc) return rc;
     mtd::ForcePtrs out;
-    for (unsigned int cv = 0; cv < MTD_MAX_CV; ++cv) out.f[cv] = cv < set->n_cv ? d_force_lamellar[cv] : nullptr;
+    for (unsigned int cv = 0; cv < MTD_MAX_CV; ++cv) out.f[cv] = cv < n_lam ? d_force_lamellar[cv] : nullptr;
     const double two_over_n = 2.0 / (double)n_global;
-    const bool fast = mtd::lam_fast_trig(k) != 0;
+    const bool fast = n_lam ? mtd::lam_fast_trig(k) != 0 : true;
+    const unsigned int n_stream = n_lam ? n_particles : 0u;        // particles the blocks stream for the lamellar forces
 #define MTD_LAUNCH_TFC(S4, NCV, FASTV) \
     k_tile_forces_chain<S4, NCV, FASTV><<<blocks, TF_THREADS, 0, s>>>(g, mesh->tg, mesh->lists, mesh->d_mode, mesh->d_packed, mesh->d_inv, (S4 *)d_force_mesh, \
-        two_over_n, mesh->n_types, mesh_slot, k, (const S4 *)d_postype, out, n_particles, m->cfg, dep, n_grid)
+        two_over_n, mesh->n_types, mesh_slot, k, (const S4 *)d_postype, out, n_stream, m->cfg, dep, n_grid)
 #define MTD_LAUNCH_TFC_NCV(S4, FASTV) \
-    switch (set->n_cv) { case 1: MTD_LAUNCH_TFC(S4, 1, FASTV); break; case 2: MTD_LAUNCH_TFC(S4, 2, FASTV); break; default: MTD_LAUNCH_TFC(S4, 3, FASTV); break; }
+    switch (n_lam) { case 0: case 1: MTD_LAUNCH_TFC(S4, 1, FASTV); break; case 2: MTD_LAUNCH_TFC(S4, 2, FASTV); break; default: MTD_LAUNCH_TFC(S4, 3, FASTV); break; }
     if (dtype == MTD_F32)
         {
         if (fast) { MTD_LAUNCH_TFC_NCV(float4, true) } else { MTD_LAUNCH_TFC_NCV(float4, false) }

@@ -1332,7 +1332,21 @@ void IntegratorMetaDynamics::updateBiasPotential(unsigned int timestep)
             mtd_check(mtd_metad_update_bias_walkers(m_engine, m_exec_conf->getWalkerCommunicator(), timestep, s), "mtd_metad_update_bias_walkers");
             }
         else if (!self_updated)
-            mtd_check(mtd_metad_update_bias(m_engine, timestep, s), "mtd_metad_update_bias");
+            {
+            // one mesh variable on the grid (alone or beside variables of other kinds): the engine's launch inside its force pass
+            std::shared_ptr<OrderParameterMeshGPU> only_mesh;
+            unsigned int mesh_slot = 0, n_mesh = 0;
+            for (unsigned int i = 0; i < m_variables.size(); ++i)
+                if (auto mesh = std::dynamic_pointer_cast<OrderParameterMeshGPU>(m_variables[i].m_cv))
+                    {
+                    only_mesh = mesh;
+                    mesh_slot = i;
+                    ++n_mesh;
+                    }
+            // (setFusedPath(false): every CV its own kernels and the engine's own launch, as the reference's classes do it)
+            if (!(m_allow_fused && n_mesh == 1 && only_mesh->forcesWithBiasUpdate(timestep, m_engine, mesh_slot, nullptr, nullptr, nullptr)))
+                mtd_check(mtd_metad_update_bias(m_engine, timestep, s), "mtd_metad_update_bias");
+            }
         // update current bias potential derivative for every collective variable (:578-584)
         const double *d_bias = mtd_metad_bias_device(m_engine);
         for (unsigned int i = 0; i < m_variables.size(); ++i) m_variables[i].m_cv->setBiasFactorDevice(d_bias + i);

@@ -653,14 +653,15 @@ def test_lamellar_and_deferred_grid_pass_ride_in_the_binning_kernel(abi, ref, dt
 
 
 @pytest.mark.parametrize("dtype,fast", [(np.float32, 1), (np.float32, 0), (np.float64, 1)])
-@pytest.mark.parametrize("n_lam,stride", [(1, 1), (2, 3)])
+@pytest.mark.parametrize("n_lam,stride", [(1, 1), (2, 3), (0, 2)])
 def test_force_pass_with_the_bias_update_inside(abi, ref, dtype, fast, n_lam, stride):
     """mtd_mesh_forces_update_bias (k_tile_forces_chain: the bias-grid engine's launch — scalar chain, first grid pass, lamellar
     forces — inside the mesh's force pass) against mtd_fused_force_pass_slots + mtd_mesh_forces on an identical engine, over a
     trajectory with deposit and non-deposit steps: CV values the same bits; bias factors, V and the grid arrays to 1e-12 (the two
     forms are compiled with different contraction settings); lamellar forces to one fp32 rounding, mesh forces to 1e-12 of the
     largest (their bias factor differs by as much); and the mesh forces of the last step against the ORACLE with the oracle's own
-    bias factor from the oracle's grid driven with the device's CV values."""
+    bias factor from the oracle's grid driven with the device's CV values.  n_lam = 0: the mesh variable alone on the grid (no
+    lamellar set: mtd_metad_update_bias + mtd_mesh_forces in one launch)."""
     from test_gpu_metad import compare
     lib = abi.load()
     N, L, T = 60013, 30.0, 6
@@ -668,11 +669,11 @@ def test_force_pass_with_the_bias_update_inside(abi, ref, dtype, fast, n_lam, st
     tdt = torch.float32 if dtype == np.float32 else torch.float64
     box, rbox = abi.Box.make(L), ref.Box.make(L)
     cvs = [(util.CV1_VECTORS, util.MODE_AB), (util.CV2_VECTORS, util.MODE_AB)][:n_lam]
-    lset = abi.LamellarSet.make(cvs)
+    lset = abi.LamellarSet.make(cvs) if n_lam else None
     n_var = n_lam + 1
     mesh_slot = 1 if n_lam == 2 else 0                                   # the mesh BETWEEN the lamellar variables / in front of it
     lam_slots = [s for s in range(n_var) if s != mesh_slot]
-    slots = (C.c_uint * n_lam)(*lam_slots)
+    slots = (C.c_uint * n_lam)(*lam_slots) if n_lam else None
     dbl = lambda v: (C.c_double * len(v))(*[float(x) for x in v])
     abi.check(lib.mtd_lamellar_set_fast_trig(fast))
     rng = np.random.default_rng(5)
@@ -695,7 +696,9 @@ def test_force_pass_with_the_bias_update_inside(abi, ref, dtype, fast, n_lam, st
     scratch = torch.zeros(lib.mtd_lamellar_scratch_doubles(N), dtype=torch.float64, device="cuda")
     fa = [torch.zeros((N, 4), dtype=tdt, device="cuda") for _ in range(n_lam + 1)]
     fb = [torch.zeros((N, 4), dtype=tdt, device="cuda") for _ in range(n_lam + 1)]
-    pa, pb = (C.c_void_p * n_lam)(*[f.data_ptr() for f in fa[:n_lam]]), (C.c_void_p * n_lam)(*[f.data_ptr() for f in fb[:n_lam]])
+    pa = (C.c_void_p * n_lam)(*[f.data_ptr() for f in fa[:n_lam]]) if n_lam else None
+    pb = (C.c_void_p * n_lam)(*[f.data_ptr() for f in fb[:n_lam]]) if n_lam else None
+    p_set = C.byref(lset) if n_lam else None
     try:
         for t in range(T):
             pos = base + rng.normal(0.0, 0.02 * t, size=base.shape)
@@ -705,7 +708,8 @@ def test_force_pass_with_the_bias_update_inside(abi, ref, dtype, fast, n_lam, st
             pos[pos >= L / 2] = -L / 2
             d_pos = torch.from_numpy(util.pack_postype(pos, types, dtype)).cuda()
             n_part = C.c_uint()
-            abi.check(lib.mtd_lamellar_cv_partials(C.byref(lset), N, d_pos.data_ptr(), dt, C.byref(box), scratch.data_ptr(), C.byref(n_part), None))
+            if n_lam:
+                abi.check(lib.mtd_lamellar_cv_partials(p_set, N, d_pos.data_ptr(), dt, C.byref(box), scratch.data_ptr(), C.byref(n_part), None))
             for h, mesh in ((ha, meshes[0]), (hb, meshes[1])):
                 parts, n = C.c_void_p(), C.c_uint()
                 abi.check(lib.mtd_mesh_compute_cv(mesh.h, N, d_pos.data_ptr(), dt, C.byref(box), N, C.byref(parts), C.byref(n), None))
@@ -715,10 +719,13 @@ def test_force_pass_with_the_bias_update_inside(abi, ref, dtype, fast, n_lam, st
             if t == T - 2:
                 assert assign_info(abi, meshes[0])[1] > 0 and assign_info(abi, meshes[1])[1] > 0
             # A: one launch
-            abi.check(lib.mtd_mesh_forces_update_bias(meshes[0].h, ha, mesh_slot, C.byref(lset), slots, N, d_pos.data_ptr(), fa[n_lam].data_ptr(), pa,
+            abi.check(lib.mtd_mesh_forces_update_bias(meshes[0].h, ha, mesh_slot, p_set, slots, N, d_pos.data_ptr(), fa[n_lam].data_ptr(), pa,
                                                       dt, N, C.byref(box), t, None))
             # B: the engine's launch with the lamellar forces, then the mesh's force pass with the device bias factor
-            abi.check(lib.mtd_fused_force_pass_slots(hb, C.byref(lset), slots, N, d_pos.data_ptr(), pb, dt, N, C.byref(box), t, None))
+            if n_lam:
+                abi.check(lib.mtd_fused_force_pass_slots(hb, p_set, slots, N, d_pos.data_ptr(), pb, dt, N, C.byref(box), t, None))
+            else:
+                abi.check(lib.mtd_metad_update_bias(hb, t, None))
             d_bias = lib.mtd_metad_bias_device(hb)
             abi.check(lib.mtd_mesh_forces(meshes[1].h, N, d_pos.data_ptr(), fb[n_lam].data_ptr(), dt, C.byref(box), N, d_bias + 8 * mesh_slot, 0.0, None))
             torch.cuda.synchronize()
@@ -753,9 +760,10 @@ def test_force_pass_with_the_bias_update_inside(abi, ref, dtype, fast, n_lam, st
         F = fa[n_lam].cpu().numpy().astype(np.float64)
         assert np.abs(F_ref[:, :3]).max() > 0
         assert np.abs(F[sl, :3] - F_ref[:, :3]).max() <= (1e-5 if dtype == np.float32 else 1e-7) * np.abs(F_ref[:, :3]).max()
-        # refusals: a mesh slot that is a lamellar slot, an engine with more grid blocks than the mesh has tiles
-        assert lib.mtd_mesh_forces_update_bias(meshes[0].h, ha, lam_slots[0], C.byref(lset), slots, N, d_pos.data_ptr(), fa[n_lam].data_ptr(), pa,
-                                               dt, N, C.byref(box), T, None) == -1
+        # refusal: a mesh slot that is a lamellar slot
+        if n_lam:
+            assert lib.mtd_mesh_forces_update_bias(meshes[0].h, ha, lam_slots[0], p_set, slots, N, d_pos.data_ptr(), fa[n_lam].data_ptr(), pa,
+                                                   dt, N, C.byref(box), T, None) == -1
     finally:
         abi.check(lib.mtd_lamellar_set_fast_trig(0))
         for m in meshes:
