@@ -3731,6 +3731,14 @@ static int mesh_assign_local(mtd_mesh *m, unsigned int n_particles, const void *
                 m->rider_armed = 0;
                 if (m->rider_engine && m->rider_n_apply) m->rider_engine->pending_apply = 0;
                 }
+            // no riders: an engine that announced a pending deferred pass on this stream (a mesh variable without lamellar CVs beside
+            // it: mtd_mesh_forces_update_bias, mtd_metad_update_bias) still gets it carried by the scatter launch's extra blocks
+            mtd_metad *passenger = nullptr;
+            if (!n_apply && !rider_kind)
+                {
+                passenger = mtd::take_pending_apply(s, apply_cfg);
+                if (passenger) n_apply = (apply_cfg.len + TP_THREADS - 1) / TP_THREADS;
+                }
             const unsigned int tiles_per = (tg.n_tiles + TB_THREADS - 1) / TB_THREADS;
             BinRiderArgs ra;
             BinNoRider no_rider;
@@ -3769,6 +3777,7 @@ static int mesh_assign_local(mtd_mesh *m, unsigned int n_particles, const void *
                 k_tile_scatter<float4><<<tg.n_tiles + 1 + n_apply, TP_THREADS, 0, s>>>(g, tg, (const float4 *)d_postype, m->d_mode, L, m->d_ids, m->d_tilebuf, m->d_packed, m->n_types, (const float4 *)m->d_possorted, plan, apply_cfg);
             else
                 k_tile_scatter<double4><<<tg.n_tiles + 1 + n_apply, TP_THREADS, 0, s>>>(g, tg, (const double4 *)d_postype, m->d_mode, L, m->d_ids, m->d_tilebuf, m->d_packed, m->n_types, (const double4 *)m->d_possorted, plan, apply_cfg);
+            if (passenger && hipPeekAtLastError() == hipSuccess) mtd::commit_pending_apply(passenger);     // (a failed launch leaves the pass pending)
             m->lists = L;
             m->plan_n = N;
             m->last_pipeline = 2;
@@ -4141,6 +4150,7 @@ int mtd_mesh_forces_update_bias(mtd_mesh *mesh, mtd_metad *m, unsigned int mesh_
     MTD_LAUNCH_CHECK();
     m->pending_apply = dep;
     m->w_stale = dep;
+    if (dep) mtd::announce_pending_apply(m, s);                  // the next assignment's scatter launch (or a rider) takes the deferred pass along
     return MTD_SUCCESS;
     }
 
