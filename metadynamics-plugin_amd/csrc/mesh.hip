@@ -2668,6 +2668,325 @@ __global__ __launch_bounds__(XY_THREADS) void k_fft_xy_inverse(const double2 *__
     XY_STAMP(1, 8);
     }
 
+// ---- 6ab'. forward x/y passes of a 128 x 128 plane from the tile images WITHOUT the redundant half: the x transform split by the
+// parity of its OUTPUT (k_x) ------------------------------------------------------------------------------------------------------
+// k_fft_xy_forward lets both blocks of a plane transform all x lines and keep half of the k_x columns.  Decimation in frequency:
+// Z[2 m] = DFT_64(z[n] + z[n + 64]), Z[2 m + 1] = DFT_64((z[n] - z[n + 64]) w^n) — block p of a plane folds every line pair while its
+// cells arrive (tile images summed as in k_fft_xy_forward<true>) and transforms lines of HALF the length; it keeps the k_x of parity p
+// (the two real rows of a pair are untangled from Z[k] and Z[128 - k]: the same parity).  The folded image of ALL 64 line pairs (67 KB)
+// fits the LDS next to the column image (68 KB): one batch, 64 lines per sweep.  A lane takes cells 2 j, 2 j + 1 and their partners
+// 64 cells on (the same entries of the next x tile) of line pair u = (wave & 3) + 4 half + 8 (g + 4 (wave >> 2)): whether a row of
+// the pair borders a tile face then depends on the wave only.
+__device__ __forceinline__ void xys_block(const int xcd_map, unsigned int &plane, unsigned int &part);
+
+struct XYSplitF
+    {
+    unsigned int hxp;
+    unsigned int xs, ys;                // row strides of the folded line image (64 pairs, odd) and of the column image (columns of a parity, odd)
+    FastDiv d_kc[2];                    // columns of parity 0 / 1 (33 / 32)
+    FastDiv d_np;                       // line pairs (64)
+    int xcd_map;
+    };
+
+__global__ __launch_bounds__(XY_THREADS) void k_fft_xy_forward_split(double2 *__restrict__ half_out, const double2 *__restrict__ tw_x,
+                                                                     const double2 *__restrict__ tw_y, const XYSplitF pl, const XYTiles tl)
+    {
+    constexpr unsigned int NX = 128, NY = 128, NP = NY / 2, NF = NX / 2;     // cells, rows, line pairs, folded positions
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double2 *X = (double2 *)smem, *Y = X + (size_t)NF * pl.xs, *TX = Y + (size_t)NY * pl.ys, *TXh = TX + NX / 2, *TY = TXh + NX / 4;
+    unsigned int plane, parity;
+    xys_block(pl.xcd_map, plane, parity);
+    const unsigned int xs = pl.xs, ys = pl.ys;
+    const FastDiv dk = parity ? pl.d_kc[1] : pl.d_kc[0];
+    const unsigned int kc = dk.d;
+    const size_t line_base = (size_t)plane * NY;
+    const unsigned int lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, j = lane & 31u, half = lane >> 5;
+    XY_STAMP(0, 0);
+    // this lane's x entries: cells 2 j, 2 j + 1 (left) and 2 j + 64, 2 j + 65 (right), and the halo entry of whichever of them
+    // is the first / last cell of its tile
+    unsigned int oL, oR, oeL, oeR;
+    int edge = -1;                                                    // which of the two cells has an x halo (the same one left and right)
+    {
+    unsigned int o0, o1;
+    bool e = xy_tile_src(tl, 0, 2 * j, o0, o1);
+    oL = o0;
+    oeL = o0;
+    if (e) { oeL = o1; edge = 0; }
+    e = xy_tile_src(tl, 0, 2 * j + 1, o0, o1);
+    if (e) { oeL = o1; edge = 1; }
+    e = xy_tile_src(tl, 0, 2 * j + NF, o0, o1);
+    oR = o0;
+    oeR = o0;
+    if (e) oeR = o1;
+    e = xy_tile_src(tl, 0, 2 * j + 1 + NF, o0, o1);
+    if (e) oeR = o1;
+    }
+    unsigned int oz0 = 0, oz1 = 0;
+    const bool z2 = xy_tile_src(tl, 2, plane, oz0, oz1);
+    // row class of this wave's line pairs: 1 the pair's first row is the first row of a tile, 2 its second row the last one, else 0
+    const unsigned int T = 1u << tl.log2t[1], um = wave & 3u;
+    const int ycls = ((2 * um) & (T - 1)) == 0 ? 1 : (((2 * um + 1) & (T - 1)) == T - 1 ? 2 : 0);
+    for (unsigned int i = threadIdx.x; i < NX / 2 + NX / 4 + NY / 2; i += XY_THREADS)
+        TX[i] = i < NX / 2 ? tw_x[i] : (i < NX / 2 + NX / 4 ? tw_x[2 * (i - NX / 2)] : tw_y[i - NX / 2 - NX / 4]);
+    struct __attribute__((aligned(8))) ll2 { long long a, b; };
+    double2 f0[4], f1[4];                                              // folded values of cells 2 j, 2 j + 1 for the four line pairs of this lane
+    auto load_pairs = [&](auto z2c, auto yclsc)
+        {
+        constexpr bool Z2 = decltype(z2c)::value;
+        constexpr int YCLS = decltype(yclsc)::value;
+        constexpr int NA = (YCLS == 1 ? 2 : 1) * (Z2 ? 2 : 1), NB = (YCLS == 2 ? 2 : 1) * (Z2 ? 2 : 1), NS = NA + NB;
+        constexpr int G = NS <= 3 ? 2 : 1;                            // line pairs whose loads are in flight together
+        const long long *b = tl.buf;
+        for (int g0 = 0; g0 < 4; g0 += G)
+            {
+            ll2 mL[G][NS], mR[G][NS];
+            long long eL[G][NS], eR[G][NS];
+#pragma unroll
+            for (int g = 0; g < G; ++g)
+                {
+                const unsigned int u = um + 4u * half + 8u * ((unsigned int)(g0 + g) + 4u * (wave >> 2));
+                unsigned int oa0, oa1, ob0, ob1;
+                (void)xy_tile_src(tl, 1, 2 * u, oa0, oa1);
+                (void)xy_tile_src(tl, 1, 2 * u + 1, ob0, ob1);
+                unsigned int off[NS];
+                int k = 0;
+                off[k++] = oz0 + oa0;
+                if (YCLS == 1) off[k++] = oz0 + oa1;
+                if (Z2)
+                    {
+                    off[k++] = oz1 + oa0;
+                    if (YCLS == 1) off[k++] = oz1 + oa1;
+                    }
+                off[k++] = oz0 + ob0;
+                if (YCLS == 2) off[k++] = oz0 + ob1;
+                if (Z2)
+                    {
+                    off[k++] = oz1 + ob0;
+                    if (YCLS == 2) off[k++] = oz1 + ob1;
+                    }
+#pragma unroll
+                for (int q = 0; q < NS; ++q)
+                    {
+                    __builtin_memcpy(&mL[g][q], b + (off[q] + oL), sizeof(ll2));
+                    __builtin_memcpy(&mR[g][q], b + (off[q] + oR), sizeof(ll2));
+                    eL[g][q] = b[off[q] + oeL];
+                    eR[g][q] = b[off[q] + oeR];
+                    }
+                }
+#pragma unroll
+            for (int g = 0; g < G; ++g)
+                {
+                long long aL0 = 0, aL1 = 0, aR0 = 0, aR1 = 0, bL0 = 0, bL1 = 0, bR0 = 0, bR1 = 0;
+#pragma unroll
+                for (int q = 0; q < NA; ++q)
+                    {
+                    aL0 += mL[g][q].a + (edge == 0 ? eL[g][q] : 0ll);
+                    aL1 += mL[g][q].b + (edge == 1 ? eL[g][q] : 0ll);
+                    aR0 += mR[g][q].a + (edge == 0 ? eR[g][q] : 0ll);
+                    aR1 += mR[g][q].b + (edge == 1 ? eR[g][q] : 0ll);
+                    }
+#pragma unroll
+                for (int q = NA; q < NS; ++q)
+                    {
+                    bL0 += mL[g][q].a + (edge == 0 ? eL[g][q] : 0ll);
+                    bL1 += mL[g][q].b + (edge == 1 ? eL[g][q] : 0ll);
+                    bR0 += mR[g][q].a + (edge == 0 ? eR[g][q] : 0ll);
+                    bR1 += mR[g][q].b + (edge == 1 ? eR[g][q] : 0ll);
+                    }
+                // the pair as one complex line (row a + i row b), folded for this block's parity
+                const double2 zL0 = make_double2((double)aL0 * tl.inv_scale, (double)bL0 * tl.inv_scale);
+                const double2 zL1 = make_double2((double)aL1 * tl.inv_scale, (double)bL1 * tl.inv_scale);
+                const double2 zR0 = make_double2((double)aR0 * tl.inv_scale, (double)bR0 * tl.inv_scale);
+                const double2 zR1 = make_double2((double)aR1 * tl.inv_scale, (double)bR1 * tl.inv_scale);
+                if (parity)
+                    {
+                    f0[g0 + g] = cmul(csub(zL0, zR0), TX[2 * j]);          // (published by the barrier in front of the first call)
+                    f1[g0 + g] = cmul(csub(zL1, zR1), TX[2 * j + 1]);
+                    }
+                else
+                    {
+                    f0[g0 + g] = cadd(zL0, zR0);
+                    f1[g0 + g] = cadd(zL1, zR1);
+                    }
+                }
+            }
+        };
+    lds_barrier();                                                   // the twiddles (the odd block's fold reads them)
+    if (z2)
+        {
+        if (ycls == 0) load_pairs(std::true_type(), std::integral_constant<int, 0>());
+        else if (ycls == 1) load_pairs(std::true_type(), std::integral_constant<int, 1>());
+        else load_pairs(std::true_type(), std::integral_constant<int, 2>());
+        }
+    else
+        {
+        if (ycls == 0) load_pairs(std::false_type(), std::integral_constant<int, 0>());
+        else if (ycls == 1) load_pairs(std::false_type(), std::integral_constant<int, 1>());
+        else load_pairs(std::false_type(), std::integral_constant<int, 2>());
+        }
+    // folded positions 2 j, 2 j + 1 of line pair u to their bit-reversed rows
+    {
+    const unsigned int r0 = lds_slot(2 * j, 6), r1 = lds_slot(2 * j + 1, 6);
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+        {
+        const unsigned int u = um + 4u * half + 8u * ((unsigned int)g + 4u * (wave >> 2));
+        X[r0 * xs + u] = f0[g];
+        X[r1 * xs + u] = f1[g];
+        }
+    }
+    lds_barrier();
+    XY_STAMP(0, 1);
+    fft_dit_xy(X, TXh, 6, pl.d_np, 0, xs);
+    XY_STAMP(0, 2);
+    // the two real rows of a pair at the k_x of this block's parity, to their (bit-reversed) y rows of the column image:
+    // k = parity + 2 kl is element kl of the even / odd half transform, its mirror 128 - k element 64 - kl (mod 64) / 63 - kl
+    for (unsigned int idx = threadIdx.x; idx < kc * NP; idx += XY_THREADS)
+        {
+        unsigned int u, kl;
+        dk.split(idx, u, kl);
+        const unsigned int mm = parity ? NF - 1 - kl : (NF - kl) & (NF - 1);
+        const double2 zk = X[kl * xs + u], zm = X[mm * xs + u];
+        Y[lds_slot(2 * u, 7) * ys + kl] = make_double2(0.5 * (zk.x + zm.x), 0.5 * (zk.y - zm.y));
+        Y[lds_slot(2 * u + 1, 7) * ys + kl] = make_double2(0.5 * (zk.y + zm.y), -0.5 * (zk.x - zm.x));
+        }
+    lds_barrier();
+    XY_STAMP(0, 3);
+    fft_dit_xy(Y, TY, 7, dk, 0, ys);
+    XY_STAMP(0, 7);
+    for (unsigned int idx = threadIdx.x; idx < kc * NY; idx += XY_THREADS)
+        {
+        unsigned int ky, kl;
+        dk.split(idx, ky, kl);
+        const double2 v = Y[ky * ys + kl];
+        half_out[(line_base + ky) * pl.hxp + parity + 2 * kl] = v;      // (plain stores: the two blocks of a plane fill the halves of every line, the L2 they share merges them)
+        }
+    XY_STAMP(0, 8);
+    }
+
+// ---- 8bc'. inverse x/y passes of a plane WITHOUT the redundant half: the y transform split by the parity of its OUTPUT ----------
+// k_fft_xy_inverse lets both blocks of a plane invert all k_x columns along y and keep half of the rows.  Decimation in frequency
+// says which half each block needs: out[2 m] = IDFT_{ny/2}(G[k] + G[k + ny/2]), out[2 m + 1] = IDFT_{ny/2}((G[k] - G[k + ny/2]) w^-k)
+// — block p of a plane folds the columns once (while they arrive from memory) and transforms lines of HALF the length; its rows are
+// y = p, p + 2, ...  Half the butterflies, and the folded column image of ALL k_x columns (ny/2 x 65 at 128^2: 67 KB) fits the LDS
+// next to the row image (68 KB): one batch instead of two, 2 x 65 lines per sweep instead of 33.  The x pass is the old one on the
+// block's rows (two of them packed into one complex line: k_fft_x_c2r).  Other rounding than the unsplit kernel (a different
+// factorisation of the same transform): the slab path, which runs the separate line passes, agrees to 1e-15, not bitwise.
+struct XYSplit
+    {
+    unsigned int nx, ny, nz, log2nx, log2ny, hx, hxp;
+    unsigned int rows;          // ny / 2: folded positions of a column = output rows of a block
+    unsigned int pairs;         // rows / 2: packed row pairs of a block
+    unsigned int xs, ys;        // row strides of the row image (pairs, odd) and of the column image (hx, odd)
+    FastDiv d_hx, d_pairs;
+    int xcd_map;                // nz % 8 == 0: the two blocks of a plane run on one XCD
+    };
+constexpr int XYS_SLOTS = 9;        // folded column elements per thread (65 x 64 / 512 at 128^2)
+
+__device__ __forceinline__ void xys_block(const int xcd_map, unsigned int &plane, unsigned int &part)
+    {
+    const unsigned int b = blockIdx.x;
+    if (xcd_map)
+        {
+        const unsigned int group = b / 16, r = b % 16;               // consecutive block ids go to consecutive XCDs: ids b and b + 8 share one
+        plane = group * 8 + (r & 7);
+        part = r >> 3;
+        }
+    else
+        {
+        plane = b >> 1;
+        part = b & 1;
+        }
+    }
+
+__global__ __launch_bounds__(XY_THREADS) void k_fft_xy_inverse_split(const double2 *__restrict__ half_in, double *__restrict__ real_out,
+                                                                     const double2 *__restrict__ tw_x, const double2 *__restrict__ tw_y,
+                                                                     const XYSplit pl, const double *__restrict__ cvp_in, const unsigned int cvp_n,
+                                                                     double *__restrict__ cvp_out)
+    {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double2 *Yi = (double2 *)smem, *X = Yi + (size_t)pl.rows * pl.ys, *TX = X + (size_t)pl.nx * pl.xs, *TY = TX + pl.nx / 2, *TYh = TY + pl.ny / 2;
+    const unsigned int cvp_k = blockIdx.x + (threadIdx.x & 63u) * gridDim.x;          // (cvp_*: see k_fft_xy_inverse)
+    double cvp = cvp_in[min(cvp_k, cvp_n ? cvp_n - 1 : 0u)];
+    unsigned int plane, parity;
+    xys_block(pl.xcd_map, plane, parity);
+    const unsigned int nx = pl.nx, rows = pl.rows, pairs = pl.pairs, xs = pl.xs, ys = pl.ys, hx = pl.hx;
+    const size_t line_base = (size_t)plane * pl.ny;
+    XY_STAMP(1, 0);
+    // 1. every column element k < ny/2 and its partner k + ny/2, requested before anything else (clamped, not predicated)
+    double2 ra[XYS_SLOTS], rb[XYS_SLOTS];
+    const unsigned int n_fold = hx * rows;
+#pragma unroll
+    for (int i = 0; i < XYS_SLOTS; ++i)
+        {
+        const unsigned int idx = min(threadIdx.x + i * XY_THREADS, n_fold - 1);
+        unsigned int k, c;
+        pl.d_hx.split(idx, k, c);
+        const double2 a = half_in[(line_base + k) * pl.hxp + c], b = half_in[(line_base + k + rows) * pl.hxp + c];
+        ra[i].x = a.x; ra[i].y = a.y;      // (by component: a 16-byte aggregate copy keeps the array in scratch)
+        rb[i].x = b.x; rb[i].y = b.y;
+        }
+    for (unsigned int i = threadIdx.x; i < nx / 2 + pl.ny / 2 + pl.ny / 4; i += XY_THREADS)
+        TX[i] = i < nx / 2 ? tw_x[i] : (i < nx / 2 + pl.ny / 2 ? tw_y[i - nx / 2] : tw_y[2 * (i - nx / 2 - pl.ny / 2)]);
+    lds_barrier();
+    // fold (this block's parity) into the column image, bit-reversed rows for the transform
+#pragma unroll
+    for (int i = 0; i < XYS_SLOTS; ++i)
+        {
+        const unsigned int idx = threadIdx.x + i * XY_THREADS;
+        if (idx < n_fold)
+            {
+            unsigned int k, c;
+            pl.d_hx.split(idx, k, c);
+            double2 f;
+            if (parity)
+                {
+                const double2 w = TY[k];                                   // exp(-2 pi i k / ny): the inverse takes its conjugate
+                const double2 d = csub(ra[i], rb[i]);
+                f = make_double2(d.x * w.x + d.y * w.y, d.y * w.x - d.x * w.y);
+                }
+            else
+                f = cadd(ra[i], rb[i]);
+            Yi[lds_slot(k, pl.log2ny - 1) * ys + c] = f;
+            }
+        }
+    lds_barrier();
+    XY_STAMP(1, 1);
+    // 2. all columns along y, half length
+    fft_dit_xy(Yi, TYh, pl.log2ny - 1, pl.d_hx, 1, ys);
+    XY_STAMP(1, 2);
+    // 3. this block's rows m = 0 .. ny/2 - 1 (y = parity + 2 m), two of them per complex line: A + i B at k_x and its mirror (k_fft_x_c2r)
+    for (unsigned int idx = threadIdx.x; idx < hx * pairs; idx += XY_THREADS)
+        {
+        unsigned int c, u;
+        pl.d_pairs.split(idx, c, u);
+        const double2 A = Yi[(2 * u) * ys + c], B = Yi[(2 * u + 1) * ys + c];
+        X[lds_slot(c, pl.log2nx) * xs + u] = make_double2(A.x - B.y, A.y + B.x);
+        if (c != 0 && 2 * c != nx) X[lds_slot(nx - c, pl.log2nx) * xs + u] = make_double2(A.x + B.y, -A.y + B.x);
+        }
+    lds_barrier();
+    XY_STAMP(1, 3);
+    // 4. the rows along x
+    fft_dit_xy(X, TX, pl.log2nx, pl.d_pairs, 1, xs);
+    XY_STAMP(1, 7);
+    // 5. out: line u holds rows y = parity + 4 u (real part) and parity + 4 u + 2 (imaginary part)
+    for (unsigned int idx = threadIdx.x; idx < nx * pairs; idx += XY_THREADS)
+        {
+        const unsigned int u = idx >> pl.log2nx, p = idx & (nx - 1);
+        const double2 z = X[p * xs + u];
+        const size_t la = line_base + parity + 4 * u;
+        __builtin_nontemporal_store(z.x, real_out + la * nx + p);
+        __builtin_nontemporal_store(z.y, real_out + (la + 2) * nx + p);
+        }
+    if (threadIdx.x < 64)                                        // (wave 0, uniform over the wave)
+        {
+        cvp = cvp_k < cvp_n ? cvp : 0.0;
+        const double tot = wave_sum(cvp);
+        if (threadIdx.x == 0 && cvp_n) cvp_out[blockIdx.x] = tot;
+        }
+    XY_STAMP(1, 8);
+    }
+
 // ---- 6c+7+8a. z lines: forward transform, spectral step, inverse transform — one pass ----------------------
 // The last forward pass, updateMeshes/computeCV and the first inverse pass all work on complete z lines, so they share one
 // staging of the lines in LDS: the Fourier mesh is written once (f, normalised: the log quantities and the virial read
@@ -3328,6 +3647,41 @@ bool xy_plan(const mtd_mesh *m, int inverse, XYPlan &pl, size_t &lds)
     return lds <= XY_LDS_MAX && per_batch <= (size_t)XY_PREFETCH * XY_THREADS;
     }
 
+// plan of the split forward transform from the tile images (k_fft_xy_forward_split): 128 x 128 planes, two x tiles of 64 cells,
+// tile height 4 or 8 (the row class of a lane's line pairs must depend on its wave only)
+bool xy_split_plan_f(const mtd_mesh *m, XYSplitF &pl, size_t &lds)
+    {
+    if (m->nx != 128 || m->ny != 128 || m->tg.tx != 64 || (m->tg.ty != 4 && m->tg.ty != 8)) return false;
+    std::memset(&pl, 0, sizeof(pl));
+    pl.hxp = m->hxp;
+    pl.xs = 65;
+    pl.ys = 33;
+    pl.d_kc[0] = fast_div(33);
+    pl.d_kc[1] = fast_div(32);
+    pl.d_np = fast_div(64);
+    pl.xcd_map = m->nz % 8 == 0;
+    lds = ((size_t)64 * pl.xs + (size_t)128 * pl.ys + 64 + 32 + 64) * sizeof(double2);
+    return lds <= XY_LDS_MAX;
+    }
+
+// plan of the split inverse (k_fft_xy_inverse_split), or false where the shapes do not allow it (the unsplit kernel runs)
+bool xy_split_plan(const mtd_mesh *m, XYSplit &pl, size_t &lds)
+    {
+    if (!is_pow2(m->nx) || !is_pow2(m->ny) || m->nx < 8 || m->ny < 16) return false;
+    std::memset(&pl, 0, sizeof(pl));
+    pl.nx = m->nx; pl.ny = m->ny; pl.nz = m->nz; pl.log2nx = ilog2(m->nx); pl.log2ny = ilog2(m->ny);
+    pl.hx = m->nx / 2 + 1; pl.hxp = m->hxp;
+    pl.rows = m->ny / 2;
+    pl.pairs = pl.rows / 2;
+    pl.xs = pl.pairs | 1u;
+    pl.ys = pl.hx | 1u;
+    pl.d_hx = fast_div(pl.hx);
+    pl.d_pairs = fast_div(pl.pairs);
+    pl.xcd_map = m->nz % 8 == 0;
+    lds = ((size_t)pl.rows * pl.ys + (size_t)pl.nx * pl.xs + pl.nx / 2 + pl.ny / 2 + pl.ny / 4) * sizeof(double2);
+    return lds <= XY_LDS_MAX && (size_t)pl.hx * pl.rows <= (size_t)XYS_SLOTS * XY_THREADS && (size_t)pl.hx * pl.rows * pl.hx < (1ull << 32);
+    }
+
 } // namespace
 
 #ifdef MTD_STAMPS
@@ -3947,8 +4301,9 @@ int mtd_mesh_spectral(mtd_mesh *m, const mtd_box *box, unsigned int n_global, co
     size_t xy_lds_f = 0, xy_lds_i = 0;
     static const bool xy_off = [] { const char *e = std::getenv("MTD_FFT_XY"); return e && e[0] == '0'; }();
     // (a runtime that refuses the 160 KB of dynamic LDS leaves the separate passes, it does not fail the step)
-    static const void *const xy_fns[3] = { (const void *)k_fft_xy_forward<false>, (const void *)k_fft_xy_inverse, (const void *)k_fft_xy_forward<true> };
-    const bool xy_lds_ok = dyn_lds_ok(2, xy_fns, 3, XY_LDS_MAX);
+    static const void *const xy_fns[5] = { (const void *)k_fft_xy_forward<false>, (const void *)k_fft_xy_inverse, (const void *)k_fft_xy_forward<true>,
+                                           (const void *)k_fft_xy_inverse_split, (const void *)k_fft_xy_forward_split };
+    const bool xy_lds_ok = dyn_lds_ok(2, xy_fns, 5, XY_LDS_MAX);
     const bool xy = !xy_off && xy_lds_ok && xy_plan(m, 0, xy_f, xy_lds_f) && xy_plan(m, 1, xy_i, xy_lds_i);
     XYTiles tiles;
     std::memset(&tiles, 0, sizeof(tiles));
@@ -3958,7 +4313,13 @@ int mtd_mesh_spectral(mtd_mesh *m, const mtd_box *box, unsigned int n_global, co
     if (xy && tile_rows_ok && !m->rho_valid && xy_tiles_ok(m, tiles))
         {
         // the assignment left the mesh in the per-tile images (mtd_mesh_compute_cv): the transform sums them itself
-        k_fft_xy_forward<true><<<m->nz * XY_PARTS, XY_THREADS, xy_lds_f, s>>>(nullptr, m->d_f, m->d_tw[0], m->d_tw[1], xy_f, tiles);
+        XYSplitF sf;
+        size_t sf_lds = 0;
+        const char *split_env = std::getenv("MTD_FFT_SPLIT");              // (read per call: a test runs both forms in one process)
+        if (!(split_env && split_env[0] == '0') && xy_split_plan_f(m, sf, sf_lds))
+            k_fft_xy_forward_split<<<m->nz * 2, XY_THREADS, sf_lds, s>>>(m->d_f, m->d_tw[0], m->d_tw[1], sf, tiles);
+        else
+            k_fft_xy_forward<true><<<m->nz * XY_PARTS, XY_THREADS, xy_lds_f, s>>>(nullptr, m->d_f, m->d_tw[0], m->d_tw[1], xy_f, tiles);
         MTD_LAUNCH_CHECK();
         m->last_forward = 2;
         }
@@ -4020,8 +4381,16 @@ int mtd_mesh_spectral(mtd_mesh *m, const mtd_box *box, unsigned int n_global, co
         // mtd_mesh_set_cv_event marks the z pass as the point where the sums are complete)
         const unsigned int xy_blocks = m->nz * XY_PARTS;
         fold_cv = !m->cv_event && z_blocks_whole > xy_blocks && z_blocks_whole <= 64 * xy_blocks;
-        k_fft_xy_inverse<<<xy_blocks, XY_THREADS, xy_lds_i, s>>>(m->d_g, m->d_inv, m->d_tw[0], m->d_tw[1], xy_i, m->d_cv_partials,
-                                                                 fold_cv ? z_blocks_whole : 0u, m->d_cv_folded);   // Re(inv)
+        XYSplit xs_i;
+        size_t xs_lds = 0;
+        const char *split_env = std::getenv("MTD_FFT_SPLIT");              // (read per call: a test runs both forms in one process)
+        const bool split = !(split_env && split_env[0] == '0') && xy_split_plan(m, xs_i, xs_lds);
+        if (split)
+            k_fft_xy_inverse_split<<<xy_blocks, XY_THREADS, xs_lds, s>>>(m->d_g, m->d_inv, m->d_tw[0], m->d_tw[1], xs_i, m->d_cv_partials,
+                                                                         fold_cv ? z_blocks_whole : 0u, m->d_cv_folded);
+        else
+            k_fft_xy_inverse<<<xy_blocks, XY_THREADS, xy_lds_i, s>>>(m->d_g, m->d_inv, m->d_tw[0], m->d_tw[1], xy_i, m->d_cv_partials,
+                                                                     fold_cv ? z_blocks_whole : 0u, m->d_cv_folded);   // Re(inv)
         MTD_LAUNCH_CHECK();
         if (fold_cv) n_folded = xy_blocks;
         }

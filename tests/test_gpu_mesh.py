@@ -379,10 +379,13 @@ def test_mesh_config3_size(abi, ref):
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
 @pytest.mark.parametrize("N,dims", [(3, (128, 16, 16)), (30011, (128, 32, 64)), (400009, (128, 128, 128)), (20011, (128, 64, 8)), (3, (128, 128, 16))])
 def test_forward_transform_from_tile_images_against_combined_mesh(abi, monkeypatch, dtype, N, dims):
-    """k_fft_xy_forward<true> (the default on meshes 128 cells wide: the transform sums the tile images' halo entries itself, two
-    cells per lane with 16-byte loads, no combine launch) against k_tile_combine_rows + k_fft_xy_forward<false>
-    (MTD_FFT_FROM_TILES=0): the sums are integers, so the CV, the spectrum's mesh, the combined mesh read back afterwards and
-    every particle's force are the same BITS; over two snapshots (counting pipeline, then the bin pipeline's other cursor set)."""
+    """k_fft_xy_forward<true> (meshes 128 cells wide: the transform sums the tile images' halo entries itself, two cells per lane
+    with 16-byte loads, no combine launch) against k_tile_combine_rows + k_fft_xy_forward<false> (MTD_FFT_FROM_TILES=0), both with
+    the unsplit x/y kernels (MTD_FFT_SPLIT=0): the sums are integers, so the CV, the Fourier mesh, the combined mesh read back
+    afterwards and every particle's force are the same BITS.  And the default — the x/y transforms split by the parity of their
+    output (k_fft_xy_forward_split on 128 x 128 planes, k_fft_xy_inverse_split) — against them: another factorisation of the same
+    transform, equal to rounding (CV 1e-12, Fourier mesh 1e-12 of its largest element, forces 1e-10 / one fp32 rounding).  Two
+    snapshots each (counting pipeline, then the bin pipeline's other cursor set)."""
     L = 21.0
     box = abi.Box.make(L)
     dt = abi.MTD_F32 if dtype == np.float32 else abi.MTD_F64
@@ -391,8 +394,9 @@ def test_forward_transform_from_tile_images_against_combined_mesh(abi, monkeypat
         pos, types = util.snapshot_random(N, L, seed=seed + N, modulated=True, dtype=dtype)
         snaps.append(torch.from_numpy(util.pack_postype(pos, types, dtype)).cuda())
     out = {}
-    for mode in ("1", "0"):
-        monkeypatch.setenv("MTD_FFT_FROM_TILES", mode)
+    for mode, (tiles, split) in dict(default=("1", "1"), tiles=("1", "0"), combine=("0", "0")).items():
+        monkeypatch.setenv("MTD_FFT_FROM_TILES", tiles)
+        monkeypatch.setenv("MTD_FFT_SPLIT", split)
         g = GpuMesh(abi, dims, [1.0, -0.6], N)
         try:
             res = []
@@ -401,17 +405,22 @@ def test_forward_transform_from_tile_images_against_combined_mesh(abi, monkeypat
                 fwd = C.c_int(-1)
                 abi.check(g.lib.mtd_mesh_transform_info(g.h, C.byref(fwd)))
                 # (the tile form needs batches of 32 line pairs: at least 64 rows; smaller planes keep the combine launch)
-                assert fwd.value == (2 if mode == "1" and dims[1] >= 64 else 1)
+                assert fwd.value == (2 if tiles == "1" and dims[1] >= 64 else 1)
                 F = g.forces(d_pos, dt, box, N, 0.7)
                 res.append((s, F.copy(), g.array(0).copy(), g.array(1).copy()))
             out[mode] = res
         finally:
             g.close()
-    for a, b in zip(out["1"], out["0"]):
+    for a, b in zip(out["tiles"], out["combine"]):
         assert a[0] == b[0] and a[0] != 0.0
         for x, y in zip(a[1:], b[1:]):
             assert np.array_equal(x, y)
         assert np.abs(a[1]).max() > 0
+    for a, b in zip(out["default"], out["tiles"]):
+        assert a[0] == pytest.approx(b[0], rel=1e-12)
+        assert np.array_equal(a[2], b[2])                               # the real mesh: integer sums, no transform in it
+        assert np.abs(a[3] - b[3]).max() <= 1e-12 * np.abs(b[3]).max()
+        assert np.abs(a[1] - b[1]).max() <= (2e-6 if dtype == np.float32 else 1e-10) * np.abs(b[1]).max()
 
 
 @pytest.mark.parametrize("tilt", [{}, dict(xy=0.1, xz=-0.05, yz=0.2)])
