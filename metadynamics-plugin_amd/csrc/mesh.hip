@@ -22,15 +22,19 @@
 //                       from global memory it cost 316 us of load latency): no atomics on the mesh, no scratch, every
 //                       mesh cell written exactly once
 //   6 k_fft_xy_forward  x and y passes of a mesh plane in one launch (power-of-two planes that fit the LDS: 128^2 does);
+//     k_fft_xy_forward_split   the same for 128 x 128 planes straight from the tile images, the x transform split by the parity
+//                       of its output between the two blocks of a plane (no line transformed twice; the default at 128^3);
 //                       otherwise, and on the slab path:
 //     k_fft_x_r2c       unnormalised DFT along x of the real mesh, only k_x = 0 .. nx/2 kept (half spectrum, padded rows);
 //     k_fft_lines       along y; lines staged in LDS in [pos][line] layout (adjacent lines per block so strided axes
 //                       still move 128-B segments)
 //   7 k_fft_z_spectral  z lines: forward transform, f = F/N, Hermitian part of G = f(|f|^2 - I^2 sum mode^2 / 2N^2), block
 //                       sums of the CV integrand (stored cell + mirror cell), inverse transform — one staging in LDS
-//   8 k_fft_xy_inverse  inverse along y and x of a plane in one launch; otherwise
+//   8 k_fft_xy_inverse  inverse along y and x of a plane in one launch (k_fft_xy_inverse_split: the y transform split by the
+//                       parity of its output rows, the default); otherwise
 //     k_fft_lines       inverse along y; k_fft_x_c2r inverse along x (other half of the line by symmetry, real part out)
-//   9 k_mesh_forces     per particle: 27 reads of Re(inv) with TSC' x TSC x TSC weights
+//   9 k_mesh_forces     per particle: 27 reads of Re(inv) with TSC' x TSC x TSC weights (tile path: k_tile_forces, or
+//                       k_tile_forces_chain with the bias-grid engine's launch inside: mtd_mesh_forces_update_bias)
 // Everything is double precision: the CV is quartic in the Fourier amplitudes, fp32 meshes cannot hold
 // 1e-6 on it.  Mesh sizes: 4 ... 256 per axis (any, direct transform in LDS for lengths that are not powers of two), or a
 // power of two up to 1024 (radix-2 stages); other sizes return MTD_ERR_UNSUPPORTED.
