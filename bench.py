@@ -963,11 +963,19 @@ def main():
 
     # A stretch of plain, untimed steps in front of the warm-up: building the host-API system left the GPU idle for ~0.1 s, and after
     # 50 ms of idling a region of 20 steps runs 1.5 us per step slower, the next one still 1 us (tools/diag/k20_shape_probe.py).
+    # The W warm-up steps come FIRST and the long untimed stretch directly in front of the timed region (everything before the timed
+    # region is untimed warm-up either way): a short run(W) between the stretch and the region left the region of K = 20 steps at
+    # 19.5-24.6 us per step (median 20.0), the stretch directly in front of it at 19.4-20.3 (median 19.5) — sixteen runs on one
+    # box, profiles/r4/k20_env_probe.log, tools/diag/k20_order_probe.sh.  MTD_BENCH_WARM_ORDER=0: the old order (diagnostic).
+    warm_first = os.environ.get("MTD_BENCH_WARM_ORDER", "1") == "1"
+    if warm_first and args.warmup > 0:
+        run_steps(args.warmup)
+        barrier()
     for _ in range(8):
         run_steps(250)
         barrier()
     barrier()                              # ranks enter the first exchange together (the mailbox waits are bounded)
-    if args.warmup > 0:
+    if args.warmup > 0 and not warm_first:
         run_steps(args.warmup)
     barrier()
     t0 = time.perf_counter()
