@@ -7,7 +7,7 @@
 # code + HIP host glue) is the regular build.  usage: tools/asan.sh [logfile]
 set -e
 ROOT="$(cd "$(dirname "$0")/.." && pwd)"
-LOG="${1:-$ROOT/profiles/r3/asan_ubsan_cpu_tests.log}"
+LOG="${1:-$ROOT/profiles/r4/asan_ubsan_cpu_tests.log}"
 WORK="${TMPDIR:-/tmp}/mtd_asan_tree"
 rm -rf "$WORK" && mkdir -p "$WORK"
 tar -C "$ROOT" --exclude=.git --exclude=gpurun_out --exclude=__pycache__ --exclude=.pytest_cache --exclude='tools/bin' -cf - . | tar -C "$WORK" -xf -
